@@ -1,0 +1,120 @@
+"""Seeded random-init Depth-Anything-V2 checkpoints in the *original upstream key format*.
+
+No real weights ship with the reference (model_weights/ holds only a README) and there is no
+network, so benchmarks, smoke tests and golden fixtures all run on synthetic weights. Plain
+PyTorch default init gives an all-zero depth map (the final ReLU, reference
+v2_depthanything/head_model.py:84, clips everything), so the recipe below is
+tuned to produce non-degenerate outputs. It is pure CPU torch RNG => reproducible anywhere.
+"""
+
+from __future__ import annotations
+
+import torch
+
+STANDARD_CONFIGS = {
+    # reference make_depthanythingv2_dpt.py:88-122
+    "vits": dict(features_per_token=384, num_heads=6, num_blocks=12, reassembly_features_list=[48, 96, 192, 384],
+                 base_patch_grid_hw=(37, 37), fusion_channels=64, patch_size_px=14),
+    "vitb": dict(features_per_token=768, num_heads=12, num_blocks=12, reassembly_features_list=[96, 192, 384, 768],
+                 base_patch_grid_hw=(37, 37), fusion_channels=128, patch_size_px=14),
+    "vitl": dict(features_per_token=1024, num_heads=16, num_blocks=24, reassembly_features_list=[256, 512, 1024, 1024],
+                 base_patch_grid_hw=(37, 37), fusion_channels=256, patch_size_px=14),
+    # not a real model: small enough for full-tensor golden fixtures (KBs) and fast CPU tests
+    "tiny": dict(features_per_token=64, num_heads=1, num_blocks=4, reassembly_features_list=[16, 32, 64, 64],
+                 base_patch_grid_hw=(5, 5), fusion_channels=32, patch_size_px=14),
+}
+
+
+def original_state_dict_shapes(cfg: dict) -> dict[str, tuple]:
+    """Every tensor of an upstream DA-V2 (non-giant) checkpoint, in upstream order, with its shape."""
+    F = cfg["features_per_token"]
+    P = cfg["patch_size_px"]
+    gh, gw = cfg["base_patch_grid_hw"]
+    C = cfg["fusion_channels"]
+    hid = cfg["reassembly_features_list"]
+    shapes: dict[str, tuple] = {}
+    shapes["pretrained.cls_token"] = (1, 1, F)
+    shapes["pretrained.pos_embed"] = (1, 1 + gh * gw, F)
+    shapes["pretrained.mask_token"] = (1, F)
+    shapes["pretrained.patch_embed.proj.weight"] = (F, 3, P, P)
+    shapes["pretrained.patch_embed.proj.bias"] = (F,)
+    for i in range(cfg["num_blocks"]):
+        b = f"pretrained.blocks.{i}"
+        shapes[f"{b}.norm1.weight"] = (F,)
+        shapes[f"{b}.norm1.bias"] = (F,)
+        shapes[f"{b}.attn.qkv.weight"] = (3 * F, F)
+        shapes[f"{b}.attn.qkv.bias"] = (3 * F,)
+        shapes[f"{b}.attn.proj.weight"] = (F, F)
+        shapes[f"{b}.attn.proj.bias"] = (F,)
+        shapes[f"{b}.ls1.gamma"] = (F,)
+        shapes[f"{b}.norm2.weight"] = (F,)
+        shapes[f"{b}.norm2.bias"] = (F,)
+        shapes[f"{b}.mlp.fc1.weight"] = (4 * F, F)
+        shapes[f"{b}.mlp.fc1.bias"] = (4 * F,)
+        shapes[f"{b}.mlp.fc2.weight"] = (F, 4 * F)
+        shapes[f"{b}.mlp.fc2.bias"] = (F,)
+        shapes[f"{b}.ls2.gamma"] = (F,)
+    shapes["pretrained.norm.weight"] = (F,)
+    shapes["pretrained.norm.bias"] = (F,)
+    for i in range(4):
+        shapes[f"depth_head.projects.{i}.weight"] = (hid[i], F, 1, 1)
+        shapes[f"depth_head.projects.{i}.bias"] = (hid[i],)
+    shapes["depth_head.resize_layers.0.weight"] = (hid[0], hid[0], 4, 4)  # ConvTranspose2d k4 s4: (Cin, Cout, kh, kw)
+    shapes["depth_head.resize_layers.0.bias"] = (hid[0],)
+    shapes["depth_head.resize_layers.1.weight"] = (hid[1], hid[1], 2, 2)  # ConvTranspose2d k2 s2
+    shapes["depth_head.resize_layers.1.bias"] = (hid[1],)
+    shapes["depth_head.resize_layers.3.weight"] = (hid[3], hid[3], 3, 3)  # Conv2d k3 s2 p1
+    shapes["depth_head.resize_layers.3.bias"] = (hid[3],)
+    for i in range(4):
+        shapes[f"depth_head.scratch.layer{i + 1}_rn.weight"] = (C, hid[i], 3, 3)
+    for n in (1, 2, 3, 4):
+        r = f"depth_head.scratch.refinenet{n}"
+        shapes[f"{r}.out_conv.weight"] = (C, C, 1, 1)
+        shapes[f"{r}.out_conv.bias"] = (C,)
+        for unit in ("resConfUnit1", "resConfUnit2"):
+            for conv in ("conv1", "conv2"):
+                shapes[f"{r}.{unit}.{conv}.weight"] = (C, C, 3, 3)
+                shapes[f"{r}.{unit}.{conv}.bias"] = (C,)
+    shapes["depth_head.scratch.output_conv1.weight"] = (C // 2, C, 3, 3)
+    shapes["depth_head.scratch.output_conv1.bias"] = (C // 2,)
+    shapes["depth_head.scratch.output_conv2.0.weight"] = (32, C // 2, 3, 3)
+    shapes["depth_head.scratch.output_conv2.0.bias"] = (32,)
+    shapes["depth_head.scratch.output_conv2.2.weight"] = (1, 32, 1, 1)
+    shapes["depth_head.scratch.output_conv2.2.bias"] = (1,)
+    return shapes
+
+
+def make_synthetic_original_state_dict(cfg: dict | str, seed: int = 0) -> dict[str, torch.Tensor]:
+    """Seeded fp32 CPU checkpoint with upstream key names (loads through the normal factory path).
+
+    Recipe: matrices/kernels ~ N(0, 1/fan_in); norm weights 1 + 0.1 N; layer-scale gammas ~ U(0.5, 1);
+    other vectors 0.1 N; position embedding 0.5 N; final 1-channel bias 0.5 (keeps the ReLU alive).
+    Tensors are drawn in `original_state_dict_shapes` order from one generator, so (cfg, seed)
+    fully determines the checkpoint.
+    """
+    if isinstance(cfg, str):
+        cfg = STANDARD_CONFIGS[cfg]
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(int(seed))
+    sd: dict[str, torch.Tensor] = {}
+    for key, shape in original_state_dict_shapes(cfg).items():
+        if key.endswith("gamma"):
+            t = 0.5 + 0.5 * torch.rand(shape, generator=gen)
+        elif ".norm" in key and key.endswith("weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=gen)
+        elif key == "pretrained.pos_embed":
+            t = 0.5 * torch.randn(shape, generator=gen)
+        elif key == "depth_head.scratch.output_conv2.2.bias":
+            t = torch.full(shape, 0.5)
+        elif len(shape) >= 2 and key.endswith("weight"):
+            if "resize_layers.0" in key or "resize_layers.1" in key:
+                fan_in = shape[0]  # transposed conv with k == s: every output pixel sees Cin inputs
+            else:
+                fan_in = 1
+                for d in shape[1:]:
+                    fan_in *= d
+            t = torch.randn(shape, generator=gen) * (float(fan_in) ** -0.5)
+        else:
+            t = 0.1 * torch.randn(shape, generator=gen)
+        sd[key] = t.to(torch.float32).contiguous()
+    return sd

@@ -1,0 +1,215 @@
+"""CPU ORACLE (TEST INFRASTRUCTURE - NOT PRODUCT CODE) for the Depth-Anything-V2 DPT hot path.
+
+A plain-torch, fp32, functional restatement of the reference's forward path:
+
+    patch-embed -> DINOv2 encoder (4 taps) -> reassemble -> RefineNet fusion -> depth head
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may import this
+module, and only as the *checker*. The product path (muggled_dpt_amd) never routes through it.
+
+Parity pinning: the reference ships no tests or golden vectors ("parity unpinned" by the
+reference itself). This oracle is instead pinned to the *imported reference*
+(torch 2.10 CPU fp32): `tools/gen_golden.py` (run in the build container, where
+/root/reference exists) asserts oracle == reference to <= 2e-5 at every stage boundary and
+writes `tests/golden/*.npz`; `tests/test_oracle_golden.py` re-checks the oracle against those
+committed fixtures on any machine.
+
+Weights are a flat dict keyed by "<component>.<new-format key>" (e.g.
+"imgencoder.stages.0.blocks.1.attn.qkv.weight"), fp32 CPU tensors.
+Every function cites the reference lines it follows (paths relative to /root/reference/muggled_dpt).
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+RGB_MEAN = (0.485, 0.456, 0.406)  # v2_depthanything/patch_embed.py:38
+RGB_STD = (0.229, 0.224, 0.225)  # v2_depthanything/patch_embed.py:39
+LN_EPS = 1e-6  # components/misc_helpers.py:190-210 (LayerNormEPS6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# pre-processing
+
+
+def prepared_size(img_h: int, img_w: int, max_side_length: int | None, use_square_sizing: bool,
+                  default_size_px: int = 518, tiling_px: int = 28) -> tuple[int, int]:
+    """Model tensor size for an input image: each side = max(1, round(side*scale/28))*28.
+
+    patch_embed.py:121-130. Python's banker's rounding matters: 518/28 = 18.5 -> 18 -> 504.
+    """
+    if max_side_length is None:
+        max_side_length = default_size_px
+    largest = max(img_h, img_w)
+    scale = max_side_length / largest
+    targ = (largest, largest) if use_square_sizing else (img_h, img_w)
+    return tuple(max(1, round(side * scale / tiling_px)) * tiling_px for side in targ)
+
+
+def prepare_image(image_bgr, max_side_length: int | None = None, use_square_sizing: bool = True,
+                  interpolation_mode: str = "bilinear", default_size_px: int = 518, tiling_px: int = 28) -> torch.Tensor:
+    """uint8 HxWx3 BGR ndarray -> normalised fp32 [1,3,H',W'] (patch_embed.py:103-145)."""
+    h, w = image_bgr.shape[0:2]
+    size_hw = prepared_size(h, w, max_side_length, use_square_sizing, default_size_px, tiling_px)
+    rgb = torch.from_numpy(image_bgr[:, :, ::-1].copy()).permute(2, 0, 1).to(torch.float32)  # :134-135
+    x = F.interpolate(rgb.unsqueeze(0), size=size_hw, align_corners=False, antialias=True, mode=interpolation_mode)
+    mean = torch.tensor(RGB_MEAN).view(1, 3, 1, 1)
+    inv_std = 1.0 / torch.tensor(RGB_STD).view(1, 3, 1, 1)
+    return ((x / 255.0) - mean) * inv_std  # :145
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# stages
+
+
+def patch_embed(w: dict, image_bchw: torch.Tensor) -> tuple[torch.Tensor, tuple[int, int]]:
+    """Conv k=s=patch, then BFHW -> BNF (patch_embed.py:77-99)."""
+    pw = w["patch_embed.proj.weight"]
+    y = F.conv2d(image_bchw, pw, w["patch_embed.proj.bias"], stride=pw.shape[-1])
+    grid_hw = (int(y.shape[2]), int(y.shape[3]))
+    return y.flatten(2).transpose(1, 2), grid_hw
+
+
+def position_embedding(w: dict, grid_hw: tuple[int, int]) -> torch.Tensor:
+    """Learned [1,Gh*Gw,F] grid resized to the patch grid with bicubic (A=-0.75), align_corners=False,
+    no antialias (components/position_encoder.py:108-143)."""
+    base = w["imgencoder.posenc.base_patch_embedding"].float()
+    n_base, feat = base.shape[1], base.shape[2]
+    g = int(math.isqrt(n_base))
+    img = base.reshape(1, g, g, feat).permute(0, 3, 1, 2)
+    img = F.interpolate(img, size=grid_hw, mode="bicubic", antialias=False)
+    return img.permute(0, 2, 3, 1).reshape(1, -1, feat)
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    return F.layer_norm(x, (x.shape[-1],), weight, bias, LN_EPS)
+
+
+def attention(w: dict, pre: str, x: torch.Tensor, num_heads: int) -> torch.Tensor:
+    """qkv Linear -> per-head softmax(q k^T / sqrt(d)) v -> proj Linear
+    (components/transformer_block.py:105-136 / :154-170; both forms are the same math)."""
+    b, n, c = x.shape
+    d = c // num_heads
+    qkv = F.linear(x, w[f"{pre}.qkv.weight"], w[f"{pre}.qkv.bias"]).reshape(b, n, 3, num_heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    att = torch.softmax((q * d**-0.5) @ k.transpose(-2, -1), dim=-1)
+    y = (att @ v).transpose(1, 2).reshape(b, n, c)
+    return F.linear(y, w[f"{pre}.proj.weight"], w[f"{pre}.proj.bias"])
+
+
+def mlp(w: dict, pre: str, x: torch.Tensor) -> torch.Tensor:
+    """Linear(F->4F) -> exact (erf) GELU -> Linear(4F->F) (components/misc_helpers.py:88-120)."""
+    h = F.gelu(F.linear(x, w[f"{pre}.layers.0.weight"], w[f"{pre}.layers.0.bias"]))
+    return F.linear(h, w[f"{pre}.layers.2.weight"], w[f"{pre}.layers.2.bias"])
+
+
+def transformer_block(w: dict, pre: str, x: torch.Tensor, num_heads: int) -> torch.Tensor:
+    """Pre-norm block with layer-scale: t + g1*attn(LN1 t); u + g2*mlp(LN2 u) (transformer_block.py:53-65)."""
+    a = attention(w, f"{pre}.attn", layernorm(x, w[f"{pre}.norm1.weight"], w[f"{pre}.norm1.bias"]), num_heads)
+    x = x + w[f"{pre}.scale_attn"] * a
+    m = mlp(w, f"{pre}.mlp", layernorm(x, w[f"{pre}.norm2.weight"], w[f"{pre}.norm2.bias"]))
+    return x + w[f"{pre}.scale_mlp"] * m
+
+
+def image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple[int, int]) -> list[torch.Tensor]:
+    """+pos-embed, prepend cls(+cls_embedding), 4 stages of round(num_blocks/4) blocks, shared out-norm on
+    each stage output (image_encoder_model.py:80-94, :69, :136-147; position_encoder.py:55-76)."""
+    b = patch_tokens.shape[0]
+    cls = w["imgencoder.cls_token"] + w["imgencoder.posenc.cls_embedding"]
+    tokens = torch.cat((cls.expand(b, -1, -1), patch_tokens + position_embedding(w, grid_hw)), dim=1)
+    per_stage = int(round(cfg["num_blocks"] / 4))
+    taps = []
+    for s in range(4):
+        for i in range(per_stage):
+            tokens = transformer_block(w, f"imgencoder.stages.{s}.blocks.{i}", tokens, cfg["num_heads"])
+        taps.append(tokens)
+    return [layernorm(t, w["imgencoder.outnorm.weight"], w["imgencoder.outnorm.bias"]) for t in taps]
+
+
+_REASM = ("spatial_upx4", "spatial_upx2", "spatial_noscale", "spatial_downx2")
+
+
+def reassemble(w: dict, stage_tokens: list[torch.Tensor], grid_hw: tuple[int, int]) -> list[torch.Tensor]:
+    """Per stage: drop cls, tokens->BCHW, 1x1 conv, {convT k4s4 | convT k2s2 | none | conv3x3 s2 p1},
+    3x3 conv (no bias) to fusion channels (reassembly_model.py:61-94, :139-149, :208-211, :238-310)."""
+    outs = []
+    for name, tok in zip(_REASM, stage_tokens):
+        p = f"reassemble.{name}"
+        x = tok[:, 1:, :].transpose(1, 2).unflatten(2, grid_hw)
+        x = F.conv2d(x, w[f"{p}.resample.0.weight"], w[f"{p}.resample.0.bias"])
+        if name == "spatial_upx4":
+            x = F.conv_transpose2d(x, w[f"{p}.resample.1.weight"], w[f"{p}.resample.1.bias"], stride=4)
+        elif name == "spatial_upx2":
+            x = F.conv_transpose2d(x, w[f"{p}.resample.1.weight"], w[f"{p}.resample.1.bias"], stride=2)
+        elif name == "spatial_downx2":
+            x = F.conv2d(x, w[f"{p}.resample.1.weight"], w[f"{p}.resample.1.bias"], stride=2, padding=1)
+        outs.append(F.conv2d(x, w[f"{p}.fuse_proj.weight"], None, padding=1))
+    return outs
+
+
+def residual_conv_unit(w: dict, pre: str, x: torch.Tensor) -> torch.Tensor:
+    """conv3x3(relu(conv3x3(relu(x)))) + x, both convs biased (fusion_model.py:205-220)."""
+    y = F.conv2d(F.relu(x), w[f"{pre}.resconv_seq.1.weight"], w[f"{pre}.resconv_seq.1.bias"], padding=1)
+    y = F.conv2d(F.relu(y), w[f"{pre}.resconv_seq.3.weight"], w[f"{pre}.resconv_seq.3.bias"], padding=1)
+    return y + x
+
+
+def upsample_bilinear_ac(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """F.interpolate(scale_factor, bilinear, align_corners=True) (components/misc_helpers.py:39-42)."""
+    return F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=True)
+
+
+def fusion_block(w: dict, idx: int, reasm: torch.Tensor, prior: torch.Tensor | None) -> torch.Tensor:
+    """blocks[idx] of the fusion model (fusion_model.py:89-114 top-most, :148-154 regular, :159-182)."""
+    p = f"fusion.blocks.{idx}"
+    x = reasm if prior is None else residual_conv_unit(w, f"{p}.conv_reassembly", reasm) + prior
+    x = residual_conv_unit(w, f"{p}.scale_proj_seq.0", x)
+    x = upsample_bilinear_ac(x, 2)
+    return F.conv2d(x, w[f"{p}.scale_proj_seq.2.weight"], w[f"{p}.scale_proj_seq.2.bias"])
+
+
+def fusion(w: dict, reasm: list[torch.Tensor]) -> torch.Tensor:
+    """Coarse-to-fine: blocks[3](r4) -> blocks[2](r3, .) -> blocks[1](r2, .) -> blocks[0](r1, .)
+    (fusion_model.py:55-80). Requires an even patch grid (odd grids mismatch at :151)."""
+    f = fusion_block(w, 3, reasm[3], None)
+    for idx in (2, 1, 0):
+        f = fusion_block(w, idx, reasm[idx], f)
+    return f
+
+
+def head(w: dict, cfg: dict, fused: torch.Tensor) -> torch.Tensor:
+    """conv3x3(C->C/2) -> bilinear x(patch/8) align_corners -> conv3x3(->32)+ReLU -> conv1x1(->1)+ReLU|Sigmoid
+    -> squeeze (head_model.py:67-85, :89-106)."""
+    x = F.conv2d(fused, w["head.spatial_upsampler.0.weight"], w["head.spatial_upsampler.0.bias"], padding=1)
+    x = upsample_bilinear_ac(x, cfg["patch_size_px"] / 8)
+    x = F.relu(F.conv2d(x, w["head.proj_1ch.0.weight"], w["head.proj_1ch.0.bias"], padding=1))
+    x = F.conv2d(x, w["head.proj_1ch.2.weight"], w["head.proj_1ch.2.bias"])
+    x = torch.sigmoid(x) if cfg.get("is_metric", False) else F.relu(x)
+    return x.squeeze(1)
+
+
+def forward(w: dict, cfg: dict, image_bchw: torch.Tensor, return_stages: bool = False):
+    """DPTModel.forward (dpt_model.py:61-83). With return_stages, also returns every stage boundary."""
+    with torch.inference_mode():
+        tokens, grid_hw = patch_embed(w, image_bchw)
+        if grid_hw[0] % 2 or grid_hw[1] % 2:
+            # the reference crashes in fusion (tensor size mismatch, fusion_model.py:151)
+            raise RuntimeError(f"patch grid {grid_hw} must be even in both dimensions")
+        taps = image_encoder(w, cfg, tokens, grid_hw)
+        reasm = reassemble(w, taps, grid_hw)
+        fused = fusion(w, reasm)
+        depth = head(w, cfg, fused)
+    if return_stages:
+        return depth, {"patch_tokens": tokens, "grid_hw": grid_hw, "stages": taps, "reasm": reasm, "fused": fused}
+    return depth
+
+
+def inference(w: dict, cfg: dict, image_bgr, max_side_length=None, use_square_sizing=True) -> torch.Tensor:
+    """DPTModel.inference (dpt_model.py:87-109): prepare_image + forward -> [1,H,W]."""
+    default_px = cfg["base_patch_grid_hw"][0] * cfg["patch_size_px"]
+    x = prepare_image(image_bgr, max_side_length, use_square_sizing, default_size_px=default_px,
+                      tiling_px=2 * cfg["patch_size_px"])
+    return forward(w, cfg, x)

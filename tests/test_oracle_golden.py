@@ -1,0 +1,118 @@
+"""The oracle (oracle/dpt_oracle.py) against the committed golden fixtures.
+
+The fixtures were produced by tools/gen_golden.py from the imported reference
+(torch 2.10 CPU fp32); these tests run anywhere (no /root/reference needed).
+Tolerance: 5e-5 absolute on O(1..10) tensors - fp32 noise of the reference against
+itself across thread counts / layouts is 2-5e-6.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dpt_oracle
+from tests.helpers import seeded_input, stats, synthetic_model
+
+ATOL = 5e-5
+
+
+def _close(a, b, atol=ATOL):
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = float((a - b).abs().max())
+    assert err <= atol, f"max abs err {err:.3e} > {atol:.1e}"
+
+
+def test_tiny_every_stage_boundary(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_full.npz"))
+    _, cfg, w = synthetic_model("tiny", int(g["seed"]))
+    x = torch.from_numpy(g["input"])
+    assert torch.equal(x, seeded_input((2, 3, 56, 56), 1)), "torch RNG drifted: seeded input differs from fixture"
+    depth, st = dpt_oracle.forward(w, cfg, x, return_stages=True)
+    assert tuple(st["grid_hw"]) == tuple(g["grid_hw"])
+    _close(st["patch_tokens"], g["patch_tokens"])
+    for i in range(4):
+        _close(st["stages"][i], g[f"tap{i}"])
+        _close(st["reasm"][i], g[f"reasm{i}"])
+    _close(st["fused"], g["fused"])
+    _close(depth, g["depth"])
+    assert float(depth.max()) > 0.1, "degenerate golden (all-zero depth)"
+
+
+def test_tiny_rectangular_grid(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_rect.npz"))
+    _, cfg, w = synthetic_model("tiny", 0)
+    depth, st = dpt_oracle.forward(w, cfg, torch.from_numpy(g["input"]), return_stages=True)
+    _close(st["fused"], g["fused"])
+    _close(depth, g["depth"])
+
+
+def test_odd_patch_grid_raises():
+    _, cfg, w = synthetic_model("tiny", 0)
+    with pytest.raises(RuntimeError):
+        dpt_oracle.forward(w, cfg, torch.randn(1, 3, 42, 42))
+
+
+def test_position_embedding_bicubic(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_posembed.npz"))
+    w = {"imgencoder.posenc.base_patch_embedding": torch.from_numpy(g["base"])}
+    for key in g.files:
+        if key == "base":
+            continue
+        gh, gw = (int(v) for v in key[1:].split("x"))
+        _close(dpt_oracle.position_embedding(w, (gh, gw)), g[key], 1e-6)
+
+
+def test_prepare_image(golden_dir):
+    g = np.load(os.path.join(golden_dir, "prepare_image.npz"))
+    names = sorted({k[: -len("_img")] for k in g.files if k.endswith("_img")})
+    assert names
+    for name in names:
+        side, square = (int(v) for v in g[f"{name}_args"])
+        out = dpt_oracle.prepare_image(g[f"{name}_img"], None if side < 0 else side, bool(square))
+        assert tuple(out.shape) == tuple(int(v) for v in g[f"{name}_shape"]), name
+        _close(out[:, :, ::7, ::7], g[f"{name}_out_strided"], 1e-5)
+        np.testing.assert_allclose(stats(out), g[f"{name}_stats"], rtol=1e-5, atol=1e-5)
+
+
+def test_prepared_size_518_becomes_504():
+    # reference quirk: round(18.5) == 18 (banker's rounding) -> 504, and 1036 stays 1036
+    assert dpt_oracle.prepared_size(518, 518, None, True) == (504, 504)
+    assert dpt_oracle.prepared_size(518, 518, 1036, True) == (1036, 1036)
+    assert dpt_oracle.prepared_size(480, 640, None, False) == (392, 504)
+
+
+def test_vits504_depth_and_inference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "vits504.npz"))
+    osd, cfg, w = synthetic_model("vits", int(g["weight_seed"]))
+    chk = np.array([float(osd["pretrained.blocks.3.attn.qkv.weight"].double().sum()),
+                    float(osd["depth_head.scratch.refinenet2.out_conv.weight"].double().sum())])
+    np.testing.assert_allclose(chk, g["weight_checksum"], rtol=0, atol=1e-9, err_msg="synthetic weight RNG drifted")
+    x = seeded_input((1, 3, 504, 504), int(g["input_seed"]))
+    np.testing.assert_allclose(float(x.double().sum()), g["input_checksum"][0], atol=1e-9)
+    depth, st = dpt_oracle.forward(w, cfg, x, return_stages=True)
+    _close(depth[:, ::4, ::4], g["depth_strided"])
+    _close(depth[:, 200:264, 100:164], g["depth_crop"])
+    np.testing.assert_allclose(stats(depth), g["depth_stats"], rtol=1e-5, atol=1e-4)
+    for i in range(4):
+        _close(st["stages"][i][:, :64, :64], g[f"tap{i}_crop"])
+        _close(st["reasm"][i][:, :16, :16, :16], g[f"reasm{i}_crop"])
+    _close(st["fused"][:, :16, 100:132, 100:132], g["fused_crop"])
+    # config 1 of BASELINE.json: inference() on a 518x518 uint8 image -> (1,504,504)
+    img = np.random.default_rng(1).integers(0, 256, (518, 518, 3), dtype=np.uint8)
+    d = dpt_oracle.inference(w, cfg, img)
+    assert tuple(d.shape) == (1, 504, 504)
+    _close(d[:, ::4, ::4], g["inference518_strided"])
+
+
+def test_key_conversion_matches_reference_names(golden_dir):
+    with open(os.path.join(golden_dir, "tiny_new_keys.json")) as f:
+        ref_keys = json.load(f)
+    _, cfg, w = synthetic_model("tiny", 0)
+    assert set(w) == set(ref_keys)
+    for k, shape in ref_keys.items():
+        assert list(w[k].shape) == shape, k
+    assert cfg["num_heads"] == 1 and cfg["num_blocks"] == 4 and tuple(cfg["base_patch_grid_hw"]) == (5, 5)

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the IMPORTED reference (build container only).
+
+Runs only where /root/reference exists. Nothing of the reference is copied: we import it
+read-only (with an in-memory stub for the absent `cv2`), feed it seeded synthetic checkpoints
+(muggled_dpt_amd.synthetic) and seeded inputs, and store inputs/outputs as small fixtures.
+While doing so it asserts that oracle/dpt_oracle.py reproduces the reference at every stage
+boundary (<= 2e-5 abs on O(1) tensors) - this is what pins the oracle.
+
+usage: PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [--skip-vitl]
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+
+# --- cv2 stub: only cvtColor(BGR2RGB) is touched on this path (v2_depthanything/patch_embed.py:134)
+cv2_stub = types.ModuleType("cv2")
+cv2_stub.COLOR_BGR2RGB = 4
+cv2_stub.cvtColor = lambda img, code: np.ascontiguousarray(img[..., ::-1])
+sys.modules["cv2"] = cv2_stub
+sys.path.insert(0, REF)
+
+from muggled_dpt.make_depthanythingv2_dpt import make_depthanythingv2_dpt_from_original_state_dict  # noqa: E402
+
+from muggled_dpt_amd.state_dict_conversion import (  # noqa: E402
+    convert_state_dict_keys, flatten_components, get_model_config_from_state_dict)
+from muggled_dpt_amd.synthetic import STANDARD_CONFIGS, make_synthetic_original_state_dict  # noqa: E402
+from oracle import dpt_oracle  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+TOL = 2e-5
+
+
+def maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+def stats(t: torch.Tensor) -> np.ndarray:
+    t = t.double()
+    return np.array([t.min(), t.max(), t.mean(), t.pow(2).sum().sqrt()], dtype=np.float64)
+
+
+def run_reference(model, x):
+    with torch.inference_mode():
+        tok, hw = model.patch_embed(x)
+        taps = model.imgencoder(tok, hw)
+        reasm = model.reassemble(*taps, hw)
+        fused = model.fusion(*reasm)
+        depth = model.head(fused)
+    return tok, tuple(hw), list(taps), list(reasm), fused, depth
+
+
+def check_against_oracle(name, ref, w, cfg, x):
+    depth, st = dpt_oracle.forward(w, cfg, x, return_stages=True)
+    tok, hw, taps, reasm, fused, rdepth = ref
+    errs = {"patch": maxdiff(tok, st["patch_tokens"]), "fused": maxdiff(fused, st["fused"]), "depth": maxdiff(rdepth, depth)}
+    for i in range(4):
+        errs[f"tap{i}"] = maxdiff(taps[i], st["stages"][i])
+        errs[f"reasm{i}"] = maxdiff(reasm[i], st["reasm"][i])
+    worst = max(errs.values())
+    print(f"[{name}] oracle-vs-reference max abs err per boundary: " + ", ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    assert worst <= TOL, f"oracle deviates from the reference on {name}: {errs}"
+    return errs
+
+
+def build(cfg_name, seed):
+    osd = make_synthetic_original_state_dict(cfg_name, seed)
+    cfg_ref, model = make_depthanythingv2_dpt_from_original_state_dict(osd, enable_cache=False, enable_optimizations=True)
+    cfg = get_model_config_from_state_dict(osd)
+    assert {k: (tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in cfg.items()} == \
+           {k: (tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in cfg_ref.items()}, (cfg, cfg_ref)
+    w = flatten_components(convert_state_dict_keys(cfg, osd))
+    return osd, cfg, model, w
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-vitl", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    report = {}
+
+    # ------------------------------------------------------------------ 1. tiny config, full tensors
+    osd, cfg, model, w = build("tiny", 0)
+    x = torch.randn(2, 3, 56, 56, generator=torch.Generator().manual_seed(1))
+    ref = run_reference(model, x)
+    report["tiny"] = check_against_oracle("tiny", ref, w, cfg, x)
+    tok, hw, taps, reasm, fused, depth = ref
+    np.savez_compressed(
+        os.path.join(GOLD, "tiny_full.npz"), seed=0, input=x.numpy(), patch_tokens=tok.numpy(), grid_hw=np.array(hw),
+        **{f"tap{i}": taps[i].numpy() for i in range(4)}, **{f"reasm{i}": reasm[i].numpy() for i in range(4)},
+        fused=fused.numpy(), depth=depth.numpy())
+    # key-conversion contract: the reference's own converted key names + shapes for this config
+    ref_keys = {}
+    for comp in ("patch_embed", "imgencoder", "reassemble", "fusion", "head"):
+        for k, v in getattr(model, comp).state_dict().items():
+            ref_keys[f"{comp}.{k}"] = list(v.shape)
+    with open(os.path.join(GOLD, "tiny_new_keys.json"), "w") as f:
+        json.dump(ref_keys, f, indent=0, sort_keys=True)
+    assert set(ref_keys) == set(w), (set(ref_keys) ^ set(w))
+    # a second, non-square tiny input (grid 2x6) to pin hw handling
+    x2 = torch.randn(1, 3, 28, 84, generator=torch.Generator().manual_seed(2))
+    ref2 = run_reference(model, x2)
+    report["tiny_rect"] = check_against_oracle("tiny_rect", ref2, w, cfg, x2)
+    np.savez_compressed(os.path.join(GOLD, "tiny_rect.npz"), input=x2.numpy(), depth=ref2[5].numpy(), fused=ref2[4].numpy())
+    # odd grid must raise in the reference (fusion_model.py:151)
+    try:
+        run_reference(model, torch.randn(1, 3, 42, 42))
+        raise AssertionError("reference accepted an odd patch grid?!")
+    except RuntimeError as e:
+        print("[tiny] odd grid raises in reference:", str(e).splitlines()[0])
+
+    # ------------------------------------------------------------------ 2. position embedding resize
+    base = w["imgencoder.posenc.base_patch_embedding"]
+    pos = {}
+    for g in ((4, 4), (2, 6), (6, 6), (10, 10)):
+        pos[f"g{g[0]}x{g[1]}"] = model.imgencoder.posenc._scale_to_patch_grid(g).detach().numpy()
+        assert maxdiff(torch.from_numpy(pos[f"g{g[0]}x{g[1]}"]), dpt_oracle.position_embedding(w, g)) <= 1e-6
+    np.savez_compressed(os.path.join(GOLD, "tiny_posembed.npz"), base=base.numpy(), **pos)
+
+    # ------------------------------------------------------------------ 4. ViT-S @504 (config 1 & 2 shapes)
+    osd, cfg, model, w = build("vits", 0)
+    # ------------------------------------------------------------------ 3. prepare_image (ViT-S model: default size 518)
+    rng = np.random.default_rng(1)
+    prep = {}
+    cases = [("sq518", (518, 518), None, True), ("land_sq", (480, 640), None, True), ("land_ar", (480, 640), None, False),
+             ("big1036", (300, 260), 1036, True), ("small", (33, 47), 140, False)]
+    for name, (h, wd), side, square in cases:
+        img = rng.integers(0, 256, (h, wd, 3), dtype=np.uint8)
+        out = model.prepare_image_bgr(img, side, square).detach()
+        mine = dpt_oracle.prepare_image(img, side, square)
+        assert out.shape == mine.shape and maxdiff(out, mine) <= 1e-5, (name, out.shape, mine.shape)
+        prep[f"{name}_img"] = img
+        prep[f"{name}_args"] = np.array([-1 if side is None else side, int(square)])
+        prep[f"{name}_shape"] = np.array(out.shape)
+        prep[f"{name}_out_strided"] = out[:, :, ::7, ::7].numpy()
+        prep[f"{name}_stats"] = stats(out)
+        print(f"[prepare_image] {name}: {img.shape} -> {tuple(out.shape)}")
+    np.savez_compressed(os.path.join(GOLD, "prepare_image.npz"), **prep)
+
+    x = torch.randn(1, 3, 504, 504, generator=torch.Generator().manual_seed(1))
+    ref = run_reference(model, x)
+    report["vits504"] = check_against_oracle("vits504", ref, w, cfg, x)
+    tok, hw, taps, reasm, fused, depth = ref
+    img518 = np.random.default_rng(1).integers(0, 256, (518, 518, 3), dtype=np.uint8)
+    with torch.inference_mode():
+        d518 = model.inference(img518)
+    mine518 = dpt_oracle.inference(w, cfg, img518)
+    assert d518.shape == (1, 504, 504) and maxdiff(d518, mine518) <= TOL
+    np.savez_compressed(
+        os.path.join(GOLD, "vits504.npz"), weight_seed=0, input_seed=1,
+        weight_checksum=np.array([float(osd["pretrained.blocks.3.attn.qkv.weight"].double().sum()),
+                                  float(osd["depth_head.scratch.refinenet2.out_conv.weight"].double().sum())]),
+        input_checksum=np.array([float(x.double().sum())]),
+        depth_strided=depth[:, ::4, ::4].numpy(), depth_stats=stats(depth), depth_crop=depth[:, 200:264, 100:164].numpy(),
+        **{f"tap{i}_crop": taps[i][:, :64, :64].numpy() for i in range(4)}, **{f"tap{i}_stats": stats(taps[i]) for i in range(4)},
+        **{f"reasm{i}_crop": reasm[i][:, :16, :16, :16].numpy() for i in range(4)},
+        **{f"reasm{i}_stats": stats(reasm[i]) for i in range(4)},
+        fused_crop=fused[:, :16, 100:132, 100:132].numpy(), fused_stats=stats(fused),
+        inference518_strided=d518[:, ::4, ::4].numpy(), inference518_stats=stats(d518))
+    print("[vits504] depth stats (min,max,mean,l2):", stats(depth))
+
+    # ------------------------------------------------------------------ 5. ViT-L @504 (headline config)
+    if not args.skip_vitl:
+        osd, cfg, model, w = build("vitl", 0)
+        x = torch.randn(1, 3, 504, 504, generator=torch.Generator().manual_seed(1))
+        ref = run_reference(model, x)
+        report["vitl504"] = check_against_oracle("vitl504", ref, w, cfg, x)
+        tok, hw, taps, reasm, fused, depth = ref
+        np.savez_compressed(
+            os.path.join(GOLD, "vitl504.npz"), weight_seed=0, input_seed=1,
+            weight_checksum=np.array([float(osd["pretrained.blocks.3.attn.qkv.weight"].double().sum()),
+                                      float(osd["depth_head.scratch.refinenet2.out_conv.weight"].double().sum())]),
+            input_checksum=np.array([float(x.double().sum())]),
+            depth_strided=depth[:, ::4, ::4].numpy(), depth_stats=stats(depth),
+            **{f"tap{i}_crop": taps[i][:, :64, :64].numpy() for i in range(4)},
+            **{f"tap{i}_stats": stats(taps[i]) for i in range(4)},
+            **{f"reasm{i}_stats": stats(reasm[i]) for i in range(4)}, fused_stats=stats(fused))
+        print("[vitl504] depth stats (min,max,mean,l2):", stats(depth))
+
+    with open(os.path.join(GOLD, "oracle_vs_reference_report.json"), "w") as f:
+        json.dump({"torch": torch.__version__, "tolerance_abs": TOL, "max_abs_err": report}, f, indent=1)
+    print("done ->", GOLD)
+
+
+if __name__ == "__main__":
+    main()
