@@ -1,0 +1,134 @@
+/* libmdpt - C ABI of the MI355X-native DPT depth-inference path (Depth-Anything-V2 family).
+ *
+ * The reference (heyoeyo/muggled_dpt) has NO FFI / operator / plugin layer: its boundary is the Python API
+ *   make_dpt_from_state_dict()            muggled_dpt/make_dpt.py:21-72
+ *   DPTModel.forward / .inference         muggled_dpt/dpt_model.py:61-83, :87-109
+ *   model.patch_embed / .imgencoder / .reassemble / .fusion / .head   (dpt_model.py:50-54; called one by one in
+ *                                          simple_examples/internal_features.py:38-45)
+ * This header is therefore the NEW boundary a binding of that API sits on: plain pointers and
+ * sizes, no torch types. Every entry point names the reference call it replaces.
+ *
+ * Conventions
+ *   - return value: 0 = OK, otherwise a negative MDPT_E_* code or a positive hipError_t; mdpt_last_error() has text.
+ *   - all `dev` pointers are device (HBM) pointers owned by the caller (PyTorch allocates them in our binding);
+ *     the library allocates no device memory and never synchronises: every kernel goes on the caller's stream.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - tensors at this boundary use the REFERENCE layouts (fp32): images/maps BCHW, tokens B x N x F, depth B x H x W.
+ *   - a handle is not thread-safe; distinct handles are independent.
+ */
+#ifndef MDPT_H
+#define MDPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDPT_ABI_VERSION 1
+
+/* arithmetic modes (all accumulate in fp32; residual stream, LayerNorm and softmax statistics are fp32) */
+#define MDPT_PREC_BF16 0   /* bf16 MFMA operands - the reference's GPU default dtype (demo_helpers/misc.py:73-77) */
+#define MDPT_PREC_BF16X3 1 /* split-bf16 (hi+lo) operands, 3 MFMA passes: fp32-class accuracy (parity mode)        */
+
+#define MDPT_E_INVALID (-1)    /* bad argument / shape                                  */
+#define MDPT_E_STATE (-2)      /* call order (e.g. forward before finalize)             */
+#define MDPT_E_MISSING (-3)    /* a weight required by the config was not bound         */
+#define MDPT_E_SHAPE (-4)      /* bound weight has the wrong shape                      */
+#define MDPT_E_WORKSPACE (-5)  /* workspace / packed buffer too small                   */
+#define MDPT_E_UNSUPPORTED (-6)/* config outside this build (e.g. ViT-G SwiGLU)         */
+#define MDPT_E_GRID (-7)       /* odd patch grid: the reference raises RuntimeError at fusion_model.py:151 */
+
+typedef struct mdpt_handle mdpt_handle;
+
+/* == the 11-key config dict of the reference (state_dict_conversion/config_from_original_state_dict.py:29-41),
+ *    minus the two Python-only flags, plus the arithmetic mode. */
+typedef struct mdpt_config {
+    int32_t features_per_token;
+    int32_t num_heads;
+    int32_t num_blocks;
+    int32_t reassembly_features[4];
+    int32_t base_patch_grid_h, base_patch_grid_w;
+    int32_t fusion_channels;
+    int32_t patch_size_px;
+    int32_t is_giant;  /* must be 0 in this build */
+    int32_t is_metric; /* sigmoid instead of the final ReLU (head_model.py:84) */
+    int32_t precision; /* MDPT_PREC_* */
+} mdpt_config;
+
+int mdpt_abi_version(void);
+const char* mdpt_last_error(void);
+
+/* replaces make_depthanythingv2_dpt(**config) (make_depthanythingv2_dpt.py:67-138): validates the config and
+ * derives the list of parameters the model needs. */
+int mdpt_create(const mdpt_config* cfg, mdpt_handle** out);
+void mdpt_destroy(mdpt_handle* h);
+
+/* Parameter inventory, named with the reference's converted ("new format") keys, prefixed by component:
+ * "patch_embed.proj.weight", "imgencoder.stages.0.blocks.0.attn.qkv.weight", "reassemble.spatial_upx4.resample.1.weight",
+ * "fusion.blocks.0.conv_reassembly.resconv_seq.1.weight", "head.proj_1ch.2.bias", ...
+ * (state_dict_conversion/convert_original_state_dict_keys.py:15-86). */
+int mdpt_num_weights(const mdpt_handle* h);
+const char* mdpt_weight_name(const mdpt_handle* h, int index);
+int mdpt_weight_shape(const mdpt_handle* h, int index, int32_t* ndim, int64_t shape[4]);
+
+/* replaces <sub-module>.load_state_dict(...) (make_depthanythingv2_dpt.py:55-59). `dev_f32` is a contiguous fp32
+ * device tensor in the PyTorch layout of that parameter; it is only read during mdpt_finalize(). */
+int mdpt_bind_weight(mdpt_handle* h, const char* name, const void* dev_f32, int32_t ndim, const int64_t* shape);
+
+/* replaces model.to(device, dtype) (run_image.py:158): one-time repack of all bound weights into MFMA-friendly
+ * bf16 (hi[/lo]) [N][K] panels inside the caller-provided `packed_dev` buffer (size from mdpt_packed_bytes).
+ * Strict: fails with MDPT_E_MISSING if any parameter is unbound. */
+int mdpt_packed_bytes(const mdpt_handle* h, size_t* bytes);
+int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream);
+
+/* Workspace (activations) needed for a batch of B images of H x W pixels. */
+int mdpt_workspace_bytes(const mdpt_handle* h, int32_t B, int32_t H, int32_t W, size_t* bytes);
+
+/* replaces DPTModel.forward (dpt_model.py:61-83): image [B,3,H,W] fp32 (RGB, normalised) -> depth [B,H,W] fp32.
+ * H, W multiples of patch_size_px with an even patch grid. */
+int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t B, int32_t H, int32_t W, void* depth_bhw, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* Stage-level entry points == the five sub-module calls (simple_examples/internal_features.py:39-45). */
+/* PatchEmbed.forward (v2_depthanything/patch_embed.py:77-99): -> tokens [B, (H/P)*(W/P), F] */
+int mdpt_patch_embed(mdpt_handle* h, const void* image_bchw, int32_t B, int32_t H, int32_t W, void* tokens_bnf, void* workspace,
+                     size_t workspace_bytes, void* stream);
+/* DinoV2Model4Stages.forward (image_encoder_model.py:80-94): tokens [B,gh*gw,F] -> 4 x [B, 1+gh*gw, F] */
+int mdpt_encoder(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, int32_t gw, void* const stage_out[4],
+                 void* workspace, size_t workspace_bytes, void* stream);
+/* ReassembleModel.forward (reassembly_model.py:61-94): 4 x [B,1+gh*gw,F] -> [B,C,4gh,4gw],[B,C,2gh,2gw],[B,C,gh,gw],[B,C,gh/2,gw/2] */
+int mdpt_reassemble(mdpt_handle* h, const void* const stage_in[4], int32_t B, int32_t gh, int32_t gw, void* const maps_out[4],
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* FusionModel.forward (fusion_model.py:55-80): the 4 maps above -> [B,C,8gh,8gw] */
+int mdpt_fusion(mdpt_handle* h, const void* const maps_in[4], int32_t B, int32_t gh, int32_t gw, void* fused_out, void* workspace,
+                size_t workspace_bytes, void* stream);
+/* MonocularDepthHead.forward (head_model.py:89-106): [B,C,8gh,8gw] -> [B, gh*P, gw*P] */
+int mdpt_head(mdpt_handle* h, const void* fused_in, int32_t B, int32_t gh, int32_t gw, void* depth_bhw, void* workspace,
+              size_t workspace_bytes, void* stream);
+
+/* Stage boundaries of the LAST mdpt_forward on `workspace`, converted to reference layouts (debug / parity taps):
+ * which = 0..3 encoder taps [B,N,F]; 4..7 reassembly maps (BCHW); 8 fused map [B,C,8gh,8gw]. */
+int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Test hooks (used by tests/ only): stop the encoder of the next mdpt_forward calls after sub-step `step` of transformer
+ * block `block` (0 LN1, 1 QKV, 2 attention, 3 proj+residual, 4 LN2, 5 fc1+GELU, 6 fc2+residual; block = -1 disables), and
+ * read an internal activation buffer ("resid","xn","q","k","vt","att","hbuf","im2col","pos","t0".."t3","u0","u1","d3",
+ * "xf0".."xf3","a10".."a13","b20".."b23","flo0".."flo3","fused","h1","h1u") of the last forward as flat fp32 in its internal layout. */
+int mdpt_debug_set_stop(mdpt_handle* h, int32_t block, int32_t step);
+int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_floats, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* Tuning knob for benchmarks: force a GEMM tile (0 = auto, 1 = 128x128, 2 = 256x256). */
+int mdpt_set_gemm_tile(mdpt_handle* h, int32_t tile);
+
+/* Data-parallel output collective (north star: "RCCL all-gather of the output depth maps"): thin wrapper over
+ * ncclAllGather on a communicator created by the caller (torch.distributed's RCCL comm is used in the binding, so
+ * this entry point is for non-torch hosts). `comm` is an ncclComm_t. Loaded lazily from librccl.so. */
+int mdpt_allgather_f32(void* comm, const void* send_dev, void* recv_dev, size_t count_per_rank, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDPT_H */

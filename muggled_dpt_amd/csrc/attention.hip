@@ -1,0 +1,222 @@
+// Fused multi-head self-attention for gfx950 (head dim 64, no mask beyond the token count), flash-style.
+//
+// Replaces the reference's  softmax(q k^T / sqrt(d)) v  (v2_depthanything/components/transformer_block.py:160-166,
+// the SDPA call at :164). Inputs come from the QKV GEMM epilogue (gemm.hip, E_QKV):
+//   Q  [B,H,npad,64]  bf16, already multiplied by 1/sqrt(64)
+//   K  [B,H,npad,64]  bf16
+//   Vt [B,H,64,npadv] bf16 (V transposed, token-contiguous; pad columns are zero)
+// Output: token-major [B*npad, F] bf16 (column h*64 + d), i.e. directly the A operand of the proj GEMM.
+//
+// Work split: one workgroup = 128 query rows of one (batch, head); 4 waves x 32 query rows.
+// Per 64-key tile (K tile 8 KiB and Vt tile 8 KiB, LDS-DMA'd into a 2-deep ring, XOR-swizzled like the GEMM):
+//   S^T = K Q^T   with 32x32x16 bf16 MFMA  (A = K rows from LDS, B = Q^T held in registers)
+//         -> each lane owns ONE query (lane&31) and 16 of the 32 keys of a block: row max/sum are
+//            in-register reductions plus a single exchange with lane^32 (wavefront softmax).
+//   O^T += Vt P^T with the SAME lane->query mapping, so the online-softmax rescale of O is lane-local.
+//         The MFMA contraction index is a free permutation, so P^T fragments are used exactly as the
+//         S^T accumulators come out (keys {0-3, 8-11} + 4*(lane>>5) per 16-key block) and the Vt fragment
+//         is gathered to match with two 8-byte LDS reads - no cross-lane shuffle of P at all.
+// x3 mode: hi/lo bf16 planes for Q, K, V and P (3 MFMAs per product) -> fp32-class accuracy.
+
+#include "mdpt_kernels.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 cat44(bf16x4 a, bf16x4 b) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r[e] = a[e]; r[e + 4] = b[e]; }
+    return r;
+}
+
+template <bool X3>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+    constexpr int NPL = X3 ? 2 : 1;           // planes per operand
+    constexpr int TILE = 8192;                // one [64][64] bf16 tile
+    constexpr int STAGE = 2 * NPL * TILE;     // K planes then Vt planes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const size_t bh = (size_t)b * p.heads + h;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): Q[q = q0 + (lane&31)][d = 16*ks + 8*half .. +8]
+    int q = qt * 128 + wave * 32 + l31;
+    const int q_ld = q < p.npad ? q : p.npad - 1;
+    bf16x8 qh[4], ql[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const size_t o = (bh * p.npad + q_ld) * 64 + ks * 16 + half * 8;
+        qh[ks] = *(const bf16x8*)(p.q_hi + o);
+        if (X3) ql[ks] = *(const bf16x8*)(p.q_lo + o);
+    }
+
+    // ---- staging: K tile rows = keys, Vt tile rows = d; 8 chunks of 1 KiB each per plane, 2 per wave
+    const int lrow = lane >> 3, slot = lane & 7;
+    const int sw_stage = ((wave & 1) * 4 + (lrow >> 1)) & 7;
+    const int koff = (slot ^ sw_stage) * 8;
+    const int ntiles = (p.N + 63) >> 6;
+    auto issue_tile = [&](int tile, int buf) {
+        char* s = smem + buf * STAGE;
+        const int kv0 = tile * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = wave + 4 * i;
+            int krow = kv0 + c * 8 + lrow;
+            krow = krow < p.npad ? krow : p.npad - 1;  // rows >= N are masked in the softmax
+            const size_t ko = (bh * p.npad + krow) * 64 + koff;
+            const size_t vo = (bh * 64 + c * 8 + lrow) * p.npadv + kv0 + koff;
+            glds16(p.k_hi + ko, s + c * 1024);
+            if (X3) glds16(p.k_lo + ko, s + TILE + c * 1024);
+            glds16(p.vt_hi + vo, s + NPL * TILE + c * 1024);
+            if (X3) glds16(p.vt_lo + vo, s + NPL * TILE + TILE + c * 1024);
+        }
+    };
+
+    const int sw_frag = (l31 >> 1) & 7;
+    f32x16 o_acc[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.0f;
+    float m_run = -1.0e30f, l_run = 0.0f;
+
+    issue_tile(0, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        if (t + 1 < ntiles) issue_tile(t + 1, (t + 1) & 1);
+        const char* sK = smem + (t & 1) * STAGE;
+        const char* sV = sK + NPL * TILE;
+
+        // ---- S^T[key][query] for 2 blocks of 32 keys
+        f32x16 s[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[blk][r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = (blk * 32 + l31) * 128 + (((ks * 2 + half) ^ sw_frag) << 4);
+                const bf16x8 kh = *(const bf16x8*)(sK + off);
+                if (X3) {
+                    const bf16x8 kl = *(const bf16x8*)(sK + TILE + off);
+                    s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], s[blk], 0, 0, 0);
+                    s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], s[blk], 0, 0, 0);
+                }
+                s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], s[blk], 0, 0, 0);
+            }
+        }
+        // key of s[blk][r] = t*64 + blk*32 + (r&3) + 8*(r>>2) + 4*half
+        if (t * 64 + 64 > p.N) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    s[blk][r] = key < p.N ? s[blk][r] : -1.0e30f;
+                }
+        }
+        // ---- online softmax: this lane and lane^32 share the query
+        float mloc = s[0][0];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[blk][r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+        const float mb = m_new * kLog2e;
+        m_run = m_new;
+        float psum = 0.0f;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(s[blk][r] * kLog2e - mb);
+                s[blk][r] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
+
+        // ---- O^T[d][query] += Vt[d][key] P^T[key][query]; 16-key blocks kb = 2*blk + kb2
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int kb2 = 0; kb2 < 2; ++kb2) {
+                bf16x8 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = s[blk][kb2 * 8 + e];
+                    ph[e] = (__bf16)pv;
+                    if (X3) pl[e] = (__bf16)(pv - (float)ph[e]);
+                }
+                const int kb = blk * 2 + kb2;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    // keys 16kb + 4half + {0..3} and 16kb + 8 + 4half + {0..3}: 16-B chunks 2kb and 2kb+1, byte 8*half
+                    const int rowoff = (db * 32 + l31) * 128 + 8 * half;
+                    const int o0 = rowoff + (((2 * kb) ^ sw_frag) << 4);
+                    const int o1 = rowoff + (((2 * kb + 1) ^ sw_frag) << 4);
+                    const bf16x8 vh = cat44(*(const bf16x4*)(sV + o0), *(const bf16x4*)(sV + o1));
+                    if (X3) {
+                        const bf16x8 vl = cat44(*(const bf16x4*)(sV + TILE + o0), *(const bf16x4*)(sV + TILE + o1));
+                        o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o_acc[db], 0, 0, 0);
+                        o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o_acc[db], 0, 0, 0);
+                    }
+                    o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o_acc[db], 0, 0, 0);
+                }
+            }
+    }
+
+    // ---- normalise and store: o_acc[db][r] = O[q][d = 32db + (r&3) + 8(r>>2) + 4half]
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (q < p.npad) {
+        const size_t orow = ((size_t)b * p.npad + q) * p.F + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 hi4, lo4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = o_acc[db][g * 4 + e] * inv;
+                    hi4[e] = (__bf16)v;
+                    if (X3) lo4[e] = (__bf16)(v - (float)hi4[e]);
+                }
+                const size_t o = orow + db * 32 + 8 * g + 4 * half;
+                *(bf16x4*)(p.out_hi + o) = hi4;
+                if (X3) *(bf16x4*)(p.out_lo + o) = lo4;
+            }
+    }
+}
+
+}  // namespace
+
+int mdpt_launch_attention(const AttnParams& p, hipStream_t stream) {
+    if (p.F != p.heads * 64 || (p.npadv & 63) || p.npadv < ((p.N + 63) & ~63) || p.npad < p.N) return (int)hipErrorInvalidValue;
+    const dim3 grid((p.npad + 127) / 128, p.heads, p.B);
+    if (p.x3) {
+        hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 2 * 2 * 2 * 8192, stream, p);
+    } else {
+        hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), 2 * 2 * 8192, stream, p);
+    }
+    return (int)hipGetLastError();
+}

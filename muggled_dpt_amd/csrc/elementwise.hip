@@ -1,0 +1,424 @@
+// HBM-bound helper kernels of the DPT path (gfx950): LayerNorm, patchify (im2col for k==s patches),
+// position-embedding bicubic resize, bilinear (align_corners) upsample, weight repack, token/map layout
+// conversion. All are coalesced 8/16-byte-per-lane streaming kernels; none reshapes work into a GEMM.
+
+#include "mdpt_kernels.h"
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+
+__device__ __forceinline__ void split_store4(bf16_t* hi, bf16_t* lo, size_t off, f32x4 v) {
+    bf16x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+    *(bf16x4*)(hi + off) = h;
+    if (lo) {
+        bf16x4 l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) l[e] = (__bf16)(v[e] - (float)h[e]);
+        *(bf16x4*)(lo + off) = l;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm (eps 1e-6, reference components/misc_helpers.py:190-210): one wave per row, row held in
+// registers (F <= 64*4*MAXV), two-pass mean / centred variance in fp32.
+// ---------------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 8;  // up to F = 2048
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16_t* out_hi, bf16_t* out_lo,
+                                                        float* out_f32, int rows, int F) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * F;
+    f32x4 v[LN_MAXV];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < F) {
+            v[i] = *(const f32x4*)(xr + c);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)F;
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < F) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                ss += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)F + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < F) {
+            const f32x4 g = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + bt[e];
+            const size_t o = (size_t)row * F + c;
+            if (out_hi) split_store4(out_hi, out_lo, o, y);
+            if (out_f32) *(f32x4*)(out_f32 + o) = y;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// patchify: NCHW fp32 -> rows [B*Np][Kp] with k = c*P*P + ky*P + kx (the conv weight's own flatten
+// order, patch_embed.py:56-62,92), zero padded to Kp. One thread = 4 consecutive k.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16_t* out_hi, bf16_t* out_lo, int B,
+                                                       int H, int W, int P, int Kp) {
+    const int gw = W / P, gh = H / P;
+    const int K = 3 * P * P;
+    const int kq = Kp / 4;
+    const size_t total = (size_t)B * gh * gw * kq;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k4 = (int)(idx % kq) * 4;
+        const size_t rowi = idx / kq;
+        const int px = (int)(rowi % gw);
+        const int py = (int)((rowi / gw) % gh);
+        const int b = (int)(rowi / ((size_t)gw * gh));
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k4 + e;
+            float val = 0.0f;
+            if (k < K) {
+                const int c = k / (P * P), rem = k - c * P * P;
+                const int ky = rem / P, kx = rem - ky * P;
+                val = img[(((size_t)b * 3 + c) * H + (py * P + ky)) * W + (px * P + kx)];
+            }
+            v[e] = val;
+        }
+        split_store4(out_hi, out_lo, rowi * Kp + k4, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// position-embedding resize: bicubic, A = -0.75, align_corners=False, taps clamped to the border
+// (what F.interpolate(mode="bicubic", antialias=False) does; position_encoder.py:108-143). fp32.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cubic_coeffs(float t, float w[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.0f, x1 = t, x2 = 1.0f - t, x3 = 2.0f - t;
+    w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+    w[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+    w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+    w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+__global__ __launch_bounds__(256) void posembed_kernel(const float* __restrict__ base, float* __restrict__ out, int Gh, int Gw,
+                                                       int gh, int gw, int F) {
+    const size_t total = (size_t)gh * gw * F;
+    const float sh = (float)Gh / (float)gh, sw = (float)Gw / (float)gw;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(idx % F);
+        const int ox = (int)((idx / F) % gw);
+        const int oy = (int)(idx / ((size_t)F * gw));
+        const float ry = sh * ((float)oy + 0.5f) - 0.5f, rx = sw * ((float)ox + 0.5f) - 0.5f;
+        const float fy = floorf(ry), fx = floorf(rx);
+        const int iy = (int)fy, ix = (int)fx;
+        float wy[4], wx[4];
+        cubic_coeffs(ry - fy, wy);
+        cubic_coeffs(rx - fx, wx);
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int yy = min(max(iy - 1 + a, 0), Gh - 1);
+            float rowv = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int xx = min(max(ix - 1 + c, 0), Gw - 1);
+                rowv += wx[c] * base[((size_t)yy * Gw + xx) * F + f];
+            }
+            acc += wy[a] * rowv;
+        }
+        out[idx] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void init_tokens_kernel(float* resid, const float* __restrict__ cls_token,
+                                                          const float* __restrict__ cls_embed, int B, int N, int npad, int F) {
+    // rows: cls (t == 0) and pad rows (t >= N) of every image; patch rows are written by the patch GEMM epilogue
+    const int rows_per_img = 1 + (npad - N);
+    const size_t total = (size_t)B * rows_per_img * F;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(idx % F);
+        const int rr = (int)((idx / F) % rows_per_img);
+        const int b = (int)(idx / ((size_t)F * rows_per_img));
+        const int t = rr == 0 ? 0 : N + rr - 1;
+        resid[((size_t)b * npad + t) * F + f] = rr == 0 ? cls_token[f] + cls_embed[f] : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void zero_vt_pad_kernel(bf16_t* vt_hi, bf16_t* vt_lo, int rows, int N, int npadv) {
+    const int padw = npadv - N;
+    const size_t total = (size_t)rows * padw;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = (idx / padw) * npadv + N + (idx % padw);
+        vt_hi[o] = (__bf16)0.0f;
+        if (vt_lo) vt_lo[o] = (__bf16)0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bilinear resize, align_corners=True (components/misc_helpers.py:39-42): src = dst*(in-1)/(out-1).
+// NHWC fp32 in -> bf16 hi(/lo) and/or fp32 out. One thread = 4 channels of one output pixel.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, bf16_t* out_hi, bf16_t* out_lo,
+                                                       float* out_f32, int B, int Hi, int Wi, int Ho, int Wo, int C) {
+    const int cq = C / 4;
+    const size_t total = (size_t)B * Ho * Wo * cq;
+    const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.0f;
+    const float sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.0f;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cq) * 4;
+        const size_t pix = idx / cq;
+        const int x = (int)(pix % Wo);
+        const int y = (int)((pix / Wo) % Ho);
+        const int b = (int)(pix / ((size_t)Wo * Ho));
+        const float fy = sy * (float)y, fx = sx * (float)x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hi - 1), x1 = x0 + (x0 < Wi - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* base = in + (size_t)b * Hi * Wi * C + c;
+        const f32x4 v00 = *(const f32x4*)(base + ((size_t)y0 * Wi + x0) * C);
+        const f32x4 v01 = *(const f32x4*)(base + ((size_t)y0 * Wi + x1) * C);
+        const f32x4 v10 = *(const f32x4*)(base + ((size_t)y1 * Wi + x0) * C);
+        const f32x4 v11 = *(const f32x4*)(base + ((size_t)y1 * Wi + x1) * C);
+        const f32x4 v = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+        const size_t o = pix * C + c;
+        if (out_hi) split_store4(out_hi, out_lo, o, v);
+        if (out_f32) *(f32x4*)(out_f32 + o) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one-time weight repack: fp32 PyTorch layouts -> bf16 hi(/lo) [Np][Kp], zero padded
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, bf16_t* dst_hi, bf16_t* dst_lo, int kind,
+                                                          int N, int K, int Np, int Kp, int ksz) {
+    const size_t total = (size_t)Np * Kp;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int kcol = (int)(idx % Kp);
+        const int nrow = (int)(idx / Kp);
+        float v = 0.0f;
+        if (kind == MDPT_PACK_LINEAR) {
+            if (nrow < N && kcol < K) v = src[(size_t)nrow * K + kcol];
+        } else if (kind == MDPT_PACK_CONV3) {
+            // src [N=Cout][K=Cin][3][3]; Kp = 9*Cinp; kcol = tap*Cinp + ci
+            const int cinp = Kp / 9;
+            const int tap = kcol / cinp, ci = kcol - tap * cinp;
+            if (nrow < N && ci < K) v = src[((size_t)nrow * K + ci) * 9 + tap];
+        } else {
+            // ConvTranspose2d weight [Cin=K][Cout=N][ksz][ksz]; rows = (ky*ksz+kx)*Coutp + co with Np = ksz*ksz*Coutp
+            const int coutp = Np / (ksz * ksz);
+            const int kidx = nrow / coutp, co = nrow - kidx * coutp;
+            if (co < N && kcol < K) v = src[((size_t)kcol * N + co) * (ksz * ksz) + kidx];
+        }
+        const __bf16 h = (__bf16)v;
+        dst_hi[idx] = h;
+        if (dst_lo) dst_lo[idx] = (__bf16)(v - (float)h);
+    }
+}
+
+__global__ __launch_bounds__(256) void pad_copy_kernel(const float* __restrict__ src, float* dst, int n, int np) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) dst[i] = i < n ? src[i] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void memset_f32_kernel(float* dst, float value, size_t n) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) dst[idx] = value;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// layout conversion (stage-level API and debug taps; not on the fused forward path)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in_f32, const bf16_t* in_hi, const bf16_t* in_lo,
+                                                           float* __restrict__ out, int B, int H, int W, int C, int Cp) {
+    const size_t total = (size_t)B * C * H * W;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        const int y = (int)((idx / W) % H);
+        const int c = (int)((idx / ((size_t)W * H)) % C);
+        const int b = (int)(idx / ((size_t)W * H * C));
+        const size_t o = (((size_t)b * H + y) * W + x) * Cp + c;
+        float v;
+        if (in_f32) v = in_f32[o];
+        else { v = (float)in_hi[o]; if (in_lo) v += (float)in_lo[o]; }
+        out[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* out_f32, bf16_t* out_hi,
+                                                           bf16_t* out_lo, int relu_bf16, int B, int H, int W, int C, int Cp) {
+    const size_t total = (size_t)B * H * W * Cp;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % Cp);
+        const size_t pix = idx / Cp;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int b = (int)(pix / ((size_t)W * H));
+        float v = c < C ? in[(((size_t)b * C + c) * H + y) * W + x] : 0.0f;
+        if (out_f32) out_f32[idx] = v;
+        if (out_hi) {
+            if (relu_bf16) v = fmaxf(v, 0.0f);
+            const __bf16 h = (__bf16)v;
+            out_hi[idx] = h;
+            if (out_lo) out_lo[idx] = (__bf16)(v - (float)h);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tokens_export_kernel(const bf16_t* in_hi, const bf16_t* in_lo, const float* in_f32,
+                                                            float* __restrict__ out, int B, int N, int npad, int F, int skip_cls) {
+    const int nout = N - skip_cls;
+    const size_t total = (size_t)B * nout * F;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(idx % F);
+        const int t = (int)((idx / F) % nout);
+        const int b = (int)(idx / ((size_t)F * nout));
+        const size_t o = ((size_t)b * npad + t + skip_cls) * F + f;
+        float v;
+        if (in_f32) v = in_f32[o];
+        else { v = (float)in_hi[o]; if (in_lo) v += (float)in_lo[o]; }
+        out[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void tokens_import_kernel(const float* __restrict__ in, bf16_t* out_hi, bf16_t* out_lo, int B,
+                                                            int N, int npad, int F) {
+    const size_t total = (size_t)B * npad * F;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(idx % F);
+        const int t = (int)((idx / F) % npad);
+        const int b = (int)(idx / ((size_t)F * npad));
+        const float v = t < N ? in[((size_t)b * N + t) * F + f] : 0.0f;
+        const __bf16 h = (__bf16)v;
+        out_hi[idx] = h;
+        if (out_lo) out_lo[idx] = (__bf16)(v - (float)h);
+    }
+}
+
+__global__ __launch_bounds__(256) void tokens_to_resid_kernel(const float* __restrict__ tokens, const float* __restrict__ pos,
+                                                              float* resid, int B, int Np, int npad, int F) {
+    const size_t total = (size_t)B * Np * F;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(idx % F);
+        const int t = (int)((idx / F) % Np);
+        const int b = (int)(idx / ((size_t)F * Np));
+        resid[((size_t)b * npad + 1 + t) * F + f] = tokens[idx] + pos[(size_t)t * F + f];
+    }
+}
+
+inline int grid_for(size_t total, int block = 256) {
+    size_t g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+}  // namespace
+
+#define LAUNCH_RET() return (int)hipGetLastError()
+
+int mdpt_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* out_hi, bf16_t* out_lo, float* out_f32,
+                          int rows, int F, hipStream_t stream) {
+    if ((F & 3) || F > 64 * 4 * LN_MAXV) return (int)hipErrorInvalidValue;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, out_hi, out_lo, out_f32, rows, F);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_patchify(const float* img, bf16_t* out_hi, bf16_t* out_lo, int B, int H, int W, int P, int Kp, hipStream_t stream) {
+    const size_t total = (size_t)B * (H / P) * (W / P) * (Kp / 4);
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, stream, img, out_hi, out_lo, B, H, W, P, Kp);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_posembed(const float* base, float* out, int Gh, int Gw, int gh, int gw, int F, hipStream_t stream) {
+    hipLaunchKernelGGL(posembed_kernel, dim3(grid_for((size_t)gh * gw * F)), dim3(256), 0, stream, base, out, Gh, Gw, gh, gw, F);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_init_tokens(float* resid, const float* cls_token, const float* cls_embed, int B, int N, int npad, int F,
+                            hipStream_t stream) {
+    const size_t total = (size_t)B * (1 + npad - N) * F;
+    hipLaunchKernelGGL(init_tokens_kernel, dim3(grid_for(total)), dim3(256), 0, stream, resid, cls_token, cls_embed, B, N, npad, F);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_zero_vt_pad(bf16_t* vt_hi, bf16_t* vt_lo, int rows, int N, int npadv, hipStream_t stream) {
+    if (npadv == N) return 0;
+    hipLaunchKernelGGL(zero_vt_pad_kernel, dim3(grid_for((size_t)rows * (npadv - N))), dim3(256), 0, stream, vt_hi, vt_lo, rows, N, npadv);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float* out_f32, int B, int Hi, int Wi, int Ho, int Wo,
+                         int C, hipStream_t stream) {
+    if (C & 3) return (int)hipErrorInvalidValue;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, stream, in, out_hi, out_lo, out_f32, B, Hi, Wi, Ho, Wo, C);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_pack_weight(const float* src, bf16_t* dst_hi, bf16_t* dst_lo, int kind, int N, int K, int Np, int Kp, int ksz,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)Np * Kp)), dim3(256), 0, stream, src, dst_hi, dst_lo, kind, N, K, Np, Kp, ksz);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_pad_copy_f32(const float* src, float* dst, int n, int np, hipStream_t stream) {
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, src, dst, n, np);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_memset_f32(float* dst, float value, size_t n, hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(memset_f32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dst, value, n);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_nhwc_to_nchw(const float* in_f32, const bf16_t* in_hi, const bf16_t* in_lo, float* out, int B, int H, int W, int C,
+                             int Cp, hipStream_t stream) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)B * C * H * W)), dim3(256), 0, stream, in_f32, in_hi, in_lo, out, B, H, W, C, Cp);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_nchw_to_nhwc(const float* in, float* out_f32, bf16_t* out_hi, bf16_t* out_lo, int relu_bf16, int B, int H, int W,
+                             int C, int Cp, hipStream_t stream) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)B * H * W * Cp)), dim3(256), 0, stream, in, out_f32, out_hi, out_lo, relu_bf16, B, H, W, C, Cp);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_tokens_export(const bf16_t* in_hi, const bf16_t* in_lo, const float* in_f32, float* out, int B, int N, int npad,
+                              int F, int skip_cls, hipStream_t stream) {
+    hipLaunchKernelGGL(tokens_export_kernel, dim3(grid_for((size_t)B * (N - skip_cls) * F)), dim3(256), 0, stream, in_hi, in_lo, in_f32, out, B, N, npad, F, skip_cls);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_tokens_import(const float* in, bf16_t* out_hi, bf16_t* out_lo, int B, int N, int npad, int F, hipStream_t stream) {
+    hipLaunchKernelGGL(tokens_import_kernel, dim3(grid_for((size_t)B * npad * F)), dim3(256), 0, stream, in, out_hi, out_lo, B, N, npad, F);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_tokens_to_resid(const float* tokens, const float* pos, float* resid, int B, int Np, int npad, int F, hipStream_t stream) {
+    hipLaunchKernelGGL(tokens_to_resid_kernel, dim3(grid_for((size_t)B * Np * F)), dim3(256), 0, stream, tokens, pos, resid, B, Np, npad, F);
+    LAUNCH_RET();
+}

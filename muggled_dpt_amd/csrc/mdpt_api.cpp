@@ -1,0 +1,940 @@
+// libmdpt: C ABI (include/mdpt.h) + host-side orchestration of the DPT forward path on one MI355X.
+//
+// What lives here: config validation, the parameter inventory (reference "new format" key names), the one-time
+// weight repack plan, the activation workspace plan (bump allocation inside a caller-provided HBM buffer) and the
+// launch sequence of the HIP kernels in gemm.hip / attention.hip / elementwise.hip. No device memory is allocated
+// here and nothing synchronises: every launch goes on the caller's stream (reference contract: work is enqueued on
+// the current torch stream, demo_helpers/misc.py:30-38).
+//
+// Stage structure mirrors DPTModel.forward (reference muggled_dpt/dpt_model.py:61-83):
+//   patch_embed -> imgencoder (4 taps) -> reassemble -> fusion -> head
+// Internal layouts: tokens are [B, npad, F] (npad = N rounded up to 8; pad rows stay finite and are never read by
+// real rows), feature maps are NHWC with channels padded to 64 (pad channels are exactly zero).
+
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mdpt.h"
+#include "mdpt_kernels.h"
+
+namespace {
+
+thread_local std::string g_err = "";
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define CHK(expr)                                                                                                   \
+    do {                                                                                                            \
+        int e_ = (int)(expr);                                                                                       \
+        if (e_ != 0) {                                                                                              \
+            if (e_ > 0) return fail(e_, "%s: hip error %d (%s)", #expr, e_, hipGetErrorString((hipError_t)e_));      \
+            return e_;                                                                                              \
+        }                                                                                                           \
+    } while (0)
+
+inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+inline size_t rup256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct WeightSpec {
+    std::string name;
+    int ndim;
+    int64_t shape[4];
+    const float* ptr;
+    size_t numel() const {
+        size_t n = 1;
+        for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+        return n;
+    }
+};
+
+struct Mat {  // packed bf16 panel [Np][Kp]
+    std::string src;
+    int kind, N, K, Np, Kp, ksz;
+    size_t off_hi, off_lo;
+    bf16_t* hi;
+    bf16_t* lo;
+};
+
+struct Vec {  // packed fp32 vector (zero padded)
+    std::string src;
+    int n, np;
+    size_t off;
+    float* ptr;
+};
+
+struct Planes {
+    bf16_t* hi = nullptr;
+    bf16_t* lo = nullptr;
+};
+
+const char* kStageNames[4] = {"spatial_upx4", "spatial_upx2", "spatial_noscale", "spatial_downx2"};
+
+// activation workspace layout for one (B, H, W)
+struct Plan {
+    int B, H, W, gh, gw, Np, N, npad, npadv;
+    size_t total;
+    // byte offsets (SIZE_MAX = absent)
+    size_t im2col[2], pos, resid, xn[2], q[2], k[2], vt[2], att[2], hbuf[2], tap[4][2], tapf32;
+    size_t t[4][2], u0[2], u1[2], d3[2];
+    size_t r_f32[4], r_bf[4][2];
+    size_t a1[4][2], x_f32[4], x_bf[4][2], b1[4][2], b2[4][2], flo[4];
+    size_t fused[2], h1, h1u[2], scratch;
+    size_t scratch_floats;
+};
+
+}  // namespace
+
+struct mdpt_handle {
+    mdpt_config cfg;
+    int F, heads, nblocks, bps, P, C, Cp, C2, C2p, Kpatch;
+    int hid[4], hidp[4];
+    bool x3;
+    int gemm_tile;
+    std::vector<WeightSpec> specs;
+    std::map<std::string, int> spec_index;
+    std::vector<Mat> mats;
+    std::map<std::string, int> mat_index;
+    std::vector<Vec> vecs;
+    std::map<std::string, int> vec_index;
+    size_t packed_total;
+    size_t zero_off;
+    bf16_t* zero_page;
+    bool finalized;
+    // last forward (for export taps)
+    Plan last_plan;
+    bool has_last;
+    int dbg_block, dbg_step;  // test hook: stop the encoder after (block, step); -1 = off
+
+    void add_spec(const std::string& name, std::initializer_list<int64_t> shape) {
+        WeightSpec s;
+        s.name = name;
+        s.ndim = (int)shape.size();
+        int i = 0;
+        for (int64_t d : shape) s.shape[i++] = d;
+        for (; i < 4; ++i) s.shape[i] = 1;
+        s.ptr = nullptr;
+        spec_index[name] = (int)specs.size();
+        specs.push_back(s);
+    }
+    void add_mat(const std::string& src, int kind, int N, int K, int Np, int Kp, int ksz) {
+        Mat m;
+        m.src = src; m.kind = kind; m.N = N; m.K = K; m.Np = Np; m.Kp = Kp; m.ksz = ksz;
+        m.off_hi = packed_total;
+        packed_total += rup256((size_t)Np * Kp * 2);
+        m.off_lo = SIZE_MAX;
+        if (x3) { m.off_lo = packed_total; packed_total += rup256((size_t)Np * Kp * 2); }
+        m.hi = m.lo = nullptr;
+        mat_index[src] = (int)mats.size();
+        mats.push_back(m);
+    }
+    void add_vec(const std::string& src, int n, int np) {
+        Vec v;
+        v.src = src; v.n = n; v.np = np;
+        v.off = packed_total;
+        packed_total += rup256((size_t)np * 4);
+        v.ptr = nullptr;
+        vec_index[src] = (int)vecs.size();
+        vecs.push_back(v);
+    }
+    const Mat& M(const std::string& name) const { return mats[mat_index.at(name)]; }
+    const float* V(const std::string& name) const { return vecs[vec_index.at(name)].ptr; }
+};
+
+namespace {
+
+std::string blk_name(const mdpt_handle* h, int block) {
+    char buf[96];
+    snprintf(buf, sizeof(buf), "imgencoder.stages.%d.blocks.%d", block / h->bps, block % h->bps);
+    return buf;
+}
+
+int build_inventory(mdpt_handle* h) {
+    const int F = h->F, P = h->P, C = h->C;
+    const int G = h->cfg.base_patch_grid_h * h->cfg.base_patch_grid_w;
+    h->packed_total = 0;
+    h->zero_off = 0;
+    h->packed_total += 256;
+
+    h->add_spec("patch_embed.proj.weight", {F, 3, P, P});
+    h->add_spec("patch_embed.proj.bias", {F});
+    h->add_mat("patch_embed.proj.weight", MDPT_PACK_LINEAR, F, 3 * P * P, F, h->Kpatch, 0);
+    h->add_vec("patch_embed.proj.bias", F, F);
+
+    h->add_spec("imgencoder.cls_token", {1, 1, F});
+    h->add_spec("imgencoder.posenc.cls_embedding", {1, 1, F});
+    h->add_spec("imgencoder.posenc.base_patch_embedding", {1, G, F});
+    h->add_spec("imgencoder.outnorm.weight", {F});
+    h->add_spec("imgencoder.outnorm.bias", {F});
+    h->add_vec("imgencoder.cls_token", F, F);
+    h->add_vec("imgencoder.posenc.cls_embedding", F, F);
+    h->add_vec("imgencoder.posenc.base_patch_embedding", G * F, G * F);
+    h->add_vec("imgencoder.outnorm.weight", F, F);
+    h->add_vec("imgencoder.outnorm.bias", F, F);
+
+    for (int b = 0; b < h->nblocks; ++b) {
+        const std::string p = blk_name(h, b);
+        for (const char* ln : {"norm1", "norm2"}) {
+            h->add_spec(p + "." + ln + ".weight", {F});
+            h->add_spec(p + "." + ln + ".bias", {F});
+            h->add_vec(p + "." + ln + ".weight", F, F);
+            h->add_vec(p + "." + ln + ".bias", F, F);
+        }
+        h->add_spec(p + ".attn.qkv.weight", {3 * F, F});
+        h->add_spec(p + ".attn.qkv.bias", {3 * F});
+        h->add_spec(p + ".attn.proj.weight", {F, F});
+        h->add_spec(p + ".attn.proj.bias", {F});
+        h->add_spec(p + ".scale_attn", {F});
+        h->add_spec(p + ".mlp.layers.0.weight", {4 * F, F});
+        h->add_spec(p + ".mlp.layers.0.bias", {4 * F});
+        h->add_spec(p + ".mlp.layers.2.weight", {F, 4 * F});
+        h->add_spec(p + ".mlp.layers.2.bias", {F});
+        h->add_spec(p + ".scale_mlp", {F});
+        h->add_mat(p + ".attn.qkv.weight", MDPT_PACK_LINEAR, 3 * F, F, 3 * F, F, 0);
+        h->add_mat(p + ".attn.proj.weight", MDPT_PACK_LINEAR, F, F, F, F, 0);
+        h->add_mat(p + ".mlp.layers.0.weight", MDPT_PACK_LINEAR, 4 * F, F, 4 * F, F, 0);
+        h->add_mat(p + ".mlp.layers.2.weight", MDPT_PACK_LINEAR, F, 4 * F, F, 4 * F, 0);
+        h->add_vec(p + ".attn.qkv.bias", 3 * F, 3 * F);
+        h->add_vec(p + ".attn.proj.bias", F, F);
+        h->add_vec(p + ".scale_attn", F, F);
+        h->add_vec(p + ".mlp.layers.0.bias", 4 * F, 4 * F);
+        h->add_vec(p + ".mlp.layers.2.bias", F, F);
+        h->add_vec(p + ".scale_mlp", F, F);
+    }
+
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = std::string("reassemble.") + kStageNames[i];
+        const int hd = h->hid[i], hp = h->hidp[i];
+        h->add_spec(p + ".resample.0.weight", {hd, F, 1, 1});
+        h->add_spec(p + ".resample.0.bias", {hd});
+        h->add_mat(p + ".resample.0.weight", MDPT_PACK_LINEAR, hd, F, hp, F, 0);
+        h->add_vec(p + ".resample.0.bias", hd, hp);
+        if (i == 0 || i == 1) {
+            const int k = i == 0 ? 4 : 2;
+            h->add_spec(p + ".resample.1.weight", {hd, hd, k, k});
+            h->add_spec(p + ".resample.1.bias", {hd});
+            h->add_mat(p + ".resample.1.weight", MDPT_PACK_CONVT, hd, hd, k * k * hp, hp, k);
+            h->add_vec(p + ".resample.1.bias", hd, hp);
+        } else if (i == 3) {
+            h->add_spec(p + ".resample.1.weight", {hd, hd, 3, 3});
+            h->add_spec(p + ".resample.1.bias", {hd});
+            h->add_mat(p + ".resample.1.weight", MDPT_PACK_CONV3, hd, hd, hp, 9 * hp, 3);
+            h->add_vec(p + ".resample.1.bias", hd, hp);
+        }
+        h->add_spec(p + ".fuse_proj.weight", {C, hd, 3, 3});
+        h->add_mat(p + ".fuse_proj.weight", MDPT_PACK_CONV3, C, hd, h->Cp, 9 * hp, 3);
+    }
+
+    for (int b = 0; b < 4; ++b) {
+        char pb[64];
+        snprintf(pb, sizeof(pb), "fusion.blocks.%d", b);
+        std::vector<std::string> units;
+        if (b < 3) units.push_back(std::string(pb) + ".conv_reassembly");
+        units.push_back(std::string(pb) + ".scale_proj_seq.0");
+        for (const std::string& u : units)
+            for (const char* idx : {"1", "3"}) {
+                const std::string n = u + ".resconv_seq." + idx;
+                h->add_spec(n + ".weight", {C, C, 3, 3});
+                h->add_spec(n + ".bias", {C});
+                h->add_mat(n + ".weight", MDPT_PACK_CONV3, C, C, h->Cp, 9 * h->Cp, 3);
+                h->add_vec(n + ".bias", C, h->Cp);
+            }
+        const std::string o = std::string(pb) + ".scale_proj_seq.2";
+        h->add_spec(o + ".weight", {C, C, 1, 1});
+        h->add_spec(o + ".bias", {C});
+        h->add_mat(o + ".weight", MDPT_PACK_LINEAR, C, C, h->Cp, h->Cp, 0);
+        h->add_vec(o + ".bias", C, h->Cp);
+    }
+
+    h->add_spec("head.spatial_upsampler.0.weight", {h->C2, C, 3, 3});
+    h->add_spec("head.spatial_upsampler.0.bias", {h->C2});
+    h->add_spec("head.proj_1ch.0.weight", {32, h->C2, 3, 3});
+    h->add_spec("head.proj_1ch.0.bias", {32});
+    h->add_spec("head.proj_1ch.2.weight", {1, 32, 1, 1});
+    h->add_spec("head.proj_1ch.2.bias", {1});
+    h->add_mat("head.spatial_upsampler.0.weight", MDPT_PACK_CONV3, h->C2, C, h->C2p, 9 * h->Cp, 3);
+    h->add_vec("head.spatial_upsampler.0.bias", h->C2, h->C2p);
+    h->add_mat("head.proj_1ch.0.weight", MDPT_PACK_CONV3, 32, h->C2, 32, 9 * h->C2p, 3);
+    h->add_vec("head.proj_1ch.0.bias", 32, 32);
+    h->add_vec("head.proj_1ch.2.weight", 32, 32);
+    h->add_vec("head.proj_1ch.2.bias", 1, 4);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// workspace planning
+// ------------------------------------------------------------------------------------------------------------
+struct Bump {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        const size_t o = off;
+        off += rup256(bytes);
+        return o;
+    }
+};
+
+void take_planes(Bump& bump, bool x3, size_t elems, size_t out[2]) {
+    out[0] = bump.take(elems * 2);
+    out[1] = x3 ? bump.take(elems * 2) : SIZE_MAX;
+}
+
+int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
+    if (B <= 0 || H <= 0 || W <= 0) return fail(MDPT_E_INVALID, "bad batch/size B=%d H=%d W=%d", B, H, W);
+    if (H % h->P || W % h->P)
+        return fail(MDPT_E_INVALID, "image size %dx%d must be divisible by the patch size %d (reference patch_embed.py:159-163)", H, W, h->P);
+    const int gh = H / h->P, gw = W / h->P;
+    if ((gh & 1) || (gw & 1))
+        return fail(MDPT_E_GRID, "patch grid %dx%d must be even in both dimensions (the reference fails in fusion_model.py:151)", gh, gw);
+    const bool x3 = h->x3;
+    const int F = h->F;
+    Plan& p = *pl;
+    p.B = B; p.H = H; p.W = W; p.gh = gh; p.gw = gw;
+    p.Np = gh * gw; p.N = p.Np + 1; p.npad = rup(p.N, 8); p.npadv = rup(p.N, 64);
+    Bump bump;
+    const size_t rows = (size_t)B * p.npad;
+    take_planes(bump, x3, (size_t)B * p.Np * h->Kpatch, p.im2col);
+    p.pos = bump.take((size_t)p.Np * F * 4);
+    p.resid = bump.take(rows * F * 4);
+    take_planes(bump, x3, rows * F, p.xn);
+    take_planes(bump, x3, (size_t)B * h->heads * p.npad * 64, p.q);
+    take_planes(bump, x3, (size_t)B * h->heads * p.npad * 64, p.k);
+    take_planes(bump, x3, (size_t)B * h->heads * 64 * p.npadv, p.vt);
+    take_planes(bump, x3, rows * F, p.att);
+    take_planes(bump, x3, rows * 4 * F, p.hbuf);
+    for (int i = 0; i < 4; ++i) take_planes(bump, x3, rows * F, p.tap[i]);
+    p.tapf32 = bump.take(rows * F * 4);
+    const size_t px[4] = {(size_t)16 * p.Np, (size_t)4 * p.Np, (size_t)p.Np, (size_t)p.Np / 4};
+    for (int i = 0; i < 4; ++i) take_planes(bump, x3, (size_t)B * p.Np * h->hidp[i], p.t[i]);
+    take_planes(bump, x3, (size_t)B * px[0] * h->hidp[0], p.u0);
+    take_planes(bump, x3, (size_t)B * px[1] * h->hidp[1], p.u1);
+    take_planes(bump, x3, (size_t)B * px[3] * h->hidp[3], p.d3);
+    for (int i = 0; i < 4; ++i) {
+        const size_t e = (size_t)B * px[i] * h->Cp;
+        p.r_f32[i] = bump.take(e * 4);
+        take_planes(bump, x3, e, p.r_bf[i]);
+        take_planes(bump, x3, e, p.a1[i]);
+        p.x_f32[i] = bump.take(e * 4);
+        take_planes(bump, x3, e, p.x_bf[i]);
+        take_planes(bump, x3, e, p.b1[i]);
+        take_planes(bump, x3, e, p.b2[i]);
+        p.flo[i] = bump.take(e * 4);
+    }
+    const size_t fpx = (size_t)64 * p.Np;  // (8gh)*(8gw)
+    take_planes(bump, x3, (size_t)B * fpx * h->Cp, p.fused);
+    p.h1 = bump.take((size_t)B * fpx * h->C2p * 4);
+    take_planes(bump, x3, (size_t)B * H * W * h->C2p, p.h1u);
+    p.scratch_floats = (size_t)B * fpx * h->Cp;
+    if (rows * F > p.scratch_floats) p.scratch_floats = rows * F;
+    p.scratch = bump.take(p.scratch_floats * 4);
+    p.total = bump.off;
+    return 0;
+}
+
+struct Ctx {
+    const mdpt_handle* h;
+    Plan p;
+    char* ws;
+    hipStream_t s;
+    template <class T> T* at(size_t off) const { return off == SIZE_MAX ? nullptr : (T*)(ws + off); }
+    Planes pl(const size_t o[2]) const {
+        Planes r;
+        r.hi = at<bf16_t>(o[0]);
+        r.lo = at<bf16_t>(o[1]);
+        return r;
+    }
+};
+
+GemmParams base_params(const Ctx& c, const Mat& w, Planes a, int M, int lda) {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.A_hi = a.hi; g.A_lo = a.lo;
+    g.W_hi = w.hi; g.W_lo = w.lo;
+    g.M = M; g.N = w.Np; g.K = w.Kp; g.lda = lda;
+    g.npass = c.h->x3 ? 3 : 1;
+    g.zero_page = c.h->zero_page;
+    g.amode = MDPT_A_DENSE; g.ekind = MDPT_E_GENERIC; g.tile = c.h->gemm_tile;
+    g.ldc = w.Np; g.ldr = w.Np;
+    return g;
+}
+
+void as_conv(GemmParams& g, int Hi, int Wi, int Cin, int Ho, int Wo, int stride) {
+    g.amode = MDPT_A_CONV3;
+    g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.cstride = stride;
+}
+
+int check_ws(const mdpt_handle* h, const Plan& p, const void* ws, size_t bytes) {
+    if (!h->finalized) return fail(MDPT_E_STATE, "mdpt_finalize() has not been called");
+    if (!ws || bytes < p.total) return fail(MDPT_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", p.total, bytes);
+    if (((uintptr_t)ws) & 255) return fail(MDPT_E_WORKSPACE, "workspace must be 256-byte aligned");
+    return 0;
+}
+
+// ---- stage: patch embed (fused form: writes the residual stream incl. position embedding)
+int run_pos(const Ctx& c) {
+    const mdpt_handle* h = c.h;
+    return mdpt_launch_posembed(h->V("imgencoder.posenc.base_patch_embedding"), c.at<float>(c.p.pos), h->cfg.base_patch_grid_h,
+                                h->cfg.base_patch_grid_w, c.p.gh, c.p.gw, h->F, c.s);
+}
+
+int run_patch_embed_fused(const Ctx& c, const float* image) {
+    const mdpt_handle* h = c.h;
+    const Plan& p = c.p;
+    Planes im = c.pl(p.im2col);
+    CHK(mdpt_launch_patchify(image, im.hi, im.lo, p.B, p.H, p.W, h->P, h->Kpatch, c.s));
+    CHK(run_pos(c));
+    CHK(mdpt_launch_init_tokens(c.at<float>(p.resid), h->V("imgencoder.cls_token"), h->V("imgencoder.posenc.cls_embedding"), p.B, p.N,
+                                p.npad, h->F, c.s));
+    GemmParams g = base_params(c, h->M("patch_embed.proj.weight"), im, p.B * p.Np, h->Kpatch);
+    g.ekind = MDPT_E_PATCH;
+    g.bias = h->V("patch_embed.proj.bias");
+    g.pos = c.at<float>(p.pos);
+    g.out_f32 = c.at<float>(p.resid);
+    g.tok_np = p.Np; g.npad = p.npad; g.ldc = h->F;
+    CHK(mdpt_launch_gemm(g, c.s));
+    return 0;
+}
+
+// ---- stage: encoder. taps_f32 != null: also emit fp32 copies of the 4 out-normed taps (reference layout)
+int run_encoder(const Ctx& c, void* const taps_f32[4]) {
+    const mdpt_handle* h = c.h;
+    const Plan& p = c.p;
+    const int F = h->F, rows = p.B * p.npad;
+    float* resid = c.at<float>(p.resid);
+    Planes xn = c.pl(p.xn), q = c.pl(p.q), k = c.pl(p.k), vt = c.pl(p.vt), att = c.pl(p.att), hb = c.pl(p.hbuf);
+    CHK(mdpt_launch_zero_vt_pad(vt.hi, vt.lo, p.B * h->heads * 64, p.N, p.npadv, c.s));
+#define DBG_STOP(step) if (h->dbg_block == b && h->dbg_step == (step)) return 0
+    for (int b = 0; b < h->nblocks; ++b) {
+        const std::string n = blk_name(h, b);
+        CHK(mdpt_launch_layernorm(resid, h->V(n + ".norm1.weight"), h->V(n + ".norm1.bias"), xn.hi, xn.lo, nullptr, rows, F, c.s));
+        DBG_STOP(0);
+        {
+            GemmParams g = base_params(c, h->M(n + ".attn.qkv.weight"), xn, rows, F);
+            g.ekind = MDPT_E_QKV;
+            g.bias = h->V(n + ".attn.qkv.bias");
+            g.q_hi = q.hi; g.q_lo = q.lo; g.k_hi = k.hi; g.k_lo = k.lo; g.vt_hi = vt.hi; g.vt_lo = vt.lo;
+            g.F = F; g.heads = h->heads; g.npad = p.npad; g.npadv = p.npadv; g.qscale = 0.125f;
+            CHK(mdpt_launch_gemm(g, c.s));
+        }
+        DBG_STOP(1);
+        {
+            AttnParams a;
+            memset(&a, 0, sizeof(a));
+            a.q_hi = q.hi; a.q_lo = q.lo; a.k_hi = k.hi; a.k_lo = k.lo; a.vt_hi = vt.hi; a.vt_lo = vt.lo;
+            a.out_hi = att.hi; a.out_lo = att.lo;
+            a.B = p.B; a.heads = h->heads; a.N = p.N; a.npad = p.npad; a.npadv = p.npadv; a.F = F; a.x3 = h->x3;
+            CHK(mdpt_launch_attention(a, c.s));
+        }
+        DBG_STOP(2);
+        {
+            GemmParams g = base_params(c, h->M(n + ".attn.proj.weight"), att, rows, F);
+            g.bias = h->V(n + ".attn.proj.bias");
+            g.gamma = h->V(n + ".scale_attn");
+            g.resid = resid; g.out_f32 = resid; g.ldr = F; g.ldc = F;
+            CHK(mdpt_launch_gemm(g, c.s));
+        }
+        DBG_STOP(3);
+        CHK(mdpt_launch_layernorm(resid, h->V(n + ".norm2.weight"), h->V(n + ".norm2.bias"), xn.hi, xn.lo, nullptr, rows, F, c.s));
+        DBG_STOP(4);
+        {
+            GemmParams g = base_params(c, h->M(n + ".mlp.layers.0.weight"), xn, rows, F);
+            g.bias = h->V(n + ".mlp.layers.0.bias");
+            g.act = MDPT_ACT_GELU;
+            g.out_hi = hb.hi; g.out_lo = hb.lo; g.ldc = 4 * F;
+            CHK(mdpt_launch_gemm(g, c.s));
+        }
+        DBG_STOP(5);
+        {
+            GemmParams g = base_params(c, h->M(n + ".mlp.layers.2.weight"), hb, rows, 4 * F);
+            g.bias = h->V(n + ".mlp.layers.2.bias");
+            g.gamma = h->V(n + ".scale_mlp");
+            g.resid = resid; g.out_f32 = resid; g.ldr = F; g.ldc = F;
+            CHK(mdpt_launch_gemm(g, c.s));
+        }
+        DBG_STOP(6);
+        if ((b + 1) % h->bps == 0) {
+            const int st = b / h->bps;
+            Planes tp = c.pl(p.tap[st]);
+            float* f32 = taps_f32 ? c.at<float>(p.tapf32) : nullptr;
+            CHK(mdpt_launch_layernorm(resid, h->V("imgencoder.outnorm.weight"), h->V("imgencoder.outnorm.bias"), tp.hi, tp.lo, f32, rows, F, c.s));
+            if (taps_f32)
+                CHK(mdpt_launch_tokens_export(nullptr, nullptr, f32, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
+        }
+    }
+    return 0;
+}
+
+// ---- stage: reassemble
+int run_reassemble(const Ctx& c) {
+    const mdpt_handle* h = c.h;
+    const Plan& p = c.p;
+    const int F = h->F, gh = p.gh, gw = p.gw;
+    for (int i = 0; i < 4; ++i) {
+        const std::string n = std::string("reassemble.") + kStageNames[i];
+        const int hp = h->hidp[i];
+        Planes tp = c.pl(p.tap[i]), t = c.pl(p.t[i]);
+        {   // 1x1 conv on the patch tokens (cls row skipped by the A-row generator)
+            GemmParams g = base_params(c, h->M(n + ".resample.0.weight"), tp, p.B * p.Np, F);
+            g.amode = MDPT_A_TOKENS; g.tok_np = p.Np; g.tok_stride = p.npad;
+            g.bias = h->V(n + ".resample.0.bias");
+            g.out_hi = t.hi; g.out_lo = t.lo; g.ldc = hp;
+            CHK(mdpt_launch_gemm(g, c.s));
+        }
+        Planes src = t;
+        int sh = gh, sw = gw;
+        if (i == 0 || i == 1) {  // ConvTranspose2d k == s: GEMM + depth-to-space
+            const int kk = i == 0 ? 4 : 2;
+            Planes u = c.pl(i == 0 ? p.u0 : p.u1);
+            GemmParams g = base_params(c, h->M(n + ".resample.1.weight"), t, p.B * p.Np, hp);
+            g.ekind = MDPT_E_D2S;
+            g.bias = h->V(n + ".resample.1.bias");
+            g.Ho = gh; g.Wo = gw; g.d2s_k = kk; g.d2s_cout = hp;
+            g.out_hi = u.hi; g.out_lo = u.lo;
+            CHK(mdpt_launch_gemm(g, c.s));
+            src = u; sh = gh * kk; sw = gw * kk;
+        } else if (i == 3) {  // 3x3 stride-2
+            Planes d = c.pl(p.d3);
+            GemmParams g = base_params(c, h->M(n + ".resample.1.weight"), t, p.B * (gh / 2) * (gw / 2), hp);
+            as_conv(g, gh, gw, hp, gh / 2, gw / 2, 2);
+            g.bias = h->V(n + ".resample.1.bias");
+            g.out_hi = d.hi; g.out_lo = d.lo; g.ldc = hp;
+            CHK(mdpt_launch_gemm(g, c.s));
+            src = d; sh = gh / 2; sw = gw / 2;
+        }
+        {   // 3x3 projection to the fusion width (no bias): fp32 copy (skip path) + ReLU'd bf16 (next conv input)
+            Planes rb = c.pl(p.r_bf[i]);
+            GemmParams g = base_params(c, h->M(n + ".fuse_proj.weight"), src, p.B * sh * sw, hp);
+            as_conv(g, sh, sw, hp, sh, sw, 1);
+            g.out_f32 = c.at<float>(p.r_f32[i]);
+            g.out_hi = rb.hi; g.out_lo = rb.lo; g.relu_bf16 = 1; g.ldc = h->Cp;
+            CHK(mdpt_launch_gemm(g, c.s));
+        }
+    }
+    return 0;
+}
+
+// one 3x3 conv C->C of a residual conv unit at level `lv` (spatial sh x sw)
+int rcu_conv(const Ctx& c, const std::string& wname, Planes in, int sh, int sw, const float* skip, const float* up_src, int Hu, int Wu,
+             float* out_f32, Planes out, int relu_bf16) {
+    const mdpt_handle* h = c.h;
+    GemmParams g = base_params(c, h->M(wname + ".weight"), in, c.p.B * sh * sw, h->Cp);
+    as_conv(g, sh, sw, h->Cp, sh, sw, 1);
+    g.bias = h->V(wname + ".bias");
+    g.resid = skip; g.ldr = h->Cp;
+    g.up_src = up_src; g.Hu = Hu; g.Wu = Wu;
+    g.out_f32 = out_f32; g.out_hi = out.hi; g.out_lo = out.lo; g.relu_bf16 = relu_bf16; g.ldc = h->Cp;
+    return mdpt_launch_gemm(g, c.s);
+}
+
+// ---- stage: fusion. Level index i: 3 = coarsest (gh/2), 0 = finest (4gh). Output: flo[0] (fp32, 4gh x 4gw, before the
+//      final x2 upsample) and `fused` planes (8gh x 8gw).
+int run_fusion(const Ctx& c) {
+    const mdpt_handle* h = c.h;
+    const Plan& p = c.p;
+    const int sh[4] = {4 * p.gh, 2 * p.gh, p.gh, p.gh / 2}, sw[4] = {4 * p.gw, 2 * p.gw, p.gw, p.gw / 2};
+    for (int i = 3; i >= 0; --i) {
+        char pb[64];
+        snprintf(pb, sizeof(pb), "fusion.blocks.%d", i);
+        const std::string blk = pb;
+        const float* x_f32;
+        Planes x_bf;
+        if (i == 3) {  // top-most block: no reassembly RCU, no prior (fusion_model.py:89-114)
+            x_f32 = c.at<float>(p.r_f32[3]);
+            x_bf = c.pl(p.r_bf[3]);
+        } else {
+            // x = RCU_a(r_i) + up2(prev)   (fusion_model.py:148-154)
+            Planes a1 = c.pl(p.a1[i]);
+            CHK(rcu_conv(c, blk + ".conv_reassembly.resconv_seq.1", c.pl(p.r_bf[i]), sh[i], sw[i], nullptr, nullptr, 0, 0, nullptr, a1, 1));
+            x_bf = c.pl(p.x_bf[i]);
+            CHK(rcu_conv(c, blk + ".conv_reassembly.resconv_seq.3", a1, sh[i], sw[i], c.at<float>(p.r_f32[i]), c.at<float>(p.flo[i + 1]),
+                         sh[i + 1], sw[i + 1], c.at<float>(p.x_f32[i]), x_bf, 1));
+            x_f32 = c.at<float>(p.x_f32[i]);
+        }
+        Planes b1 = c.pl(p.b1[i]), b2 = c.pl(p.b2[i]);
+        CHK(rcu_conv(c, blk + ".scale_proj_seq.0.resconv_seq.1", x_bf, sh[i], sw[i], nullptr, nullptr, 0, 0, nullptr, b1, 1));
+        CHK(rcu_conv(c, blk + ".scale_proj_seq.0.resconv_seq.3", b1, sh[i], sw[i], x_f32, nullptr, 0, 0, nullptr, b2, 0));
+        {   // 1x1 projection at LOW resolution; the x2 bilinear upsample commutes with it exactly (both linear, weights
+            // sum to 1) and is applied by the consumer (next level's epilogue / final upsample kernel)
+            GemmParams g = base_params(c, h->M(blk + ".scale_proj_seq.2.weight"), b2, p.B * sh[i] * sw[i], h->Cp);
+            g.bias = h->V(blk + ".scale_proj_seq.2.bias");
+            g.out_f32 = c.at<float>(p.flo[i]); g.ldc = h->Cp;
+            CHK(mdpt_launch_gemm(g, c.s));
+        }
+    }
+    Planes fu = c.pl(p.fused);
+    CHK(mdpt_launch_upsample(c.at<float>(p.flo[0]), fu.hi, fu.lo, nullptr, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
+    return 0;
+}
+
+// ---- stage: head
+int run_head(const Ctx& c, float* depth) {
+    const mdpt_handle* h = c.h;
+    const Plan& p = c.p;
+    const int fh = 8 * p.gh, fw = 8 * p.gw;
+    {
+        GemmParams g = base_params(c, h->M("head.spatial_upsampler.0.weight"), c.pl(p.fused), p.B * fh * fw, h->Cp);
+        as_conv(g, fh, fw, h->Cp, fh, fw, 1);
+        g.bias = h->V("head.spatial_upsampler.0.bias");
+        g.out_f32 = c.at<float>(p.h1); g.ldc = h->C2p;
+        CHK(mdpt_launch_gemm(g, c.s));
+    }
+    Planes hu = c.pl(p.h1u);
+    CHK(mdpt_launch_upsample(c.at<float>(p.h1), hu.hi, hu.lo, nullptr, p.B, fh, fw, p.H, p.W, h->C2p, c.s));
+    {
+        GemmParams g = base_params(c, h->M("head.proj_1ch.0.weight"), hu, p.B * p.H * p.W, h->C2p);
+        as_conv(g, p.H, p.W, h->C2p, p.H, p.W, 1);
+        g.ekind = MDPT_E_HEAD;
+        g.bias = h->V("head.proj_1ch.0.bias");
+        g.head_w = h->V("head.proj_1ch.2.weight");
+        g.head_b = h->V("head.proj_1ch.2.bias");
+        g.head_sigmoid = h->cfg.is_metric;
+        g.head_out = depth;
+        CHK(mdpt_launch_gemm(g, c.s));
+    }
+    return 0;
+}
+
+int make_ctx(mdpt_handle* h, int B, int H, int W, void* ws, size_t ws_bytes, void* stream, Ctx* c) {
+    Plan p;
+    CHK(make_plan(h, B, H, W, &p));
+    CHK(check_ws(h, p, ws, ws_bytes));
+    c->h = h; c->p = p; c->ws = (char*)ws; c->s = (hipStream_t)stream;
+    return 0;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+extern "C" {
+
+int mdpt_abi_version(void) { return MDPT_ABI_VERSION; }
+const char* mdpt_last_error(void) { return g_err.c_str(); }
+
+int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
+    if (!cfg || !out) return fail(MDPT_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->is_giant) return fail(MDPT_E_UNSUPPORTED, "ViT-G (SwiGLU MLP) is not built in this version");
+    if (cfg->features_per_token <= 0 || cfg->features_per_token % 64)
+        return fail(MDPT_E_INVALID, "features_per_token must be a positive multiple of 64, got %d", cfg->features_per_token);
+    if (cfg->num_heads * 64 != cfg->features_per_token)
+        return fail(MDPT_E_UNSUPPORTED, "head dim must be 64 (heads=%d, features=%d)", cfg->num_heads, cfg->features_per_token);
+    if (cfg->num_blocks <= 0 || cfg->num_blocks % 4) return fail(MDPT_E_INVALID, "num_blocks must be a positive multiple of 4, got %d", cfg->num_blocks);
+    if (cfg->fusion_channels <= 0 || cfg->fusion_channels % 8) return fail(MDPT_E_INVALID, "fusion_channels must be a multiple of 8");
+    if (cfg->patch_size_px <= 0 || cfg->patch_size_px % 2) return fail(MDPT_E_INVALID, "patch_size_px must be even (head scale = patch/8)");
+    if (cfg->base_patch_grid_h <= 0 || cfg->base_patch_grid_w <= 0) return fail(MDPT_E_INVALID, "bad base patch grid");
+    if (cfg->precision != MDPT_PREC_BF16 && cfg->precision != MDPT_PREC_BF16X3) return fail(MDPT_E_INVALID, "unknown precision %d", cfg->precision);
+    for (int i = 0; i < 4; ++i)
+        if (cfg->reassembly_features[i] <= 0 || cfg->reassembly_features[i] % 4) return fail(MDPT_E_INVALID, "reassembly_features[%d] must be a multiple of 4", i);
+    mdpt_handle* h = new mdpt_handle();
+    h->cfg = *cfg;
+    h->F = cfg->features_per_token; h->heads = cfg->num_heads; h->nblocks = cfg->num_blocks; h->bps = cfg->num_blocks / 4;
+    h->P = cfg->patch_size_px; h->C = cfg->fusion_channels; h->Cp = rup(h->C, 64);
+    h->C2 = h->C / 2; h->C2p = rup(h->C2, 64);
+    h->Kpatch = rup(3 * h->P * h->P, 64);
+    for (int i = 0; i < 4; ++i) { h->hid[i] = cfg->reassembly_features[i]; h->hidp[i] = rup(h->hid[i], 64); }
+    h->x3 = cfg->precision == MDPT_PREC_BF16X3;
+    h->gemm_tile = MDPT_TILE_AUTO;
+    h->finalized = false;
+    h->has_last = false;
+    h->zero_page = nullptr;
+    h->dbg_block = h->dbg_step = -1;
+    build_inventory(h);
+    *out = h;
+    return 0;
+}
+
+void mdpt_destroy(mdpt_handle* h) { delete h; }
+
+int mdpt_num_weights(const mdpt_handle* h) { return h ? (int)h->specs.size() : 0; }
+
+const char* mdpt_weight_name(const mdpt_handle* h, int index) {
+    if (!h || index < 0 || index >= (int)h->specs.size()) return nullptr;
+    return h->specs[index].name.c_str();
+}
+
+int mdpt_weight_shape(const mdpt_handle* h, int index, int32_t* ndim, int64_t shape[4]) {
+    if (!h || index < 0 || index >= (int)h->specs.size() || !ndim || !shape) return fail(MDPT_E_INVALID, "bad weight index");
+    *ndim = h->specs[index].ndim;
+    for (int i = 0; i < 4; ++i) shape[i] = h->specs[index].shape[i];
+    return 0;
+}
+
+int mdpt_bind_weight(mdpt_handle* h, const char* name, const void* dev_f32, int32_t ndim, const int64_t* shape) {
+    if (!h || !name || !dev_f32 || !shape) return fail(MDPT_E_INVALID, "null argument");
+    auto it = h->spec_index.find(name);
+    if (it == h->spec_index.end()) return fail(MDPT_E_INVALID, "unexpected parameter \"%s\" (not part of this model config)", name);
+    WeightSpec& s = h->specs[it->second];
+    bool ok = ndim == s.ndim;
+    for (int i = 0; ok && i < ndim; ++i) ok = shape[i] == s.shape[i];
+    if (!ok) {
+        std::string got, want;
+        for (int i = 0; i < ndim; ++i) got += (i ? "x" : "") + std::to_string(shape[i]);
+        for (int i = 0; i < s.ndim; ++i) want += (i ? "x" : "") + std::to_string(s.shape[i]);
+        return fail(MDPT_E_SHAPE, "size mismatch for %s: got %s, model expects %s", name, got.c_str(), want.c_str());
+    }
+    s.ptr = (const float*)dev_f32;
+    h->finalized = false;
+    return 0;
+}
+
+int mdpt_packed_bytes(const mdpt_handle* h, size_t* bytes) {
+    if (!h || !bytes) return fail(MDPT_E_INVALID, "null argument");
+    *bytes = h->packed_total;
+    return 0;
+}
+
+int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) {
+    if (!h || !packed_dev) return fail(MDPT_E_INVALID, "null argument");
+    if (bytes < h->packed_total) return fail(MDPT_E_WORKSPACE, "packed buffer too small: need %zu bytes, got %zu", h->packed_total, bytes);
+    if (((uintptr_t)packed_dev) & 255) return fail(MDPT_E_WORKSPACE, "packed buffer must be 256-byte aligned");
+    for (const WeightSpec& s : h->specs)
+        if (!s.ptr) return fail(MDPT_E_MISSING, "missing parameter \"%s\" (strict load)", s.name.c_str());
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)packed_dev;
+    CHK(hipMemsetAsync(base + h->zero_off, 0, 256, st));
+    h->zero_page = (bf16_t*)(base + h->zero_off);
+    for (Mat& m : h->mats) {
+        m.hi = (bf16_t*)(base + m.off_hi);
+        m.lo = m.off_lo == SIZE_MAX ? nullptr : (bf16_t*)(base + m.off_lo);
+        const float* src = h->specs[h->spec_index.at(m.src)].ptr;
+        CHK(mdpt_launch_pack_weight(src, m.hi, m.lo, m.kind, m.N, m.K, m.Np, m.Kp, m.ksz, st));
+    }
+    for (Vec& v : h->vecs) {
+        v.ptr = (float*)(base + v.off);
+        CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(v.src)].ptr, v.ptr, v.n, v.np, st));
+    }
+    h->finalized = true;
+    h->has_last = false;
+    return 0;
+}
+
+int mdpt_workspace_bytes(const mdpt_handle* h, int32_t B, int32_t H, int32_t W, size_t* bytes) {
+    if (!h || !bytes) return fail(MDPT_E_INVALID, "null argument");
+    Plan p;
+    CHK(make_plan(h, B, H, W, &p));
+    *bytes = p.total;
+    return 0;
+}
+
+int mdpt_set_gemm_tile(mdpt_handle* h, int32_t tile) {
+    if (!h || tile < 0 || tile > 2) return fail(MDPT_E_INVALID, "tile must be 0 (auto), 1 (128x128) or 2 (256x256)");
+    h->gemm_tile = tile;
+    return 0;
+}
+
+int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t B, int32_t H, int32_t W, void* depth_bhw, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+    if (!h || !image_bchw || !depth_bhw) return fail(MDPT_E_INVALID, "null argument");
+    Ctx c;
+    CHK(make_ctx(h, B, H, W, workspace, workspace_bytes, stream, &c));
+    CHK(run_patch_embed_fused(c, (const float*)image_bchw));
+    h->last_plan = c.p;
+    h->has_last = true;
+    CHK(run_encoder(c, nullptr));
+    if (h->dbg_block >= 0) return 0;  // test hook: encoder truncated, skip the decoder
+    CHK(run_reassemble(c));
+    CHK(run_fusion(c));
+    CHK(run_head(c, (float*)depth_bhw));
+    return 0;
+}
+
+int mdpt_patch_embed(mdpt_handle* h, const void* image_bchw, int32_t B, int32_t H, int32_t W, void* tokens_bnf, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (!h || !image_bchw || !tokens_bnf) return fail(MDPT_E_INVALID, "null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || H % h->P || W % h->P)
+        return fail(MDPT_E_INVALID, "image size %dx%d must be divisible by the patch size %d", H, W, h->P);
+    // PatchEmbed alone accepts odd grids (the reference only fails later, in fusion): plan with an even-rounded size
+    Ctx c;
+    const int He = rup(H, 2 * h->P), We = rup(W, 2 * h->P);
+    CHK(make_ctx(h, B, He, We, workspace, workspace_bytes, stream, &c));
+    const int Np = (H / h->P) * (W / h->P);
+    Planes im = c.pl(c.p.im2col);
+    CHK(mdpt_launch_patchify((const float*)image_bchw, im.hi, im.lo, B, H, W, h->P, h->Kpatch, c.s));
+    GemmParams g = base_params(c, h->M("patch_embed.proj.weight"), im, B * Np, h->Kpatch);
+    g.bias = h->V("patch_embed.proj.bias");
+    g.out_f32 = (float*)tokens_bnf; g.ldc = h->F;
+    CHK(mdpt_launch_gemm(g, c.s));
+    h->has_last = false;
+    return 0;
+}
+
+int mdpt_encoder(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, int32_t gw, void* const stage_out[4], void* workspace,
+                 size_t workspace_bytes, void* stream) {
+    if (!h || !tokens_bnf || !stage_out) return fail(MDPT_E_INVALID, "null argument");
+    for (int i = 0; i < 4; ++i)
+        if (!stage_out[i]) return fail(MDPT_E_INVALID, "null stage output %d", i);
+    if (gh <= 0 || gw <= 0) return fail(MDPT_E_INVALID, "bad grid");
+    Ctx c;
+    CHK(make_ctx(h, B, rup(gh, 2) * h->P, rup(gw, 2) * h->P, workspace, workspace_bytes, stream, &c));
+    // the encoder itself does not need an even grid: re-derive token counts for the true grid
+    c.p.gh = gh; c.p.gw = gw; c.p.Np = gh * gw; c.p.N = c.p.Np + 1;
+    if (rup(c.p.N, 8) > c.p.npad) return fail(MDPT_E_INVALID, "internal: plan too small");
+    c.p.npad = rup(c.p.N, 8); c.p.npadv = rup(c.p.N, 64);
+    CHK(run_pos(c));
+    CHK(mdpt_launch_init_tokens(c.at<float>(c.p.resid), h->V("imgencoder.cls_token"), h->V("imgencoder.posenc.cls_embedding"), B, c.p.N,
+                                c.p.npad, h->F, c.s));
+    CHK(mdpt_launch_tokens_to_resid((const float*)tokens_bnf, c.at<float>(c.p.pos), c.at<float>(c.p.resid), B, c.p.Np, c.p.npad, h->F, c.s));
+    CHK(run_encoder(c, stage_out));
+    h->has_last = false;
+    return 0;
+}
+
+int mdpt_reassemble(mdpt_handle* h, const void* const stage_in[4], int32_t B, int32_t gh, int32_t gw, void* const maps_out[4],
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !stage_in || !maps_out) return fail(MDPT_E_INVALID, "null argument");
+    Ctx c;
+    CHK(make_ctx(h, B, gh * h->P, gw * h->P, workspace, workspace_bytes, stream, &c));
+    const Plan& p = c.p;
+    for (int i = 0; i < 4; ++i) {
+        if (!stage_in[i] || !maps_out[i]) return fail(MDPT_E_INVALID, "null stage tensor %d", i);
+        Planes tp = c.pl(p.tap[i]);
+        CHK(mdpt_launch_tokens_import((const float*)stage_in[i], tp.hi, tp.lo, B, p.N, p.npad, h->F, c.s));
+    }
+    CHK(run_reassemble(c));
+    const int sh[4] = {4 * gh, 2 * gh, gh, gh / 2}, sw[4] = {4 * gw, 2 * gw, gw, gw / 2};
+    for (int i = 0; i < 4; ++i)
+        CHK(mdpt_launch_nhwc_to_nchw(c.at<float>(p.r_f32[i]), nullptr, nullptr, (float*)maps_out[i], B, sh[i], sw[i], h->C, h->Cp, c.s));
+    h->has_last = false;
+    return 0;
+}
+
+int mdpt_fusion(mdpt_handle* h, const void* const maps_in[4], int32_t B, int32_t gh, int32_t gw, void* fused_out, void* workspace,
+                size_t workspace_bytes, void* stream) {
+    if (!h || !maps_in || !fused_out) return fail(MDPT_E_INVALID, "null argument");
+    Ctx c;
+    CHK(make_ctx(h, B, gh * h->P, gw * h->P, workspace, workspace_bytes, stream, &c));
+    const Plan& p = c.p;
+    const int sh[4] = {4 * gh, 2 * gh, gh, gh / 2}, sw[4] = {4 * gw, 2 * gw, gw, gw / 2};
+    for (int i = 0; i < 4; ++i) {
+        if (!maps_in[i]) return fail(MDPT_E_INVALID, "null map %d", i);
+        Planes rb = c.pl(p.r_bf[i]);
+        CHK(mdpt_launch_nchw_to_nhwc((const float*)maps_in[i], c.at<float>(p.r_f32[i]), rb.hi, rb.lo, 1, B, sh[i], sw[i], h->C, h->Cp, c.s));
+    }
+    CHK(run_fusion(c));
+    float* tmp = c.at<float>(p.scratch);
+    CHK(mdpt_launch_upsample(c.at<float>(p.flo[0]), nullptr, nullptr, tmp, B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
+    CHK(mdpt_launch_nhwc_to_nchw(tmp, nullptr, nullptr, (float*)fused_out, B, 8 * gh, 8 * gw, h->C, h->Cp, c.s));
+    h->has_last = false;
+    return 0;
+}
+
+int mdpt_head(mdpt_handle* h, const void* fused_in, int32_t B, int32_t gh, int32_t gw, void* depth_bhw, void* workspace,
+              size_t workspace_bytes, void* stream) {
+    if (!h || !fused_in || !depth_bhw) return fail(MDPT_E_INVALID, "null argument");
+    Ctx c;
+    CHK(make_ctx(h, B, gh * h->P, gw * h->P, workspace, workspace_bytes, stream, &c));
+    Planes fu = c.pl(c.p.fused);
+    CHK(mdpt_launch_nchw_to_nhwc((const float*)fused_in, nullptr, fu.hi, fu.lo, 0, B, 8 * gh, 8 * gw, h->C, h->Cp, c.s));
+    CHK(run_head(c, (float*)depth_bhw));
+    h->has_last = false;
+    return 0;
+}
+
+int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !out_f32) return fail(MDPT_E_INVALID, "null argument");
+    if (!h->has_last) return fail(MDPT_E_STATE, "mdpt_export_tap needs a preceding mdpt_forward on this workspace");
+    Ctx c;
+    c.h = h; c.p = h->last_plan; c.ws = (char*)workspace; c.s = (hipStream_t)stream;
+    CHK(check_ws(h, c.p, workspace, workspace_bytes));
+    const Plan& p = c.p;
+    const int sh[4] = {4 * p.gh, 2 * p.gh, p.gh, p.gh / 2}, sw[4] = {4 * p.gw, 2 * p.gw, p.gw, p.gw / 2};
+    if (which >= 0 && which < 4) {
+        Planes tp = c.pl(p.tap[which]);
+        CHK(mdpt_launch_tokens_export(tp.hi, tp.lo, nullptr, (float*)out_f32, p.B, p.N, p.npad, h->F, 0, c.s));
+    } else if (which >= 4 && which < 8) {
+        const int i = which - 4;
+        CHK(mdpt_launch_nhwc_to_nchw(c.at<float>(p.r_f32[i]), nullptr, nullptr, (float*)out_f32, p.B, sh[i], sw[i], h->C, h->Cp, c.s));
+    } else if (which == 8) {
+        float* tmp = c.at<float>(p.scratch);
+        CHK(mdpt_launch_upsample(c.at<float>(p.flo[0]), nullptr, nullptr, tmp, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
+        CHK(mdpt_launch_nhwc_to_nchw(tmp, nullptr, nullptr, (float*)out_f32, p.B, 8 * p.gh, 8 * p.gw, h->C, h->Cp, c.s));
+    } else {
+        return fail(MDPT_E_INVALID, "unknown tap %d", which);
+    }
+    return 0;
+}
+
+// ---- test hooks (tests/ only): truncate the encoder after (block, step) and read raw internal buffers as fp32
+int mdpt_debug_set_stop(mdpt_handle* h, int32_t block, int32_t step) {
+    if (!h) return fail(MDPT_E_INVALID, "null handle");
+    h->dbg_block = block; h->dbg_step = step;
+    return 0;
+}
+
+int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_floats, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+    if (!h || !name || !out_f32) return fail(MDPT_E_INVALID, "null argument");
+    if (!h->has_last) return fail(MDPT_E_STATE, "mdpt_debug_read needs a preceding mdpt_forward");
+    Ctx c;
+    c.h = h; c.p = h->last_plan; c.ws = (char*)workspace; c.s = (hipStream_t)stream;
+    CHK(check_ws(h, c.p, workspace, workspace_bytes));
+    const Plan& p = c.p;
+    const size_t rows = (size_t)p.B * p.npad;
+    const std::string n = name;
+    const size_t* planes = nullptr;
+    size_t f32_off = SIZE_MAX, elems = 0;
+    const size_t px[4] = {(size_t)16 * p.Np, (size_t)4 * p.Np, (size_t)p.Np, (size_t)p.Np / 4};
+    if (n == "im2col") { planes = p.im2col; elems = (size_t)p.B * p.Np * h->Kpatch; }
+    else if (n == "pos") { f32_off = p.pos; elems = (size_t)p.Np * h->F; }
+    else if (n == "resid") { f32_off = p.resid; elems = rows * h->F; }
+    else if (n == "xn") { planes = p.xn; elems = rows * h->F; }
+    else if (n == "q") { planes = p.q; elems = (size_t)p.B * h->heads * p.npad * 64; }
+    else if (n == "k") { planes = p.k; elems = (size_t)p.B * h->heads * p.npad * 64; }
+    else if (n == "vt") { planes = p.vt; elems = (size_t)p.B * h->heads * 64 * p.npadv; }
+    else if (n == "att") { planes = p.att; elems = rows * h->F; }
+    else if (n == "hbuf") { planes = p.hbuf; elems = rows * 4 * h->F; }
+    else if (n == "h1") { f32_off = p.h1; elems = (size_t)p.B * 64 * p.Np * h->C2p; }
+    else if (n == "h1u") { planes = p.h1u; elems = (size_t)p.B * p.H * p.W * h->C2p; }
+    else if (n == "fused") { planes = p.fused; elems = (size_t)p.B * 64 * p.Np * h->Cp; }
+    else if (n == "u0") { planes = p.u0; elems = (size_t)p.B * px[0] * h->hidp[0]; }
+    else if (n == "u1") { planes = p.u1; elems = (size_t)p.B * px[1] * h->hidp[1]; }
+    else if (n == "d3") { planes = p.d3; elems = (size_t)p.B * px[3] * h->hidp[3]; }
+    else if (n.size() == 2 && n[0] == 't' && n[1] >= '0' && n[1] <= '3') { const int i = n[1] - '0'; planes = p.t[i]; elems = (size_t)p.B * p.Np * h->hidp[i]; }
+    else if (n.size() == 4 && n.compare(0, 3, "flo") == 0 && n[3] >= '0' && n[3] <= '3') { const int i = n[3] - '0'; f32_off = p.flo[i]; elems = (size_t)p.B * px[i] * h->Cp; }
+    else if (n.size() == 3 && n.compare(0, 2, "xf") == 0 && n[2] >= '0' && n[2] <= '3') { const int i = n[2] - '0'; f32_off = p.x_f32[i]; elems = (size_t)p.B * px[i] * h->Cp; }
+    else if (n.size() == 3 && n.compare(0, 2, "a1") == 0 && n[2] >= '0' && n[2] <= '3') { const int i = n[2] - '0'; planes = p.a1[i]; elems = (size_t)p.B * px[i] * h->Cp; }
+    else if (n.size() == 3 && n.compare(0, 2, "b2") == 0 && n[2] >= '0' && n[2] <= '3') { const int i = n[2] - '0'; planes = p.b2[i]; elems = (size_t)p.B * px[i] * h->Cp; }
+    else return fail(MDPT_E_INVALID, "unknown debug buffer \"%s\"", name);
+    if (out_floats < elems) return fail(MDPT_E_WORKSPACE, "debug buffer %s needs %zu floats, got %zu", name, elems, out_floats);
+    // reuse the token exporter as a flat converter: B=1, N=npad=elems/F' with F'=4 keeps indices simple
+    if (planes) {
+        Planes pl = c.pl(planes);
+        CHK(mdpt_launch_tokens_export(pl.hi, pl.lo, nullptr, (float*)out_f32, 1, (int)(elems / 4), (int)(elems / 4), 4, 0, c.s));
+    } else {
+        CHK(mdpt_launch_tokens_export(nullptr, nullptr, c.at<float>(f32_off), (float*)out_f32, 1, (int)(elems / 4), (int)(elems / 4), 4, 0, c.s));
+    }
+    return 0;
+}
+
+// ---- RCCL all-gather wrapper (resolved lazily so the library itself has no link-time dependency on RCCL)
+int mdpt_allgather_f32(void* comm, const void* send_dev, void* recv_dev, size_t count_per_rank, void* stream) {
+    typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, void*);
+    static allgather_fn fn = nullptr;
+    if (!fn) {
+        void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return fail(MDPT_E_STATE, "cannot load librccl.so: %s", dlerror());
+        fn = (allgather_fn)dlsym(lib, "ncclAllGather");
+        if (!fn) return fail(MDPT_E_STATE, "ncclAllGather not found in librccl.so");
+    }
+    const int ncclFloat32 = 7;
+    const int rc = fn(send_dev, recv_dev, count_per_rank, ncclFloat32, comm, stream);
+    if (rc != 0) return fail(MDPT_E_STATE, "ncclAllGather failed with code %d", rc);
+    return 0;
+}
+
+}  // extern "C"

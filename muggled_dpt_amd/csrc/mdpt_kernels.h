@@ -1,0 +1,102 @@
+// Internal kernel-launcher interface of libmdpt (gfx950 only). Not part of the public C ABI
+// (that is include/mdpt.h); this header is shared by the .hip kernel files and mdpt_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+
+// ------------------------------------------------------------------------------------------------
+// GEMM / implicit-GEMM convolution family:  C[M,N] = A[M,K] * W[N,K]^T   (both operands K-contiguous)
+// A and W are bf16 "hi" planes plus optional "lo" planes (x = hi + lo, bf16x3 split precision).
+// ------------------------------------------------------------------------------------------------
+enum { MDPT_A_DENSE = 0, MDPT_A_TOKENS = 1, MDPT_A_CONV3 = 2 };
+enum { MDPT_E_GENERIC = 0, MDPT_E_QKV = 1, MDPT_E_PATCH = 2, MDPT_E_D2S = 3, MDPT_E_HEAD = 4 };
+enum { MDPT_ACT_NONE = 0, MDPT_ACT_RELU = 1, MDPT_ACT_GELU = 2 };
+enum { MDPT_TILE_AUTO = 0, MDPT_TILE_128x128 = 1, MDPT_TILE_256x256 = 2, MDPT_TILE_128x32 = 3, MDPT_TILE_256x128 = 4 };
+
+struct GemmParams {
+    // operands
+    const bf16_t* A_hi; const bf16_t* A_lo;   // activations, row stride lda (elements)
+    const bf16_t* W_hi; const bf16_t* W_lo;   // weights [N][K]
+    int M, N, K;                              // K % 64 == 0 (conv: K = 9 * Cin)
+    int lda;
+    int npass;                                // 1 = bf16, 3 = bf16x3 (A_lo*W_hi + A_hi*W_lo + A_hi*W_hi)
+    const bf16_t* zero_page;                  // >= 256 B of zeros (source for padded conv taps)
+    int amode, ekind, tile;
+    // A_TOKENS: logical row m = (b, p) reads source row b*tok_stride + 1 + p (skips the cls row)
+    int tok_np, tok_stride;
+    // A_CONV3: input NHWC [B,Hi,Wi,Cin] (Cin % 64 == 0), 3x3, pad 1, stride cstride -> [B,Ho,Wo,N]
+    int Hi, Wi, Cin, Ho, Wo, cstride;
+    // generic epilogue: v = acc (+bias[n]) -> act -> (*gamma[n]) (+resid[m,n]) (+up2x(up_src)[m,n])
+    const float* bias; const float* gamma; const float* resid; int ldr;
+    const float* up_src; int Hu, Wu;          // fp32 NHWC [B,Hu,Wu,N] added through x2 bilinear (align_corners)
+    int act;
+    float* out_f32; bf16_t* out_hi; bf16_t* out_lo; int ldc;
+    int relu_bf16;                            // apply ReLU to the bf16 planes only (fp32 copy stays raw)
+    // E_QKV: scatter to head-major Q (pre-scaled), K and transposed V
+    bf16_t* q_hi; bf16_t* q_lo; bf16_t* k_hi; bf16_t* k_lo; bf16_t* vt_hi; bf16_t* vt_lo;
+    int F, heads, npad, npadv; float qscale;
+    // E_PATCH: out_f32[(b*npad + 1 + p), n] = acc + bias[n] + pos[p, n]   (m = b*tok_np + p)
+    const float* pos;
+    // E_D2S: transposed conv k==s as GEMM: n = (ky*k + kx)*Cout + co ; out NHWC [B, Ho*k, Wo*k, Cout]
+    int d2s_k, d2s_cout;
+    // E_HEAD: N == 32: depth[m] = final( sum_n relu(acc+bias[n]) * head_w[n] + head_b )
+    const float* head_w; const float* head_b; int head_sigmoid; float* head_out;
+};
+
+int mdpt_launch_gemm(const GemmParams& p, hipStream_t stream);   // returns hipError_t as int
+
+// ------------------------------------------------------------------------------------------------
+// fused multi-head attention (head dim 64), Q/K head-major [B,H,npad,64], Vt [B,H,64,npadv]
+// ------------------------------------------------------------------------------------------------
+struct AttnParams {
+    const bf16_t* q_hi; const bf16_t* q_lo; const bf16_t* k_hi; const bf16_t* k_lo;
+    const bf16_t* vt_hi; const bf16_t* vt_lo;
+    bf16_t* out_hi; bf16_t* out_lo;           // [B*npad, F] token-major, column h*64 + d
+    int B, heads, N, npad, npadv, F;
+    int x3;
+};
+int mdpt_launch_attention(const AttnParams& p, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// bandwidth-bound helpers
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (eps 1e-6): fp32 rows -> bf16 hi (+lo) (+ optional fp32 copy)
+int mdpt_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* out_hi, bf16_t* out_lo,
+                          float* out_f32, int rows, int F, hipStream_t stream);
+// NCHW fp32 image -> im2col rows [B*Np, Kp] bf16 hi (+lo), k = c*P*P + ky*P + kx, zero padded to Kp
+int mdpt_launch_patchify(const float* img, bf16_t* out_hi, bf16_t* out_lo, int B, int H, int W, int P, int Kp,
+                         hipStream_t stream);
+// bicubic (A=-0.75, align_corners=False) resize of the [Gh*Gw, F] position grid to [gh*gw, F]
+int mdpt_launch_posembed(const float* base, float* out, int Gh, int Gw, int gh, int gw, int F, hipStream_t stream);
+// residual-stream init: cls rows = cls_token + cls_embedding, pad rows = 0 (patch rows are written by E_PATCH)
+int mdpt_launch_init_tokens(float* resid, const float* cls_token, const float* cls_embed, int B, int N, int npad, int F,
+                            hipStream_t stream);
+// zero the pad columns [N, npadv) of the transposed-V planes
+int mdpt_launch_zero_vt_pad(bf16_t* vt_hi, bf16_t* vt_lo, int rows, int N, int npadv, hipStream_t stream);
+// bilinear align_corners=True resize of fp32 NHWC [B,Hi,Wi,C] -> [B,Ho,Wo,C] as bf16 hi (+lo) and/or fp32
+int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float* out_f32, int B, int Hi, int Wi, int Ho,
+                         int Wo, int C, hipStream_t stream);
+// weight repack: fp32 source in PyTorch layout -> bf16 hi (+lo) [Np][Kp] rows, zero padded. Layout kinds:
+enum { MDPT_PACK_LINEAR = 0,   // src [N][K]
+       MDPT_PACK_CONV3 = 1,    // src [Cout][Cin][3][3] -> k = (ky*3+kx)*Cinp + ci
+       MDPT_PACK_CONVT = 2 };  // src [Cin][Cout][k][k] -> row n = (ky*k+kx)*Coutp + co, col ci
+int mdpt_launch_pack_weight(const float* src, bf16_t* dst_hi, bf16_t* dst_lo, int kind, int N, int K, int Np, int Kp,
+                            int ksz, hipStream_t stream);
+// fp32 vector copy with zero padding (biases); `rep` repeats are not needed: plain copy
+int mdpt_launch_pad_copy_f32(const float* src, float* dst, int n, int np, hipStream_t stream);
+// layout conversions for the stage-level API / debug taps
+int mdpt_launch_nhwc_to_nchw(const float* in_f32, const bf16_t* in_hi, const bf16_t* in_lo, float* out, int B, int H, int W,
+                             int C, int Cp, hipStream_t stream);
+int mdpt_launch_tokens_export(const bf16_t* in_hi, const bf16_t* in_lo, const float* in_f32, float* out, int B, int N,
+                              int npad, int F, int skip_cls, hipStream_t stream);
+int mdpt_launch_tokens_import(const float* in, bf16_t* out_hi, bf16_t* out_lo, int B, int N, int npad, int F,
+                              hipStream_t stream);
+int mdpt_launch_nchw_to_nhwc(const float* in, float* out_f32, bf16_t* out_hi, bf16_t* out_lo, int relu_bf16, int B, int H,
+                             int W, int C, int Cp, hipStream_t stream);
+// stage-level encoder entry: resid[b, 1+t, :] = tokens[b, t, :] + pos[t, :]
+int mdpt_launch_tokens_to_resid(const float* tokens, const float* pos, float* resid, int B, int Np, int npad, int F,
+                                hipStream_t stream);
+int mdpt_launch_memset_f32(float* dst, float value, size_t n, hipStream_t stream);

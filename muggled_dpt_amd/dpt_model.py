@@ -1,0 +1,397 @@
+"""DPTModel facade over libmdpt (MI355X-native). Mirrors the reference's public surface:
+
+    DPTModel.forward / inference / prepare_image_bgr / verify_input      reference muggled_dpt/dpt_model.py:61,87,113,133
+    model.patch_embed / imgencoder / reassemble / fusion / head           dpt_model.py:50-54 (callable one by one,
+                                                                           simple_examples/internal_features.py:39-45)
+    nn.Module plumbing: .to(device, dtype), .parameters(), .state_dict(), sub-module load_state_dict with the
+    reference's converted key names (make_depthanythingv2_dpt.py:55-59)
+
+The five sub-modules hold the parameters (fp32/bf16 nn.Parameters named exactly like the reference's) and forward to
+the stage entry points of the C ABI. All compute happens in hand-written HIP kernels; there is NO CPU or PyTorch
+fallback: calling the model on a CPU tensor raises.
+
+dtype semantics (the C ABI's `precision`):
+    model dtype float32   -> MDPT_PREC_BF16X3 (split-bf16 MFMA, fp32-class accuracy; the parity configuration)
+    model dtype bfloat16  -> MDPT_PREC_BF16   (single-pass bf16 MFMA; the reference's GPU default, misc.py:73-77)
+    model dtype float16   -> MDPT_PREC_BF16 arithmetic with fp16 tensors at the boundary
+Outputs have the model dtype and live on the model device; nothing synchronises (callers do `.cpu()` themselves).
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import native
+from .state_dict_conversion import COMPONENTS, expected_new_keys
+
+RGB_MEAN = (0.485, 0.456, 0.406)  # reference v2_depthanything/patch_embed.py:38
+RGB_STD = (0.229, 0.224, 0.225)   # :39
+
+
+class _Node(nn.Module):
+    """Anonymous container so dotted reference keys ("stages.0.blocks.1.attn.qkv.weight") become real module paths."""
+
+    def forward(self, *args, **kwargs):  # pragma: no cover - containers are not callable
+        raise RuntimeError("parameter container, not a callable layer")
+
+
+def _register_tree(root: nn.Module, shapes: dict[str, tuple]) -> None:
+    for key, shape in shapes.items():
+        parts = key.split(".")
+        mod = root
+        for name in parts[:-1]:
+            if not hasattr(mod, name):
+                mod.add_module(name, _Node())
+            mod = getattr(mod, name)
+        mod.register_parameter(parts[-1], nn.Parameter(torch.zeros(tuple(shape)), requires_grad=False))
+
+
+class _Stage(nn.Module):
+    """Base of the five sub-modules: owns its parameters, forwards to the engine of the parent DPTModel."""
+
+    def __init__(self, component: str, shapes: dict[str, tuple]):
+        super().__init__()
+        self._component = component
+        _register_tree(self, shapes)
+        self.__dict__["_owner"] = None  # set by DPTModel (kept out of the module tree to avoid cycles)
+
+    def _engine(self):
+        owner = self.__dict__["_owner"]
+        if owner is None:
+            raise RuntimeError("sub-module is not attached to a DPTModel")
+        return owner._get_engine()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        owner = self.__dict__["_owner"]
+        if owner is not None:
+            owner._invalidate()
+
+
+class PatchEmbed(_Stage):
+    """Image -> patch tokens. reference v2_depthanything/patch_embed.py:23-165."""
+
+    def __init__(self, shapes, patch_size_px: int, default_image_size: int):
+        super().__init__("patch_embed", shapes)
+        self.patch_size_px = patch_size_px
+        self._default_size_px = round(default_image_size)
+        self._tiling_size = round(2 * patch_size_px)  # patch_embed.py:69
+
+    def forward(self, image_tensor_bchw: Tensor) -> tuple[Tensor, tuple[int, int]]:
+        eng = self._engine()
+        x = eng.as_input(image_tensor_bchw, 4)
+        b, _, h, w = x.shape
+        gh, gw = h // self.patch_size_px, w // self.patch_size_px
+        out = torch.empty((b, gh * gw, eng.F), device=x.device, dtype=torch.float32)
+        eng.call("mdpt_patch_embed", x, b, h, w, out, size_hw=(h, w), batch=b)
+        return eng.as_output(out), (gh, gw)
+
+    def prepare_image(self, image_bgr: np.ndarray, max_side_length: int | None = None, use_square_sizing: bool = True,
+                      interpolation_mode: str = "bilinear") -> Tensor:
+        """uint8 HxWx3 BGR -> normalised [1,3,H',W'] on the model device/dtype (patch_embed.py:103-145).
+        Sides snap to multiples of 2*patch (so a 518x518 image is processed at 504x504)."""
+        if max_side_length is None:
+            max_side_length = self._default_size_px
+        img_h, img_w = image_bgr.shape[0:2]
+        largest_side = max(img_h, img_w)
+        scale = max_side_length / largest_side
+        targ_hw = (largest_side, largest_side) if use_square_sizing else (img_h, img_w)
+        scaled_hw = [max(1, round(side * scale / self._tiling_size)) * self._tiling_size for side in targ_hw]
+        p = next(self.parameters())
+        rgb = np.ascontiguousarray(image_bgr[:, :, ::-1].transpose(2, 0, 1))
+        x = torch.from_numpy(rgb).to(device=p.device, dtype=p.dtype)
+        x = nn.functional.interpolate(x.unsqueeze(0), size=scaled_hw, align_corners=False, antialias=True, mode=interpolation_mode)
+        mean = torch.tensor(RGB_MEAN, device=p.device, dtype=p.dtype).view(1, 3, 1, 1)
+        inv_std = 1.0 / torch.tensor(RGB_STD, device=p.device, dtype=p.dtype).view(1, 3, 1, 1)
+        return ((x / 255.0) - mean) * inv_std
+
+    def verify_input(self, image_tensor_bchw: Tensor) -> bool:
+        _, c, h, w = image_tensor_bchw.shape
+        assert c == 3, f"Bad channel count! Expected 3 got {c}"
+        s = self.patch_size_px
+        assert h % s == 0, f"Bad height! Image must have height ({h}) divisble by {s}"
+        assert w % s == 0, f"Bad width! Image must have width ({w}) divisble by {s}"
+        return True
+
+
+class ImageEncoder(_Stage):
+    """DINOv2 encoder with 4 taps. reference v2_depthanything/image_encoder_model.py:23-147."""
+
+    def forward(self, patch_tokens: Tensor, patch_grid_hw: tuple[int, int]):
+        eng = self._engine()
+        x = eng.as_input(patch_tokens, 3)
+        gh, gw = int(patch_grid_hw[0]), int(patch_grid_hw[1])
+        b = x.shape[0]
+        assert x.shape[1] == gh * gw and x.shape[2] == eng.F, f"tokens {tuple(x.shape)} do not match grid {gh}x{gw}, F={eng.F}"
+        outs = [torch.empty((b, gh * gw + 1, eng.F), device=x.device, dtype=torch.float32) for _ in range(4)]
+        eng.call("mdpt_encoder", x, b, gh, gw, eng.ptr_array(outs), size_hw=((gh + gh % 2) * eng.P, (gw + gw % 2) * eng.P), batch=b)
+        return tuple(eng.as_output(o) for o in outs)
+
+
+class ReassembleModel(_Stage):
+    """4 token stages -> 4 image-like maps. reference v2_depthanything/reassembly_model.py:21-310."""
+
+    def forward(self, stage_1_tokens, stage_2_tokens, stage_3_tokens, stage_4_tokens, patch_grid_hw):
+        eng = self._engine()
+        gh, gw = int(patch_grid_hw[0]), int(patch_grid_hw[1])
+        xs = [eng.as_input(t, 3) for t in (stage_1_tokens, stage_2_tokens, stage_3_tokens, stage_4_tokens)]
+        b = xs[0].shape[0]
+        c = eng.C
+        sizes = [(4 * gh, 4 * gw), (2 * gh, 2 * gw), (gh, gw), (gh // 2, gw // 2)]
+        outs = [torch.empty((b, c, sh, sw), device=xs[0].device, dtype=torch.float32) for sh, sw in sizes]
+        eng.call("mdpt_reassemble", eng.ptr_array(xs), b, gh, gw, eng.ptr_array(outs), size_hw=(gh * eng.P, gw * eng.P), batch=b)
+        return tuple(eng.as_output(o) for o in outs)
+
+
+class FusionModel(_Stage):
+    """RefineNet-style coarse-to-fine fusion. reference v2_depthanything/fusion_model.py:20-220."""
+
+    def forward(self, upx4_featuremap, upx2_featuremap, noscale_featuremap, downx2_featuremap):
+        eng = self._engine()
+        xs = [eng.as_input(t, 4) for t in (upx4_featuremap, upx2_featuremap, noscale_featuremap, downx2_featuremap)]
+        b, _, gh, gw = xs[2].shape
+        if xs[3].shape[2] * 2 != gh or xs[3].shape[3] * 2 != gw or xs[0].shape[2] != 4 * gh or xs[1].shape[2] != 2 * gh:
+            # same failure class as the reference (size mismatch at fusion_model.py:151)
+            raise RuntimeError(f"fusion inputs are not scaled x2 relative to each other: {[tuple(x.shape) for x in xs]}")
+        out = torch.empty((b, eng.C, 8 * gh, 8 * gw), device=xs[0].device, dtype=torch.float32)
+        eng.call("mdpt_fusion", eng.ptr_array(xs), b, gh, gw, out, size_hw=(gh * eng.P, gw * eng.P), batch=b)
+        return eng.as_output(out)
+
+
+class MonocularDepthHead(_Stage):
+    """Feature map -> inverse depth. reference v2_depthanything/head_model.py:20-106."""
+
+    def forward(self, imagelike_bchw: Tensor) -> Tensor:
+        eng = self._engine()
+        x = eng.as_input(imagelike_bchw, 4)
+        b, _, fh, fw = x.shape
+        gh, gw = fh // 8, fw // 8
+        out = torch.empty((b, gh * eng.P, gw * eng.P), device=x.device, dtype=torch.float32)
+        eng.call("mdpt_head", x, b, gh, gw, out, size_hw=(gh * eng.P, gw * eng.P), batch=b)
+        return eng.as_output(out)
+
+
+class _Engine:
+    """Owns the C handle, the packed-weight buffer and cached workspaces for one (device, dtype) of a DPTModel."""
+
+    def __init__(self, model: "DPTModel", device: torch.device, dtype: torch.dtype):
+        if device.type != "cuda":
+            raise RuntimeError(
+                f"muggled_dpt_amd runs on MI355X GPUs only (model is on '{device}'); there is no CPU fallback. "
+                "Move the model with .to('cuda').")
+        self.lib = native.load()
+        self.device, self.dtype = device, dtype
+        cfg = model.config
+        self.F, self.C, self.P = cfg["features_per_token"], cfg["fusion_channels"], cfg["patch_size_px"]
+        c = native.MdptConfig()
+        c.features_per_token, c.num_heads, c.num_blocks = cfg["features_per_token"], cfg["num_heads"], cfg["num_blocks"]
+        for i in range(4):
+            c.reassembly_features[i] = int(cfg["reassembly_features_list"][i])
+        c.base_patch_grid_h, c.base_patch_grid_w = (int(v) for v in cfg["base_patch_grid_hw"])
+        c.fusion_channels, c.patch_size_px = cfg["fusion_channels"], cfg["patch_size_px"]
+        c.is_giant, c.is_metric = int(bool(cfg.get("is_giant", False))), int(bool(cfg.get("is_metric", False)))
+        c.precision = native.PREC_BF16X3 if dtype == torch.float32 else native.PREC_BF16
+        self.precision = c.precision
+        handle = ctypes.c_void_p()
+        native.check(self.lib, self.lib.mdpt_create(ctypes.byref(c), ctypes.byref(handle)))
+        self.handle = handle
+        self._workspaces: dict[tuple, torch.Tensor] = {}
+        tile = model.__dict__.get("_gemm_tile", 0)
+        if tile:
+            native.check(self.lib, self.lib.mdpt_set_gemm_tile(self.handle, tile))
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            keep = []
+            params = {f"{comp}.{k}": v for comp in COMPONENTS for k, v in getattr(model, comp).state_dict().items()}
+            for i in range(self.lib.mdpt_num_weights(self.handle)):
+                name = self.lib.mdpt_weight_name(self.handle, i).decode()
+                if name not in params:
+                    raise RuntimeError(f"Missing key(s) in state_dict: \"{name}\"")
+                t = params[name].detach().to(device=device, dtype=torch.float32).contiguous()
+                keep.append(t)
+                shape = (ctypes.c_int64 * t.dim())(*t.shape)
+                native.check(self.lib, self.lib.mdpt_bind_weight(self.handle, name.encode(), t.data_ptr(), t.dim(), shape))
+            nbytes = ctypes.c_size_t()
+            native.check(self.lib, self.lib.mdpt_packed_bytes(self.handle, ctypes.byref(nbytes)))
+            self.packed = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=device)
+            self._packed_ptr = (self.packed.data_ptr() + 255) & ~255
+            native.check(self.lib, self.lib.mdpt_finalize(self.handle, self._packed_ptr, nbytes.value, stream))
+            torch.cuda.current_stream(device).synchronize()  # fp32 sources in `keep` may be freed after this
+            del keep
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.mdpt_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- tensor plumbing
+    def as_input(self, t: Tensor, ndim: int) -> Tensor:
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("expected a torch.Tensor")
+        if t.dim() != ndim:
+            raise RuntimeError(f"expected a {ndim}-D tensor, got shape {tuple(t.shape)}")
+        if t.device != self.device:
+            raise RuntimeError(f"Expected all tensors to be on the same device, model is on {self.device} but input is on {t.device}")
+        return t.detach().to(dtype=torch.float32).contiguous()
+
+    def as_output(self, t: Tensor) -> Tensor:
+        return t if self.dtype == torch.float32 else t.to(self.dtype)
+
+    def ptr_array(self, tensors):
+        arr = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in tensors])
+        arr._keep = tensors
+        return arr
+
+    def workspace(self, batch: int, size_hw: tuple[int, int]) -> tuple[int, int]:
+        key = (batch, int(size_hw[0]), int(size_hw[1]))
+        ws = self._workspaces.get(key)
+        if ws is None:
+            nbytes = ctypes.c_size_t()
+            native.check(self.lib, self.lib.mdpt_workspace_bytes(self.handle, batch, key[1], key[2], ctypes.byref(nbytes)))
+            if len(self._workspaces) >= 2:
+                self._workspaces.clear()
+            ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
+            self._workspaces[key] = ws
+        ptr = (ws.data_ptr() + 255) & ~255
+        return ptr, ws.numel() - (ptr - ws.data_ptr())
+
+    def call(self, fn_name: str, *args, size_hw, batch):
+        """Invoke a stage entry point: (handle, *args, workspace, ws_bytes, stream) on the current torch stream."""
+        with torch.cuda.device(self.device):
+            ws_ptr, ws_bytes = self.workspace(batch, size_hw)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            cargs = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
+            native.check(self.lib, getattr(self.lib, fn_name)(self.handle, *cargs, ws_ptr, ws_bytes, stream))
+
+    def export_tap(self, which: int, out: Tensor, batch: int, size_hw):
+        with torch.cuda.device(self.device):
+            ws_ptr, ws_bytes = self.workspace(batch, size_hw)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            native.check(self.lib, self.lib.mdpt_export_tap(self.handle, which, out.data_ptr(), ws_ptr, ws_bytes, stream))
+
+
+class DPTModel(nn.Module):
+    """Drop-in for the reference's DPTModel (muggled_dpt/dpt_model.py:21-168) running on libmdpt."""
+
+    def __init__(self, config: dict):
+        super().__init__()
+        self.config = dict(config)
+        keys = expected_new_keys(self.config)
+        shapes = _new_key_shapes(self.config)
+        per = {comp: {k: shapes[f"{comp}.{k}"] for k in keys[comp]} for comp in COMPONENTS}
+        default_px = self.config["base_patch_grid_hw"][0] * self.config["patch_size_px"]
+        self.patch_embed = PatchEmbed(per["patch_embed"], self.config["patch_size_px"], default_px)
+        self.imgencoder = ImageEncoder("imgencoder", per["imgencoder"])
+        self.reassemble = ReassembleModel("reassemble", per["reassemble"])
+        self.fusion = FusionModel("fusion", per["fusion"])
+        self.head = MonocularDepthHead("head", per["head"])
+        for comp in COMPONENTS:
+            getattr(self, comp).__dict__["_owner"] = self
+        self.__dict__["_engine_obj"] = None
+        self.__dict__["_gemm_tile"] = 0
+        self.eval()  # inference only (dpt_model.py:57)
+
+    # ---- engine lifetime
+    def _invalidate(self):
+        self.__dict__["_engine_obj"] = None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._invalidate()
+        return out
+
+    def _get_engine(self) -> _Engine:
+        p = next(self.parameters())
+        eng = self.__dict__["_engine_obj"]
+        if eng is None or eng.device != p.device or eng.dtype != p.dtype:
+            eng = _Engine(self, p.device, p.dtype)
+            self.__dict__["_engine_obj"] = eng
+        return eng
+
+    def set_gemm_tile(self, tile: int) -> None:
+        """Benchmark knob: 0 auto, 1 = 128x128, 2 = 256x256 GEMM tiles."""
+        self.__dict__["_gemm_tile"] = int(tile)
+        self._invalidate()
+
+    # ---- reference API
+    def forward(self, image_rgb_normalized_bchw: Tensor) -> Tensor:
+        """[B,3,H,W] normalised RGB -> inverse depth [B,H,W] (dpt_model.py:61-83), one fused C-ABI call."""
+        eng = self._get_engine()
+        x = eng.as_input(image_rgb_normalized_bchw, 4)
+        b, c, h, w = x.shape
+        if c != 3:
+            raise RuntimeError(f"expected 3 input channels, got {c}")
+        out = torch.empty((b, h, w), device=x.device, dtype=torch.float32)
+        try:
+            eng.call("mdpt_forward", x, b, h, w, out, size_hw=(h, w), batch=b)
+        except native.MdptError as e:
+            if e.code == native.E_GRID:
+                raise RuntimeError(str(e)) from None  # the reference raises RuntimeError for odd grids too
+            raise
+        return eng.as_output(out)
+
+    def inference(self, image_bgr: np.ndarray, max_side_length: int | None = None, use_square_sizing: bool = True) -> Tensor:
+        """prepare_image + forward under inference_mode -> [1,H,W] (dpt_model.py:87-109)."""
+        with torch.inference_mode():
+            x = self.patch_embed.prepare_image(image_bgr, max_side_length, use_square_sizing)
+            return self(x)
+
+    def prepare_image_bgr(self, image_bgr: np.ndarray, max_side_length: int | None = None, use_square_sizing: bool = True,
+                          interpolation_mode: str = "bilinear") -> Tensor:
+        return self.patch_embed.prepare_image(image_bgr, max_side_length, use_square_sizing, interpolation_mode)
+
+    def verify_input(self, image_rgb_normalized_bchw: Tensor) -> bool:
+        """Same assertions as dpt_model.py:133-166."""
+        assert isinstance(image_rgb_normalized_bchw, torch.Tensor), "Image must be provided as a tensor!"
+        p = next(self.parameters())
+        img = image_rgb_normalized_bchw
+        assert img.device == p.device, f"Device mismatch! Image: {img.device}, model: {p.device}"
+        assert img.dtype == p.dtype, f"Data type mismatch! Image: {img.dtype}, model: {p.dtype}"
+        shape_str = "x".join(str(v) for v in img.shape)
+        assert len(img.shape) == 4, f"Bad image shape! Image ({shape_str}) should have a shape of BxCXHxW"
+        return self.patch_embed.verify_input(img)
+
+    # ---- extras (not in the reference): stage boundaries of the last forward, for parity tests
+    def debug_taps(self, batch: int, size_hw: tuple[int, int]) -> dict:
+        eng = self._get_engine()
+        h, w = size_hw
+        gh, gw = h // eng.P, w // eng.P
+        n = gh * gw + 1
+        dev = eng.device
+        out = {"stages": [], "reasm": []}
+        for i in range(4):
+            t = torch.empty((batch, n, eng.F), device=dev, dtype=torch.float32)
+            eng.export_tap(i, t, batch, size_hw)
+            out["stages"].append(t)
+        for i, (sh, sw) in enumerate([(4 * gh, 4 * gw), (2 * gh, 2 * gw), (gh, gw), (gh // 2, gw // 2)]):
+            t = torch.empty((batch, eng.C, sh, sw), device=dev, dtype=torch.float32)
+            eng.export_tap(4 + i, t, batch, size_hw)
+            out["reasm"].append(t)
+        t = torch.empty((batch, eng.C, 8 * gh, 8 * gw), device=dev, dtype=torch.float32)
+        eng.export_tap(8, t, batch, size_hw)
+        out["fused"] = t
+        return out
+
+
+def _new_key_shapes(cfg: dict) -> dict[str, tuple]:
+    """Shapes of every new-format parameter, derived from the config (same inventory as the C side)."""
+    from .synthetic import original_state_dict_shapes
+    from .state_dict_conversion import original_to_new_key_table
+
+    orig = original_state_dict_shapes(cfg)
+    table = original_to_new_key_table(cfg)
+    shapes = {}
+    for old, (comp, new) in table.items():
+        shapes[f"{comp}.{new}"] = tuple(orig[old])
+    pe = orig["pretrained.pos_embed"]
+    shapes["imgencoder.posenc.cls_embedding"] = (1, 1, pe[2])
+    shapes["imgencoder.posenc.base_patch_embedding"] = (1, pe[1] - 1, pe[2])
+    return shapes

@@ -1,0 +1,149 @@
+"""Build + ctypes binding of libmdpt.so (the C ABI declared in include/mdpt.h).
+
+The shared library is built IN-TREE (muggled_dpt_amd/csrc/libmdpt.so) with hipcc for gfx950 only;
+it links against the HIP runtime and nothing else (no torch types cross the boundary).
+There is no fallback: if the library is missing and cannot be built, importing callers get a loud
+RuntimeError - the product never silently runs on a CPU/PyTorch path.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(CSRC, "libmdpt.so")
+SOURCES = ("gemm.hip", "attention.hip", "elementwise.hip", "mdpt_api.cpp")
+HEADERS = ("mdpt_kernels.h", os.path.join(REPO, "include", "mdpt.h"))
+
+PREC_BF16 = 0
+PREC_BF16X3 = 1
+E_GRID = -7
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libmdpt.so cannot be built (set HIPCC or install ROCm)")
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into csrc/libmdpt.so (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = _hipcc()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(REPO, "include"), "-I", CSRC,
+             "-Wno-unused-result"]
+    objs = []
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc, *flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    tmp = LIB_PATH + ".tmp"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp, "-ldl"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+class MdptConfig(ctypes.Structure):
+    _fields_ = [
+        ("features_per_token", ctypes.c_int32),
+        ("num_heads", ctypes.c_int32),
+        ("num_blocks", ctypes.c_int32),
+        ("reassembly_features", ctypes.c_int32 * 4),
+        ("base_patch_grid_h", ctypes.c_int32),
+        ("base_patch_grid_w", ctypes.c_int32),
+        ("fusion_channels", ctypes.c_int32),
+        ("patch_size_px", ctypes.c_int32),
+        ("is_giant", ctypes.c_int32),
+        ("is_metric", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
+    ]
+
+
+# every symbol include/mdpt.h declares: (restype, argtypes)
+_VP = ctypes.c_void_p
+_SZ = ctypes.c_size_t
+_I = ctypes.c_int32
+_VP4 = ctypes.POINTER(ctypes.c_void_p)
+SYMBOLS = {
+    "mdpt_abi_version": (ctypes.c_int, []),
+    "mdpt_last_error": (ctypes.c_char_p, []),
+    "mdpt_create": (ctypes.c_int, [ctypes.POINTER(MdptConfig), ctypes.POINTER(_VP)]),
+    "mdpt_destroy": (None, [_VP]),
+    "mdpt_num_weights": (ctypes.c_int, [_VP]),
+    "mdpt_weight_name": (ctypes.c_char_p, [_VP, ctypes.c_int]),
+    "mdpt_weight_shape": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_int64)]),
+    "mdpt_bind_weight": (ctypes.c_int, [_VP, ctypes.c_char_p, _VP, _I, ctypes.POINTER(ctypes.c_int64)]),
+    "mdpt_packed_bytes": (ctypes.c_int, [_VP, ctypes.POINTER(_SZ)]),
+    "mdpt_finalize": (ctypes.c_int, [_VP, _VP, _SZ, _VP]),
+    "mdpt_workspace_bytes": (ctypes.c_int, [_VP, _I, _I, _I, ctypes.POINTER(_SZ)]),
+    "mdpt_forward": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
+    "mdpt_patch_embed": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
+    "mdpt_encoder": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP4, _VP, _SZ, _VP]),
+    "mdpt_reassemble": (ctypes.c_int, [_VP, _VP4, _I, _I, _I, _VP4, _VP, _SZ, _VP]),
+    "mdpt_fusion": (ctypes.c_int, [_VP, _VP4, _I, _I, _I, _VP, _VP, _SZ, _VP]),
+    "mdpt_head": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
+    "mdpt_export_tap": (ctypes.c_int, [_VP, _I, _VP, _VP, _SZ, _VP]),
+    "mdpt_set_gemm_tile": (ctypes.c_int, [_VP, _I]),
+    "mdpt_debug_set_stop": (ctypes.c_int, [_VP, _I, _I]),
+    "mdpt_debug_read": (ctypes.c_int, [_VP, ctypes.c_char_p, _VP, _SZ, _VP, _SZ, _VP]),
+    "mdpt_allgather_f32": (ctypes.c_int, [_VP, _VP, _VP, _SZ, _VP]),
+}
+
+_LIB = None
+
+
+def load(auto_build: bool = True) -> ctypes.CDLL:
+    """dlopen csrc/libmdpt.so (building it first if needed) and type every entry point."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if auto_build and _stale():
+        build()
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI drift between mdpt.h and the .so
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mdpt_abi_version() != 1:
+        raise RuntimeError("libmdpt ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+class MdptError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libmdpt error {code}: {message}")
+        self.code = code
+
+
+def check(lib: ctypes.CDLL, rc: int) -> None:
+    if rc != 0:
+        raise MdptError(rc, lib.mdpt_last_error().decode("utf-8", "replace"))
