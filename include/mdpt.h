@@ -120,6 +120,17 @@ int mdpt_debug_set_stop(mdpt_handle* h, int32_t block, int32_t step);
 int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_floats, void* workspace, size_t workspace_bytes,
                     void* stream);
 
+/* Kernel micro-benchmark hook: `iters` launches of the dense GEMM kernel, out[M,N] = A[M,K] * W[N,K]^T (bf16 operands,
+ * fp32 and/or bf16 output), tile as in mdpt_set_gemm_tile. */
+int mdpt_debug_gemm(const void* a_bf16, const void* w_bf16, void* out_f32, void* out_bf16, int32_t M, int32_t N, int32_t K,
+                    int32_t tile, int32_t iters, void* stream, void* dbg_times_or_null);
+
+/* Per-launch HIP-event profiler (bench.py's roofline leg): events are recorded on the launch stream around every
+ * kernel launch while enabled. mdpt_profile_report() waits for the recorded events and writes a JSON summary
+ * {"kernels":[{"name","launches","total_ms","avg_us","gflop","tflops"}...]} (algorithmic flops: 2*M*N*K per GEMM). */
+int mdpt_profile_enable(int on);
+int mdpt_profile_report(char* json_buf, size_t capacity);
+
 /* Tuning knob for benchmarks: force a GEMM tile (0 = auto, 1 = 128x128, 2 = 256x256). */
 int mdpt_set_gemm_tile(mdpt_handle* h, int32_t tile);
 

@@ -19,6 +19,7 @@
 // x3 mode: hi/lo bf16 planes for Q, K, V and P (3 MFMAs per product) -> fp32-class accuracy.
 
 #include "mdpt_kernels.h"
+#include "mdpt_prof.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -96,6 +97,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 
     issue_tile(0, 0);
     for (int t = 0; t < ntiles; ++t) {
+        // LDS-DMA completion is tracked by vmcnt; hipcc does NOT reliably wait for it before the barrier
+        // (observed: only lgkmcnt(0) in this loop -> rare stale K/V tiles). Wait explicitly, then publish.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < ntiles) issue_tile(t + 1, (t + 1) & 1);
         const char* sK = smem + (t & 1) * STAGE;
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 int mdpt_launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.F != p.heads * 64 || (p.npadv & 63) || p.npadv < ((p.N + 63) & ~63) || p.npad < p.N) return (int)hipErrorInvalidValue;
     const dim3 grid((p.npad + 127) / 128, p.heads, p.B);
+    MdptProfScope prof(p.x3 ? "attn_kernel<true>" : "attn_kernel<false>", 4.0 * p.B * p.heads * (double)p.N * p.N * 64.0, stream);
     if (p.x3) {
         hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 2 * 2 * 2 * 8192, stream, p);
     } else {

@@ -3,6 +3,7 @@
 // conversion. All are coalesced 8/16-byte-per-lane streaming kernels; none reshapes work into a GEMM.
 
 #include "mdpt_kernels.h"
+#include "mdpt_prof.h"
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -34,6 +35,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ---------------------------------------------------------------------------------------------------
 constexpr int LN_MAXV = 8;  // up to F = 2048
 
+template <int NV>  // NV float4 per lane: F <= 256*NV
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, bf16_t* out_hi, bf16_t* out_lo,
                                                         float* out_f32, int rows, int F) {
@@ -41,10 +43,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (size_t)row * F;
-    f32x4 v[LN_MAXV];
+    f32x4 v[NV];
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < F) {
             v[i] = *(const f32x4*)(xr + c);
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float mean = wave_sum(s) / (float)F;
     float ss = 0.0f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < F) {
 #pragma unroll
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     const float rstd = rsqrtf(wave_sum(ss) / (float)F + 1e-6f);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < F) {
             const f32x4 g = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
@@ -342,17 +344,27 @@ int mdpt_launch_layernorm(const float* x, const float* gamma, const float* beta,
                           int rows, int F, hipStream_t stream) {
     if ((F & 3) || F > 64 * 4 * LN_MAXV) return (int)hipErrorInvalidValue;
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, out_hi, out_lo, out_f32, rows, F);
+    MdptProfScope prof("layernorm_kernel", 0.0, stream);
+    const dim3 grid((rows + 3) / 4), block(256);
+#define LN_CASE(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, stream, x, gamma, beta, out_hi, out_lo, out_f32, rows, F)
+    if (F <= 256) LN_CASE(1);
+    else if (F <= 512) LN_CASE(2);
+    else if (F <= 1024) LN_CASE(4);
+    else if (F <= 1536) LN_CASE(6);
+    else LN_CASE(8);
+#undef LN_CASE
     LAUNCH_RET();
 }
 
 int mdpt_launch_patchify(const float* img, bf16_t* out_hi, bf16_t* out_lo, int B, int H, int W, int P, int Kp, hipStream_t stream) {
     const size_t total = (size_t)B * (H / P) * (W / P) * (Kp / 4);
+    MdptProfScope prof("patchify_kernel", 0.0, stream);
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, stream, img, out_hi, out_lo, B, H, W, P, Kp);
     LAUNCH_RET();
 }
 
 int mdpt_launch_posembed(const float* base, float* out, int Gh, int Gw, int gh, int gw, int F, hipStream_t stream) {
+    MdptProfScope prof("posembed_kernel", 0.0, stream);
     hipLaunchKernelGGL(posembed_kernel, dim3(grid_for((size_t)gh * gw * F)), dim3(256), 0, stream, base, out, Gh, Gw, gh, gw, F);
     LAUNCH_RET();
 }
@@ -360,12 +372,14 @@ int mdpt_launch_posembed(const float* base, float* out, int Gh, int Gw, int gh, 
 int mdpt_launch_init_tokens(float* resid, const float* cls_token, const float* cls_embed, int B, int N, int npad, int F,
                             hipStream_t stream) {
     const size_t total = (size_t)B * (1 + npad - N) * F;
+    MdptProfScope prof("init_tokens_kernel", 0.0, stream);
     hipLaunchKernelGGL(init_tokens_kernel, dim3(grid_for(total)), dim3(256), 0, stream, resid, cls_token, cls_embed, B, N, npad, F);
     LAUNCH_RET();
 }
 
 int mdpt_launch_zero_vt_pad(bf16_t* vt_hi, bf16_t* vt_lo, int rows, int N, int npadv, hipStream_t stream) {
     if (npadv == N) return 0;
+    MdptProfScope prof("zero_vt_pad_kernel", 0.0, stream);
     hipLaunchKernelGGL(zero_vt_pad_kernel, dim3(grid_for((size_t)rows * (npadv - N))), dim3(256), 0, stream, vt_hi, vt_lo, rows, N, npadv);
     LAUNCH_RET();
 }
@@ -374,6 +388,7 @@ int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float*
                          int C, hipStream_t stream) {
     if (C & 3) return (int)hipErrorInvalidValue;
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    MdptProfScope prof("upsample_kernel", 0.0, stream);
     hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, stream, in, out_hi, out_lo, out_f32, B, Hi, Wi, Ho, Wo, C);
     LAUNCH_RET();
 }

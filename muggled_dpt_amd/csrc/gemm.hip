@@ -28,6 +28,14 @@
 // each XCD is given a contiguous run of tiles (same A rows, all N tiles) to keep operand panels L2-resident.
 
 #include "mdpt_kernels.h"
+#include "mdpt_prof.h"
+#include <stdio.h>
+
+// Results must not depend on which tile instantiation a launch picks (the tile is chosen from the batch size, and
+// data-parallel sharding must reproduce the single-GPU result bit for bit): with the default fp-contract=fast the
+// compiler fuses the epilogue's mul/add chains differently per instantiation (seen: 2e-6 differences in the
+// bilinear-add epilogue between the 128x128 and 256x256 kernels). Epilogue arithmetic is a negligible cost.
+#pragma clang fp contract(off)
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -40,6 +48,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
     // 64 lanes x 16 B -> lds_wave_base + lane*16 (destination is wave-uniform base + lane*16)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ unsigned long long memtime_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
 }
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
@@ -57,20 +71,43 @@ __device__ __forceinline__ void split_store4(bf16_t* hi, bf16_t* lo, size_t off,
     }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int EKIND>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ void split_store8(bf16_t* hi, bf16_t* lo, size_t off, f32x4 v0, f32x4 v1) {
+    bf16x8 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v0[e]; h[e + 4] = (__bf16)v1[e]; }
+    *(bf16x8*)(hi + off) = h;
+    if (lo) {
+        bf16x8 l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { l[e] = (__bf16)(v0[e] - (float)h[e]); l[e + 4] = (__bf16)(v1[e] - (float)h[e + 4]); }
+        *(bf16x8*)(lo + off) = l;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int NST, int MINW, int AMODE, int EKIND>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int CA = BM / 8 / NW, CB = BN / 8 / NW;  // 1-KiB LDS-DMA chunks (8 rows x 128 B) per wave
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "chunk split");
+    constexpr int ROWB = BK * 2;        // bytes per LDS row (one K slab of one tile row)
+    constexpr int CPR = BK / 8;         // 16-B chunks per row
+    constexpr int RPC = 64 / CPR;       // rows per 1-KiB LDS-DMA chunk (one wave instruction)
+    constexpr int RPB = 256 / ROWB;     // rows per 256-B LDS bank row
+    constexpr int KSTEPS = BK / 16;     // 32x32x16 MFMA k-steps per slab
+    constexpr int CA = BM / RPC / NW, CB = BN / RPC / NW;  // DMA chunks per wave per stage
+    constexpr int NLOAD = CA + CB;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    static_assert(BK == 32 || BK == 64, "BK");
+    static_assert(NST == 2 || NST == 3, "ring depth");
+    static_assert(BM % (RPC * NW) == 0 && BN % (RPC * NW) == 0, "chunk split");
     static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
-    static_assert(32 * WTN * 4 * NW <= 2 * STAGE, "epilogue strip must fit in the ring");
+    static_assert(32 * WTN * 4 * NW <= NST * STAGE, "epilogue strip must fit in the ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long t_start = 0, t_first = 0, t_loop = 0;
+    if (p.dbg_times) t_start = memtime_now();
 
     // ---- XCD-aware tile mapping (bijective for any grid size)
     const int tiles_n = (p.N + BN - 1) / BN;
@@ -81,23 +118,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
     const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- per-lane staging addresses. Lane feeds LDS row (chunk*8 + lane>>3), slot (lane&7) of that row,
-    //      which must hold global 16-B chunk (slot ^ swizzle(row)).
-    const int lrow = lane >> 3, slot = lane & 7;
-    const int sw_stage = ((wave & 1) * 4 + (lrow >> 1)) & 7;  // ((row>>1)&7) for row = (wave + NW*i)*8 + lrow
-    const int koff = (slot ^ sw_stage) * 8;                   // element offset inside the 64-wide K slab
-
-    size_t a_off[CA];
-    int a_pix[CA], a_y[CA], a_x[CA];
+    // ---- per-lane staging addresses. A DMA chunk is RPC rows x ROWB bytes; the lane feeds LDS row
+    //      (chunk*RPC + lane/CPR), 16-B slot (lane%CPR), which must hold global chunk (slot ^ key(row)) with
+    //      key(row) = (row / RPB) & (CPR-1)  (spreads 16 consecutive rows over the 16 slots of a 256-B bank row).
+    const int lrow = lane / CPR, slot = lane % CPR;
+    // row = (wave + NW*i)*RPC + lrow; RPC is a multiple of RPB*CPR only for... compute the key per chunk below.
+    const bf16_t* a_ptr[CA];   // DENSE/TOKENS: running source pointer (advanced by BK per stage)
+    int a_pix[CA], a_y[CA], a_x[CA], a_ko[CA];
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
-        int m = m0 + (wave + NW * i) * 8 + lrow;
+        const int r = (wave + NW * i) * RPC + lrow;
+        const int koff = (slot ^ ((r / RPB) & (CPR - 1))) * 8;
+        int m = m0 + r;
         m = m < p.M ? m : p.M - 1;  // clamp: rows past M are computed and discarded
+        const bf16_t* A0 = p.npass == 3 ? p.A_lo : p.A_hi;  // pass 0 plane
         if (AMODE == MDPT_A_DENSE) {
-            a_off[i] = (size_t)m * p.lda;
+            a_ptr[i] = A0 + (size_t)m * p.lda + koff;
         } else if (AMODE == MDPT_A_TOKENS) {
             const int b = m / p.tok_np, t = m - b * p.tok_np;
-            a_off[i] = ((size_t)b * p.tok_stride + 1 + t) * p.lda;
+            a_ptr[i] = A0 + ((size_t)b * p.tok_stride + 1 + t) * p.lda + koff;
         } else {
             const int hw = p.Ho * p.Wo;
             const int b = m / hw, rem = m - b * hw;
@@ -105,21 +144,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
             a_pix[i] = b * p.Hi * p.Wi;
             a_y[i] = y * p.cstride - 1;
             a_x[i] = x * p.cstride - 1;
-            a_off[i] = 0;
+            a_ko[i] = koff;
+            a_ptr[i] = nullptr;
         }
     }
-    size_t b_off[CB];
+    const bf16_t* b_ptr[CB];
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
-        int n = n0 + (wave + NW * i) * 8 + lrow;
+        const int r = (wave + NW * i) * RPC + lrow;
+        const int koff = (slot ^ ((r / RPB) & (CPR - 1))) * 8;
+        int n = n0 + r;
         n = n < p.N ? n : p.N - 1;
-        b_off[i] = (size_t)n * p.K;
+        b_ptr[i] = p.W_hi + (size_t)n * p.K + koff;
     }
+    // plane switches at pass roll-over (bf16x3: passes are A_lo*W_hi, A_hi*W_lo, A_hi*W_hi); all wave-uniform
+    const ptrdiff_t a_hi_minus_lo = p.npass == 3 ? p.A_hi - p.A_lo : 0;
+    const ptrdiff_t w_lo_minus_hi = p.npass == 3 ? p.W_lo - p.W_hi : 0;
+    const bf16_t* conv_plane = p.npass == 3 ? p.A_lo : p.A_hi;
 
     int st_pass = 0, st_k0 = 0, st_tap = 0, st_ci = 0;
     auto issue_stage = [&](int buf) {
-        const bf16_t* Ap = (p.npass == 3 && st_pass == 0) ? p.A_lo : p.A_hi;
-        const bf16_t* Wp = (p.npass == 3 && st_pass == 1) ? p.W_lo : p.W_hi;
         char* sA = smem + buf * STAGE;
         char* sB = sA + A_BYTES;
 #pragma unroll
@@ -129,28 +173,43 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
                 const int ky = (st_tap * 11) >> 5, kx = st_tap - 3 * ky;
                 const int iy = a_y[i] + ky, ix = a_x[i] + kx;
                 const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-                src = ok ? Ap + ((size_t)(a_pix[i] + iy * p.Wi + ix) * p.Cin + st_ci + koff) : p.zero_page + koff;
+                src = ok ? conv_plane + ((size_t)(a_pix[i] + iy * p.Wi + ix) * p.Cin + st_ci + a_ko[i]) : p.zero_page + a_ko[i];
             } else {
-                src = Ap + a_off[i] + st_k0 + koff;
+                src = a_ptr[i];
+                a_ptr[i] += BK;
             }
             glds16(src, sA + (wave + NW * i) * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < CB; ++i) glds16(Wp + b_off[i] + st_k0 + koff, sB + (wave + NW * i) * 1024);
-        st_k0 += 64;
+        for (int i = 0; i < CB; ++i) {
+            glds16(b_ptr[i], sB + (wave + NW * i) * 1024);
+            b_ptr[i] += BK;
+        }
+        st_k0 += BK;
         if (AMODE == MDPT_A_CONV3) {
-            st_ci += 64;
+            st_ci += BK;
             if (st_ci == p.Cin) { st_ci = 0; ++st_tap; }
         }
-        if (st_k0 == p.K) { st_k0 = 0; st_tap = 0; st_ci = 0; ++st_pass; }
+        if (st_k0 == p.K) {  // next pass: rewind K and switch operand planes
+            st_k0 = 0; st_tap = 0; st_ci = 0;
+            const ptrdiff_t da = (st_pass == 0 ? a_hi_minus_lo : 0) - p.K;
+            const ptrdiff_t dw = (st_pass == 0 ? w_lo_minus_hi : -w_lo_minus_hi) - p.K;
+            if (st_pass == 0) conv_plane = p.A_hi;
+#pragma unroll
+            for (int i = 0; i < CA; ++i)
+                if (AMODE != MDPT_A_CONV3) a_ptr[i] += da;
+#pragma unroll
+            for (int i = 0; i < CB; ++i) b_ptr[i] += dw;
+            ++st_pass;
+        }
     };
 
-    // ---- fragment read offsets: row = 32*blk + (lane&31), chunk = 2*kk + (lane>>5), swizzled
+    // ---- fragment read offsets: row = 32*blk + (lane&31), chunk = 2*kk + (lane>>5), swizzled with key(row)
     const int l31 = lane & 31, half = lane >> 5;
-    const int sw_frag = (l31 >> 1) & 7;
-    int frag_off[4];
+    const int sw_frag = (l31 / RPB) & (CPR - 1);
+    int frag_off[KSTEPS];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) frag_off[kk] = l31 * 128 + (((kk * 2 + half) ^ sw_frag) << 4);
+    for (int kk = 0; kk < KSTEPS; ++kk) frag_off[kk] = l31 * ROWB + (((kk * 2 + half) ^ sw_frag) << 4);
     const int wm = wave / WN, wn = wave % WN;
 
     f32x16 acc[TM][TN];
@@ -161,34 +220,81 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int total = (p.K >> 6) * p.npass;
-    issue_stage(0);
+    // ---- main loop: NST-deep LDS ring. Iteration t: wait for THIS wave's DMA of slab t (counted vmcnt: with a
+    //      3-deep ring the DMA of slab t+1 stays in flight across the barrier), barrier (everybody's part of slab t
+    //      has landed AND everybody finished reading slab t-1), refill the slot of slab t-1 with slab t+NST-1, compute.
+    //      LDS-DMA completion is only tracked by vmcnt: the waits are explicit (hipcc does not reliably insert them).
+    const int total = (p.K / BK) * p.npass;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < total) issue_stage(s);
+    int rd = 0, wr = NST - 1;
     for (int t = 0; t < total; ++t) {
-        __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) and publishes every wave's tile t
-        if (t + 1 < total) issue_stage((t + 1) & 1);
-        const char* sA = smem + (t & 1) * STAGE + wm * WTM * 128;
-        const char* sB = smem + (t & 1) * STAGE + A_BYTES + wn * WTN * 128;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(sA + i * 4096 + frag_off[kk]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8*)(sB + j * 4096 + frag_off[kk]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        if (NST == 3 && t + 1 < total) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        __builtin_amdgcn_s_barrier();
+        if (p.dbg_times && t == 0) t_first = memtime_now();
+        if (t + NST - 1 < total) issue_stage(wr);
+        const char* sA = smem + rd * STAGE + wm * WTM * ROWB;
+        const char* sB = smem + rd * STAGE + A_BYTES + wn * WTN * ROWB;
+        // fragments are double-buffered in registers: the ds_reads of k-step kk+1 are issued before the MFMAs of
+        // k-step kk, so LDS latency hides behind 8 MFMAs instead of stalling both waves of the SIMD
+        bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+#define LOAD_FRAGS(A_, B_, KK_)                                                                           \
+    do {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) A_[i] = *(const bf16x8*)(sA + i * 32 * ROWB + frag_off[KK_]); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) B_[j] = *(const bf16x8*)(sB + j * 32 * ROWB + frag_off[KK_]); \
+    } while (0)
+#define MFMA_RANGE(A_, B_, LO_, HI_)                                                                      \
+    do {                                                                                                  \
+        _Pragma("unroll") for (int ij = LO_; ij < HI_; ++ij)                                              \
+            acc[ij / TN][ij % TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[ij / TN], B_[ij % TN], acc[ij / TN][ij % TN], 0, 0, 0); \
+    } while (0)
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+        // Fragment reads are double-buffered in registers and the issue order is pinned (hipcc would otherwise sink
+        // every ds_read next to its MFMA: read; wait; mfma). hipcc's waits are always lgkmcnt(0), so the order is
+        // chosen such that each wait sits a full MFMA block (>= 7 x 32 cycles) after the newest outstanding read:
+        //   L0 L1 | M0 | L2 | M1 | M2[first] | L3 | M2[rest] | M3
+        LOAD_FRAGS(a0, b0, 0);
+        LOAD_FRAGS(a1, b1, 1);
+        PIN();
+        MFMA_RANGE(a0, b0, 0, TM * TN);
+        PIN();
+        if (KSTEPS == 4) {
+            LOAD_FRAGS(a0, b0, 2);
+            PIN();
+        }
+        MFMA_RANGE(a1, b1, 0, TM * TN);
+        PIN();
+        if (KSTEPS == 4) {
+            MFMA_RANGE(a0, b0, 0, 1);
+            PIN();
+            LOAD_FRAGS(a1, b1, 3);
+            PIN();
+            MFMA_RANGE(a0, b0, 1, TM * TN);
+            PIN();
+            MFMA_RANGE(a1, b1, 0, TM * TN);
+            PIN();
+        }
+#undef LOAD_FRAGS
+#undef MFMA_RANGE
+#undef PIN
+        rd = rd + 1 == NST ? 0 : rd + 1;
+        wr = wr + 1 == NST ? 0 : wr + 1;
     }
+    if (p.dbg_times) t_loop = memtime_now();
     __syncthreads();  // every wave is done reading the ring: reuse it as epilogue staging
 
-    // ---- epilogue: per 32-row block, accumulators -> wave-private LDS strip [32][WTN] fp32 -> row-major vectors
+    // ---- epilogue: per 32-row block, accumulators -> wave-private LDS strip [32][WTN] fp32 -> row-major vectors.
+    //      A CU retires roughly one wave store instruction per ~66 cycles whatever its width (measured), so every
+    //      store is 16 bytes per lane: each lane owns 8 consecutive columns (one bf16x8 store, two fp32x4 stores).
     float* strip = (float*)smem + wave * (32 * WTN);
-    constexpr int LPR = WTN / 4;     // lanes per row (each lane owns 4 consecutive columns)
+    constexpr int LPR = WTN / 8;     // lanes per row
     constexpr int RPP = 64 / LPR;    // rows per pass
-    const int erow = lane / LPR, ecol = (lane % LPR) * 4;
+    const int erow = lane / LPR, ecol = (lane % LPR) * 8;
     const int nbase = n0 + wn * WTN;
 
 #pragma unroll
@@ -201,19 +307,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
         const int mbase = m0 + wm * WTM + i * 32;
 
         if (EKIND == MDPT_E_QKV && nbase >= 2 * p.F) {
-            // V columns: write transposed, Vt[(b,h,d), t..t+3] (4 consecutive tokens per lane, 8-byte stores)
-#pragma unroll 2
-            for (int pr = 0; pr < 8 * (WTN / 64 > 0 ? WTN / 64 : 1); ++pr) {
-                const int col = (pr / 8) * 64 + lane, rg = pr % 8;
-                if (col >= WTN) continue;
-                const int m = mbase + rg * 4, n = nbase + col;
+            // V columns: write transposed, Vt[(b,h,d), t..t+7] (8 consecutive tokens per lane, 16-byte stores)
+            for (int pr = 0; pr < 4 * (WTN / 64); ++pr) {
+                const int col = (pr / 4) * 64 + lane, rg = pr % 4;
+                const int m = mbase + rg * 8, n = nbase + col;
                 if (m >= p.M || n >= p.N) continue;
-                f32x4 v;
+                const float bz = p.bias[n];
+                f32x4 v0, v1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = strip[(rg * 4 + e) * WTN + col] + p.bias[n];
+                for (int e = 0; e < 4; ++e) {
+                    v0[e] = strip[(rg * 8 + e) * WTN + col] + bz;
+                    v1[e] = strip[(rg * 8 + 4 + e) * WTN + col] + bz;
+                }
                 const int f = n - 2 * p.F, h = f >> 6, d = f & 63;
                 const int b = m / p.npad, tk = m - b * p.npad;
-                split_store4(p.vt_hi, p.vt_lo, ((size_t)(b * p.heads + h) * 64 + d) * p.npadv + tk, v);
+                split_store8(p.vt_hi, p.vt_lo, ((size_t)(b * p.heads + h) * 64 + d) * p.npadv + tk, v0, v1);
             }
             continue;
         }
@@ -222,19 +330,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
             const int row = pr * RPP + erow;
             const int m = mbase + row, n = nbase + ecol;
             if (m >= p.M || n >= p.N) continue;
-            f32x4 v = *(const f32x4*)(strip + row * WTN + ecol);
+            f32x4 v[2];
+            v[0] = *(const f32x4*)(strip + row * WTN + ecol);
+            v[1] = *(const f32x4*)(strip + row * WTN + ecol + 4);
 
             if (EKIND == MDPT_E_GENERIC) {
-                if (p.bias) v += *(const f32x4*)(p.bias + n);
+                if (p.bias) { v[0] += *(const f32x4*)(p.bias + n); v[1] += *(const f32x4*)(p.bias + n + 4); }
                 if (p.act == MDPT_ACT_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    for (int e = 0; e < 4; ++e) { v[0][e] = gelu_erf(v[0][e]); v[1][e] = gelu_erf(v[1][e]); }
                 } else if (p.act == MDPT_ACT_RELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                    for (int e = 0; e < 4; ++e) { v[0][e] = fmaxf(v[0][e], 0.0f); v[1][e] = fmaxf(v[1][e], 0.0f); }
                 }
-                if (p.gamma) v *= *(const f32x4*)(p.gamma + n);
-                if (p.resid) v += *(const f32x4*)(p.resid + (size_t)m * p.ldr + n);
+                if (p.gamma) { v[0] *= *(const f32x4*)(p.gamma + n); v[1] *= *(const f32x4*)(p.gamma + n + 4); }
+                if (p.resid) {
+                    const float* rp = p.resid + (size_t)m * p.ldr + n;
+                    v[0] += *(const f32x4*)rp;
+                    v[1] += *(const f32x4*)(rp + 4);
+                }
                 if (p.up_src) {
                     // + bilinear x2 (align_corners=True) of the previous fusion level (fusion_model.py:151,178)
                     const int hw = p.Ho * p.Wo;
@@ -246,80 +360,100 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmParams p) 
                     const int y1 = y0 + (y0 < p.Hu - 1), x1 = x0 + (x0 < p.Wu - 1);
                     const float ly = sy - (float)y0, lx = sx - (float)x0;
                     const float* base = p.up_src + (size_t)b * p.Hu * p.Wu * p.N + n;
-                    const f32x4 v00 = *(const f32x4*)(base + ((size_t)y0 * p.Wu + x0) * p.N);
-                    const f32x4 v01 = *(const f32x4*)(base + ((size_t)y0 * p.Wu + x1) * p.N);
-                    const f32x4 v10 = *(const f32x4*)(base + ((size_t)y1 * p.Wu + x0) * p.N);
-                    const f32x4 v11 = *(const f32x4*)(base + ((size_t)y1 * p.Wu + x1) * p.N);
-                    v += (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const f32x4 v00 = *(const f32x4*)(base + ((size_t)y0 * p.Wu + x0) * p.N + 4 * q);
+                        const f32x4 v01 = *(const f32x4*)(base + ((size_t)y0 * p.Wu + x1) * p.N + 4 * q);
+                        const f32x4 v10 = *(const f32x4*)(base + ((size_t)y1 * p.Wu + x0) * p.N + 4 * q);
+                        const f32x4 v11 = *(const f32x4*)(base + ((size_t)y1 * p.Wu + x1) * p.N + 4 * q);
+                        v[q] += (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+                    }
                 }
                 const size_t o = (size_t)m * p.ldc + n;
-                if (p.out_f32) *(f32x4*)(p.out_f32 + o) = v;
+                if (p.out_f32) { *(f32x4*)(p.out_f32 + o) = v[0]; *(f32x4*)(p.out_f32 + o + 4) = v[1]; }
                 if (p.out_hi) {
                     if (p.relu_bf16) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                        for (int e = 0; e < 4; ++e) { v[0][e] = fmaxf(v[0][e], 0.0f); v[1][e] = fmaxf(v[1][e], 0.0f); }
                     }
-                    split_store4(p.out_hi, p.out_lo, o, v);
+                    split_store8(p.out_hi, p.out_lo, o, v[0], v[1]);
                 }
             } else if (EKIND == MDPT_E_QKV) {
                 // Q (pre-scaled by 1/sqrt(d), exact power of two) and K, head-major [B,H,npad,64]
-                v += *(const f32x4*)(p.bias + n);
+                v[0] += *(const f32x4*)(p.bias + n);
+                v[1] += *(const f32x4*)(p.bias + n + 4);
                 const int which = n >= p.F;
                 const int f = n - which * p.F, h = f >> 6, d = f & 63;
                 const int b = m / p.npad, tk = m - b * p.npad;
                 const size_t o = ((size_t)(b * p.heads + h) * p.npad + tk) * 64 + d;
                 if (!which) {
-                    v *= p.qscale;
-                    split_store4(p.q_hi, p.q_lo, o, v);
+                    v[0] *= p.qscale; v[1] *= p.qscale;
+                    split_store8(p.q_hi, p.q_lo, o, v[0], v[1]);
                 } else {
-                    split_store4(p.k_hi, p.k_lo, o, v);
+                    split_store8(p.k_hi, p.k_lo, o, v[0], v[1]);
                 }
             } else if (EKIND == MDPT_E_PATCH) {
                 const int b = m / p.tok_np, t = m - b * p.tok_np;
-                v += *(const f32x4*)(p.bias + n);
-                v += *(const f32x4*)(p.pos + (size_t)t * p.N + n);
-                *(f32x4*)(p.out_f32 + ((size_t)b * p.npad + 1 + t) * p.ldc + n) = v;
+                const float* pp = p.pos + (size_t)t * p.N + n;
+                v[0] += *(const f32x4*)(p.bias + n) + *(const f32x4*)pp;
+                v[1] += *(const f32x4*)(p.bias + n + 4) + *(const f32x4*)(pp + 4);
+                float* op = p.out_f32 + ((size_t)b * p.npad + 1 + t) * p.ldc + n;
+                *(f32x4*)op = v[0];
+                *(f32x4*)(op + 4) = v[1];
             } else if (EKIND == MDPT_E_D2S) {
-                const int kk2 = p.d2s_k * p.d2s_k;
                 const int kidx = n / p.d2s_cout, co = n - kidx * p.d2s_cout;
                 const int ky = kidx / p.d2s_k, kx = kidx - ky * p.d2s_k;
                 const int hw = p.Ho * p.Wo;
                 const int b = m / hw, rem = m - b * hw;
                 const int y = rem / p.Wo, x = rem - y * p.Wo;
-                (void)kk2;
-                v += *(const f32x4*)(p.bias + co);
+                v[0] += *(const f32x4*)(p.bias + co);
+                v[1] += *(const f32x4*)(p.bias + co + 4);
                 const size_t o =
                     (((size_t)b * p.Ho * p.d2s_k + (y * p.d2s_k + ky)) * (p.Wo * p.d2s_k) + (x * p.d2s_k + kx)) * p.d2s_cout + co;
-                split_store4(p.out_hi, p.out_lo, o, v);
+                split_store8(p.out_hi, p.out_lo, o, v[0], v[1]);
             } else if (EKIND == MDPT_E_HEAD) {
                 // relu(conv3x3 -> 32) . w[32] + b -> relu | sigmoid   (head_model.py:80-85)
-                v += *(const f32x4*)(p.bias + n);
-                const f32x4 w4 = *(const f32x4*)(p.head_w + n);
-                float s = 0.0f;
+                v[0] += *(const f32x4*)(p.bias + n);
+                v[1] += *(const f32x4*)(p.bias + n + 4);
+                const f32x4 w0 = *(const f32x4*)(p.head_w + n), w1 = *(const f32x4*)(p.head_w + n + 4);
+                float sacc = 0.0f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s += fmaxf(v[e], 0.0f) * w4[e];
+                for (int e = 0; e < 4; ++e) sacc += fmaxf(v[0][e], 0.0f) * w0[e];
 #pragma unroll
-                for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+                for (int e = 0; e < 4; ++e) sacc += fmaxf(v[1][e], 0.0f) * w1[e];
+#pragma unroll
+                for (int o = 1; o < LPR; o <<= 1) sacc += __shfl_xor(sacc, o);
                 if ((lane % LPR) == 0) {
-                    s += p.head_b[0];
-                    p.head_out[m] = p.head_sigmoid ? 1.0f / (1.0f + __expf(-s)) : fmaxf(s, 0.0f);
+                    sacc += p.head_b[0];
+                    p.head_out[m] = p.head_sigmoid ? 1.0f / (1.0f + __expf(-sacc)) : fmaxf(sacc, 0.0f);
                 }
             }
         }
     }
+    if (p.dbg_times && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = p.dbg_times + (size_t)blockIdx.x * 6;
+        d[0] = t_start; d[1] = t_first; d[2] = t_loop; d[3] = memtime_now();
+        d[4] = __builtin_amdgcn_s_getreg(20 << 0 | 0 << 6 | 3 << 11);  // HW_REG_XCC_ID bits [3:0]
+        d[5] = __builtin_amdgcn_s_getreg(4 << 0 | 0 << 6 | 31 << 11);  // HW_REG_HW_ID
+    }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int EKIND>
+template <int BM, int BN, int WM, int WN, int BK, int NST, int MINW, int AMODE, int EKIND>
 int launch_cfg(const GemmParams& p, hipStream_t stream) {
-    constexpr int LDS = 2 * (BM + BN) * 128;
+    constexpr int LDS = NST * (BM + BN) * BK * 2;
     static bool attr_done = false;
-    auto kern = gemm_kernel<BM, BN, WM, WN, AMODE, EKIND>;
+    auto kern = gemm_kernel<BM, BN, WM, WN, BK, NST, MINW, AMODE, EKIND>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    static char prof_name[112] = "";
+    if (!prof_name[0])
+        snprintf(prof_name, sizeof(prof_name), "gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, BK, NST, MINW, AMODE, EKIND);
+    MdptProfScope prof(prof_name, 2.0 * p.M * p.N * p.K, stream);  // algorithmic flops (one pass, whatever npass is)
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), LDS, stream, p);
     return (int)hipGetLastError();
 }
@@ -328,19 +462,23 @@ template <int AMODE, int EKIND>
 int launch_tile(const GemmParams& p, hipStream_t stream) {
     int tile = p.tile;
     if (tile == MDPT_TILE_AUTO) {
-        // 256x256 pays once there are enough big tiles to fill 256 CUs; otherwise 128x128
+        // measured on MI355X (tests/gpu_gemm_bench.py, M = 41728): 256x256x64 wins whenever there are >= 2 rounds of
+        // big tiles or the K loop is deep enough to amortise its ~17k-cycle epilogue; otherwise 128x128x64 (2 workgroups
+        // per CU, finer tile quantisation). The 256x128x32 3-deep-ring variant is kept selectable but never won.
         const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        tile = (p.N % 256 == 0 && tiles256 >= 512) ? MDPT_TILE_256x256 : MDPT_TILE_128x128;
+        const bool big = p.N % 256 == 0 && (tiles256 >= 512 || (tiles256 >= 256 && p.K >= 2048));
+        tile = big ? MDPT_TILE_256x256 : MDPT_TILE_128x128;
     }
-    if (tile == MDPT_TILE_256x256) return launch_cfg<256, 256, 2, 4, AMODE, EKIND>(p, stream);
-    return launch_cfg<128, 128, 2, 2, AMODE, EKIND>(p, stream);
+    if (tile == MDPT_TILE_256x128) return launch_cfg<256, 128, 2, 2, 32, 3, 2, AMODE, EKIND>(p, stream);
+    if (tile == MDPT_TILE_256x256) return launch_cfg<256, 256, 2, 4, 64, 2, 1, AMODE, EKIND>(p, stream);
+    return launch_cfg<128, 128, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);
 }
 
 }  // namespace
 
 int mdpt_launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0) return 0;
-    if (p.K <= 0 || (p.K & 63) || (p.N & 3)) return (int)hipErrorInvalidValue;
+    if (p.K <= 0 || (p.K & 63) || (p.N & 7)) return (int)hipErrorInvalidValue;
     if (p.npass != 1 && p.npass != 3) return (int)hipErrorInvalidValue;
     switch (p.ekind) {
         case MDPT_E_GENERIC:
@@ -349,17 +487,17 @@ int mdpt_launch_gemm(const GemmParams& p, hipStream_t stream) {
             if (p.amode == MDPT_A_CONV3) return launch_tile<MDPT_A_CONV3, MDPT_E_GENERIC>(p, stream);
             break;
         case MDPT_E_QKV:
-            if (p.amode == MDPT_A_DENSE && (p.F & 63) == 0 && (p.npad & 3) == 0)
+            if (p.amode == MDPT_A_DENSE && (p.F & 63) == 0 && (p.npad & 7) == 0 && (p.npadv & 7) == 0)
                 return launch_tile<MDPT_A_DENSE, MDPT_E_QKV>(p, stream);
             break;
         case MDPT_E_PATCH:
             if (p.amode == MDPT_A_DENSE) return launch_tile<MDPT_A_DENSE, MDPT_E_PATCH>(p, stream);
             break;
         case MDPT_E_D2S:
-            if (p.amode == MDPT_A_DENSE && (p.d2s_cout & 3) == 0) return launch_tile<MDPT_A_DENSE, MDPT_E_D2S>(p, stream);
+            if (p.amode == MDPT_A_DENSE && (p.d2s_cout & 7) == 0) return launch_tile<MDPT_A_DENSE, MDPT_E_D2S>(p, stream);
             break;
         case MDPT_E_HEAD:
-            if (p.amode == MDPT_A_CONV3 && p.N == 32) return launch_cfg<128, 32, 4, 1, MDPT_A_CONV3, MDPT_E_HEAD>(p, stream);
+            if (p.amode == MDPT_A_CONV3 && p.N == 32) return launch_cfg<128, 32, 4, 1, 64, 2, 1, MDPT_A_CONV3, MDPT_E_HEAD>(p, stream);
             break;
     }
     return (int)hipErrorInvalidValue;

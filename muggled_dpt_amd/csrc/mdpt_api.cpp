@@ -731,7 +731,7 @@ int mdpt_workspace_bytes(const mdpt_handle* h, int32_t B, int32_t H, int32_t W, 
 }
 
 int mdpt_set_gemm_tile(mdpt_handle* h, int32_t tile) {
-    if (!h || tile < 0 || tile > 2) return fail(MDPT_E_INVALID, "tile must be 0 (auto), 1 (128x128) or 2 (256x256)");
+    if (!h || tile < 0 || tile > 4 || tile == 3) return fail(MDPT_E_INVALID, "tile must be 0 (auto), 1 (128x128x64), 2 (256x256x64) or 4 (256x128x32, 3-deep ring)");
     h->gemm_tile = tile;
     return 0;
 }
@@ -917,6 +917,22 @@ int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_
     } else {
         CHK(mdpt_launch_tokens_export(nullptr, nullptr, c.at<float>(f32_off), (float*)out_f32, 1, (int)(elems / 4), (int)(elems / 4), 4, 0, c.s));
     }
+    return 0;
+}
+
+// ---- test/bench hook: the plain dense GEMM kernel on caller-provided bf16 operands (out_f32[M,N] = A[M,K] W[N,K]^T)
+int mdpt_debug_gemm(const void* a_bf16, const void* w_bf16, void* out_f32, void* out_bf16, int32_t M, int32_t N, int32_t K,
+                    int32_t tile, int32_t iters, void* stream, void* dbg_times) {
+    if (!a_bf16 || !w_bf16 || (!out_f32 && !out_bf16)) return fail(MDPT_E_INVALID, "null argument");
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.A_hi = (const bf16_t*)a_bf16; g.W_hi = (const bf16_t*)w_bf16;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.npass = 1;
+    g.zero_page = (const bf16_t*)w_bf16;
+    g.amode = MDPT_A_DENSE; g.ekind = MDPT_E_GENERIC; g.tile = tile;
+    g.out_f32 = (float*)out_f32; g.out_hi = (bf16_t*)out_bf16; g.ldc = N; g.ldr = N;
+    g.dbg_times = (unsigned long long*)dbg_times;
+    for (int i = 0; i < iters; ++i) CHK(mdpt_launch_gemm(g, (hipStream_t)stream));
     return 0;
 }
 

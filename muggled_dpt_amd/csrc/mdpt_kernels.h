@@ -44,6 +44,8 @@ struct GemmParams {
     int d2s_k, d2s_cout;
     // E_HEAD: N == 32: depth[m] = final( sum_n relu(acc+bias[n]) * head_w[n] + head_b )
     const float* head_w; const float* head_b; int head_sigmoid; float* head_out;
+    // test hook: per-workgroup phase timestamps (s_memtime): [start, first barrier passed, main loop done, epilogue done]
+    unsigned long long* dbg_times;
 };
 
 int mdpt_launch_gemm(const GemmParams& p, hipStream_t stream);   // returns hipError_t as int

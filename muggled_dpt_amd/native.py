@@ -17,8 +17,8 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(CSRC, "libmdpt.so")
-SOURCES = ("gemm.hip", "attention.hip", "elementwise.hip", "mdpt_api.cpp")
-HEADERS = ("mdpt_kernels.h", os.path.join(REPO, "include", "mdpt.h"))
+SOURCES = ("gemm.hip", "attention.hip", "elementwise.hip", "mdpt_api.cpp", "mdpt_prof.cpp")
+HEADERS = ("mdpt_kernels.h", "mdpt_prof.h", os.path.join(REPO, "include", "mdpt.h"))
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1
@@ -110,6 +110,9 @@ SYMBOLS = {
     "mdpt_head": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_export_tap": (ctypes.c_int, [_VP, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_set_gemm_tile": (ctypes.c_int, [_VP, _I]),
+    "mdpt_debug_gemm": (ctypes.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _VP]),
+    "mdpt_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "mdpt_profile_report": (ctypes.c_int, [ctypes.c_char_p, _SZ]),
     "mdpt_debug_set_stop": (ctypes.c_int, [_VP, _I, _I]),
     "mdpt_debug_read": (ctypes.c_int, [_VP, ctypes.c_char_p, _VP, _SZ, _VP, _SZ, _VP]),
     "mdpt_allgather_f32": (ctypes.c_int, [_VP, _VP, _VP, _SZ, _VP]),

@@ -1,0 +1,186 @@
+"""Parity of the HIP path (called through the C ABI via the Python facade) against the CPU oracle and the committed
+golden fixtures. Run with `pytest -m gpu` on an MI355X.
+
+Tolerances (rel = max|y - ref| / max|ref|, the north-star metric):
+  * float32 model  = MDPT_PREC_BF16X3 (split-bf16 MFMA, fp32 accumulate): REL_TOL_X3 = 1e-3  (north-star bar; measured ~2e-5)
+  * bfloat16 model = MDPT_PREC_BF16 (single-pass bf16 MFMA):             REL_TOL_BF16 = 3e-2 (measured ~1e-2; PyTorch's own
+    bf16 CPU path is 1.9e-2 off its fp32 path on the same weights, BASELINE.md §2 - a pure-bf16 pipeline cannot meet 1e-3)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import rel_err, seeded_input, synthetic_model
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL_X3 = 1e-3
+REL_TOL_BF16 = 3e-2
+MODES = [(torch.float32, REL_TOL_X3), (torch.bfloat16, REL_TOL_BF16)]
+
+
+def _oracle():
+    from oracle import dpt_oracle
+    return dpt_oracle
+
+
+def _model(name, dtype, seed=0):
+    from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+    osd, cfg, w = synthetic_model(name, seed)
+    _, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
+    return model.to("cuda", dtype), cfg, w
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu_and_native_lib():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from muggled_dpt_amd import native
+    native.load()  # loud failure if libmdpt.so is missing: there is no fallback path
+
+
+@pytest.mark.parametrize("dtype,tol", MODES)
+def test_tiny_every_stage_boundary_vs_golden(golden_dir, dtype, tol):
+    g = np.load(os.path.join(golden_dir, "tiny_full.npz"))
+    model, cfg, w = _model("tiny", dtype)
+    x = torch.from_numpy(g["input"])
+    y = model(x.to("cuda", dtype))
+    assert y.dtype == dtype and y.device.type == "cuda" and tuple(y.shape) == (2, 56, 56)
+    assert rel_err(y.float().cpu(), torch.from_numpy(g["depth"])) <= tol
+    taps = model.debug_taps(2, (56, 56))
+    for i in range(4):
+        assert rel_err(taps["stages"][i].cpu(), torch.from_numpy(g[f"tap{i}"])) <= tol, f"tap{i}"
+        assert rel_err(taps["reasm"][i].cpu(), torch.from_numpy(g[f"reasm{i}"])) <= tol, f"reasm{i}"
+    assert rel_err(taps["fused"].cpu(), torch.from_numpy(g["fused"])) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", MODES)
+def test_stage_entry_points_match_reference_submodule_calls(golden_dir, dtype, tol):
+    """simple_examples/internal_features.py:39-45 usage: each sub-module called on the previous stage's (golden) output."""
+    g = np.load(os.path.join(golden_dir, "tiny_full.npz"))
+    model, cfg, w = _model("tiny", dtype)
+    dev = lambda a: torch.from_numpy(np.asarray(a)).to("cuda", dtype)  # noqa: E731
+    tok, hw = model.patch_embed(dev(g["input"]))
+    assert tuple(hw) == tuple(g["grid_hw"]) and rel_err(tok.float().cpu(), torch.from_numpy(g["patch_tokens"])) <= tol
+    enc = model.imgencoder(dev(g["patch_tokens"]), hw)
+    for i in range(4):
+        assert rel_err(enc[i].float().cpu(), torch.from_numpy(g[f"tap{i}"])) <= tol
+    rs = model.reassemble(*[dev(g[f"tap{i}"]) for i in range(4)], hw)
+    for i in range(4):
+        assert tuple(rs[i].shape) == tuple(g[f"reasm{i}"].shape)
+        assert rel_err(rs[i].float().cpu(), torch.from_numpy(g[f"reasm{i}"])) <= tol
+    fu = model.fusion(*[dev(g[f"reasm{i}"]) for i in range(4)])
+    assert rel_err(fu.float().cpu(), torch.from_numpy(g["fused"])) <= tol
+    hd = model.head(dev(g["fused"]))
+    assert rel_err(hd.float().cpu(), torch.from_numpy(g["depth"])) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", MODES)
+def test_rectangular_grid_and_odd_batch(golden_dir, dtype, tol):
+    g = np.load(os.path.join(golden_dir, "tiny_rect.npz"))
+    model, cfg, w = _model("tiny", dtype)
+    y = model(torch.from_numpy(g["input"]).to("cuda", dtype))
+    assert rel_err(y.float().cpu(), torch.from_numpy(g["depth"])) <= tol
+    x3 = seeded_input((3, 3, 84, 56), 5)  # batch 3, grid 6x4
+    assert rel_err(model(x3.to("cuda", dtype)).float().cpu(), _oracle().forward(w, cfg, x3)) <= tol
+
+
+def test_odd_patch_grid_raises_like_the_reference():
+    model, _, _ = _model("tiny", torch.float32)
+    with pytest.raises(RuntimeError):
+        model(torch.randn(1, 3, 42, 42, device="cuda"))  # 3x3 grid: reference dies at fusion_model.py:151
+    with pytest.raises(AssertionError):
+        model.verify_input(torch.randn(1, 3, 50, 56, device="cuda"))
+    assert model.verify_input(torch.randn(1, 3, 56, 56, device="cuda")) is True
+
+
+def test_cpu_tensor_or_cpu_model_fails_loudly():
+    from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+    osd, _, _ = synthetic_model("tiny", 0)
+    _, cpu_model = make_depthanythingv2_dpt_from_original_state_dict(osd)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cpu_model(torch.randn(1, 3, 56, 56))
+    with pytest.raises(RuntimeError):
+        cpu_model.to("cuda")(torch.randn(1, 3, 56, 56))  # input left on the CPU
+
+
+@pytest.mark.parametrize("dtype,tol", MODES)
+def test_vits_504_vs_golden_fixture_and_inference(golden_dir, dtype, tol):
+    """BASELINE configs[1]/[0] shapes: ViT-S, 504x504 tensor, batch 1; plus inference() on a 518x518 uint8 image."""
+    g = np.load(os.path.join(golden_dir, "vits504.npz"))
+    model, cfg, w = _model("vits", dtype, int(g["weight_seed"]))
+    x = seeded_input((1, 3, 504, 504), int(g["input_seed"]))
+    y = model(x.to("cuda", dtype)).float().cpu()
+    ref_max = float(g["depth_stats"][1])
+    assert float((y[:, ::4, ::4].double() - torch.from_numpy(g["depth_strided"]).double()).abs().max()) / ref_max <= tol
+    assert float((y[:, 200:264, 100:164].double() - torch.from_numpy(g["depth_crop"]).double()).abs().max()) / ref_max <= tol
+    taps = model.debug_taps(1, (504, 504))
+    for i in range(4):
+        a, b = taps["stages"][i][:, :64, :64].cpu().double(), torch.from_numpy(g[f"tap{i}_crop"]).double()
+        assert float((a - b).abs().max()) / max(abs(g[f"tap{i}_stats"][0]), abs(g[f"tap{i}_stats"][1])) <= tol
+    img = np.random.default_rng(1).integers(0, 256, (518, 518, 3), dtype=np.uint8)
+    d = model.inference(img)
+    assert tuple(d.shape) == (1, 504, 504) and d.dtype == dtype
+    # preprocessing runs in the model dtype (reference patch_embed.py:133): allow the bf16 input rounding on top
+    ptol = tol if dtype == torch.float32 else 2 * tol
+    assert float((d.float().cpu()[:, ::4, ::4].double() - torch.from_numpy(g["inference518_strided"]).double()).abs().max()) / float(g["inference518_stats"][1]) <= ptol
+
+
+def test_vitl_504_vs_golden_fixture(golden_dir):
+    """Headline model (BASELINE configs[2]), one image, both modes, against the reference-generated fixture."""
+    g = np.load(os.path.join(golden_dir, "vitl504.npz"))
+    x = seeded_input((1, 3, 504, 504), int(g["input_seed"]))
+    ref_max = float(g["depth_stats"][1])
+    for dtype, tol in MODES:
+        model, cfg, w = _model("vitl", dtype, int(g["weight_seed"]))
+        y = model(x.to("cuda", dtype)).float().cpu()
+        err = float((y[:, ::4, ::4].double() - torch.from_numpy(g["depth_strided"]).double()).abs().max()) / ref_max
+        assert err <= tol, f"{dtype}: {err}"
+        del model
+        torch.cuda.empty_cache()
+
+
+def test_full_size_batch32_properties():
+    """BASELINE configs[2] at full size (ViT-L, batch 32, 504x504) through size-independent properties:
+    batch independence (sharding a batch never changes a map: the basis of data parallelism), determinism, finiteness."""
+    model, cfg, w = _model("vitl", torch.bfloat16)
+    x = torch.randn(32, 3, 504, 504, generator=torch.Generator().manual_seed(7)).to("cuda", torch.bfloat16)
+    y = model(x)
+    assert tuple(y.shape) == (32, 504, 504) and bool(torch.isfinite(y).all())
+    assert torch.equal(model(x), y), "same input twice must be bit-identical"
+    for i in (0, 13, 31):
+        assert torch.equal(model(x[i:i + 1])[0], y[i]), f"image {i}: batch-of-1 result differs from its row in the batch of 32"
+    y_halves = torch.cat((model(x[:16]), model(x[16:])), dim=0)
+    assert torch.equal(y_halves, y), "two shards of 16 must reproduce the batch of 32 bit-for-bit"
+    assert float(y.float().max()) > 0.1, "degenerate (all-zero) output"
+
+
+def test_vits_1036_matches_oracle():
+    """The other BASELINE size: 1036x1036 (grid 74x74, N = 5477 tokens) - long-sequence attention + big decoder maps."""
+    model, cfg, w = _model("vits", torch.float32)
+    x = seeded_input((1, 3, 1036, 1036), 3)
+    assert rel_err(model(x.to("cuda")).cpu(), _oracle().forward(w, cfg, x)) <= REL_TOL_X3
+
+
+def test_metric_head_sigmoid():
+    from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+    osd, cfg, w = synthetic_model("tiny", 0)
+    osd = dict(osd)
+    osd["is_metric"] = torch.tensor(1.0)
+    cfg_m, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
+    assert cfg_m["is_metric"] is True
+    x = seeded_input((1, 3, 56, 56), 4)
+    ref = _oracle().forward(w, dict(cfg, is_metric=True), x)
+    assert rel_err(model.to("cuda")(x.to("cuda")).cpu(), ref) <= REL_TOL_X3
+
+
+def test_make_dpt_from_state_dict_file_roundtrip(tmp_path):
+    from muggled_dpt_amd import make_dpt_from_state_dict
+    osd, cfg, w = synthetic_model("tiny", 0)
+    path = str(tmp_path / "depth_anything_v2_tiny.pth")
+    torch.save(osd, path)
+    cfg2, model = make_dpt_from_state_dict(path, enable_cache=True)
+    assert cfg2["features_per_token"] == 64 and cfg2["enable_cache"] is True
+    x = seeded_input((1, 3, 56, 56), 9)
+    assert rel_err(model.to("cuda")(x.to("cuda")).cpu(), _oracle().forward(w, cfg, x)) <= REL_TOL_X3

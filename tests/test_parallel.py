@@ -1,0 +1,62 @@
+"""Data-parallel path on CPU: world_size-2 gloo run of the sharding + all-gather logic that bench.py uses on RCCL."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from muggled_dpt_amd.parallel import shard_bounds
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_cover_the_batch_contiguously():
+    for gb, world in ((256, 8), (32, 1), (10, 4), (3, 4)):
+        spans = [shard_bounds(gb, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == gb
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        sizes = [e - s for s, e in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _fake_depth(images):  # stand-in for model.forward: per-image independent, like the real path
+    return images.mean(dim=1) * 2.0 + 1.0
+
+
+def _worker(rank, world, port, global_batch, ret):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from muggled_dpt_amd.parallel import DataParallelDepth, all_gather_ragged, init_distributed, shard_bounds as sb
+
+    r, w, _ = init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    full = torch.randn(global_batch, 3, 8, 8, generator=torch.Generator().manual_seed(0))
+    s, e = sb(global_batch, rank, world)
+    dp = DataParallelDepth(_fake_depth, rank, world)
+    if global_batch % world == 0:
+        out = dp.forward_shard(full[s:e])
+    else:
+        out = all_gather_ragged(_fake_depth(full[s:e]), global_batch, rank, world)
+    ok = torch.equal(out, _fake_depth(full))  # gathered result == single-process result, bit for bit
+    t = torch.tensor([1.0 + rank])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the bench's max-over-ranks timing reduction
+    ret[rank] = bool(ok) and float(t) == float(world)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("global_batch", [8, 7])
+def test_two_rank_gloo_allgather_matches_single_process(global_batch):
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), global_batch, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: True, 1: True}
