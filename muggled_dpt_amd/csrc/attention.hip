@@ -24,6 +24,8 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 namespace {
 
@@ -41,28 +43,50 @@ __device__ __forceinline__ bf16x8 cat44(bf16x4 a, bf16x4 b) {
     return r;
 }
 
-template <bool X3>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+// QB = query blocks of 32 per wave: 2 in bf16 mode (64 queries per wave, 256 per workgroup: every K / Vt fragment read
+// from LDS and every LDS-DMA'd tile feeds twice the MFMAs - the kernel is vector-memory/LDS bound otherwise), 1 in x3
+// mode (register budget: hi+lo planes of Q, K, V and P).
+template <bool X3, int QB>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     constexpr int NPL = X3 ? 2 : 1;           // planes per operand
     constexpr int TILE = 8192;                // one [64][64] bf16 tile
     constexpr int STAGE = 2 * NPL * TILE;     // K planes then Vt planes
+    constexpr int QPW = 32 * QB, QPB = 4 * QPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const size_t bh = (size_t)b * p.heads + h;
+    // 1-D grid, XCD-aware: the dispatcher sends block id to XCD id%8, and all q-tiles of one (batch, head) re-read the
+    // same K/V (332 KB at N=1297) -> give every (batch, head) to ONE XCD so its K/V stay in that XCD's 4 MB L2
+    // (measured before: 1.49 GB fetched per launch vs 0.26 GB algorithmic).
+    const int nq = (p.npad + QPB - 1) / QPB, nbh = p.B * p.heads;
+    int qt, bhi;
+    if ((nbh & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        bhi = (slot / nq) * 8 + xcd;
+        qt = slot - (slot / nq) * nq;
+    } else {
+        bhi = blockIdx.x / nq;
+        qt = blockIdx.x - bhi * nq;
+    }
+    const int b = bhi / p.heads, h = bhi - b * p.heads;
+    const size_t bh = (size_t)bhi;
+    const int q0 = qt * QPB + wave * QPW;
+    const bool active = q0 < p.npad;  // tail waves of the last q-tile only help with DMA and barriers
 
-    // ---- Q fragments (B operand of S^T = K Q^T): Q[q = q0 + (lane&31)][d = 16*ks + 8*half .. +8]
-    int q = qt * 128 + wave * 32 + l31;
-    const int q_ld = q < p.npad ? q : p.npad - 1;
-    bf16x8 qh[4], ql[4];
+    // ---- Q fragments (B operand of S^T = K Q^T): Q[q][d = 16*ks + 8*half .. +8]
+    bf16x8 qh[QB][4], ql[QB][4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const size_t o = (bh * p.npad + q_ld) * 64 + ks * 16 + half * 8;
-        qh[ks] = *(const bf16x8*)(p.q_hi + o);
-        if (X3) ql[ks] = *(const bf16x8*)(p.q_lo + o);
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q0 + qb * 32 + l31;
+        const int q_ld = q < p.npad ? q : p.npad - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const size_t o = (bh * p.npad + q_ld) * 64 + ks * 16 + half * 8;
+            qh[qb][ks] = *(const bf16x8*)(p.q_hi + o);
+            if (X3) ql[qb][ks] = *(const bf16x8*)(p.q_lo + o);
+        }
     }
 
     // ---- staging: K tile rows = keys, Vt tile rows = d; 8 chunks of 1 KiB each per plane, 2 per wave
@@ -88,12 +112,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     };
 
     const int sw_frag = (l31 >> 1) & 7;
-    f32x16 o_acc[2];
+    f32x16 o_acc[QB][2];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = -1.0e30f;
+        l_run[qb] = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.0f;
-    float m_run = -1.0e30f, l_run = 0.0f;
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[qb][db][r] = 0.0f;
+    }
 
     issue_tile(0, 0);
     for (int t = 0; t < ntiles; ++t) {
@@ -102,113 +131,162 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < ntiles) issue_tile(t + 1, (t + 1) & 1);
+        if (!active) continue;
         const char* sK = smem + (t & 1) * STAGE;
         const char* sV = sK + NPL * TILE;
 
-        // ---- S^T[key][query] for 2 blocks of 32 keys
-        f32x16 s[2];
+        // ---- S^T[key][query] for 2 blocks of 32 keys x QB blocks of 32 queries
+        f32x16 s[QB][2];
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
+        for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[blk][r] = 0.0f;
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[qb][blk][r] = 0.0f;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int off = (blk * 32 + l31) * 128 + (((ks * 2 + half) ^ sw_frag) << 4);
                 const bf16x8 kh = *(const bf16x8*)(sK + off);
-                if (X3) {
-                    const bf16x8 kl = *(const bf16x8*)(sK + TILE + off);
-                    s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], s[blk], 0, 0, 0);
-                    s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], s[blk], 0, 0, 0);
+                bf16x8 kl;
+                if (X3) kl = *(const bf16x8*)(sK + TILE + off);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    if (X3) {
+                        s[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[qb][ks], s[qb][blk], 0, 0, 0);
+                        s[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[qb][ks], s[qb][blk], 0, 0, 0);
+                    }
+                    s[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[qb][ks], s[qb][blk], 0, 0, 0);
                 }
-                s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], s[blk], 0, 0, 0);
             }
-        }
-        // key of s[blk][r] = t*64 + blk*32 + (r&3) + 8*(r>>2) + 4*half
+        // key of s[..][blk][r] = t*64 + blk*32 + (r&3) + 8*(r>>2) + 4*half
         if (t * 64 + 64 > p.N) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * 64 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        s[qb][blk][r] = key < p.N ? s[qb][blk][r] : -1.0e30f;
+                    }
+        }
+        // ---- online softmax per query block: this lane and lane^32 share the query
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float mloc = s[qb][0][0];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[qb][blk][r]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float m_new = fmaxf(m_run[qb], mloc);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kLog2e);
+            const float mb = m_new * kLog2e;
+            m_run[qb] = m_new;
+            float psum = 0.0f;
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = t * 64 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    s[blk][r] = key < p.N ? s[blk][r] : -1.0e30f;
+                    const float e = __builtin_amdgcn_exp2f(s[qb][blk][r] * kLog2e - mb);
+                    s[qb][blk][r] = e;
+                    psum += e;
                 }
-        }
-        // ---- online softmax: this lane and lane^32 share the query
-        float mloc = s[0][0];
+            l_run[qb] = l_run[qb] * alpha + psum;
+            if (__any(alpha != 1.0f)) {  // after the first tiles the running max rarely moves: skip 32 multiplies
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+                for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[blk][r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
-        const float mb = m_new * kLog2e;
-        m_run = m_new;
-        float psum = 0.0f;
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(s[blk][r] * kLog2e - mb);
-                s[blk][r] = e;
-                psum += e;
+                    for (int r = 0; r < 16; ++r) o_acc[qb][db][r] *= alpha;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
+        }
 
-        // ---- O^T[d][query] += Vt[d][key] P^T[key][query]; 16-key blocks kb = 2*blk + kb2
+        // ---- O^T[d][query] += Vt[d][key] P^T[key][query]; 16-key blocks kb = 2*blk + kb2.
+        // The S^T accumulators hold, per lane (query = lane&31, hi = lane>>5), keys {0-3, 8-11} + 4*hi of each 16-key
+        // block. Packed to bf16 pairs, ONE v_permlane32_swap per register pair exchanges the halves so that the lane
+        // ends up with the standard B fragment (keys 16kb + 8*hi + 0..7): lower lanes keep (0,1),(2,3) and receive
+        // (4,5),(6,7) from lane+32; upper lanes receive (8,9),(10,11) and keep (12,13),(14,15). Vt fragments are then
+        // plain conflict-free ds_read_b128, shared by all query blocks.
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int kb2 = 0; kb2 < 2; ++kb2) {
-                bf16x8 ph, pl;
+                bf16x8 ph[QB], pl[QB];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float pv = s[blk][kb2 * 8 + e];
-                    ph[e] = (__bf16)pv;
-                    if (X3) pl[e] = (__bf16)(pv - (float)ph[e]);
+                for (int qb = 0; qb < QB; ++qb) {
+                    unsigned hw[4], lw[4];  // packed bf16x2: [0],[1] = keys (0,1),(2,3)+4hi ; [2],[3] = keys (8,9),(10,11)+4hi
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        const f32x2 pp = {s[qb][blk][kb2 * 8 + 2 * w2], s[qb][blk][kb2 * 8 + 2 * w2 + 1]};
+                        const bf16x2 hh = __builtin_convertvector(pp, bf16x2);   // one v_cvt_pk_bf16_f32
+                        hw[w2] = __builtin_bit_cast(unsigned, hh);
+                        if (X3) {
+                            const f32x2 rr = pp - __builtin_convertvector(hh, f32x2);
+                            lw[w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                        }
+                    }
+                    unsigned pw[4], qw[4];
+#pragma unroll
+                    for (int w2 = 0; w2 < 2; ++w2) {
+                        auto r = __builtin_amdgcn_permlane32_swap(hw[w2], hw[w2 + 2], false, false);
+                        pw[w2] = r[0];
+                        pw[w2 + 2] = r[1];
+                        if (X3) {
+                            auto rl = __builtin_amdgcn_permlane32_swap(lw[w2], lw[w2 + 2], false, false);
+                            qw[w2] = rl[0];
+                            qw[w2 + 2] = rl[1];
+                        }
+                    }
+                    ph[qb] = __builtin_bit_cast(bf16x8, (u32x4){pw[0], pw[1], pw[2], pw[3]});
+                    if (X3) pl[qb] = __builtin_bit_cast(bf16x8, (u32x4){qw[0], qw[1], qw[2], qw[3]});
                 }
                 const int kb = blk * 2 + kb2;
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    // keys 16kb + 4half + {0..3} and 16kb + 8 + 4half + {0..3}: 16-B chunks 2kb and 2kb+1, byte 8*half
-                    const int rowoff = (db * 32 + l31) * 128 + 8 * half;
-                    const int o0 = rowoff + (((2 * kb) ^ sw_frag) << 4);
-                    const int o1 = rowoff + (((2 * kb + 1) ^ sw_frag) << 4);
-                    const bf16x8 vh = cat44(*(const bf16x4*)(sV + o0), *(const bf16x4*)(sV + o1));
-                    if (X3) {
-                        const bf16x8 vl = cat44(*(const bf16x4*)(sV + TILE + o0), *(const bf16x4*)(sV + TILE + o1));
-                        o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o_acc[db], 0, 0, 0);
-                        o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o_acc[db], 0, 0, 0);
+                    const int off = (db * 32 + l31) * 128 + (((2 * kb + half) ^ sw_frag) << 4);
+                    const bf16x8 vh = *(const bf16x8*)(sV + off);
+                    bf16x8 vl;
+                    if (X3) vl = *(const bf16x8*)(sV + TILE + off);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        if (X3) {
+                            o_acc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[qb], o_acc[qb][db], 0, 0, 0);
+                            o_acc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[qb], o_acc[qb][db], 0, 0, 0);
+                        }
+                        o_acc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[qb], o_acc[qb][db], 0, 0, 0);
                     }
-                    o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o_acc[db], 0, 0, 0);
                 }
             }
     }
 
-    // ---- normalise and store: o_acc[db][r] = O[q][d = 32db + (r&3) + 8(r>>2) + 4half]
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
-    if (q < p.npad) {
-        const size_t orow = ((size_t)b * p.npad + q) * p.F + h * 64;
+    // ---- normalise and store: o_acc[qb][db][r] = O[q][d = 32db + (r&3) + 8(r>>2) + 4half]
+    if (!active) return;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+        const float inv = 1.0f / l_tot;
+        const int q = q0 + qb * 32 + l31;
+        if (q < p.npad) {
+            const size_t orow = ((size_t)b * p.npad + q) * p.F + h * 64;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 hi4, lo4;
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = o_acc[db][g * 4 + e] * inv;
-                    hi4[e] = (__bf16)v;
-                    if (X3) lo4[e] = (__bf16)(v - (float)hi4[e]);
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 hi4, lo4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = o_acc[qb][db][g * 4 + e] * inv;
+                        hi4[e] = (__bf16)v;
+                        if (X3) lo4[e] = (__bf16)(v - (float)hi4[e]);
+                    }
+                    const size_t o = orow + db * 32 + 8 * g + 4 * half;
+                    *(bf16x4*)(p.out_hi + o) = hi4;
+                    if (X3) *(bf16x4*)(p.out_lo + o) = lo4;
                 }
-                const size_t o = orow + db * 32 + 8 * g + 4 * half;
-                *(bf16x4*)(p.out_hi + o) = hi4;
-                if (X3) *(bf16x4*)(p.out_lo + o) = lo4;
-            }
+        }
     }
 }
 
@@ -216,12 +294,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 
 int mdpt_launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.F != p.heads * 64 || (p.npadv & 63) || p.npadv < ((p.N + 63) & ~63) || p.npad < p.N) return (int)hipErrorInvalidValue;
-    const dim3 grid((p.npad + 127) / 128, p.heads, p.B);
-    MdptProfScope prof(p.x3 ? "attn_kernel<true>" : "attn_kernel<false>", 4.0 * p.B * p.heads * (double)p.N * p.N * 64.0, stream);
+    MdptProfScope prof(p.x3 ? "attn_kernel<true, 1>" : "attn_kernel<false, 2>", 4.0 * p.B * p.heads * (double)p.N * p.N * 64.0, stream);
     if (p.x3) {
-        hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 2 * 2 * 2 * 8192, stream, p);
+        hipLaunchKernelGGL((attn_kernel<true, 1>), dim3(((p.npad + 127) / 128) * p.heads * p.B), dim3(256), 2 * 2 * 2 * 8192, stream, p);
     } else {
-        hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), 2 * 2 * 8192, stream, p);
+        hipLaunchKernelGGL((attn_kernel<false, 2>), dim3(((p.npad + 255) / 256) * p.heads * p.B), dim3(256), 2 * 2 * 8192, stream, p);
     }
     return (int)hipGetLastError();
 }

@@ -56,7 +56,21 @@ __device__ __forceinline__ unsigned long long memtime_now() {
     return t;
 }
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+// Exact-GELU 0.5 v (1 + erf(v/sqrt2)) (reference: nn.GELU() default, components/misc_helpers.py:113) with erf from
+// Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute) on the hardware rcp/exp units: libm's erff costs ~180 us per
+// fc1 launch (measured 618 us vs 438 us without it), this form a handful of FMAs.
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float x = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const float e = __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);
+    const float erf_abs = 1.0f - poly * t * e;
+    return 0.5f * v * (1.0f + copysignf(erf_abs, v));
+}
 
 __device__ __forceinline__ void split_store4(bf16_t* hi, bf16_t* lo, size_t off, f32x4 v) {
     bf16x4 h;
@@ -84,88 +98,74 @@ __device__ __forceinline__ void split_store8(bf16_t* hi, bf16_t* lo, size_t off,
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int NST, int MINW, int AMODE, int EKIND>
-__global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmParams p) {
-    constexpr int NW = WM * WN;
-    constexpr int WTM = BM / WM, WTN = BN / WN;
-    constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int ROWB = BK * 2;        // bytes per LDS row (one K slab of one tile row)
-    constexpr int CPR = BK / 8;         // 16-B chunks per row
-    constexpr int RPC = 64 / CPR;       // rows per 1-KiB LDS-DMA chunk (one wave instruction)
-    constexpr int RPB = 256 / ROWB;     // rows per 256-B LDS bank row
-    constexpr int KSTEPS = BK / 16;     // 32x32x16 MFMA k-steps per slab
-    constexpr int CA = BM / RPC / NW, CB = BN / RPC / NW;  // DMA chunks per wave per stage
-    constexpr int NLOAD = CA + CB;
-    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-    static_assert(BK == 32 || BK == 64, "BK");
-    static_assert(NST == 2 || NST == 3, "ring depth");
+// ------------------------------------------------------------------------------------------------------------
+// Operand stager: per-lane source addresses of this wave's LDS-DMA chunks for one (BM+BN) x BK slab, and the
+// state machine that walks K (dense/token rows: a running pointer; 3x3 conv: tap / channel counters) and the
+// bf16x3 operand planes.
+// A DMA chunk (one global_load_lds_dwordx4 wave instruction, 1 KiB) is RPC rows x ROWB bytes; the lane feeds LDS
+// row (chunk*RPC + lane/CPR), 16-B slot (lane%CPR), which must hold global chunk (slot ^ key(row)) with
+// key(row) = (row / RPB) & (CPR-1): 16 consecutive rows then cover the 16 slots of a 256-B LDS bank row, so the
+// ds_read_b128 fragment pattern (16 rows x 16 B per service group) is conflict-free.
+// ------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int NW, int BK, int AMODE>
+struct Stager {
+    static constexpr int ROWB = BK * 2, CPR = BK / 8, RPC = 64 / CPR, RPB = 256 / ROWB;
+    static constexpr int CA = BM / RPC / NW, CB = BN / RPC / NW, NLOAD = CA + CB;
+    static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, SLAB = A_BYTES + B_BYTES;
     static_assert(BM % (RPC * NW) == 0 && BN % (RPC * NW) == 0, "chunk split");
-    static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
-    static_assert(32 * WTN * 4 * NW <= NST * STAGE, "epilogue strip must fit in the ring");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned long long t_start = 0, t_first = 0, t_loop = 0;
-    if (p.dbg_times) t_start = memtime_now();
-
-    // ---- XCD-aware tile mapping (bijective for any grid size)
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    const int bid = blockIdx.x;
-    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // ---- per-lane staging addresses. A DMA chunk is RPC rows x ROWB bytes; the lane feeds LDS row
-    //      (chunk*RPC + lane/CPR), 16-B slot (lane%CPR), which must hold global chunk (slot ^ key(row)) with
-    //      key(row) = (row / RPB) & (CPR-1)  (spreads 16 consecutive rows over the 16 slots of a 256-B bank row).
-    const int lrow = lane / CPR, slot = lane % CPR;
-    // row = (wave + NW*i)*RPC + lrow; RPC is a multiple of RPB*CPR only for... compute the key per chunk below.
-    const bf16_t* a_ptr[CA];   // DENSE/TOKENS: running source pointer (advanced by BK per stage)
+    const bf16_t* a_ptr[CA];
     int a_pix[CA], a_y[CA], a_x[CA], a_ko[CA];
+    const bf16_t* b_ptr[CB];
+    ptrdiff_t a_hi_minus_lo, w_lo_minus_hi;
+    const bf16_t* conv_plane;
+    int st_pass, st_k0, st_tap, st_ci;
+
+    __device__ __forceinline__ void init(const GemmParams& p, int m0, int n0, int wave, int lane) {
+        const int lrow = lane / CPR, slot = lane % CPR;
+        const bf16_t* A0 = p.npass == 3 ? p.A_lo : p.A_hi;  // operand plane of pass 0
 #pragma unroll
-    for (int i = 0; i < CA; ++i) {
-        const int r = (wave + NW * i) * RPC + lrow;
-        const int koff = (slot ^ ((r / RPB) & (CPR - 1))) * 8;
-        int m = m0 + r;
-        m = m < p.M ? m : p.M - 1;  // clamp: rows past M are computed and discarded
-        const bf16_t* A0 = p.npass == 3 ? p.A_lo : p.A_hi;  // pass 0 plane
-        if (AMODE == MDPT_A_DENSE) {
-            a_ptr[i] = A0 + (size_t)m * p.lda + koff;
-        } else if (AMODE == MDPT_A_TOKENS) {
-            const int b = m / p.tok_np, t = m - b * p.tok_np;
-            a_ptr[i] = A0 + ((size_t)b * p.tok_stride + 1 + t) * p.lda + koff;
-        } else {
-            const int hw = p.Ho * p.Wo;
-            const int b = m / hw, rem = m - b * hw;
-            const int y = rem / p.Wo, x = rem - y * p.Wo;
-            a_pix[i] = b * p.Hi * p.Wi;
-            a_y[i] = y * p.cstride - 1;
-            a_x[i] = x * p.cstride - 1;
+        for (int i = 0; i < CA; ++i) {
+            const int r = (wave + NW * i) * RPC + lrow;
+            const int koff = (slot ^ ((r / RPB) & (CPR - 1))) * 8;
+            int m = m0 + r;
+            m = m < p.M ? m : p.M - 1;  // clamp: rows past M are computed and discarded
+            a_pix[i] = a_y[i] = a_x[i] = 0;
             a_ko[i] = koff;
             a_ptr[i] = nullptr;
+            if (AMODE == MDPT_A_DENSE) {
+                a_ptr[i] = A0 + (size_t)m * p.lda + koff;
+            } else if (AMODE == MDPT_A_TOKENS) {
+                const int b = m / p.tok_np, t = m - b * p.tok_np;
+                a_ptr[i] = A0 + ((size_t)b * p.tok_stride + 1 + t) * p.lda + koff;
+            } else {
+                const int hw = p.Ho * p.Wo;
+                const int b = m / hw, rem = m - b * hw;
+                const int y = rem / p.Wo, x = rem - y * p.Wo;
+                a_pix[i] = b * p.Hi * p.Wi;
+                a_y[i] = y * p.cstride - 1;
+                a_x[i] = x * p.cstride - 1;
+            }
         }
-    }
-    const bf16_t* b_ptr[CB];
 #pragma unroll
-    for (int i = 0; i < CB; ++i) {
-        const int r = (wave + NW * i) * RPC + lrow;
-        const int koff = (slot ^ ((r / RPB) & (CPR - 1))) * 8;
-        int n = n0 + r;
-        n = n < p.N ? n : p.N - 1;
-        b_ptr[i] = p.W_hi + (size_t)n * p.K + koff;
+        for (int i = 0; i < CB; ++i) {
+            const int r = (wave + NW * i) * RPC + lrow;
+            const int koff = (slot ^ ((r / RPB) & (CPR - 1))) * 8;
+            int n = n0 + r;
+            n = n < p.N ? n : p.N - 1;
+            b_ptr[i] = p.W_hi + (size_t)n * p.K + koff;
+        }
+        // plane switches at pass roll-over (bf16x3 passes: A_lo*W_hi, A_hi*W_lo, A_hi*W_hi); all wave-uniform
+        a_hi_minus_lo = p.npass == 3 ? p.A_hi - p.A_lo : 0;
+        w_lo_minus_hi = p.npass == 3 ? p.W_lo - p.W_hi : 0;
+        conv_plane = A0;
+        st_pass = st_k0 = st_tap = st_ci = 0;
     }
-    // plane switches at pass roll-over (bf16x3: passes are A_lo*W_hi, A_hi*W_lo, A_hi*W_hi); all wave-uniform
-    const ptrdiff_t a_hi_minus_lo = p.npass == 3 ? p.A_hi - p.A_lo : 0;
-    const ptrdiff_t w_lo_minus_hi = p.npass == 3 ? p.W_lo - p.W_hi : 0;
-    const bf16_t* conv_plane = p.npass == 3 ? p.A_lo : p.A_hi;
 
-    int st_pass = 0, st_k0 = 0, st_tap = 0, st_ci = 0;
-    auto issue_stage = [&](int buf) {
-        char* sA = smem + buf * STAGE;
-        char* sB = sA + A_BYTES;
+    // issue this wave's NLOAD LDS-DMA instructions for the next slab into the ring slot at `slab_base`, then advance
+    __device__ __forceinline__ void issue(const GemmParams& p, char* slab_base, int wave) {
+        char* sA = slab_base;
+        char* sB = slab_base + A_BYTES;
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
             const bf16_t* src;
@@ -202,100 +202,32 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
             for (int i = 0; i < CB; ++i) b_ptr[i] += dw;
             ++st_pass;
         }
-    };
-
-    // ---- fragment read offsets: row = 32*blk + (lane&31), chunk = 2*kk + (lane>>5), swizzled with key(row)
-    const int l31 = lane & 31, half = lane >> 5;
-    const int sw_frag = (l31 / RPB) & (CPR - 1);
-    int frag_off[KSTEPS];
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) frag_off[kk] = l31 * ROWB + (((kk * 2 + half) ^ sw_frag) << 4);
-    const int wm = wave / WN, wn = wave % WN;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // ---- main loop: NST-deep LDS ring. Iteration t: wait for THIS wave's DMA of slab t (counted vmcnt: with a
-    //      3-deep ring the DMA of slab t+1 stays in flight across the barrier), barrier (everybody's part of slab t
-    //      has landed AND everybody finished reading slab t-1), refill the slot of slab t-1 with slab t+NST-1, compute.
-    //      LDS-DMA completion is only tracked by vmcnt: the waits are explicit (hipcc does not reliably insert them).
-    const int total = (p.K / BK) * p.npass;
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-        if (s < total) issue_stage(s);
-    int rd = 0, wr = NST - 1;
-    for (int t = 0; t < total; ++t) {
-        if (NST == 3 && t + 1 < total) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        if (p.dbg_times && t == 0) t_first = memtime_now();
-        if (t + NST - 1 < total) issue_stage(wr);
-        const char* sA = smem + rd * STAGE + wm * WTM * ROWB;
-        const char* sB = smem + rd * STAGE + A_BYTES + wn * WTN * ROWB;
-        // fragments are double-buffered in registers: the ds_reads of k-step kk+1 are issued before the MFMAs of
-        // k-step kk, so LDS latency hides behind 8 MFMAs instead of stalling both waves of the SIMD
-        bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
-#define LOAD_FRAGS(A_, B_, KK_)                                                                           \
-    do {                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) A_[i] = *(const bf16x8*)(sA + i * 32 * ROWB + frag_off[KK_]); \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) B_[j] = *(const bf16x8*)(sB + j * 32 * ROWB + frag_off[KK_]); \
-    } while (0)
-#define MFMA_RANGE(A_, B_, LO_, HI_)                                                                      \
-    do {                                                                                                  \
-        _Pragma("unroll") for (int ij = LO_; ij < HI_; ++ij)                                              \
-            acc[ij / TN][ij % TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[ij / TN], B_[ij % TN], acc[ij / TN][ij % TN], 0, 0, 0); \
-    } while (0)
-#define PIN() __builtin_amdgcn_sched_barrier(0)
-        // Fragment reads are double-buffered in registers and the issue order is pinned (hipcc would otherwise sink
-        // every ds_read next to its MFMA: read; wait; mfma). hipcc's waits are always lgkmcnt(0), so the order is
-        // chosen such that each wait sits a full MFMA block (>= 7 x 32 cycles) after the newest outstanding read:
-        //   L0 L1 | M0 | L2 | M1 | M2[first] | L3 | M2[rest] | M3
-        LOAD_FRAGS(a0, b0, 0);
-        LOAD_FRAGS(a1, b1, 1);
-        PIN();
-        MFMA_RANGE(a0, b0, 0, TM * TN);
-        PIN();
-        if (KSTEPS == 4) {
-            LOAD_FRAGS(a0, b0, 2);
-            PIN();
-        }
-        MFMA_RANGE(a1, b1, 0, TM * TN);
-        PIN();
-        if (KSTEPS == 4) {
-            MFMA_RANGE(a0, b0, 0, 1);
-            PIN();
-            LOAD_FRAGS(a1, b1, 3);
-            PIN();
-            MFMA_RANGE(a0, b0, 1, TM * TN);
-            PIN();
-            MFMA_RANGE(a1, b1, 0, TM * TN);
-            PIN();
-        }
-#undef LOAD_FRAGS
-#undef MFMA_RANGE
-#undef PIN
-        rd = rd + 1 == NST ? 0 : rd + 1;
-        wr = wr + 1 == NST ? 0 : wr + 1;
     }
-    if (p.dbg_times) t_loop = memtime_now();
-    __syncthreads();  // every wave is done reading the ring: reuse it as epilogue staging
+};
 
-    // ---- epilogue: per 32-row block, accumulators -> wave-private LDS strip [32][WTN] fp32 -> row-major vectors.
-    //      A CU retires roughly one wave store instruction per ~66 cycles whatever its width (measured), so every
-    //      store is 16 bytes per lane: each lane owns 8 consecutive columns (one bf16x8 store, two fp32x4 stores).
+// XCD-aware tile mapping (bijective for any grid size): the dispatcher places block b on XCD b%8; give every XCD a
+// contiguous run of tiles (same A rows, all N tiles) so operand panels stay in that XCD's L2.
+__device__ __forceinline__ void tile_coords(int tiles_n, int BM, int BN, int& m0, int& n0) {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    m0 = (swz / tiles_n) * BM;
+    n0 = (swz % tiles_n) * BN;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Epilogue shared by both main-loop variants: per 32-row block, accumulators -> wave-private LDS strip [32][WTN] fp32
+// -> row-major vectors. A CU retires roughly one wave store instruction per ~66 cycles whatever its width (measured),
+// so every store is 16 bytes per lane: each lane owns 8 consecutive columns (one bf16x8 store, two fp32x4 stores).
+// ------------------------------------------------------------------------------------------------------------
+template <int WTN, int TM, int TN, int EKIND>
+__device__ __forceinline__ void run_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], char* smem, int wave, int lane, int mwave0,
+                                             int nbase) {
+    const int l31 = lane & 31, half = lane >> 5;
     float* strip = (float*)smem + wave * (32 * WTN);
     constexpr int LPR = WTN / 8;     // lanes per row
     constexpr int RPP = 64 / LPR;    // rows per pass
     const int erow = lane / LPR, ecol = (lane % LPR) * 8;
-    const int nbase = n0 + wn * WTN;
 
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -304,7 +236,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 strip[((r & 3) + 8 * (r >> 2) + 4 * half) * WTN + j * 32 + l31] = acc[i][j][r];
-        const int mbase = m0 + wm * WTM + i * 32;
+        const int mbase = mwave0 + i * 32;
 
         if (EKIND == MDPT_E_QKV && nbase >= 2 * p.F) {
             // V columns: write transposed, Vt[(b,h,d), t..t+7] (8 consecutive tokens per lane, 16-byte stores)
@@ -430,6 +362,117 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Variant A ("lockstep"): all waves run  wait-DMA -> barrier -> issue next DMA -> LDS reads -> MFMAs  together.
+// Used for small tiles (128x128, 2 workgroups per CU) and the 32-wide head tile.
+// ------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int BK, int NST, int MINW, int AMODE, int EKIND>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmParams p) {
+    constexpr int NW = WM * WN;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    using St = Stager<BM, BN, NW, BK, AMODE>;
+    constexpr int ROWB = St::ROWB, CPR = St::CPR, RPB = St::RPB, NLOAD = St::NLOAD, A_BYTES = St::A_BYTES, STAGE = St::SLAB;
+    constexpr int KSTEPS = BK / 16;     // 32x32x16 MFMA k-steps per slab
+    static_assert(BK == 32 || BK == 64, "BK");
+    static_assert(NST == 2 || NST == 3, "ring depth");
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+    static_assert(32 * WTN * 4 * NW <= NST * STAGE, "epilogue strip must fit in the ring");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long t_start = 0, t_first = 0, t_loop = 0;
+    if (p.dbg_times) t_start = memtime_now();
+
+    int m0, n0;
+    tile_coords((p.N + BN - 1) / BN, BM, BN, m0, n0);
+    St st;
+    st.init(p, m0, n0, wave, lane);
+
+    // ---- fragment read offsets: row = 32*blk + (lane&31), chunk = 2*kk + (lane>>5), swizzled with key(row)
+    const int l31 = lane & 31, half = lane >> 5;
+    const int sw_frag = (l31 / RPB) & (CPR - 1);
+    int frag_off[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) frag_off[kk] = l31 * ROWB + (((kk * 2 + half) ^ sw_frag) << 4);
+    const int wm = wave / WN, wn = wave % WN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // ---- main loop: NST-deep LDS ring. Iteration t: wait for THIS wave's DMA of slab t (counted vmcnt: with a
+    //      3-deep ring the DMA of slab t+1 stays in flight across the barrier), barrier (everybody's part of slab t
+    //      has landed AND everybody finished reading slab t-1), refill the slot of slab t-1 with slab t+NST-1, compute.
+    //      LDS-DMA completion is only tracked by vmcnt: the waits are explicit (hipcc does not reliably insert them).
+    const int total = (p.K / BK) * p.npass;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < total) st.issue(p, smem + s * STAGE, wave);
+    int rd = 0, wr = NST - 1;
+    for (int t = 0; t < total; ++t) {
+        if (NST == 3 && t + 1 < total) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (p.dbg_times && t == 0) t_first = memtime_now();
+        if (t + NST - 1 < total) st.issue(p, smem + wr * STAGE, wave);
+        const char* sA = smem + rd * STAGE + wm * WTM * ROWB;
+        const char* sB = smem + rd * STAGE + A_BYTES + wn * WTN * ROWB;
+        bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+#define LOAD_FRAGS(A_, B_, KK_)                                                                           \
+    do {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) A_[i] = *(const bf16x8*)(sA + i * 32 * ROWB + frag_off[KK_]); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) B_[j] = *(const bf16x8*)(sB + j * 32 * ROWB + frag_off[KK_]); \
+    } while (0)
+#define MFMA_RANGE(A_, B_, LO_, HI_)                                                                      \
+    do {                                                                                                  \
+        _Pragma("unroll") for (int ij = LO_; ij < HI_; ++ij)                                              \
+            acc[ij / TN][ij % TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[ij / TN], B_[ij % TN], acc[ij / TN][ij % TN], 0, 0, 0); \
+    } while (0)
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+        // Fragment reads are double-buffered in registers and the issue order is pinned (hipcc would otherwise sink
+        // every ds_read next to its MFMA: read; wait; mfma). hipcc's waits are always lgkmcnt(0), so the order is
+        // chosen such that each wait sits a full MFMA block after the newest outstanding read:
+        //   L0 L1 | M0 | L2 | M1 | M2[first] | L3 | M2[rest] | M3
+        LOAD_FRAGS(a0, b0, 0);
+        LOAD_FRAGS(a1, b1, 1);
+        PIN();
+        MFMA_RANGE(a0, b0, 0, TM * TN);
+        PIN();
+        if (KSTEPS == 4) {
+            LOAD_FRAGS(a0, b0, 2);
+            PIN();
+        }
+        MFMA_RANGE(a1, b1, 0, TM * TN);
+        PIN();
+        if (KSTEPS == 4) {
+            MFMA_RANGE(a0, b0, 0, 1);
+            PIN();
+            LOAD_FRAGS(a1, b1, 3);
+            PIN();
+            MFMA_RANGE(a0, b0, 1, TM * TN);
+            PIN();
+            MFMA_RANGE(a1, b1, 0, TM * TN);
+            PIN();
+        }
+#undef LOAD_FRAGS
+#undef MFMA_RANGE
+        rd = rd + 1 == NST ? 0 : rd + 1;
+        wr = wr + 1 == NST ? 0 : wr + 1;
+    }
+    if (p.dbg_times) t_loop = memtime_now();
+    __syncthreads();  // every wave is done reading the ring: reuse it as epilogue staging
+    run_epilogue<WTN, TM, TN, EKIND>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
     if (p.dbg_times && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long* d = p.dbg_times + (size_t)blockIdx.x * 6;
@@ -437,6 +480,148 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
         d[4] = __builtin_amdgcn_s_getreg(20 << 0 | 0 << 6 | 3 << 11);  // HW_REG_XCC_ID bits [3:0]
         d[5] = __builtin_amdgcn_s_getreg(4 << 0 | 0 << 6 | 31 << 11);  // HW_REG_HW_ID
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Variant B ("ping-pong"), 256x256 tile, 8 waves (2 row groups x 4), 32-deep K slabs in a 4-slot LDS ring (128 KiB),
+// DMA issued three slabs ahead.
+//
+// Measured on variant A (s_memtime probes, tests/gpu_gemm_timeline.py): the CU's vector-memory path accepts one 1-KiB
+// LDS-DMA instruction per ~35 cycles, so the 64 of them a 256x256x64 K-step needs take ~2240 cycles - as long as the
+// step's 2048 MFMA cycles - and in the lockstep loop they sit IN FRONT of the MFMAs (DMA issue 650..2240 cycles, then
+// ~240 cycles LDS latency, then ~1130 cycles of MFMA issue: ~3300-3700 cycles per step, ~60 % MFMA efficiency).
+// Here the two row groups (waves 0-3 / 4-7: one wave of each group per SIMD) run the same program one barrier apart:
+//     L-phase: issue DMA for slab j+3, read slab j's fragments LDS -> registers, confirm own DMA of slab j+1
+//     C-phase: 16 register-only MFMAs (raised priority)
+// so while one group computes, the other issues DMA and reads LDS. Hazards (B#n = n-th workgroup barrier; group 0 runs
+// L_j in (B#2j, B#2j+1), group 1 in (B#2j+1, B#2j+2)):
+//   RAW  slab j is read after B#2j: group 0 confirmed its DMA parts of slab j at the end of L_{j-1} (before B#2j-1),
+//        group 1 at the end of its L_{j-1} (before B#2j).
+//   WAR  slab j+3 reuses the slot of slab j-1, whose last reader (group 1, L_{j-1}, ended by lgkmcnt(0)) finished before
+//        B#2j; group 0 issues that DMA after B#2j, group 1 after B#2j+1.
+// ------------------------------------------------------------------------------------------------------------
+template <int AMODE, int EKIND>
+__global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
+    constexpr int BM = 256, BN = 256, NW = 8, WN = 4, BK = 32, NSLOT = 4, DIST = 3;
+    constexpr int WTM = 128, WTN = 64, TM = 4, TN = 2;
+    using St = Stager<BM, BN, NW, BK, AMODE>;
+    constexpr int ROWB = St::ROWB, CPR = St::CPR, RPB = St::RPB, NLOAD = St::NLOAD, A_BYTES = St::A_BYTES, SLAB = St::SLAB;
+    static_assert(NLOAD == 4 && SLAB == 32768, "slab geometry");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;  // row group (= skew group) and column quarter
+    unsigned long long t_start = 0, t_first = 0, t_loop = 0;
+    if (p.dbg_times) t_start = memtime_now();
+
+    int m0, n0;
+    tile_coords((p.N + BN - 1) / BN, BM, BN, m0, n0);
+    St st;
+    st.init(p, m0, n0, wave, lane);
+
+    const int l31 = lane & 31, half = lane >> 5;
+    const int sw_frag = (l31 / RPB) & (CPR - 1);
+    const int frag0 = l31 * ROWB + (((0 + half) ^ sw_frag) << 4);
+    const int frag1 = l31 * ROWB + (((2 + half) ^ sw_frag) << 4);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int total = (p.K / BK) * p.npass;  // >= 2 (K % 64 == 0)
+#pragma unroll
+    for (int s = 0; s < DIST; ++s)
+        if (s < total) st.issue(p, smem + s * SLAB, wave);
+    if (total >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // B#0: slab 0 complete
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // B#1: group 1 runs one phase behind group 0
+    if (p.dbg_times) t_first = memtime_now();
+
+    for (int j = 0; j < total; ++j) {
+        // ------------------------------ L-phase
+        const int rem = total - 1 - j;
+        const bool probe = p.dbg_times && j == (total >> 1) && (wave == 0 || wave == 4) && lane == 0;
+        unsigned long long q0 = 0, q1 = 0, q2 = 0;
+        if (probe) q0 = memtime_now();
+        const char* sA = smem + (j & (NSLOT - 1)) * SLAB + grp * WTM * ROWB;
+        const char* sB = smem + (j & (NSLOT - 1)) * SLAB + A_BYTES + wn * WTN * ROWB;
+        bf16x8 fa[TM][2], fb[TN][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            fa[i][0] = *(const bf16x8*)(sA + i * 32 * ROWB + frag0);
+            fa[i][1] = *(const bf16x8*)(sA + i * 32 * ROWB + frag1);
+        }
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj) {
+            fb[jj][0] = *(const bf16x8*)(sB + jj * 32 * ROWB + frag0);
+            fb[jj][1] = *(const bf16x8*)(sB + jj * 32 * ROWB + frag1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // DMA issue AFTER the fragment reads: the LDS-DMA instructions stall in the CU's (contended) vector-memory queue
+        // for hundreds of cycles; issued first they would delay the ds_reads behind them (measured: L-phase 870 cycles)
+        if (rem >= DIST) st.issue(p, smem + ((j + DIST) & (NSLOT - 1)) * SLAB, wave);
+        __builtin_amdgcn_sched_barrier(0);
+        // own DMA parts of slab j+1 have landed (slabs j+2, j+3 may stay in flight), fragments are in registers
+        if (rem >= 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (rem == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (probe) q1 = memtime_now();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ------------------------------ C-phase: 16 register-only MFMAs
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][kk], fb[jj][kk], acc[i][jj], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (probe) {
+            q2 = memtime_now();
+            unsigned long long* d = p.dbg_times + (size_t)gridDim.x * 6 + ((size_t)blockIdx.x * 2 + (wave != 0)) * 8;
+            d[0] = q0; d[1] = q1; d[2] = q2;
+        }
+        if (!(grp == 1 && rem == 0)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (p.dbg_times) t_loop = memtime_now();
+    __syncthreads();  // every wave is done with the ring: reuse it as epilogue staging
+    run_epilogue<WTN, TM, TN, EKIND>(p, acc, smem, wave, lane, m0 + grp * WTM, n0 + wn * WTN);
+    if (p.dbg_times && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = p.dbg_times + (size_t)blockIdx.x * 6;
+        d[0] = t_start; d[1] = t_first; d[2] = t_loop; d[3] = memtime_now();
+        d[4] = __builtin_amdgcn_s_getreg(20 << 0 | 0 << 6 | 3 << 11);
+        d[5] = __builtin_amdgcn_s_getreg(4 << 0 | 0 << 6 | 31 << 11);
+    }
+}
+
+template <int AMODE, int EKIND>
+int launch_pp(const GemmParams& p, hipStream_t stream) {
+    constexpr int LDS = 4 * 32768;
+    static bool attr_done = false;
+    auto kern = gemm_pp_kernel<AMODE, EKIND>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    static char prof_name[64] = "";
+    if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "gemm_pp_kernel<%d, %d>", AMODE, EKIND);
+    MdptProfScope prof(prof_name, 2.0 * p.M * p.N * p.K, stream);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, p);
+    return (int)hipGetLastError();
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int NST, int MINW, int AMODE, int EKIND>
@@ -469,6 +654,7 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
         const bool big = p.N % 256 == 0 && (tiles256 >= 512 || (tiles256 >= 256 && p.K >= 2048));
         tile = big ? MDPT_TILE_256x256 : MDPT_TILE_128x128;
     }
+    if (tile == MDPT_TILE_PP256) return launch_pp<AMODE, EKIND>(p, stream);
     if (tile == MDPT_TILE_256x128) return launch_cfg<256, 128, 2, 2, 32, 3, 2, AMODE, EKIND>(p, stream);
     if (tile == MDPT_TILE_256x256) return launch_cfg<256, 256, 2, 4, 64, 2, 1, AMODE, EKIND>(p, stream);
     return launch_cfg<128, 128, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);

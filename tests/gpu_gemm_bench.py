@@ -16,7 +16,7 @@ from muggled_dpt_amd import native  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--tiles", default="1,2,4")
+    ap.add_argument("--tiles", default="1,2,5")
     args = ap.parse_args()
     lib = native.load()
     stream = torch.cuda.current_stream().cuda_stream
