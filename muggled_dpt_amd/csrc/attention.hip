@@ -294,11 +294,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 
 int mdpt_launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.F != p.heads * 64 || (p.npadv & 63) || p.npadv < ((p.N + 63) & ~63) || p.npad < p.N) return (int)hipErrorInvalidValue;
-    MdptProfScope prof(p.x3 ? "attn_kernel<true, 1>" : "attn_kernel<false, 2>", 4.0 * p.B * p.heads * (double)p.N * p.N * 64.0, stream);
+    // 64 queries per wave (256 per workgroup) when that still gives >= 2 workgroups per CU, else 128-query workgroups
+    const long blocks256 = (long)((p.npad + 255) / 256) * p.heads * p.B;
+    const bool wide = !p.x3 && blocks256 >= 512;
+    MdptProfScope prof(p.x3 ? "attn_kernel<true, 1>" : (wide ? "attn_kernel<false, 2>" : "attn_kernel<false, 1>"),
+                       4.0 * p.B * p.heads * (double)p.N * p.N * 64.0, stream);
     if (p.x3) {
         hipLaunchKernelGGL((attn_kernel<true, 1>), dim3(((p.npad + 127) / 128) * p.heads * p.B), dim3(256), 2 * 2 * 2 * 8192, stream, p);
+    } else if (wide) {
+        hipLaunchKernelGGL((attn_kernel<false, 2>), dim3((unsigned)blocks256), dim3(256), 2 * 2 * 8192, stream, p);
     } else {
-        hipLaunchKernelGGL((attn_kernel<false, 2>), dim3(((p.npad + 255) / 256) * p.heads * p.B), dim3(256), 2 * 2 * 8192, stream, p);
+        hipLaunchKernelGGL((attn_kernel<false, 1>), dim3(((p.npad + 127) / 128) * p.heads * p.B), dim3(256), 2 * 2 * 8192, stream, p);
     }
     return (int)hipGetLastError();
 }

@@ -240,8 +240,9 @@ __device__ __forceinline__ void run_epilogue(const GemmParams& p, f32x16 (&acc)[
 
         if (EKIND == MDPT_E_QKV && nbase >= 2 * p.F) {
             // V columns: write transposed, Vt[(b,h,d), t..t+7] (8 consecutive tokens per lane, 16-byte stores)
-            for (int pr = 0; pr < 4 * (WTN / 64); ++pr) {
-                const int col = (pr / 4) * 64 + lane, rg = pr % 4;
+            for (int pr = 0; pr < WTN * 4 / 64; ++pr) {  // WTN columns x 4 groups of 8 rows, 64 items per pass
+                const int item = pr * 64 + lane;
+                const int col = item % WTN, rg = item / WTN;
                 const int m = mbase + rg * 8, n = nbase + col;
                 if (m >= p.M || n >= p.N) continue;
                 const float bz = p.bias[n];
@@ -651,9 +652,12 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
         // big tiles or the K loop is deep enough to amortise its ~17k-cycle epilogue; otherwise 128x128x64 (2 workgroups
         // per CU, finer tile quantisation). The 256x128x32 3-deep-ring variant is kept selectable but never won.
         const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+        const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         const bool big = p.N % 256 == 0 && (tiles256 >= 512 || (tiles256 >= 256 && p.K >= 2048));
-        tile = big ? MDPT_TILE_256x256 : MDPT_TILE_128x128;
+        // small problems (batch 1): 128x128 tiles would leave most of the 256 CUs idle -> 64x64 tiles
+        tile = big ? MDPT_TILE_256x256 : (tiles128 < 384 ? MDPT_TILE_64x64 : MDPT_TILE_128x128);
     }
+    if (tile == MDPT_TILE_64x64) return launch_cfg<64, 64, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);
     if (tile == MDPT_TILE_PP256) return launch_pp<AMODE, EKIND>(p, stream);
     if (tile == MDPT_TILE_256x128) return launch_cfg<256, 128, 2, 2, 32, 3, 2, AMODE, EKIND>(p, stream);
     if (tile == MDPT_TILE_256x256) return launch_cfg<256, 256, 2, 4, 64, 2, 1, AMODE, EKIND>(p, stream);

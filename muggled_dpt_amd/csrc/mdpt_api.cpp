@@ -731,7 +731,7 @@ int mdpt_workspace_bytes(const mdpt_handle* h, int32_t B, int32_t H, int32_t W, 
 }
 
 int mdpt_set_gemm_tile(mdpt_handle* h, int32_t tile) {
-    if (!h || tile < 0 || tile > 5 || tile == 3) return fail(MDPT_E_INVALID, "tile must be 0 (auto), 1 (128x128x64), 2 (256x256x64 lockstep), 4 (256x128x32) or 5 (256x256x32 ping-pong)");
+    if (!h || tile < 0 || tile > 6 || tile == 3) return fail(MDPT_E_INVALID, "tile must be 0 (auto), 1 (128x128x64), 2 (256x256x64 lockstep), 4 (256x128x32) or 5 (256x256x32 ping-pong)");
     h->gemm_tile = tile;
     return 0;
 }

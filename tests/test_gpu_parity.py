@@ -156,6 +156,21 @@ def test_full_size_batch32_properties():
     assert float(y.float().max()) > 0.1, "degenerate (all-zero) output"
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_every_gemm_tile_variant_is_bitwise_identical(dtype):
+    """All main-loop variants (128x128x64, 256x256x64 lockstep, 256x128x32 3-deep ring, 256x256x32 ping-pong, 64x64x64)
+    through every A-row generator and epilogue of the model: same K order + fp-contract off => identical bits."""
+    model, cfg, w = _model("vits", dtype)
+    x = seeded_input((2, 3, 252, 252), 11).to("cuda", dtype)
+    y_auto = model(x)
+    ref = _oracle().forward(w, cfg, x.float().cpu())
+    assert rel_err(y_auto.float().cpu(), ref) <= (REL_TOL_X3 if dtype == torch.float32 else REL_TOL_BF16)
+    for tile in (1, 2, 4, 5, 6):
+        model.set_gemm_tile(tile)
+        assert torch.equal(model(x), y_auto), f"tile variant {tile} changed the result"
+    model.set_gemm_tile(0)
+
+
 def test_vits_1036_matches_oracle():
     """The other BASELINE size: 1036x1036 (grid 74x74, N = 5477 tokens) - long-sequence attention + big decoder maps."""
     model, cfg, w = _model("vits", torch.float32)
