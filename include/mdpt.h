@@ -108,6 +108,11 @@ int mdpt_fusion(mdpt_handle* h, const void* const maps_in[4], int32_t B, int32_t
 int mdpt_head(mdpt_handle* h, const void* fused_in, int32_t B, int32_t gh, int32_t gw, void* depth_bhw, void* workspace,
               size_t workspace_bytes, void* stream);
 
+/* PatchEmbed.prepare_image (v2_depthanything/patch_embed.py:103-145): uint8 [in_h,in_w,3] BGR on the device ->
+ * fp32 [3,out_h,out_w] RGB, antialiased-bilinear resized exactly like F.interpolate(..., antialias=True) and normalised with the
+ * ImageNet mean/std. The caller picks out_h/out_w with the reference's size rule (multiples of 2*patch). */
+int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void* out_chw_f32, int32_t out_h, int32_t out_w, void* stream);
+
 /* Stage boundaries of the LAST mdpt_forward on `workspace`, converted to reference layouts (debug / parity taps):
  * which = 0..3 encoder taps [B,N,F]; 4..7 reassembly maps (BCHW); 8 fused map [B,C,8gh,8gw]. */
 int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspace, size_t workspace_bytes, void* stream);

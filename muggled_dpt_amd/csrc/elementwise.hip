@@ -331,6 +331,59 @@ __global__ __launch_bounds__(256) void tokens_to_resid_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// prepare_image (reference v2_depthanything/patch_embed.py:103-145): uint8 HxWx3 BGR ->
+// [3, oh, ow] fp32, RGB order, resized with PyTorch's *antialiased* bilinear (F.interpolate(mode="bilinear",
+// antialias=True, align_corners=False)) and normalised ((v/255) - mean) / std. The antialias filter is the
+// separable triangle filter of aten's _upsample_bilinear2d_aa: per output index i, scale = in/out,
+// support = max(scale, 1), centre = scale*(i+0.5), taps j in [floor(centre-support+0.5), floor(centre+support+0.5))
+// clipped to the image, weight = max(0, 1 - |(j - centre + 0.5) / max(scale,1)|), normalised to sum 1.
+// One thread per output pixel (all 3 channels): rows of weights are recomputed per pixel (<= ~2*scale+2 taps).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void aa_span(int i, float scale, int in_size, int& lo, int& n, float& center, float& invscale) {
+    const float support = scale >= 1.0f ? scale : 1.0f;
+    invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
+    center = scale * ((float)i + 0.5f);
+    lo = max((int)(center - support + 0.5f), 0);
+    const int hi = min((int)(center + support + 0.5f), in_size);
+    n = hi - lo;
+}
+
+__global__ __launch_bounds__(256) void prepare_image_kernel(const unsigned char* __restrict__ bgr, float* __restrict__ out, int ih,
+                                                            int iw, int oh, int ow, float m0, float m1, float m2, float s0,
+                                                            float s1, float s2) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= oh * ow) return;
+    const int ox = idx % ow, oy = idx / ow;
+    const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
+    int ylo, yn, xlo, xn;
+    float yc, yinv, xc, xinv;
+    aa_span(oy, sy, ih, ylo, yn, yc, yinv);
+    aa_span(ox, sx, iw, xlo, xn, xc, xinv);
+    float wxs = 0.0f, wys = 0.0f;
+    for (int j = 0; j < xn; ++j) wxs += fmaxf(0.0f, 1.0f - fabsf(((float)(j + xlo) - xc + 0.5f) * xinv));
+    for (int j = 0; j < yn; ++j) wys += fmaxf(0.0f, 1.0f - fabsf(((float)(j + ylo) - yc + 0.5f) * yinv));
+    float acc_b = 0.0f, acc_g = 0.0f, acc_r = 0.0f;
+    for (int a = 0; a < yn; ++a) {
+        const float wy = fmaxf(0.0f, 1.0f - fabsf(((float)(a + ylo) - yc + 0.5f) * yinv)) / wys;
+        const unsigned char* row = bgr + ((size_t)(ylo + a) * iw + xlo) * 3;
+        float rb = 0.0f, rg = 0.0f, rr = 0.0f;  // horizontal pass first (like the reference's separable CPU kernel)
+        for (int c = 0; c < xn; ++c) {
+            const float wx = fmaxf(0.0f, 1.0f - fabsf(((float)(c + xlo) - xc + 0.5f) * xinv)) / wxs;
+            rb += wx * (float)row[c * 3 + 0];
+            rg += wx * (float)row[c * 3 + 1];
+            rr += wx * (float)row[c * 3 + 2];
+        }
+        acc_b += wy * rb;
+        acc_g += wy * rg;
+        acc_r += wy * rr;
+    }
+    const size_t plane = (size_t)oh * ow;
+    out[idx] = (acc_r / 255.0f - m0) * s0;              // channel 0 = R
+    out[plane + idx] = (acc_g / 255.0f - m1) * s1;      // channel 1 = G
+    out[2 * plane + idx] = (acc_b / 255.0f - m2) * s2;  // channel 2 = B
+}
+
 inline int grid_for(size_t total, int block = 256) {
     size_t g = (total + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -435,5 +488,14 @@ int mdpt_launch_tokens_import(const float* in, bf16_t* out_hi, bf16_t* out_lo, i
 
 int mdpt_launch_tokens_to_resid(const float* tokens, const float* pos, float* resid, int B, int Np, int npad, int F, hipStream_t stream) {
     hipLaunchKernelGGL(tokens_to_resid_kernel, dim3(grid_for((size_t)B * Np * F)), dim3(256), 0, stream, tokens, pos, resid, B, Np, npad, F);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_prepare_image(const unsigned char* bgr, float* out, int ih, int iw, int oh, int ow, const float mean[3],
+                              const float inv_std[3], hipStream_t stream) {
+    if (ih <= 0 || iw <= 0 || oh <= 0 || ow <= 0) return (int)hipErrorInvalidValue;
+    MdptProfScope prof("prepare_image_kernel", 0.0, stream);
+    hipLaunchKernelGGL(prepare_image_kernel, dim3((oh * ow + 255) / 256), dim3(256), 0, stream, bgr, out, ih, iw, oh, ow, mean[0], mean[1],
+                       mean[2], inv_std[0], inv_std[1], inv_std[2]);
     LAUNCH_RET();
 }

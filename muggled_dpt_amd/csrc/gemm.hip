@@ -540,19 +540,38 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
         if (s < total) st.issue(p, smem + s * SLAB, wave);
     if (total >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                 // B#0: slab 0 complete
-    if (grp == 1) __builtin_amdgcn_s_barrier();   // B#1: group 1 runs one phase behind group 0
+    __builtin_amdgcn_s_barrier();  // slab 0 complete
     if (p.dbg_times) t_first = memtime_now();
 
+    // One workgroup barrier per slab. Inside interval j (between two barriers):
+    //     group 0:  L_j (read slab j -> registers, issue DMA of slab j+3, confirm own DMA of slab j+1)  then  C_j (16 MFMAs)
+    //     group 1:  C_{j-1} (16 MFMAs on the fragments it loaded in interval j-1)                       then  L_j
+    // so on every SIMD one wave's MFMA block always runs beside the other wave's DMA-issue / LDS-read block.
+    //   RAW  slab j is read in interval j; every wave confirmed its DMA parts of slab j (vmcnt) before the barrier that
+    //        ends interval j-1.
+    //   WAR  slab j+3 reuses the slot of slab j-1, last read (and waited for, lgkmcnt(0)) in interval j-1.
+    bf16x8 fa[TM][2], fb[TN][2];
+#define PP_COMPUTE()                                                                                                   \
+    do {                                                                                                               \
+        __builtin_amdgcn_s_setprio(1);                                                                                 \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < TM; ++i)                \
+            _Pragma("unroll") for (int jj = 0; jj < TN; ++jj) acc[i][jj] =                                             \
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][kk], fb[jj][kk], acc[i][jj], 0, 0, 0);                   \
+        __builtin_amdgcn_s_setprio(0);                                                                                 \
+    } while (0)
     for (int j = 0; j < total; ++j) {
-        // ------------------------------ L-phase
         const int rem = total - 1 - j;
         const bool probe = p.dbg_times && j == (total >> 1) && (wave == 0 || wave == 4) && lane == 0;
         unsigned long long q0 = 0, q1 = 0, q2 = 0;
         if (probe) q0 = memtime_now();
+        if (grp == 1 && j > 0) {
+            PP_COMPUTE();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (probe) q1 = memtime_now();
+        // ------------------------------ L-phase
         const char* sA = smem + (j & (NSLOT - 1)) * SLAB + grp * WTM * ROWB;
         const char* sB = smem + (j & (NSLOT - 1)) * SLAB + A_BYTES + wn * WTN * ROWB;
-        bf16x8 fa[TM][2], fb[TN][2];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             fa[i][0] = *(const bf16x8*)(sA + i * 32 * ROWB + frag0);
@@ -573,28 +592,20 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
         else if (rem == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (probe) q1 = memtime_now();
+        if (probe) q2 = memtime_now();
+        if (grp == 0) {
+            PP_COMPUTE();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (probe) {
+            unsigned long long* d = p.dbg_times + (size_t)gridDim.x * 6 + ((size_t)blockIdx.x * 2 + (wave != 0)) * 8;
+            d[0] = q0; d[1] = q1; d[2] = q2; d[3] = memtime_now();
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // ------------------------------ C-phase: 16 register-only MFMAs
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jj = 0; jj < TN; ++jj)
-                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][kk], fb[jj][kk], acc[i][jj], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (probe) {
-            q2 = memtime_now();
-            unsigned long long* d = p.dbg_times + (size_t)gridDim.x * 6 + ((size_t)blockIdx.x * 2 + (wave != 0)) * 8;
-            d[0] = q0; d[1] = q1; d[2] = q2;
-        }
-        if (!(grp == 1 && rem == 0)) __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
     }
+    if (grp == 1) PP_COMPUTE();
+#undef PP_COMPUTE
     if (p.dbg_times) t_loop = memtime_now();
     __syncthreads();  // every wave is done with the ring: reuse it as epilogue staging
     run_epilogue<WTN, TM, TN, EKIND>(p, acc, smem, wave, lane, m0 + grp * WTM, n0 + wn * WTN);

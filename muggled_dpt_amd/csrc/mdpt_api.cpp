@@ -868,6 +868,16 @@ int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspac
     return 0;
 }
 
+// ---- PatchEmbed.prepare_image (reference v2_depthanything/patch_embed.py:103-145): resize + BGR->RGB + normalise on the GPU
+int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void* out_chw_f32, int32_t out_h, int32_t out_w, void* stream) {
+    if (!bgr_u8_hwc || !out_chw_f32) return fail(MDPT_E_INVALID, "null argument");
+    if (in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) return fail(MDPT_E_INVALID, "bad image size %dx%d -> %dx%d", in_h, in_w, out_h, out_w);
+    const float mean[3] = {0.485f, 0.456f, 0.406f};                                  // patch_embed.py:38
+    const float inv_std[3] = {1.0f / 0.229f, 1.0f / 0.224f, 1.0f / 0.225f};           // patch_embed.py:39,62
+    CHK(mdpt_launch_prepare_image((const unsigned char*)bgr_u8_hwc, (float*)out_chw_f32, in_h, in_w, out_h, out_w, mean, inv_std, (hipStream_t)stream));
+    return 0;
+}
+
 // ---- test hooks (tests/ only): truncate the encoder after (block, step) and read raw internal buffers as fp32
 int mdpt_debug_set_stop(mdpt_handle* h, int32_t block, int32_t step) {
     if (!h) return fail(MDPT_E_INVALID, "null handle");

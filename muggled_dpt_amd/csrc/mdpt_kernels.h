@@ -101,4 +101,7 @@ int mdpt_launch_nchw_to_nhwc(const float* in, float* out_f32, bf16_t* out_hi, bf
 // stage-level encoder entry: resid[b, 1+t, :] = tokens[b, t, :] + pos[t, :]
 int mdpt_launch_tokens_to_resid(const float* tokens, const float* pos, float* resid, int B, int Np, int npad, int F,
                                 hipStream_t stream);
+// uint8 HWC BGR -> normalised fp32 [3,oh,ow] RGB through PyTorch-compatible antialiased bilinear resize
+int mdpt_launch_prepare_image(const unsigned char* bgr, float* out, int ih, int iw, int oh, int ow, const float mean[3],
+                              const float inv_std[3], hipStream_t stream);
 int mdpt_launch_memset_f32(float* dst, float value, size_t n, hipStream_t stream);

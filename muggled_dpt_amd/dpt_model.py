@@ -103,6 +103,17 @@ class PatchEmbed(_Stage):
         targ_hw = (largest_side, largest_side) if use_square_sizing else (img_h, img_w)
         scaled_hw = [max(1, round(side * scale / self._tiling_size)) * self._tiling_size for side in targ_hw]
         p = next(self.parameters())
+        if interpolation_mode == "bilinear" and p.device.type == "cuda" and image_bgr.dtype == np.uint8 and image_bgr.ndim == 3 \
+                and image_bgr.shape[2] == 3:
+            # native path: one HIP kernel (antialiased bilinear resize + BGR->RGB + normalisation), mdpt_prepare_image
+            lib = native.load()
+            src = torch.from_numpy(np.ascontiguousarray(image_bgr)).to(p.device, non_blocking=True)
+            out = torch.empty((1, 3, scaled_hw[0], scaled_hw[1]), device=p.device, dtype=torch.float32)
+            with torch.cuda.device(p.device):
+                stream = torch.cuda.current_stream(p.device).cuda_stream
+                native.check(lib, lib.mdpt_prepare_image(src.data_ptr(), img_h, img_w, out.data_ptr(), scaled_hw[0], scaled_hw[1], stream))
+            return out if p.dtype == torch.float32 else out.to(p.dtype)
+        # other interpolation modes / non-uint8 inputs: the reference's own torch ops on the model device
         rgb = np.ascontiguousarray(image_bgr[:, :, ::-1].transpose(2, 0, 1))
         x = torch.from_numpy(rgb).to(device=p.device, dtype=p.dtype)
         x = nn.functional.interpolate(x.unsqueeze(0), size=scaled_hw, align_corners=False, antialias=True, mode=interpolation_mode)

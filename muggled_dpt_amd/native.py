@@ -108,6 +108,7 @@ SYMBOLS = {
     "mdpt_reassemble": (ctypes.c_int, [_VP, _VP4, _I, _I, _I, _VP4, _VP, _SZ, _VP]),
     "mdpt_fusion": (ctypes.c_int, [_VP, _VP4, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_head": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
+    "mdpt_prepare_image": (ctypes.c_int, [_VP, _I, _I, _VP, _I, _I, _VP]),
     "mdpt_export_tap": (ctypes.c_int, [_VP, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_set_gemm_tile": (ctypes.c_int, [_VP, _I]),
     "mdpt_debug_gemm": (ctypes.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _VP]),

@@ -43,10 +43,10 @@ for (M, N, K, tag) in [(41728, 1024, 1024, "proj"), (41728, 4096, 1024, "fc1"), 
                   f"(p10 {np.percentile(epi,10):6.0f} p90 {np.percentile(epi,90):6.0f}) total {(pro+loop+epi).mean():8.0f}", flush=True)
             for wv in (0, 1):
                 if tile == 5:
-                    qq = q[:, wv, :3].astype(np.float64)
+                    qq = q[:, wv, :4].astype(np.float64)
                     ok = qq[:, 0] > 0
                     dd = np.diff(qq[ok], axis=1)
-                    print(f"        mid slab, wave {'0' if wv == 0 else '4'}: L-phase (DMA issue + LDS reads + waits) {dd[:,0].mean():6.0f} | barrier + 16 MFMA {dd[:,1].mean():6.0f}", flush=True)
+                    print(f"        mid slab, wave {'0' if wv == 0 else '4'}: C(prev, grp1 only) {dd[:,0].mean():6.0f} | L-phase {dd[:,1].mean():6.0f} | C(grp0 only) {dd[:,2].mean():6.0f}", flush=True)
                     continue
                 qq = q[:, wv, :5].astype(np.float64)
                 ok = qq[:, 0] > 0

@@ -178,6 +178,23 @@ def test_vits_1036_matches_oracle():
     assert rel_err(model(x.to("cuda")).cpu(), _oracle().forward(w, cfg, x)) <= REL_TOL_X3
 
 
+def test_prepare_image_kernel_vs_golden(golden_dir):
+    """mdpt_prepare_image (HIP antialiased bilinear + BGR->RGB + normalise) against outputs of the reference's
+    prepare_image_bgr (tools/gen_golden.py): same shapes (518->504 snapping, aspect-ratio mode, 1036, upscaling) and values."""
+    from tests.helpers import stats
+    g = np.load(os.path.join(golden_dir, "prepare_image.npz"))
+    model, _, _ = _model("vits", torch.float32)
+    names = sorted({k[: -len("_img")] for k in g.files if k.endswith("_img")})
+    assert len(names) >= 5
+    for name in names:
+        side, square = (int(v) for v in g[f"{name}_args"])
+        out = model.prepare_image_bgr(g[f"{name}_img"], None if side < 0 else side, bool(square))
+        assert out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == tuple(int(v) for v in g[f"{name}_shape"]), name
+        err = float((out[:, :, ::7, ::7].cpu().double() - torch.from_numpy(g[f"{name}_out_strided"]).double()).abs().max())
+        assert err <= 2e-5, f"{name}: max abs err {err}"   # normalised pixel units (~[-2.1, 2.6]); fp32 summation-order noise only
+        np.testing.assert_allclose(stats(out.cpu()), g[f"{name}_stats"], rtol=2e-5, atol=2e-4)
+
+
 def test_metric_head_sigmoid():
     from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
     osd, cfg, w = synthetic_model("tiny", 0)
