@@ -32,6 +32,9 @@ extern "C" {
 #define MDPT_PREC_BF16 0   /* bf16 MFMA operands - the reference's GPU default dtype (demo_helpers/misc.py:73-77) */
 #define MDPT_PREC_BF16X3 1 /* split-bf16 (hi+lo) operands, 3 MFMA passes: fp32-class accuracy (parity mode)        */
 
+#define MDPT_TAPS_STAGES 0
+#define MDPT_TAPS_LAST4 1
+
 #define MDPT_E_INVALID (-1)    /* bad argument / shape                                  */
 #define MDPT_E_STATE (-2)      /* call order (e.g. forward before finalize)             */
 #define MDPT_E_MISSING (-3)    /* a weight required by the config was not bound         */
@@ -55,6 +58,9 @@ typedef struct mdpt_config {
     int32_t is_giant;  /* must be 0 in this build */
     int32_t is_metric; /* sigmoid instead of the final ReLU (head_model.py:84) */
     int32_t precision; /* MDPT_PREC_* */
+    int32_t encoder_taps; /* MDPT_TAPS_STAGES (Depth-Anything V2: after each quarter of the blocks, image_encoder_model.py:88-93)
+                             or MDPT_TAPS_LAST4 (Depth-Anything V1: after each of the last four blocks,
+                             v1_depthanything/image_encoder_model.py:55-61; parameters are then named imgencoder.blocks.N...) */
 } mdpt_config;
 
 int mdpt_abi_version(void);

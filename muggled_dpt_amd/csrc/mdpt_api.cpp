@@ -158,7 +158,8 @@ namespace {
 
 std::string blk_name(const mdpt_handle* h, int block) {
     char buf[96];
-    snprintf(buf, sizeof(buf), "imgencoder.stages.%d.blocks.%d", block / h->bps, block % h->bps);
+    if (h->cfg.encoder_taps == MDPT_TAPS_LAST4) snprintf(buf, sizeof(buf), "imgencoder.blocks.%d", block);
+    else snprintf(buf, sizeof(buf), "imgencoder.stages.%d.blocks.%d", block / h->bps, block % h->bps);
     return buf;
 }
 
@@ -464,8 +465,9 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             CHK(mdpt_launch_gemm(g, c.s));
         }
         DBG_STOP(6);
-        if ((b + 1) % h->bps == 0) {
-            const int st = b / h->bps;
+        const bool v1 = h->cfg.encoder_taps == MDPT_TAPS_LAST4;
+        if (v1 ? b >= h->nblocks - 4 : (b + 1) % h->bps == 0) {
+            const int st = v1 ? b - (h->nblocks - 4) : b / h->bps;
             Planes tp = c.pl(p.tap[st]);
             float* f32 = taps_f32 ? c.at<float>(p.tapf32) : nullptr;
             CHK(mdpt_launch_layernorm(resid, h->V("imgencoder.outnorm.weight"), h->V("imgencoder.outnorm.bias"), tp.hi, tp.lo, f32, rows, F, c.s));
@@ -637,6 +639,7 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     if (cfg->patch_size_px <= 0 || cfg->patch_size_px % 2) return fail(MDPT_E_INVALID, "patch_size_px must be even (head scale = patch/8)");
     if (cfg->base_patch_grid_h <= 0 || cfg->base_patch_grid_w <= 0) return fail(MDPT_E_INVALID, "bad base patch grid");
     if (cfg->precision != MDPT_PREC_BF16 && cfg->precision != MDPT_PREC_BF16X3) return fail(MDPT_E_INVALID, "unknown precision %d", cfg->precision);
+    if (cfg->encoder_taps != MDPT_TAPS_STAGES && cfg->encoder_taps != MDPT_TAPS_LAST4) return fail(MDPT_E_INVALID, "unknown encoder_taps %d", cfg->encoder_taps);
     for (int i = 0; i < 4; ++i)
         if (cfg->reassembly_features[i] <= 0 || cfg->reassembly_features[i] % 4) return fail(MDPT_E_INVALID, "reassembly_features[%d] must be a multiple of 4", i);
     mdpt_handle* h = new mdpt_handle();

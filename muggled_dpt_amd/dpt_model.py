@@ -207,6 +207,7 @@ class _Engine:
         c.fusion_channels, c.patch_size_px = cfg["fusion_channels"], cfg["patch_size_px"]
         c.is_giant, c.is_metric = int(bool(cfg.get("is_giant", False))), int(bool(cfg.get("is_metric", False)))
         c.precision = native.PREC_BF16X3 if dtype == torch.float32 else native.PREC_BF16
+        c.encoder_taps = native.TAPS_LAST4 if model.family == "v1" else native.TAPS_STAGES
         self.precision = c.precision
         handle = ctypes.c_void_p()
         native.check(self.lib, self.lib.mdpt_create(ctypes.byref(c), ctypes.byref(handle)))
@@ -292,11 +293,12 @@ class _Engine:
 class DPTModel(nn.Module):
     """Drop-in for the reference's DPTModel (muggled_dpt/dpt_model.py:21-168) running on libmdpt."""
 
-    def __init__(self, config: dict):
+    def __init__(self, config: dict, family: str = "v2"):
         super().__init__()
         self.config = dict(config)
-        keys = expected_new_keys(self.config)
-        shapes = _new_key_shapes(self.config)
+        self.family = family  # "v2": Depth-Anything V2 (taps after each quarter of the blocks); "v1": taps after the last 4 blocks
+        keys = expected_new_keys(self.config, family)
+        shapes = _new_key_shapes(self.config, family)
         per = {comp: {k: shapes[f"{comp}.{k}"] for k in keys[comp]} for comp in COMPONENTS}
         default_px = self.config["base_patch_grid_hw"][0] * self.config["patch_size_px"]
         self.patch_embed = PatchEmbed(per["patch_embed"], self.config["patch_size_px"], default_px)
@@ -392,13 +394,13 @@ class DPTModel(nn.Module):
         return out
 
 
-def _new_key_shapes(cfg: dict) -> dict[str, tuple]:
+def _new_key_shapes(cfg: dict, family: str = "v2") -> dict[str, tuple]:
     """Shapes of every new-format parameter, derived from the config (same inventory as the C side)."""
     from .synthetic import original_state_dict_shapes
     from .state_dict_conversion import original_to_new_key_table
 
     orig = original_state_dict_shapes(cfg)
-    table = original_to_new_key_table(cfg)
+    table = original_to_new_key_table(cfg, family)
     shapes = {}
     for old, (comp, new) in table.items():
         shapes[f"{comp}.{new}"] = tuple(orig[old])

@@ -22,6 +22,8 @@ HEADERS = ("mdpt_kernels.h", "mdpt_prof.h", os.path.join(REPO, "include", "mdpt.
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1
+TAPS_STAGES = 0
+TAPS_LAST4 = 1
 E_GRID = -7
 
 
@@ -82,6 +84,7 @@ class MdptConfig(ctypes.Structure):
         ("is_giant", ctypes.c_int32),
         ("is_metric", ctypes.c_int32),
         ("precision", ctypes.c_int32),
+        ("encoder_taps", ctypes.c_int32),
     ]
 
 

@@ -27,7 +27,8 @@ _STAGE_NAMES = ("spatial_upx4", "spatial_upx2", "spatial_noscale", "spatial_down
 # config
 
 
-def get_model_config_from_state_dict(state_dict: dict, enable_cache: bool = False, enable_optimizations: bool = True) -> dict:
+def get_model_config_from_state_dict(state_dict: dict, enable_cache: bool = False, enable_optimizations: bool = True,
+                                     family: str = "v2") -> dict:
     """Infer the 11-key model config from an *original-format* DA-V2 state dict.
 
     Mirrors config_from_original_state_dict.py:17-43 (same keys, same derivations:
@@ -53,7 +54,7 @@ def get_model_config_from_state_dict(state_dict: dict, enable_cache: bool = Fals
     num_pos = int(need("pretrained.pos_embed").shape[1]) - 1
     base_grid = int(math.isqrt(num_pos))
 
-    return {
+    cfg = {
         "features_per_token": features_per_token,
         "num_blocks": num_blocks,
         "num_heads": features_per_token // 64,
@@ -61,18 +62,20 @@ def get_model_config_from_state_dict(state_dict: dict, enable_cache: bool = Fals
         "fusion_channels": fusion_channels,
         "patch_size_px": patch_size_px,
         "base_patch_grid_hw": (base_grid, base_grid),
-        "is_giant": "pretrained.blocks.0.mlp.w12.weight" in state_dict,
-        "is_metric": "is_metric" in state_dict,
-        "enable_cache": enable_cache,
-        "enable_optimizations": enable_optimizations,
     }
+    if family == "v2":  # the Depth-Anything V1 sniffer returns 9 keys (v1_depthanything/.../config_from_original_state_dict.py:17-36)
+        cfg["is_giant"] = "pretrained.blocks.0.mlp.w12.weight" in state_dict
+        cfg["is_metric"] = "is_metric" in state_dict
+    cfg["enable_cache"] = enable_cache
+    cfg["enable_optimizations"] = enable_optimizations
+    return cfg
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # key table
 
 
-def original_to_new_key_table(config: dict) -> dict[str, tuple[str, str]]:
+def original_to_new_key_table(config: dict, family: str = "v2") -> dict[str, tuple[str, str]]:
     """Explicit {original_key: (component, new_key)} table for a given config.
 
     New-format names are the reference's module attribute paths, e.g.
@@ -93,7 +96,8 @@ def original_to_new_key_table(config: dict) -> dict[str, tuple[str, str]]:
         table[f"pretrained.norm.{s}"] = ("imgencoder", f"outnorm.{s}")
     for i in range(config["num_blocks"]):
         old = f"pretrained.blocks.{i}"
-        new = f"stages.{i // blocks_per_stage}.blocks.{i % blocks_per_stage}"
+        # V1 keeps a flat block list (v1_depthanything/.../convert_original_state_dict_keys.py:139-140)
+        new = f"blocks.{i}" if family == "v1" else f"stages.{i // blocks_per_stage}.blocks.{i % blocks_per_stage}"
         for s in wb:
             table[f"{old}.norm1.{s}"] = ("imgencoder", f"{new}.norm1.{s}")
             table[f"{old}.norm2.{s}"] = ("imgencoder", f"{new}.norm2.{s}")
@@ -142,13 +146,13 @@ _IGNORED_ORIGINAL_PREFIXES = (
 )
 
 
-def convert_state_dict_keys(config: dict, original_state_dict: dict) -> dict[str, dict]:
+def convert_state_dict_keys(config: dict, original_state_dict: dict, family: str = "v2") -> dict[str, dict]:
     """Original upstream state dict -> {"patch_embed":{}, "imgencoder":{}, "reassemble":{}, "fusion":{}, "head":{}}.
 
     Same output contract as convert_original_state_dict_keys.py:15-86 (unknown keys are silently
     skipped there too; strictness is enforced later by load_state_dict).
     """
-    table = original_to_new_key_table(config)
+    table = original_to_new_key_table(config, family)
     out: dict[str, dict] = {name: {} for name in COMPONENTS}
     for key, data in original_state_dict.items():
         key = str(key)
@@ -163,10 +167,10 @@ def convert_state_dict_keys(config: dict, original_state_dict: dict) -> dict[str
     return out
 
 
-def expected_new_keys(config: dict) -> dict[str, list[str]]:
+def expected_new_keys(config: dict, family: str = "v2") -> dict[str, list[str]]:
     """All new-format keys a complete model must have (used for strict loading)."""
     keys: dict[str, list[str]] = {name: [] for name in COMPONENTS}
-    for comp, new_key in original_to_new_key_table(config).values():
+    for comp, new_key in original_to_new_key_table(config, family).values():
         keys[comp].append(new_key)
     keys["imgencoder"] += ["posenc.cls_embedding", "posenc.base_patch_embedding"]
     return keys

@@ -120,12 +120,21 @@ def image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple
     b = patch_tokens.shape[0]
     cls = w["imgencoder.cls_token"] + w["imgencoder.posenc.cls_embedding"]
     tokens = torch.cat((cls.expand(b, -1, -1), patch_tokens + position_embedding(w, grid_hw)), dim=1)
-    per_stage = int(round(cfg["num_blocks"] / 4))
     taps = []
-    for s in range(4):
-        for i in range(per_stage):
-            tokens = transformer_block(w, f"imgencoder.stages.{s}.blocks.{i}", tokens, cfg["num_heads"])
-        taps.append(tokens)
+    if "imgencoder.blocks.0.norm1.weight" in w:
+        # Depth-Anything V1: flat block list, tapped after each of the LAST FOUR blocks
+        # (v1_depthanything/image_encoder_model.py:55-61)
+        n = cfg["num_blocks"]
+        for i in range(n):
+            tokens = transformer_block(w, f"imgencoder.blocks.{i}", tokens, cfg["num_heads"])
+            if i >= n - 4:
+                taps.append(tokens)
+    else:
+        per_stage = int(round(cfg["num_blocks"] / 4))
+        for s in range(4):
+            for i in range(per_stage):
+                tokens = transformer_block(w, f"imgencoder.stages.{s}.blocks.{i}", tokens, cfg["num_heads"])
+            taps.append(tokens)
     return [layernorm(t, w["imgencoder.outnorm.weight"], w["imgencoder.outnorm.bias"]) for t in taps]
 
 

@@ -94,3 +94,23 @@ def test_workspace_planning_and_grid_rules(lib):
     p = ctypes.c_size_t()
     assert lib.mdpt_packed_bytes(h, ctypes.byref(p)) == 0 and 600e6 < p.value < 800e6  # ~334 M params in bf16
     lib.mdpt_destroy(h)
+
+
+def test_make_dpt_routes_v1_and_v2_by_file_name(tmp_path):
+    """determine_model_type_from_state_dict: same key sniffing / file-name rules as the reference (make_dpt.py:78-116)."""
+    import torch
+    from muggled_dpt_amd.make_dpt import determine_model_type_from_state_dict, make_dpt_from_state_dict
+    from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict
+    osd = make_synthetic_original_state_dict("tiny", 0)
+    assert determine_model_type_from_state_dict("/x/depth_anything_v2_vits.pth", osd) == "depthanythingv2"
+    assert determine_model_type_from_state_dict("/x/depth_anything_vitl14.pth", osd) == "depthanythingv1"
+    assert determine_model_type_from_state_dict("/x/whatever.pth", {"pretrained.model.blocks.0.attn.relative_position_bias_table": 0}) == "beit"
+    assert determine_model_type_from_state_dict("/x/whatever.pth", {"foo": 0}) == "unknown"
+    p1 = str(tmp_path / "depth_anything_vits14.pth")
+    torch.save(osd, p1)
+    cfg, model = make_dpt_from_state_dict(p1)
+    assert model.family == "v1" and len(cfg) == 9
+    with pytest.raises(NotImplementedError):
+        make_dpt_from_state_dict(p1, model_type="swinv2")
+    with pytest.raises(NotImplementedError):
+        make_dpt_from_state_dict(p1, model_type="nonsense")

@@ -195,6 +195,32 @@ def test_prepare_image_kernel_vs_golden(golden_dir):
         np.testing.assert_allclose(stats(out.cpu()), g[f"{name}_stats"], rtol=2e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("dtype,tol", MODES)
+def test_depth_anything_v1_family(golden_dir, dtype, tol):
+    """§8(f) row 3: Depth-Anything V1 (taps after the last four blocks) through make_dpt_from_state_dict's v1 route."""
+    from muggled_dpt_amd import make_depthanythingv1_dpt_from_original_state_dict
+    from muggled_dpt_amd.synthetic import STANDARD_CONFIGS, make_synthetic_original_state_dict
+    g = np.load(os.path.join(golden_dir, "tiny_v1.npz"))
+    osd = make_synthetic_original_state_dict(dict(STANDARD_CONFIGS["tiny"], num_blocks=int(g["num_blocks"])), int(g["weight_seed"]))
+    cfg, model = make_depthanythingv1_dpt_from_original_state_dict(osd)
+    assert len(cfg) == 9 and "blocks.7.attn.qkv.weight" in model.imgencoder.state_dict()
+    model = model.to("cuda", dtype)
+    x = torch.from_numpy(g["input"]).to("cuda", dtype)
+    y = model(x)
+    assert rel_err(y.float().cpu(), torch.from_numpy(g["depth"])) <= tol
+    taps = model.debug_taps(2, (56, 84))
+    for i in range(4):
+        assert rel_err(taps["stages"][i].cpu(), torch.from_numpy(g[f"tap{i}"])) <= tol, f"tap{i}"
+    assert rel_err(taps["fused"].cpu(), torch.from_numpy(g["fused"])) <= tol
+
+
+def test_vit_base_config_matches_oracle():
+    """ViT-B sized model (F=768, 12 heads; reference make_depthanythingv2_dpt.py:97-104 standard configs)."""
+    model, cfg, w = _model("vitb", torch.float32)
+    x = seeded_input((1, 3, 252, 308), 21)
+    assert rel_err(model(x.to("cuda")).cpu(), _oracle().forward(w, cfg, x)) <= REL_TOL_X3
+
+
 def test_metric_head_sigmoid():
     from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
     osd, cfg, w = synthetic_model("tiny", 0)

@@ -116,3 +116,20 @@ def test_key_conversion_matches_reference_names(golden_dir):
     for k, shape in ref_keys.items():
         assert list(w[k].shape) == shape, k
     assert cfg["num_heads"] == 1 and cfg["num_blocks"] == 4 and tuple(cfg["base_patch_grid_hw"]) == (5, 5)
+
+
+def test_depth_anything_v1_last_four_block_taps(golden_dir):
+    """Depth-Anything V1 (reference v1_depthanything/): same checkpoint format, encoder tapped after the last 4 blocks."""
+    from muggled_dpt_amd.state_dict_conversion import convert_state_dict_keys, flatten_components, get_model_config_from_state_dict
+    from muggled_dpt_amd.synthetic import STANDARD_CONFIGS, make_synthetic_original_state_dict
+    g = np.load(os.path.join(golden_dir, "tiny_v1.npz"))
+    osd = make_synthetic_original_state_dict(dict(STANDARD_CONFIGS["tiny"], num_blocks=int(g["num_blocks"])), int(g["weight_seed"]))
+    cfg = get_model_config_from_state_dict(osd, family="v1")
+    assert "is_giant" not in cfg and "is_metric" not in cfg and len(cfg) == 9
+    w = flatten_components(convert_state_dict_keys(cfg, osd, family="v1"))
+    assert "imgencoder.blocks.7.attn.qkv.weight" in w and not any(".stages." in k for k in w)
+    depth, st = dpt_oracle.forward(w, cfg, torch.from_numpy(g["input"]), return_stages=True)
+    for i in range(4):
+        _close(st["stages"][i], g[f"tap{i}"])
+    _close(st["fused"], g["fused"])
+    _close(depth, g["depth"])

@@ -124,6 +124,23 @@ def main():
     except RuntimeError as e:
         print("[tiny] odd grid raises in reference:", str(e).splitlines()[0])
 
+    # ------------------------------------------------------------------ 1b. Depth-Anything V1 (taps = last 4 blocks), tiny config with 8 blocks
+    from muggled_dpt.make_depthanythingv1_dpt import make_depthanythingv1_dpt_from_original_state_dict as ref_make_v1
+    cfg8 = dict(STANDARD_CONFIGS["tiny"], num_blocks=8)
+    osd1 = make_synthetic_original_state_dict(cfg8, 3)
+    cfg_ref1, model1 = ref_make_v1(osd1, enable_cache=False, enable_optimizations=True)
+    cfg1 = get_model_config_from_state_dict(osd1, family="v1")
+    assert {k: (tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in cfg1.items()} == \
+           {k: (tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in cfg_ref1.items()}, (cfg1, cfg_ref1)
+    w1 = flatten_components(convert_state_dict_keys(cfg1, osd1, family="v1"))
+    ref_keys1 = {f"{comp}.{k}" for comp in ("patch_embed", "imgencoder", "reassemble", "fusion", "head") for k in getattr(model1, comp).state_dict()}
+    assert ref_keys1 == set(w1), ref_keys1 ^ set(w1)
+    x1 = torch.randn(2, 3, 56, 84, generator=torch.Generator().manual_seed(4))
+    ref1 = run_reference(model1, x1)
+    report["tiny_v1"] = check_against_oracle("tiny_v1", ref1, w1, cfg1, x1)
+    np.savez_compressed(os.path.join(GOLD, "tiny_v1.npz"), weight_seed=3, num_blocks=8, input=x1.numpy(), depth=ref1[5].numpy(),
+                        fused=ref1[4].numpy(), **{f"tap{i}": ref1[2][i].numpy() for i in range(4)})
+
     # ------------------------------------------------------------------ 2. position embedding resize
     base = w["imgencoder.posenc.base_patch_embedding"]
     pos = {}
