@@ -32,8 +32,9 @@ extern "C" {
 #define MDPT_PREC_BF16 0   /* bf16 MFMA operands - the reference's GPU default dtype (demo_helpers/misc.py:73-77) */
 #define MDPT_PREC_BF16X3 1 /* split-bf16 (hi+lo) operands, 3 MFMA passes: fp32-class accuracy (parity mode)        */
 
-#define MDPT_TAPS_STAGES 0
-#define MDPT_TAPS_LAST4 1
+#define MDPT_FAMILY_DAV2 0
+#define MDPT_FAMILY_DAV1 1
+#define MDPT_FAMILY_BEIT 2
 
 #define MDPT_E_INVALID (-1)    /* bad argument / shape                                  */
 #define MDPT_E_STATE (-2)      /* call order (e.g. forward before finalize)             */
@@ -58,9 +59,11 @@ typedef struct mdpt_config {
     int32_t is_giant;  /* must be 0 in this build */
     int32_t is_metric; /* sigmoid instead of the final ReLU (head_model.py:84) */
     int32_t precision; /* MDPT_PREC_* */
-    int32_t encoder_taps; /* MDPT_TAPS_STAGES (Depth-Anything V2: after each quarter of the blocks, image_encoder_model.py:88-93)
-                             or MDPT_TAPS_LAST4 (Depth-Anything V1: after each of the last four blocks,
-                             v1_depthanything/image_encoder_model.py:55-61; parameters are then named imgencoder.blocks.N...) */
+    int32_t family;    /* MDPT_FAMILY_DAV2: Depth-Anything V2 (encoder tapped after each quarter of the blocks, image_encoder_model.py:88-93)
+                          MDPT_FAMILY_DAV1: Depth-Anything V1 (tapped after each of the last four blocks,
+                                            v1_depthanything/image_encoder_model.py:55-61; parameters named imgencoder.blocks.N...)
+                          MDPT_FAMILY_BEIT: MiDaS v3.1 BEiT (v31_beit/: relative-position-bias attention with q/v bias, no position
+                                            embedding or out-norm, readout projection in the reassembly, patch 16) */
 } mdpt_config;
 
 int mdpt_abi_version(void);
@@ -116,8 +119,9 @@ int mdpt_head(mdpt_handle* h, const void* fused_in, int32_t B, int32_t gh, int32
 
 /* PatchEmbed.prepare_image (v2_depthanything/patch_embed.py:103-145): uint8 [in_h,in_w,3] BGR on the device ->
  * fp32 [3,out_h,out_w] RGB, antialiased-bilinear resized exactly like F.interpolate(..., antialias=True) and normalised with the
- * ImageNet mean/std. The caller picks out_h/out_w with the reference's size rule (multiples of 2*patch). */
-int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void* out_chw_f32, int32_t out_h, int32_t out_w, void* stream);
+ * given per-channel mean/std (ImageNet values for Depth-Anything, 0.5/0.5 for BEiT). The caller picks out_h/out_w with the reference's size rule (multiples of 2*patch). */
+int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void* out_chw_f32, int32_t out_h, int32_t out_w,
+                       const float rgb_mean[3], const float rgb_std[3], void* stream);
 
 /* Stage boundaries of the LAST mdpt_forward on `workspace`, converted to reference layouts (debug / parity taps):
  * which = 0..3 encoder taps [B,N,F]; 4..7 reassembly maps (BCHW); 8 fused map [B,C,8gh,8gw]. */

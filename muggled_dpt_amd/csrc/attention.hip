@@ -46,7 +46,7 @@ __device__ __forceinline__ bf16x8 cat44(bf16x4 a, bf16x4 b) {
 // QB = query blocks of 32 per wave: 2 in bf16 mode (64 queries per wave, 256 per workgroup: every K / Vt fragment read
 // from LDS and every LDS-DMA'd tile feeds twice the MFMAs - the kernel is vector-memory/LDS bound otherwise), 1 in x3
 // mode (register budget: hi+lo planes of Q, K, V and P).
-template <bool X3, int QB>
+template <bool X3, int QB, bool BIAS>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     constexpr int NPL = X3 ? 2 : 1;           // planes per operand
     constexpr int TILE = 8192;                // one [64][64] bf16 tile
@@ -86,6 +86,23 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             const size_t o = (bh * p.npad + q_ld) * 64 + ks * 16 + half * 8;
             qh[qb][ks] = *(const bf16x8*)(p.q_hi + o);
             if (X3) ql[qb][ks] = *(const bf16x8*)(p.q_lo + o);
+        }
+    }
+
+    // ---- BEiT relative position bias: this head's resized table (ext LUT) and the per-key index terms live in LDS
+    //      behind the K/V ring; bias(q,k) = lut[tq[q] - tk[k]] (see beit_relpos_kernel)
+    float* lds_lut = (float*)(smem + 2 * STAGE);
+    int* lds_tk = (int*)(lds_lut + (BIAS ? p.bias_elen : 0));
+    int tqv[QB];
+    if (BIAS) {
+        const float* lut = p.bias_lut + (size_t)h * p.bias_elen;
+        for (int i = tid; i < p.bias_elen; i += 256) lds_lut[i] = lut[i];
+        const int nk = ((p.N + 63) >> 6) << 6;
+        for (int i = tid; i < nk; i += 256) lds_tk[i] = p.tk[i < p.npad ? i : p.npad - 1];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int q = q0 + qb * 32 + l31;
+            tqv[qb] = p.tq[q < p.npad ? q : p.npad - 1];
         }
     }
 
@@ -160,6 +177,19 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                     s[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[qb][ks], s[qb][blk], 0, 0, 0);
                 }
             }
+        if (BIAS) {
+            typedef __attribute__((ext_vector_type(4))) int i32x4;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const i32x4 tk4 = *(const i32x4*)(lds_tk + t * 64 + blk * 32 + 8 * g + 4 * half);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s[qb][blk][4 * g + e] += lds_lut[tqv[qb] - tk4[e]];
+                }
+        }
         // key of s[..][blk][r] = t*64 + blk*32 + (r&3) + 8*(r>>2) + 4*half
         if (t * 64 + 64 > p.N) {
 #pragma unroll
@@ -297,14 +327,37 @@ int mdpt_launch_attention(const AttnParams& p, hipStream_t stream) {
     // 64 queries per wave (256 per workgroup) when that still gives >= 2 workgroups per CU, else 128-query workgroups
     const long blocks256 = (long)((p.npad + 255) / 256) * p.heads * p.B;
     const bool wide = !p.x3 && blocks256 >= 512;
-    MdptProfScope prof(p.x3 ? "attn_kernel<true, 1>" : (wide ? "attn_kernel<false, 2>" : "attn_kernel<false, 1>"),
-                       4.0 * p.B * p.heads * (double)p.N * p.N * 64.0, stream);
-    if (p.x3) {
-        hipLaunchKernelGGL((attn_kernel<true, 1>), dim3(((p.npad + 127) / 128) * p.heads * p.B), dim3(256), 2 * 2 * 2 * 8192, stream, p);
-    } else if (wide) {
-        hipLaunchKernelGGL((attn_kernel<false, 2>), dim3((unsigned)blocks256), dim3(256), 2 * 2 * 8192, stream, p);
-    } else {
-        hipLaunchKernelGGL((attn_kernel<false, 1>), dim3(((p.npad + 127) / 128) * p.heads * p.B), dim3(256), 2 * 2 * 8192, stream, p);
+    const bool bias = p.bias_lut != nullptr;
+    const int ntk = ((p.N + 63) / 64) * 64;
+    const size_t extra = bias ? (size_t)p.bias_elen * 4 + (size_t)ntk * 4 : 0;
+    const size_t ring = (size_t)2 * 2 * (p.x3 ? 2 : 1) * 8192;
+    if (ring + extra > 160 * 1024 / 2) {
+        if (ring + extra > 160 * 1024) return (int)hipErrorInvalidValue;  // relative-position table does not fit in LDS
     }
+    MdptProfScope prof(p.x3 ? (bias ? "attn_kernel<true, 1, true>" : "attn_kernel<true, 1, false>")
+                            : (wide ? (bias ? "attn_kernel<false, 2, true>" : "attn_kernel<false, 2, false>")
+                                    : (bias ? "attn_kernel<false, 1, true>" : "attn_kernel<false, 1, false>")),
+                       4.0 * p.B * p.heads * (double)p.N * p.N * 64.0, stream);
+    const unsigned lds = (unsigned)(ring + extra);
+    const dim3 grid128(((p.npad + 127) / 128) * p.heads * p.B), grid256((unsigned)blocks256), block(256);
+#define ATTN_LAUNCH(X3_, QB_, BIAS_, GRID_)                                                                              \
+    do {                                                                                                                \
+        auto kern = attn_kernel<X3_, QB_, BIAS_>;                                                                       \
+        static bool attr_done = false;                                                                                  \
+        if (!attr_done) {                                                                                               \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return (int)e;                                                                         \
+            attr_done = true;                                                                                           \
+        }                                                                                                               \
+        hipLaunchKernelGGL(kern, GRID_, block, lds, stream, p);                                                         \
+    } while (0)
+    if (p.x3) {
+        if (bias) ATTN_LAUNCH(true, 1, true, grid128); else ATTN_LAUNCH(true, 1, false, grid128);
+    } else if (wide) {
+        if (bias) ATTN_LAUNCH(false, 2, true, grid256); else ATTN_LAUNCH(false, 2, false, grid256);
+    } else {
+        if (bias) ATTN_LAUNCH(false, 1, true, grid128); else ATTN_LAUNCH(false, 1, false, grid128);
+    }
+#undef ATTN_LAUNCH
     return (int)hipGetLastError();
 }

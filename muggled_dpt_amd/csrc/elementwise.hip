@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void init_tokens_kernel(float* resid, const fl
         const int rr = (int)((idx / F) % rows_per_img);
         const int b = (int)(idx / ((size_t)F * rows_per_img));
         const int t = rr == 0 ? 0 : N + rr - 1;
-        resid[((size_t)b * npad + t) * F + f] = rr == 0 ? cls_token[f] + cls_embed[f] : 0.0f;
+        resid[((size_t)b * npad + t) * F + f] = rr == 0 ? cls_token[f] + (cls_embed ? cls_embed[f] : 0.0f) : 0.0f;
     }
 }
 
@@ -217,14 +217,14 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
 // one-time weight repack: fp32 PyTorch layouts -> bf16 hi(/lo) [Np][Kp], zero padded
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, bf16_t* dst_hi, bf16_t* dst_lo, int kind,
-                                                          int N, int K, int Np, int Kp, int ksz) {
+                                                          int N, int K, int Np, int Kp, int ksz, int src_ld, int src_col0) {
     const size_t total = (size_t)Np * Kp;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int kcol = (int)(idx % Kp);
         const int nrow = (int)(idx / Kp);
         float v = 0.0f;
         if (kind == MDPT_PACK_LINEAR) {
-            if (nrow < N && kcol < K) v = src[(size_t)nrow * K + kcol];
+            if (nrow < N && kcol < K) v = src[(size_t)nrow * src_ld + src_col0 + kcol];
         } else if (kind == MDPT_PACK_CONV3) {
             // src [N=Cout][K=Cin][3][3]; Kp = 9*Cinp; kcol = tap*Cinp + ci
             const int cinp = Kp / 9;
@@ -384,6 +384,58 @@ __global__ __launch_bounds__(256) void prepare_image_kernel(const unsigned char*
     out[2 * plane + idx] = (acc_b / 255.0f - m2) * s2;  // channel 2 = B
 }
 
+// ---------------------------------------------------------------------------------------------------
+// BEiT relative position bias. Reference builds a [1,heads,N,N] tensor per layer by bilinear-resizing the learned
+// table and gathering it with an index matrix (relative_positional_encoder.py:117-309). Here only the resized table
+// is kept, laid out per head so that the attention kernel can hold it in LDS and look the bias up as
+//     ext[tq[q] - tk[k]]      tq = (yq + gh-1)(2gw-1) + xq + gw-1,  tk = yk(2gw-1) + xk     (token-token, in [0,R))
+// with the three cls cases mapped onto constant regions: tq[cls] = R+T, tk[cls] = -(R+T+1):
+//     [R, R+T] = cls->token value, [R+T+1, 2R+T] = token->cls value, [2R+2T+1] = cls->cls   (R=(2gh-1)(2gw-1), T=(gh-1)(2gw-1)+gw-1)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void beit_relpos_kernel(const float* __restrict__ ref, float* __restrict__ ext, int* tq, int* tk,
+                                                          int heads, int Gh, int Gw, int gh, int gw, int N, int ntok_pad) {
+    const int rh = 2 * gh - 1, rw = 2 * gw - 1, Rh = 2 * Gh - 1, Rw = 2 * Gw - 1;
+    const int R = rh * rw, T = (gh - 1) * rw + gw - 1, Rref = Rh * Rw;
+    const int elen = 2 * R + 2 * T + 2;
+    const int total = heads * elen;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < ntok_pad) {
+        int t = gid;
+        if (t >= N) t = 1;  // pad tokens: any in-range value (their scores are masked / never stored)
+        if (t == 0) {
+            tq[gid] = R + T;
+            tk[gid] = -(R + T + 1);
+        } else {
+            const int p = t - 1, y = p / gw, x = p - y * gw;
+            tq[gid] = (y + gh - 1) * rw + x + gw - 1;
+            tk[gid] = y * rw + x;
+        }
+    }
+    for (int idx = gid; idx < total; idx += gridDim.x * blockDim.x) {
+        const int h = idx / elen, e = idx - h * elen;
+        float v = 0.0f;
+        if (e < R) {
+            // F.interpolate(mode="bilinear", align_corners=False): src = max(0, scale*(dst+0.5)-0.5)
+            const int oy = e / rw, ox = e - oy * rw;
+            const float sy = fmaxf((float)Rh / (float)rh * ((float)oy + 0.5f) - 0.5f, 0.0f);
+            const float sx = fmaxf((float)Rw / (float)rw * ((float)ox + 0.5f) - 0.5f, 0.0f);
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < Rh - 1), x1 = x0 + (x0 < Rw - 1);
+            const float ly = sy - (float)y0, lx = sx - (float)x0;
+            const float v00 = ref[(size_t)(y0 * Rw + x0) * heads + h], v01 = ref[(size_t)(y0 * Rw + x1) * heads + h];
+            const float v10 = ref[(size_t)(y1 * Rw + x0) * heads + h], v11 = ref[(size_t)(y1 * Rw + x1) * heads + h];
+            v = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+        } else if (e <= R + T) {
+            v = ref[(size_t)(Rref + 0) * heads + h];       // cls query -> token key
+        } else if (e <= 2 * R + T) {
+            v = ref[(size_t)(Rref + 1) * heads + h];       // token query -> cls key
+        } else if (e == 2 * R + 2 * T + 1) {
+            v = ref[(size_t)(Rref + 2) * heads + h];       // cls -> cls
+        }
+        ext[idx] = v;
+    }
+}
+
 inline int grid_for(size_t total, int block = 256) {
     size_t g = (total + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -447,8 +499,9 @@ int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float*
 }
 
 int mdpt_launch_pack_weight(const float* src, bf16_t* dst_hi, bf16_t* dst_lo, int kind, int N, int K, int Np, int Kp, int ksz,
-                            hipStream_t stream) {
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)Np * Kp)), dim3(256), 0, stream, src, dst_hi, dst_lo, kind, N, K, Np, Kp, ksz);
+                            hipStream_t stream, int src_ld, int src_col0) {
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)Np * Kp)), dim3(256), 0, stream, src, dst_hi, dst_lo, kind, N, K, Np, Kp, ksz,
+                       src_ld > 0 ? src_ld : K, src_col0);
     LAUNCH_RET();
 }
 
@@ -497,5 +550,18 @@ int mdpt_launch_prepare_image(const unsigned char* bgr, float* out, int ih, int 
     MdptProfScope prof("prepare_image_kernel", 0.0, stream);
     hipLaunchKernelGGL(prepare_image_kernel, dim3((oh * ow + 255) / 256), dim3(256), 0, stream, bgr, out, ih, iw, oh, ow, mean[0], mean[1],
                        mean[2], inv_std[0], inv_std[1], inv_std[2]);
+    LAUNCH_RET();
+}
+
+int mdpt_beit_relpos_elen(int gh, int gw) {
+    const int rw = 2 * gw - 1, R = (2 * gh - 1) * rw, T = (gh - 1) * rw + gw - 1;
+    return 2 * R + 2 * T + 2;
+}
+
+int mdpt_launch_beit_relpos(const float* ref_lut, float* ext_lut, int* tq, int* tk, int heads, int Gh, int Gw, int gh, int gw, int N,
+                            int ntok_pad, hipStream_t stream) {
+    const size_t total = (size_t)heads * mdpt_beit_relpos_elen(gh, gw);
+    size_t work = total > (size_t)ntok_pad ? total : (size_t)ntok_pad;
+    hipLaunchKernelGGL(beit_relpos_kernel, dim3(grid_for(work)), dim3(256), 0, stream, ref_lut, ext_lut, tq, tk, heads, Gh, Gw, gh, gw, N, ntok_pad);
     LAUNCH_RET();
 }

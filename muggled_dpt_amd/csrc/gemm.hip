@@ -268,7 +268,11 @@ __device__ __forceinline__ void run_epilogue(const GemmParams& p, f32x16 (&acc)[
             v[1] = *(const f32x4*)(strip + row * WTN + ecol + 4);
 
             if (EKIND == MDPT_E_GENERIC) {
-                if (p.bias) { v[0] += *(const f32x4*)(p.bias + n); v[1] += *(const f32x4*)(p.bias + n + 4); }
+                if (p.bias) {
+                    const float* bp = p.bias + n + (p.bias_img_stride ? (size_t)(m / p.tok_np) * p.bias_img_stride : 0);
+                    v[0] += *(const f32x4*)bp;
+                    v[1] += *(const f32x4*)(bp + 4);
+                }
                 if (p.act == MDPT_ACT_GELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[0][e] = gelu_erf(v[0][e]); v[1][e] = gelu_erf(v[1][e]); }
@@ -327,9 +331,13 @@ __device__ __forceinline__ void run_epilogue(const GemmParams& p, f32x16 (&acc)[
                 }
             } else if (EKIND == MDPT_E_PATCH) {
                 const int b = m / p.tok_np, t = m - b * p.tok_np;
-                const float* pp = p.pos + (size_t)t * p.N + n;
-                v[0] += *(const f32x4*)(p.bias + n) + *(const f32x4*)pp;
-                v[1] += *(const f32x4*)(p.bias + n + 4) + *(const f32x4*)(pp + 4);
+                v[0] += *(const f32x4*)(p.bias + n);
+                v[1] += *(const f32x4*)(p.bias + n + 4);
+                if (p.pos) {  // BEiT has no absolute position embedding
+                    const float* pp = p.pos + (size_t)t * p.N + n;
+                    v[0] += *(const f32x4*)pp;
+                    v[1] += *(const f32x4*)(pp + 4);
+                }
                 float* op = p.out_f32 + ((size_t)b * p.npad + 1 + t) * p.ldc + n;
                 *(f32x4*)op = v[0];
                 *(f32x4*)(op + 4) = v[1];

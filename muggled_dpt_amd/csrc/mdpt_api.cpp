@@ -94,6 +94,7 @@ struct Plan {
     size_t a1[4][2], x_f32[4], x_bf[4][2], b1[4][2], b2[4][2], flo[4];
     size_t fused[2], h1, h1u[2], scratch;
     size_t scratch_floats;
+    size_t tokr[2], cbuf, relpos_lut, relpos_tq, relpos_tk;  // BEiT: readout-projected tokens, per-image cls term, bias LUT
 };
 
 }  // namespace
@@ -158,10 +159,15 @@ namespace {
 
 std::string blk_name(const mdpt_handle* h, int block) {
     char buf[96];
-    if (h->cfg.encoder_taps == MDPT_TAPS_LAST4) snprintf(buf, sizeof(buf), "imgencoder.blocks.%d", block);
+    if (h->cfg.family == MDPT_FAMILY_DAV1) snprintf(buf, sizeof(buf), "imgencoder.blocks.%d", block);
     else snprintf(buf, sizeof(buf), "imgencoder.stages.%d.blocks.%d", block / h->bps, block % h->bps);
     return buf;
 }
+
+inline bool is_beit(const mdpt_handle* h) { return h->cfg.family == MDPT_FAMILY_BEIT; }
+// reference attribute names differ between the families (v2: fusion_model.py:100,138 / v31_beit/fusion_model.py:47,66,...)
+inline const char* rcu_seq(const mdpt_handle* h) { return is_beit(h) ? "conv_seq" : "resconv_seq"; }
+inline const char* proj_seq(const mdpt_handle* h) { return is_beit(h) ? "proj_seq" : "scale_proj_seq"; }
 
 int build_inventory(mdpt_handle* h) {
     const int F = h->F, P = h->P, C = h->C;
@@ -175,16 +181,20 @@ int build_inventory(mdpt_handle* h) {
     h->add_mat("patch_embed.proj.weight", MDPT_PACK_LINEAR, F, 3 * P * P, F, h->Kpatch, 0);
     h->add_vec("patch_embed.proj.bias", F, F);
 
+    const bool beit = is_beit(h);
+    const int nlut = (2 * h->cfg.base_patch_grid_h - 1) * (2 * h->cfg.base_patch_grid_w - 1) + 3;
     h->add_spec("imgencoder.cls_token", {1, 1, F});
-    h->add_spec("imgencoder.posenc.cls_embedding", {1, 1, F});
-    h->add_spec("imgencoder.posenc.base_patch_embedding", {1, G, F});
-    h->add_spec("imgencoder.outnorm.weight", {F});
-    h->add_spec("imgencoder.outnorm.bias", {F});
     h->add_vec("imgencoder.cls_token", F, F);
-    h->add_vec("imgencoder.posenc.cls_embedding", F, F);
-    h->add_vec("imgencoder.posenc.base_patch_embedding", G * F, G * F);
-    h->add_vec("imgencoder.outnorm.weight", F, F);
-    h->add_vec("imgencoder.outnorm.bias", F, F);
+    if (!beit) {
+        h->add_spec("imgencoder.posenc.cls_embedding", {1, 1, F});
+        h->add_spec("imgencoder.posenc.base_patch_embedding", {1, G, F});
+        h->add_spec("imgencoder.outnorm.weight", {F});
+        h->add_spec("imgencoder.outnorm.bias", {F});
+        h->add_vec("imgencoder.posenc.cls_embedding", F, F);
+        h->add_vec("imgencoder.posenc.base_patch_embedding", G * F, G * F);
+        h->add_vec("imgencoder.outnorm.weight", F, F);
+        h->add_vec("imgencoder.outnorm.bias", F, F);
+    }
 
     for (int b = 0; b < h->nblocks; ++b) {
         const std::string p = blk_name(h, b);
@@ -195,7 +205,14 @@ int build_inventory(mdpt_handle* h) {
             h->add_vec(p + "." + ln + ".bias", F, F);
         }
         h->add_spec(p + ".attn.qkv.weight", {3 * F, F});
-        h->add_spec(p + ".attn.qkv.bias", {3 * F});
+        if (beit) {  // qkv Linear has no bias; q and v get separate biases, k none (v31_beit/image_encoder_model.py:296-297,341-342)
+            h->add_spec(p + ".attn.q_bias", {1, h->heads, 1, 64});
+            h->add_spec(p + ".attn.v_bias", {1, h->heads, 1, 64});
+            h->add_spec(p + ".attn.relpos_enc.ref_bias_lut", {nlut, h->heads});
+            h->add_vec(p + ".attn.relpos_enc.ref_bias_lut", nlut * h->heads, nlut * h->heads);
+        } else {
+            h->add_spec(p + ".attn.qkv.bias", {3 * F});
+        }
         h->add_spec(p + ".attn.proj.weight", {F, F});
         h->add_spec(p + ".attn.proj.bias", {F});
         h->add_spec(p + ".scale_attn", {F});
@@ -208,7 +225,8 @@ int build_inventory(mdpt_handle* h) {
         h->add_mat(p + ".attn.proj.weight", MDPT_PACK_LINEAR, F, F, F, F, 0);
         h->add_mat(p + ".mlp.layers.0.weight", MDPT_PACK_LINEAR, 4 * F, F, 4 * F, F, 0);
         h->add_mat(p + ".mlp.layers.2.weight", MDPT_PACK_LINEAR, F, 4 * F, F, 4 * F, 0);
-        h->add_vec(p + ".attn.qkv.bias", 3 * F, 3 * F);
+        if (beit) h->add_vec(p + ".attn.qkv.bias@beit", 0, 3 * F);  // assembled in finalize: [q_bias, 0, v_bias]
+        else h->add_vec(p + ".attn.qkv.bias", 3 * F, 3 * F);
         h->add_vec(p + ".attn.proj.bias", F, F);
         h->add_vec(p + ".scale_attn", F, F);
         h->add_vec(p + ".mlp.layers.0.bias", 4 * F, 4 * F);
@@ -219,6 +237,13 @@ int build_inventory(mdpt_handle* h) {
     for (int i = 0; i < 4; ++i) {
         const std::string p = std::string("reassemble.") + kStageNames[i];
         const int hd = h->hid[i], hp = h->hidp[i];
+        if (beit) {  // ReadoutProjectLayer: cat(token, cls) -> Linear(2F->F) -> GELU (components/readout_projection.py:42-46)
+            h->add_spec(p + ".readout_proj.1.weight", {F, 2 * F});
+            h->add_spec(p + ".readout_proj.1.bias", {F});
+            h->add_mat(p + ".readout_proj.1.weight", MDPT_PACK_LINEAR, F, F, F, F, 0);          // token half (columns 0..F)
+            h->add_mat(p + ".readout_proj.1.weight@cls", MDPT_PACK_LINEAR, F, F, F, F, 0);      // cls half (columns F..2F)
+            h->add_vec(p + ".readout_proj.1.bias", F, F);
+        }
         h->add_spec(p + ".resample.0.weight", {hd, F, 1, 1});
         h->add_spec(p + ".resample.0.bias", {hd});
         h->add_mat(p + ".resample.0.weight", MDPT_PACK_LINEAR, hd, F, hp, F, 0);
@@ -244,16 +269,16 @@ int build_inventory(mdpt_handle* h) {
         snprintf(pb, sizeof(pb), "fusion.blocks.%d", b);
         std::vector<std::string> units;
         if (b < 3) units.push_back(std::string(pb) + ".conv_reassembly");
-        units.push_back(std::string(pb) + ".scale_proj_seq.0");
+        units.push_back(std::string(pb) + "." + proj_seq(h) + ".0");
         for (const std::string& u : units)
             for (const char* idx : {"1", "3"}) {
-                const std::string n = u + ".resconv_seq." + idx;
+                const std::string n = u + "." + rcu_seq(h) + "." + idx;
                 h->add_spec(n + ".weight", {C, C, 3, 3});
                 h->add_spec(n + ".bias", {C});
                 h->add_mat(n + ".weight", MDPT_PACK_CONV3, C, C, h->Cp, 9 * h->Cp, 3);
                 h->add_vec(n + ".bias", C, h->Cp);
             }
-        const std::string o = std::string(pb) + ".scale_proj_seq.2";
+        const std::string o = std::string(pb) + "." + proj_seq(h) + ".2";
         h->add_spec(o + ".weight", {C, C, 1, 1});
         h->add_spec(o + ".bias", {C});
         h->add_mat(o + ".weight", MDPT_PACK_LINEAR, C, C, h->Cp, h->Cp, 0);
@@ -340,6 +365,14 @@ int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
     p.scratch_floats = (size_t)B * fpx * h->Cp;
     if (rows * F > p.scratch_floats) p.scratch_floats = rows * F;
     p.scratch = bump.take(p.scratch_floats * 4);
+    p.tokr[0] = p.tokr[1] = p.cbuf = p.relpos_lut = p.relpos_tq = p.relpos_tk = SIZE_MAX;
+    if (is_beit(h)) {
+        take_planes(bump, x3, (size_t)B * p.Np * F, p.tokr);
+        p.cbuf = bump.take((size_t)B * F * 4);
+        p.relpos_lut = bump.take((size_t)h->heads * mdpt_beit_relpos_elen(gh, gw) * 4);
+        p.relpos_tq = bump.take((size_t)p.npadv * 4);
+        p.relpos_tk = bump.take((size_t)p.npadv * 4);
+    }
     p.total = bump.off;
     return 0;
 }
@@ -395,13 +428,14 @@ int run_patch_embed_fused(const Ctx& c, const float* image) {
     const Plan& p = c.p;
     Planes im = c.pl(p.im2col);
     CHK(mdpt_launch_patchify(image, im.hi, im.lo, p.B, p.H, p.W, h->P, h->Kpatch, c.s));
-    CHK(run_pos(c));
-    CHK(mdpt_launch_init_tokens(c.at<float>(p.resid), h->V("imgencoder.cls_token"), h->V("imgencoder.posenc.cls_embedding"), p.B, p.N,
-                                p.npad, h->F, c.s));
+    const bool beit = is_beit(h);
+    if (!beit) CHK(run_pos(c));
+    CHK(mdpt_launch_init_tokens(c.at<float>(p.resid), h->V("imgencoder.cls_token"), beit ? nullptr : h->V("imgencoder.posenc.cls_embedding"),
+                                p.B, p.N, p.npad, h->F, c.s));
     GemmParams g = base_params(c, h->M("patch_embed.proj.weight"), im, p.B * p.Np, h->Kpatch);
     g.ekind = MDPT_E_PATCH;
     g.bias = h->V("patch_embed.proj.bias");
-    g.pos = c.at<float>(p.pos);
+    g.pos = beit ? nullptr : c.at<float>(p.pos);
     g.out_f32 = c.at<float>(p.resid);
     g.tok_np = p.Np; g.npad = p.npad; g.ldc = h->F;
     CHK(mdpt_launch_gemm(g, c.s));
@@ -424,7 +458,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
         {
             GemmParams g = base_params(c, h->M(n + ".attn.qkv.weight"), xn, rows, F);
             g.ekind = MDPT_E_QKV;
-            g.bias = h->V(n + ".attn.qkv.bias");
+            g.bias = h->V(is_beit(h) ? n + ".attn.qkv.bias@beit" : n + ".attn.qkv.bias");
             g.q_hi = q.hi; g.q_lo = q.lo; g.k_hi = k.hi; g.k_lo = k.lo; g.vt_hi = vt.hi; g.vt_lo = vt.lo;
             g.F = F; g.heads = h->heads; g.npad = p.npad; g.npadv = p.npadv; g.qscale = 0.125f;
             CHK(mdpt_launch_gemm(g, c.s));
@@ -436,6 +470,13 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             a.q_hi = q.hi; a.q_lo = q.lo; a.k_hi = k.hi; a.k_lo = k.lo; a.vt_hi = vt.hi; a.vt_lo = vt.lo;
             a.out_hi = att.hi; a.out_lo = att.lo;
             a.B = p.B; a.heads = h->heads; a.N = p.N; a.npad = p.npad; a.npadv = p.npadv; a.F = F; a.x3 = h->x3;
+            if (is_beit(h)) {  // this layer's relative-position table, resized to the current grid (tiny kernel)
+                CHK(mdpt_launch_beit_relpos(h->V(n + ".attn.relpos_enc.ref_bias_lut"), c.at<float>(p.relpos_lut), c.at<int>(p.relpos_tq),
+                                            c.at<int>(p.relpos_tk), h->heads, h->cfg.base_patch_grid_h, h->cfg.base_patch_grid_w, p.gh, p.gw,
+                                            p.N, p.npadv, c.s));
+                a.bias_lut = c.at<float>(p.relpos_lut); a.bias_elen = mdpt_beit_relpos_elen(p.gh, p.gw);
+                a.tq = c.at<int>(p.relpos_tq); a.tk = c.at<int>(p.relpos_tk);
+            }
             CHK(mdpt_launch_attention(a, c.s));
         }
         DBG_STOP(2);
@@ -465,14 +506,19 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             CHK(mdpt_launch_gemm(g, c.s));
         }
         DBG_STOP(6);
-        const bool v1 = h->cfg.encoder_taps == MDPT_TAPS_LAST4;
+        const bool v1 = h->cfg.family == MDPT_FAMILY_DAV1;
         if (v1 ? b >= h->nblocks - 4 : (b + 1) % h->bps == 0) {
             const int st = v1 ? b - (h->nblocks - 4) : b / h->bps;
             Planes tp = c.pl(p.tap[st]);
             float* f32 = taps_f32 ? c.at<float>(p.tapf32) : nullptr;
-            CHK(mdpt_launch_layernorm(resid, h->V("imgencoder.outnorm.weight"), h->V("imgencoder.outnorm.bias"), tp.hi, tp.lo, f32, rows, F, c.s));
-            if (taps_f32)
-                CHK(mdpt_launch_tokens_export(nullptr, nullptr, f32, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
+            if (is_beit(h)) {  // BEiT taps the raw residual stream (no out-norm, v31_beit/image_encoder_model.py:84-91)
+                CHK(mdpt_launch_tokens_import(resid, tp.hi, tp.lo, p.B, p.npad, p.npad, F, c.s));
+                if (taps_f32) CHK(mdpt_launch_tokens_export(nullptr, nullptr, resid, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
+            } else {
+                CHK(mdpt_launch_layernorm(resid, h->V("imgencoder.outnorm.weight"), h->V("imgencoder.outnorm.bias"), tp.hi, tp.lo, f32, rows, F, c.s));
+                if (taps_f32)
+                    CHK(mdpt_launch_tokens_export(nullptr, nullptr, f32, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
+            }
         }
     }
     return 0;
@@ -487,9 +533,30 @@ int run_reassemble(const Ctx& c) {
         const std::string n = std::string("reassemble.") + kStageNames[i];
         const int hp = h->hidp[i];
         Planes tp = c.pl(p.tap[i]), t = c.pl(p.t[i]);
+        bool tokens_mode = true;
+        if (is_beit(h)) {
+            // readout projection: GELU(W [tok ; cls] + b) = GELU(W_tok tok + (W_cls cls + b)); the cls term is one row per image
+            {
+                GemmParams g = base_params(c, h->M(n + ".readout_proj.1.weight@cls"), tp, p.B, p.npad * F);  // row b = cls token of image b
+                g.bias = h->V(n + ".readout_proj.1.bias");
+                g.out_f32 = c.at<float>(p.cbuf); g.ldc = F;
+                CHK(mdpt_launch_gemm(g, c.s));
+            }
+            Planes tr = c.pl(p.tokr);
+            {
+                GemmParams g = base_params(c, h->M(n + ".readout_proj.1.weight"), tp, p.B * p.Np, F);
+                g.amode = MDPT_A_TOKENS; g.tok_np = p.Np; g.tok_stride = p.npad;
+                g.bias = c.at<float>(p.cbuf); g.bias_img_stride = F;
+                g.act = MDPT_ACT_GELU;
+                g.out_hi = tr.hi; g.out_lo = tr.lo; g.ldc = F;
+                CHK(mdpt_launch_gemm(g, c.s));
+            }
+            tp = tr;
+            tokens_mode = false;
+        }
         {   // 1x1 conv on the patch tokens (cls row skipped by the A-row generator)
             GemmParams g = base_params(c, h->M(n + ".resample.0.weight"), tp, p.B * p.Np, F);
-            g.amode = MDPT_A_TOKENS; g.tok_np = p.Np; g.tok_stride = p.npad;
+            if (tokens_mode) { g.amode = MDPT_A_TOKENS; g.tok_np = p.Np; g.tok_stride = p.npad; }
             g.bias = h->V(n + ".resample.0.bias");
             g.out_hi = t.hi; g.out_lo = t.lo; g.ldc = hp;
             CHK(mdpt_launch_gemm(g, c.s));
@@ -558,19 +625,19 @@ int run_fusion(const Ctx& c) {
         } else {
             // x = RCU_a(r_i) + up2(prev)   (fusion_model.py:148-154)
             Planes a1 = c.pl(p.a1[i]);
-            CHK(rcu_conv(c, blk + ".conv_reassembly.resconv_seq.1", c.pl(p.r_bf[i]), sh[i], sw[i], nullptr, nullptr, 0, 0, nullptr, a1, 1));
+            CHK(rcu_conv(c, blk + ".conv_reassembly." + rcu_seq(h) + ".1", c.pl(p.r_bf[i]), sh[i], sw[i], nullptr, nullptr, 0, 0, nullptr, a1, 1));
             x_bf = c.pl(p.x_bf[i]);
-            CHK(rcu_conv(c, blk + ".conv_reassembly.resconv_seq.3", a1, sh[i], sw[i], c.at<float>(p.r_f32[i]), c.at<float>(p.flo[i + 1]),
+            CHK(rcu_conv(c, blk + ".conv_reassembly." + rcu_seq(h) + ".3", a1, sh[i], sw[i], c.at<float>(p.r_f32[i]), c.at<float>(p.flo[i + 1]),
                          sh[i + 1], sw[i + 1], c.at<float>(p.x_f32[i]), x_bf, 1));
             x_f32 = c.at<float>(p.x_f32[i]);
         }
         Planes b1 = c.pl(p.b1[i]), b2 = c.pl(p.b2[i]);
-        CHK(rcu_conv(c, blk + ".scale_proj_seq.0.resconv_seq.1", x_bf, sh[i], sw[i], nullptr, nullptr, 0, 0, nullptr, b1, 1));
-        CHK(rcu_conv(c, blk + ".scale_proj_seq.0.resconv_seq.3", b1, sh[i], sw[i], x_f32, nullptr, 0, 0, nullptr, b2, 0));
+        CHK(rcu_conv(c, blk + "." + proj_seq(h) + ".0." + rcu_seq(h) + ".1", x_bf, sh[i], sw[i], nullptr, nullptr, 0, 0, nullptr, b1, 1));
+        CHK(rcu_conv(c, blk + "." + proj_seq(h) + ".0." + rcu_seq(h) + ".3", b1, sh[i], sw[i], x_f32, nullptr, 0, 0, nullptr, b2, 0));
         {   // 1x1 projection at LOW resolution; the x2 bilinear upsample commutes with it exactly (both linear, weights
             // sum to 1) and is applied by the consumer (next level's epilogue / final upsample kernel)
-            GemmParams g = base_params(c, h->M(blk + ".scale_proj_seq.2.weight"), b2, p.B * sh[i] * sw[i], h->Cp);
-            g.bias = h->V(blk + ".scale_proj_seq.2.bias");
+            GemmParams g = base_params(c, h->M(blk + "." + proj_seq(h) + ".2.weight"), b2, p.B * sh[i] * sw[i], h->Cp);
+            g.bias = h->V(blk + "." + proj_seq(h) + ".2.bias");
             g.out_f32 = c.at<float>(p.flo[i]); g.ldc = h->Cp;
             CHK(mdpt_launch_gemm(g, c.s));
         }
@@ -639,7 +706,7 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     if (cfg->patch_size_px <= 0 || cfg->patch_size_px % 2) return fail(MDPT_E_INVALID, "patch_size_px must be even (head scale = patch/8)");
     if (cfg->base_patch_grid_h <= 0 || cfg->base_patch_grid_w <= 0) return fail(MDPT_E_INVALID, "bad base patch grid");
     if (cfg->precision != MDPT_PREC_BF16 && cfg->precision != MDPT_PREC_BF16X3) return fail(MDPT_E_INVALID, "unknown precision %d", cfg->precision);
-    if (cfg->encoder_taps != MDPT_TAPS_STAGES && cfg->encoder_taps != MDPT_TAPS_LAST4) return fail(MDPT_E_INVALID, "unknown encoder_taps %d", cfg->encoder_taps);
+    if (cfg->family < MDPT_FAMILY_DAV2 || cfg->family > MDPT_FAMILY_BEIT) return fail(MDPT_E_INVALID, "unknown model family %d", cfg->family);
     for (int i = 0; i < 4; ++i)
         if (cfg->reassembly_features[i] <= 0 || cfg->reassembly_features[i] % 4) return fail(MDPT_E_INVALID, "reassembly_features[%d] must be a multiple of 4", i);
     mdpt_handle* h = new mdpt_handle();
@@ -713,11 +780,26 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
     for (Mat& m : h->mats) {
         m.hi = (bf16_t*)(base + m.off_hi);
         m.lo = m.off_lo == SIZE_MAX ? nullptr : (bf16_t*)(base + m.off_lo);
-        const float* src = h->specs[h->spec_index.at(m.src)].ptr;
-        CHK(mdpt_launch_pack_weight(src, m.hi, m.lo, m.kind, m.N, m.K, m.Np, m.Kp, m.ksz, st));
+        std::string src_name = m.src;
+        int src_ld = 0, src_col0 = 0;
+        const size_t at = src_name.find("@cls");
+        if (src_name.find(".readout_proj.1.weight") != std::string::npos) {  // [F, 2F] split into token / cls halves
+            src_ld = 2 * h->F;
+            if (at != std::string::npos) { src_col0 = h->F; src_name = src_name.substr(0, at); }
+        }
+        const float* src = h->specs[h->spec_index.at(src_name)].ptr;
+        CHK(mdpt_launch_pack_weight(src, m.hi, m.lo, m.kind, m.N, m.K, m.Np, m.Kp, m.ksz, st, src_ld, src_col0));
     }
     for (Vec& v : h->vecs) {
         v.ptr = (float*)(base + v.off);
+        const size_t at = v.src.find(".attn.qkv.bias@beit");
+        if (at != std::string::npos) {  // [q_bias (H*64 = F), zeros(F), v_bias (F)]
+            const std::string blk = v.src.substr(0, at);
+            CHK(hipMemsetAsync(v.ptr, 0, (size_t)v.np * 4, st));
+            CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(blk + ".attn.q_bias")].ptr, v.ptr, h->F, h->F, st));
+            CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(blk + ".attn.v_bias")].ptr, v.ptr + 2 * h->F, h->F, h->F, st));
+            continue;
+        }
         CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(v.src)].ptr, v.ptr, v.n, v.np, st));
     }
     h->finalized = true;
@@ -787,9 +869,13 @@ int mdpt_encoder(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, 
     c.p.gh = gh; c.p.gw = gw; c.p.Np = gh * gw; c.p.N = c.p.Np + 1;
     if (rup(c.p.N, 8) > c.p.npad) return fail(MDPT_E_INVALID, "internal: plan too small");
     c.p.npad = rup(c.p.N, 8); c.p.npadv = rup(c.p.N, 64);
-    CHK(run_pos(c));
-    CHK(mdpt_launch_init_tokens(c.at<float>(c.p.resid), h->V("imgencoder.cls_token"), h->V("imgencoder.posenc.cls_embedding"), B, c.p.N,
-                                c.p.npad, h->F, c.s));
+    if (is_beit(h)) {
+        CHK(mdpt_launch_memset_f32(c.at<float>(c.p.pos), 0.0f, (size_t)c.p.Np * h->F, c.s));
+    } else {
+        CHK(run_pos(c));
+    }
+    CHK(mdpt_launch_init_tokens(c.at<float>(c.p.resid), h->V("imgencoder.cls_token"), is_beit(h) ? nullptr : h->V("imgencoder.posenc.cls_embedding"),
+                                B, c.p.N, c.p.npad, h->F, c.s));
     CHK(mdpt_launch_tokens_to_resid((const float*)tokens_bnf, c.at<float>(c.p.pos), c.at<float>(c.p.resid), B, c.p.Np, c.p.npad, h->F, c.s));
     CHK(run_encoder(c, stage_out));
     h->has_last = false;
@@ -872,12 +958,12 @@ int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspac
 }
 
 // ---- PatchEmbed.prepare_image (reference v2_depthanything/patch_embed.py:103-145): resize + BGR->RGB + normalise on the GPU
-int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void* out_chw_f32, int32_t out_h, int32_t out_w, void* stream) {
-    if (!bgr_u8_hwc || !out_chw_f32) return fail(MDPT_E_INVALID, "null argument");
+int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void* out_chw_f32, int32_t out_h, int32_t out_w,
+                       const float rgb_mean[3], const float rgb_std[3], void* stream) {
+    if (!bgr_u8_hwc || !out_chw_f32 || !rgb_mean || !rgb_std) return fail(MDPT_E_INVALID, "null argument");
     if (in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) return fail(MDPT_E_INVALID, "bad image size %dx%d -> %dx%d", in_h, in_w, out_h, out_w);
-    const float mean[3] = {0.485f, 0.456f, 0.406f};                                  // patch_embed.py:38
-    const float inv_std[3] = {1.0f / 0.229f, 1.0f / 0.224f, 1.0f / 0.225f};           // patch_embed.py:39,62
-    CHK(mdpt_launch_prepare_image((const unsigned char*)bgr_u8_hwc, (float*)out_chw_f32, in_h, in_w, out_h, out_w, mean, inv_std, (hipStream_t)stream));
+    const float inv_std[3] = {1.0f / rgb_std[0], 1.0f / rgb_std[1], 1.0f / rgb_std[2]};  // patch_embed.py:38-39,62
+    CHK(mdpt_launch_prepare_image((const unsigned char*)bgr_u8_hwc, (float*)out_chw_f32, in_h, in_w, out_h, out_w, rgb_mean, inv_std, (hipStream_t)stream));
     return 0;
 }
 

@@ -31,6 +31,7 @@ struct GemmParams {
     int Hi, Wi, Cin, Ho, Wo, cstride;
     // generic epilogue: v = acc (+bias[n]) -> act -> (*gamma[n]) (+resid[m,n]) (+up2x(up_src)[m,n])
     const float* bias; const float* gamma; const float* resid; int ldr;
+    int bias_img_stride;                      // != 0: bias row (m / tok_np) * stride is used (per-image bias, BEiT readout)
     const float* up_src; int Hu, Wu;          // fp32 NHWC [B,Hu,Wu,N] added through x2 bilinear (align_corners)
     int act;
     float* out_f32; bf16_t* out_hi; bf16_t* out_lo; int ldc;
@@ -59,6 +60,8 @@ struct AttnParams {
     bf16_t* out_hi; bf16_t* out_lo;           // [B*npad, F] token-major, column h*64 + d
     int B, heads, N, npad, npadv, F;
     int x3;
+    // additive relative-position bias (BEiT): per-head extended LUT [heads][bias_elen] fp32, s[q][k] += lut[tq[q] - tk[k]]
+    const float* bias_lut; int bias_elen; const int* tq; const int* tk;
 };
 int mdpt_launch_attention(const AttnParams& p, hipStream_t stream);
 
@@ -86,7 +89,7 @@ enum { MDPT_PACK_LINEAR = 0,   // src [N][K]
        MDPT_PACK_CONV3 = 1,    // src [Cout][Cin][3][3] -> k = (ky*3+kx)*Cinp + ci
        MDPT_PACK_CONVT = 2 };  // src [Cin][Cout][k][k] -> row n = (ky*k+kx)*Coutp + co, col ci
 int mdpt_launch_pack_weight(const float* src, bf16_t* dst_hi, bf16_t* dst_lo, int kind, int N, int K, int Np, int Kp,
-                            int ksz, hipStream_t stream);
+                            int ksz, hipStream_t stream, int src_ld = 0, int src_col0 = 0);
 // fp32 vector copy with zero padding (biases); `rep` repeats are not needed: plain copy
 int mdpt_launch_pad_copy_f32(const float* src, float* dst, int n, int np, hipStream_t stream);
 // layout conversions for the stage-level API / debug taps
@@ -104,4 +107,10 @@ int mdpt_launch_tokens_to_resid(const float* tokens, const float* pos, float* re
 // uint8 HWC BGR -> normalised fp32 [3,oh,ow] RGB through PyTorch-compatible antialiased bilinear resize
 int mdpt_launch_prepare_image(const unsigned char* bgr, float* out, int ih, int iw, int oh, int ow, const float mean[3],
                               const float inv_std[3], hipStream_t stream);
+// BEiT relative position bias (reference v31_beit/components/relative_positional_encoder.py:117-309): bilinear-resize the
+// learned [(2Gh-1)(2Gw-1)+3, heads] table to the current grid and lay it out per head as an extended LUT so that the bias of
+// (query q, key k) is ext[tq[q] - tk[k]] including the three cls cases; also fills the per-token index terms tq / tk.
+int mdpt_launch_beit_relpos(const float* ref_lut, float* ext_lut, int* tq, int* tk, int heads, int Gh, int Gw, int gh, int gw,
+                            int N, int ntok_pad, hipStream_t stream);
+int mdpt_beit_relpos_elen(int gh, int gw);
 int mdpt_launch_memset_f32(float* dst, float value, size_t n, hipStream_t stream);

@@ -31,6 +31,8 @@ from .state_dict_conversion import COMPONENTS, expected_new_keys
 
 RGB_MEAN = (0.485, 0.456, 0.406)  # reference v2_depthanything/patch_embed.py:38
 RGB_STD = (0.229, 0.224, 0.225)   # :39
+BEIT_RGB_MEAN = (0.5, 0.5, 0.5)   # reference v31_beit/patch_embed.py:39-40
+BEIT_RGB_STD = (0.5, 0.5, 0.5)
 
 
 class _Node(nn.Module):
@@ -76,11 +78,12 @@ class _Stage(nn.Module):
 class PatchEmbed(_Stage):
     """Image -> patch tokens. reference v2_depthanything/patch_embed.py:23-165."""
 
-    def __init__(self, shapes, patch_size_px: int, default_image_size: int):
+    def __init__(self, shapes, patch_size_px: int, default_image_size: int, rgb_mean=RGB_MEAN, rgb_std=RGB_STD):
         super().__init__("patch_embed", shapes)
         self.patch_size_px = patch_size_px
         self._default_size_px = round(default_image_size)
         self._tiling_size = round(2 * patch_size_px)  # patch_embed.py:69
+        self.rgb_offset, self.rgb_stdev = tuple(rgb_mean), tuple(rgb_std)
 
     def forward(self, image_tensor_bchw: Tensor) -> tuple[Tensor, tuple[int, int]]:
         eng = self._engine()
@@ -111,14 +114,16 @@ class PatchEmbed(_Stage):
             out = torch.empty((1, 3, scaled_hw[0], scaled_hw[1]), device=p.device, dtype=torch.float32)
             with torch.cuda.device(p.device):
                 stream = torch.cuda.current_stream(p.device).cuda_stream
-                native.check(lib, lib.mdpt_prepare_image(src.data_ptr(), img_h, img_w, out.data_ptr(), scaled_hw[0], scaled_hw[1], stream))
+                mean3, std3 = (ctypes.c_float * 3)(*self.rgb_offset), (ctypes.c_float * 3)(*self.rgb_stdev)
+                native.check(lib, lib.mdpt_prepare_image(src.data_ptr(), img_h, img_w, out.data_ptr(), scaled_hw[0], scaled_hw[1],
+                                                         mean3, std3, stream))
             return out if p.dtype == torch.float32 else out.to(p.dtype)
         # other interpolation modes / non-uint8 inputs: the reference's own torch ops on the model device
         rgb = np.ascontiguousarray(image_bgr[:, :, ::-1].transpose(2, 0, 1))
         x = torch.from_numpy(rgb).to(device=p.device, dtype=p.dtype)
         x = nn.functional.interpolate(x.unsqueeze(0), size=scaled_hw, align_corners=False, antialias=True, mode=interpolation_mode)
-        mean = torch.tensor(RGB_MEAN, device=p.device, dtype=p.dtype).view(1, 3, 1, 1)
-        inv_std = 1.0 / torch.tensor(RGB_STD, device=p.device, dtype=p.dtype).view(1, 3, 1, 1)
+        mean = torch.tensor(self.rgb_offset, device=p.device, dtype=p.dtype).view(1, 3, 1, 1)
+        inv_std = 1.0 / torch.tensor(self.rgb_stdev, device=p.device, dtype=p.dtype).view(1, 3, 1, 1)
         return ((x / 255.0) - mean) * inv_std
 
     def verify_input(self, image_tensor_bchw: Tensor) -> bool:
@@ -207,7 +212,7 @@ class _Engine:
         c.fusion_channels, c.patch_size_px = cfg["fusion_channels"], cfg["patch_size_px"]
         c.is_giant, c.is_metric = int(bool(cfg.get("is_giant", False))), int(bool(cfg.get("is_metric", False)))
         c.precision = native.PREC_BF16X3 if dtype == torch.float32 else native.PREC_BF16
-        c.encoder_taps = native.TAPS_LAST4 if model.family == "v1" else native.TAPS_STAGES
+        c.family = {"v2": native.FAMILY_DAV2, "v1": native.FAMILY_DAV1, "beit": native.FAMILY_BEIT}[model.family]
         self.precision = c.precision
         handle = ctypes.c_void_p()
         native.check(self.lib, self.lib.mdpt_create(ctypes.byref(c), ctypes.byref(handle)))
@@ -296,12 +301,20 @@ class DPTModel(nn.Module):
     def __init__(self, config: dict, family: str = "v2"):
         super().__init__()
         self.config = dict(config)
-        self.family = family  # "v2": Depth-Anything V2 (taps after each quarter of the blocks); "v1": taps after the last 4 blocks
-        keys = expected_new_keys(self.config, family)
+        # "v2": Depth-Anything V2 (taps after each quarter of the blocks); "v1": taps after the last 4 blocks; "beit": MiDaS v3.1 BEiT
+        self.family = family
+        if family == "beit":
+            from .state_dict_conversion_beit import expected_new_keys as beit_keys
+            keys = beit_keys(self.config)
+        else:
+            keys = expected_new_keys(self.config, family)
         shapes = _new_key_shapes(self.config, family)
         per = {comp: {k: shapes[f"{comp}.{k}"] for k in keys[comp]} for comp in COMPONENTS}
         default_px = self.config["base_patch_grid_hw"][0] * self.config["patch_size_px"]
-        self.patch_embed = PatchEmbed(per["patch_embed"], self.config["patch_size_px"], default_px)
+        if family == "beit":
+            self.patch_embed = PatchEmbed(per["patch_embed"], self.config["patch_size_px"], default_px, BEIT_RGB_MEAN, BEIT_RGB_STD)
+        else:
+            self.patch_embed = PatchEmbed(per["patch_embed"], self.config["patch_size_px"], default_px)
         self.imgencoder = ImageEncoder("imgencoder", per["imgencoder"])
         self.reassemble = ReassembleModel("reassemble", per["reassemble"])
         self.fusion = FusionModel("fusion", per["fusion"])
@@ -399,6 +412,17 @@ def _new_key_shapes(cfg: dict, family: str = "v2") -> dict[str, tuple]:
     from .synthetic import original_state_dict_shapes
     from .state_dict_conversion import original_to_new_key_table
 
+    if family == "beit":
+        from .state_dict_conversion_beit import original_to_new_key_table as beit_table
+        from .synthetic import beit_original_state_dict_shapes
+        orig = beit_original_state_dict_shapes(cfg)
+        shapes = {}
+        for old, (comp, new) in beit_table(cfg).items():
+            shp = tuple(orig[old])
+            if new.endswith("q_bias") or new.endswith("v_bias"):
+                shp = (1, cfg["num_heads"], 1, shp[0] // cfg["num_heads"])
+            shapes[f"{comp}.{new}"] = shp
+        return shapes
     orig = original_state_dict_shapes(cfg)
     table = original_to_new_key_table(cfg, family)
     shapes = {}

@@ -28,8 +28,13 @@ def make_dpt_from_state_dict(
     if model_type not in known_model_types:
         print("Accepted model types:", *known_model_types, sep="\n")
         raise NotImplementedError(f"Bad model type: {model_type}, no support for this yet!")
-    if model_type not in ("depthanythingv2", "depthanythingv1"):
-        raise NotImplementedError(f"Model type '{model_type}' is not available on the MI355X path yet (Depth-Anything V1/V2 only)")
+    if model_type not in ("depthanythingv2", "depthanythingv1", "beit"):
+        raise NotImplementedError(f"Model type '{model_type}' is not available on the MI355X path yet (Depth-Anything V1/V2 and BEiT only)")
+
+    if model_type == "beit":
+        from .make_beit_dpt import make_beit_dpt_from_midas_v31_state_dict as make_beit
+
+        return make_beit(state_dict, enable_cache, enable_optimizations, strict_load)
 
     if model_type == "depthanythingv1":
         from .make_depthanythingv1_dpt import make_depthanythingv1_dpt_from_original_state_dict as make_v1

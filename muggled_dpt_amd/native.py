@@ -22,8 +22,9 @@ HEADERS = ("mdpt_kernels.h", "mdpt_prof.h", os.path.join(REPO, "include", "mdpt.
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1
-TAPS_STAGES = 0
-TAPS_LAST4 = 1
+FAMILY_DAV2 = 0
+FAMILY_DAV1 = 1
+FAMILY_BEIT = 2
 E_GRID = -7
 
 
@@ -84,7 +85,7 @@ class MdptConfig(ctypes.Structure):
         ("is_giant", ctypes.c_int32),
         ("is_metric", ctypes.c_int32),
         ("precision", ctypes.c_int32),
-        ("encoder_taps", ctypes.c_int32),
+        ("family", ctypes.c_int32),
     ]
 
 
@@ -111,7 +112,7 @@ SYMBOLS = {
     "mdpt_reassemble": (ctypes.c_int, [_VP, _VP4, _I, _I, _I, _VP4, _VP, _SZ, _VP]),
     "mdpt_fusion": (ctypes.c_int, [_VP, _VP4, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_head": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
-    "mdpt_prepare_image": (ctypes.c_int, [_VP, _I, _I, _VP, _I, _I, _VP]),
+    "mdpt_prepare_image": (ctypes.c_int, [_VP, _I, _I, _VP, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _VP]),
     "mdpt_export_tap": (ctypes.c_int, [_VP, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_set_gemm_tile": (ctypes.c_int, [_VP, _I]),
     "mdpt_debug_gemm": (ctypes.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _VP]),

@@ -25,6 +25,111 @@ STANDARD_CONFIGS = {
 }
 
 
+BEIT_CONFIGS = {
+    # reference make_beit_dpt.py:86-113
+    "beit_large_384": dict(features_per_token=1024, num_heads=16, num_blocks=24, reassembly_features_list=[256, 512, 1024, 1024],
+                           base_patch_grid_hw=(24, 24), fusion_channels=256, patch_size_px=16),
+    "beit_large_512": dict(features_per_token=1024, num_heads=16, num_blocks=24, reassembly_features_list=[256, 512, 1024, 1024],
+                           base_patch_grid_hw=(32, 32), fusion_channels=256, patch_size_px=16),
+    "beit_base_384": dict(features_per_token=768, num_heads=12, num_blocks=12, reassembly_features_list=[96, 192, 384, 768],
+                          base_patch_grid_hw=(24, 24), fusion_channels=256, patch_size_px=16),
+    "beit_tiny": dict(features_per_token=128, num_heads=2, num_blocks=4, reassembly_features_list=[16, 32, 64, 64],
+                      base_patch_grid_hw=(4, 4), fusion_channels=32, patch_size_px=16),
+}
+
+
+def beit_original_state_dict_shapes(cfg: dict) -> dict[str, tuple]:
+    """Every tensor of a MiDaS v3.1 BEiT DPT checkpoint (the keys the reference's converter consumes), with its shape."""
+    F, P, C, H = cfg["features_per_token"], cfg["patch_size_px"], cfg["fusion_channels"], cfg["num_heads"]
+    gh, gw = cfg["base_patch_grid_hw"]
+    hid = cfg["reassembly_features_list"]
+    nlut = (2 * gh - 1) * (2 * gw - 1) + 3
+    s: dict[str, tuple] = {}
+    s["pretrained.model.cls_token"] = (1, 1, F)
+    s["pretrained.model.patch_embed.proj.weight"] = (F, 3, P, P)
+    s["pretrained.model.patch_embed.proj.bias"] = (F,)
+    for i in range(cfg["num_blocks"]):
+        b = f"pretrained.model.blocks.{i}"
+        s[f"{b}.gamma_1"] = (F,)
+        s[f"{b}.gamma_2"] = (F,)
+        s[f"{b}.norm1.weight"] = (F,)
+        s[f"{b}.norm1.bias"] = (F,)
+        s[f"{b}.attn.q_bias"] = (F,)
+        s[f"{b}.attn.v_bias"] = (F,)
+        s[f"{b}.attn.relative_position_bias_table"] = (nlut, H)
+        s[f"{b}.attn.qkv.weight"] = (3 * F, F)
+        s[f"{b}.attn.proj.weight"] = (F, F)
+        s[f"{b}.attn.proj.bias"] = (F,)
+        s[f"{b}.norm2.weight"] = (F,)
+        s[f"{b}.norm2.bias"] = (F,)
+        s[f"{b}.mlp.fc1.weight"] = (4 * F, F)
+        s[f"{b}.mlp.fc1.bias"] = (4 * F,)
+        s[f"{b}.mlp.fc2.weight"] = (F, 4 * F)
+        s[f"{b}.mlp.fc2.bias"] = (F,)
+    for i in range(4):
+        a = f"pretrained.act_postprocess{i + 1}"
+        s[f"{a}.0.project.0.weight"] = (F, 2 * F)
+        s[f"{a}.0.project.0.bias"] = (F,)
+        s[f"{a}.3.weight"] = (hid[i], F, 1, 1)
+        s[f"{a}.3.bias"] = (hid[i],)
+    s["pretrained.act_postprocess1.4.weight"] = (hid[0], hid[0], 4, 4)
+    s["pretrained.act_postprocess1.4.bias"] = (hid[0],)
+    s["pretrained.act_postprocess2.4.weight"] = (hid[1], hid[1], 2, 2)
+    s["pretrained.act_postprocess2.4.bias"] = (hid[1],)
+    s["pretrained.act_postprocess4.4.weight"] = (hid[3], hid[3], 3, 3)
+    s["pretrained.act_postprocess4.4.bias"] = (hid[3],)
+    for i in range(4):
+        s[f"scratch.layer{i + 1}_rn.weight"] = (C, hid[i], 3, 3)
+    for n in (1, 2, 3, 4):
+        r = f"scratch.refinenet{n}"
+        s[f"{r}.out_conv.weight"] = (C, C, 1, 1)
+        s[f"{r}.out_conv.bias"] = (C,)
+        for unit in ("resConfUnit1", "resConfUnit2"):
+            for conv in ("conv1", "conv2"):
+                s[f"{r}.{unit}.{conv}.weight"] = (C, C, 3, 3)
+                s[f"{r}.{unit}.{conv}.bias"] = (C,)
+    s["scratch.output_conv.0.weight"] = (C // 2, C, 3, 3)
+    s["scratch.output_conv.0.bias"] = (C // 2,)
+    s["scratch.output_conv.2.weight"] = (32, C // 2, 3, 3)
+    s["scratch.output_conv.2.bias"] = (32,)
+    s["scratch.output_conv.4.weight"] = (1, 32, 1, 1)
+    s["scratch.output_conv.4.bias"] = (1,)
+    return s
+
+
+def make_synthetic_beit_state_dict(cfg: dict | str, seed: int = 0) -> dict[str, torch.Tensor]:
+    """Seeded fp32 MiDaS-format BEiT checkpoint (every parameter explicitly initialised: the reference creates several
+    with torch.empty). Same recipe as the Depth-Anything one; relative-position tables ~ 0.5 N."""
+    if isinstance(cfg, str):
+        cfg = BEIT_CONFIGS[cfg]
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(int(seed))
+    sd: dict[str, torch.Tensor] = {}
+    for key, shape in beit_original_state_dict_shapes(cfg).items():
+        if "gamma_" in key:
+            t = 0.5 + 0.5 * torch.rand(shape, generator=gen)
+        elif ".norm" in key and key.endswith("weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=gen)
+        elif key.endswith("relative_position_bias_table"):
+            t = 0.5 * torch.randn(shape, generator=gen)
+        elif key == "scratch.output_conv.4.bias":
+            t = torch.full(shape, 0.5)
+        elif len(shape) >= 2 and key.endswith("weight"):
+            if key.endswith("act_postprocess1.4.weight") or key.endswith("act_postprocess2.4.weight"):
+                fan_in = shape[0]
+            else:
+                fan_in = 1
+                for d in shape[1:]:
+                    fan_in *= d
+            t = torch.randn(shape, generator=gen) * (float(fan_in) ** -0.5)
+        elif key == "pretrained.model.cls_token":
+            t = 0.5 * torch.randn(shape, generator=gen)
+        else:
+            t = 0.1 * torch.randn(shape, generator=gen)
+        sd[key] = t.to(torch.float32).contiguous()
+    return sd
+
+
 def original_state_dict_shapes(cfg: dict) -> dict[str, tuple]:
     """Every tensor of an upstream DA-V2 (non-giant) checkpoint, in upstream order, with its shape."""
     F = cfg["features_per_token"]

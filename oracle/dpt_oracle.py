@@ -50,14 +50,16 @@ def prepared_size(img_h: int, img_w: int, max_side_length: int | None, use_squar
 
 
 def prepare_image(image_bgr, max_side_length: int | None = None, use_square_sizing: bool = True,
-                  interpolation_mode: str = "bilinear", default_size_px: int = 518, tiling_px: int = 28) -> torch.Tensor:
-    """uint8 HxWx3 BGR ndarray -> normalised fp32 [1,3,H',W'] (patch_embed.py:103-145)."""
+                  interpolation_mode: str = "bilinear", default_size_px: int = 518, tiling_px: int = 28,
+                  rgb_mean=RGB_MEAN, rgb_std=RGB_STD) -> torch.Tensor:
+    """uint8 HxWx3 BGR ndarray -> normalised fp32 [1,3,H',W'] (patch_embed.py:103-145; BEiT uses mean = std = 0.5,
+    v31_beit/patch_embed.py:39-40)."""
     h, w = image_bgr.shape[0:2]
     size_hw = prepared_size(h, w, max_side_length, use_square_sizing, default_size_px, tiling_px)
     rgb = torch.from_numpy(image_bgr[:, :, ::-1].copy()).permute(2, 0, 1).to(torch.float32)  # :134-135
     x = F.interpolate(rgb.unsqueeze(0), size=size_hw, align_corners=False, antialias=True, mode=interpolation_mode)
-    mean = torch.tensor(RGB_MEAN).view(1, 3, 1, 1)
-    inv_std = 1.0 / torch.tensor(RGB_STD).view(1, 3, 1, 1)
+    mean = torch.tensor(rgb_mean).view(1, 3, 1, 1)
+    inv_std = 1.0 / torch.tensor(rgb_std).view(1, 3, 1, 1)
     return ((x / 255.0) - mean) * inv_std  # :145
 
 
@@ -141,6 +143,118 @@ def image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple
 _REASM = ("spatial_upx4", "spatial_upx2", "spatial_noscale", "spatial_downx2")
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# MiDaS v3.1 BEiT family (reference muggled_dpt/v31_beit/*)
+
+
+def is_beit(w: dict) -> bool:
+    return "imgencoder.stages.0.blocks.0.attn.q_bias" in w
+
+
+def beit_relative_position_index(grid_hw: tuple[int, int]) -> torch.Tensor:
+    """[N,N] int64 index into the (resized table ++ 3 cls entries) LUT; token i attends token j with
+    idx = (yi - yj + gh - 1) * (2 gw - 1) + (xi - xj + gw - 1); row 0 / column 0 / [0,0] take the three cls entries
+    (components/relative_positional_encoder.py:126-186)."""
+    gh, gw = grid_hw
+    ys, xs = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+    ys, xs = ys.flatten(), xs.flatten()
+    rel = (ys[:, None] - ys[None, :] + gh - 1) * (2 * gw - 1) + (xs[:, None] - xs[None, :] + gw - 1)
+    num_rel = (2 * gh - 1) * (2 * gw - 1)
+    idx = torch.zeros((gh * gw + 1, gh * gw + 1), dtype=torch.int64)
+    idx[1:, 1:] = rel
+    idx[0, :] = num_rel
+    idx[:, 0] = num_rel + 1
+    idx[0, 0] = num_rel + 2
+    return idx
+
+
+def beit_relpos_bias(lut: torch.Tensor, base_grid_hw: tuple[int, int], grid_hw: tuple[int, int]) -> torch.Tensor:
+    """[1,H,N,N] additive attention bias: the learned [(2G-1)^2 + 3, H] table is resized (bilinear, align_corners=False,
+    no antialias) to (2gh-1)x(2gw-1), the 3 cls entries are appended and the result is gathered by
+    beit_relative_position_index (relative_positional_encoder.py:190-229)."""
+    heads = lut.shape[1]
+    rh, rw = 2 * base_grid_hw[0] - 1, 2 * base_grid_hw[1] - 1
+    table = lut[: rh * rw].reshape(1, rh, rw, heads).permute(0, 3, 1, 2)
+    nh, nw = 2 * grid_hw[0] - 1, 2 * grid_hw[1] - 1
+    table = F.interpolate(table, size=(nh, nw), mode="bilinear")
+    full = torch.cat([table.permute(0, 2, 3, 1).reshape(nh * nw, heads), lut[rh * rw:]])
+    idx = beit_relative_position_index(grid_hw)
+    n = idx.shape[0]
+    return full[idx.reshape(-1)].reshape(n, n, heads).permute(2, 0, 1).unsqueeze(0)
+
+
+def beit_attention(w: dict, pre: str, x: torch.Tensor, cfg: dict, grid_hw: tuple[int, int]) -> torch.Tensor:
+    """qkv Linear without bias, +q_bias / +v_bias (k has none), softmax(q k^T / sqrt(d) + relpos) v, proj
+    (image_encoder_model.py:331-356)."""
+    b, n, c = x.shape
+    heads = cfg["num_heads"]
+    qkv = F.linear(x, w[f"{pre}.qkv.weight"]).reshape(b, n, 3, heads, -1).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] + w[f"{pre}.q_bias"], qkv[1], qkv[2] + w[f"{pre}.v_bias"]
+    att = (q * (c // heads) ** -0.5) @ k.transpose(-2, -1)
+    att = att + beit_relpos_bias(w[f"{pre}.relpos_enc.ref_bias_lut"], cfg["base_patch_grid_hw"], grid_hw)
+    y = (torch.softmax(att, dim=-1) @ v).transpose(1, 2).reshape(b, n, c)
+    return F.linear(y, w[f"{pre}.proj.weight"], w[f"{pre}.proj.bias"])
+
+
+def beit_image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple[int, int]) -> list[torch.Tensor]:
+    """cls ++ patch tokens (no absolute position embedding), 4 stages, raw stage outputs are the taps (no out-norm)
+    (image_encoder_model.py:80-99, block :241-251)."""
+    tokens = torch.cat((w["imgencoder.cls_token"].expand(patch_tokens.shape[0], -1, -1), patch_tokens), dim=1)
+    per_stage = int(round(cfg["num_blocks"] / 4))
+    taps = []
+    for s in range(4):
+        for i in range(per_stage):
+            pre = f"imgencoder.stages.{s}.blocks.{i}"
+            a = beit_attention(w, f"{pre}.attn", layernorm(tokens, w[f"{pre}.norm1.weight"], w[f"{pre}.norm1.bias"]), cfg, grid_hw)
+            tokens = tokens + w[f"{pre}.scale_attn"] * a
+            m = mlp(w, f"{pre}.mlp", layernorm(tokens, w[f"{pre}.norm2.weight"], w[f"{pre}.norm2.bias"]))
+            tokens = tokens + w[f"{pre}.scale_mlp"] * m
+        taps.append(tokens)
+    return taps
+
+
+def beit_readout(w: dict, pre: str, tokens: torch.Tensor) -> torch.Tensor:
+    """GELU(Linear(concat(patch token, cls token))) -> [B, N-1, F] (components/readout_projection.py:41-79)."""
+    cls, img = tokens[:, :1], tokens[:, 1:]
+    cat = torch.cat((img, cls.expand_as(img)), dim=-1)
+    return F.gelu(F.linear(cat, w[f"{pre}.readout_proj.1.weight"], w[f"{pre}.readout_proj.1.bias"]))
+
+
+def beit_reassemble(w: dict, stage_tokens: list[torch.Tensor], grid_hw: tuple[int, int]) -> list[torch.Tensor]:
+    """readout projection, tokens->BCHW, then the same project/resample/fuse_proj chain as Depth-Anything
+    (v31_beit/reassembly_model.py:114-127)."""
+    outs = []
+    for name, tok in zip(_REASM, stage_tokens):
+        p = f"reassemble.{name}"
+        x = beit_readout(w, p, tok).transpose(1, 2).unflatten(2, grid_hw)
+        x = F.conv2d(x, w[f"{p}.resample.0.weight"], w[f"{p}.resample.0.bias"])
+        if name == "spatial_upx4":
+            x = F.conv_transpose2d(x, w[f"{p}.resample.1.weight"], w[f"{p}.resample.1.bias"], stride=4)
+        elif name == "spatial_upx2":
+            x = F.conv_transpose2d(x, w[f"{p}.resample.1.weight"], w[f"{p}.resample.1.bias"], stride=2)
+        elif name == "spatial_downx2":
+            x = F.conv2d(x, w[f"{p}.resample.1.weight"], w[f"{p}.resample.1.bias"], stride=2, padding=1)
+        outs.append(F.conv2d(x, w[f"{p}.fuse_proj.weight"], None, padding=1))
+    return outs
+
+
+def beit_fusion(w: dict, reasm: list[torch.Tensor]) -> torch.Tensor:
+    """Same dataflow as fusion(); parameter names differ (conv_seq / proj_seq, v31_beit/fusion_model.py:95-164)."""
+
+    def rcu(pre, x):
+        y = F.conv2d(F.relu(x), w[f"{pre}.conv_seq.1.weight"], w[f"{pre}.conv_seq.1.bias"], padding=1)
+        y = F.conv2d(F.relu(y), w[f"{pre}.conv_seq.3.weight"], w[f"{pre}.conv_seq.3.bias"], padding=1)
+        return y + x
+
+    f = None
+    for idx in (3, 2, 1, 0):
+        p = f"fusion.blocks.{idx}"
+        x = reasm[idx] if f is None else rcu(f"{p}.conv_reassembly", reasm[idx]) + f
+        x = upsample_bilinear_ac(rcu(f"{p}.proj_seq.0", x), 2)
+        f = F.conv2d(x, w[f"{p}.proj_seq.2.weight"], w[f"{p}.proj_seq.2.bias"])
+    return f
+
+
 def reassemble(w: dict, stage_tokens: list[torch.Tensor], grid_hw: tuple[int, int]) -> list[torch.Tensor]:
     """Per stage: drop cls, tokens->BCHW, 1x1 conv, {convT k4s4 | convT k2s2 | none | conv3x3 s2 p1},
     3x3 conv (no bias) to fusion channels (reassembly_model.py:61-94, :139-149, :208-211, :238-310)."""
@@ -207,9 +321,14 @@ def forward(w: dict, cfg: dict, image_bchw: torch.Tensor, return_stages: bool = 
         if grid_hw[0] % 2 or grid_hw[1] % 2:
             # the reference crashes in fusion (tensor size mismatch, fusion_model.py:151)
             raise RuntimeError(f"patch grid {grid_hw} must be even in both dimensions")
-        taps = image_encoder(w, cfg, tokens, grid_hw)
-        reasm = reassemble(w, taps, grid_hw)
-        fused = fusion(w, reasm)
+        if is_beit(w):
+            taps = beit_image_encoder(w, cfg, tokens, grid_hw)
+            reasm = beit_reassemble(w, taps, grid_hw)
+            fused = beit_fusion(w, reasm)
+        else:
+            taps = image_encoder(w, cfg, tokens, grid_hw)
+            reasm = reassemble(w, taps, grid_hw)
+            fused = fusion(w, reasm)
         depth = head(w, cfg, fused)
     if return_stages:
         return depth, {"patch_tokens": tokens, "grid_hw": grid_hw, "stages": taps, "reasm": reasm, "fused": fused}
@@ -219,6 +338,7 @@ def forward(w: dict, cfg: dict, image_bchw: torch.Tensor, return_stages: bool = 
 def inference(w: dict, cfg: dict, image_bgr, max_side_length=None, use_square_sizing=True) -> torch.Tensor:
     """DPTModel.inference (dpt_model.py:87-109): prepare_image + forward -> [1,H,W]."""
     default_px = cfg["base_patch_grid_hw"][0] * cfg["patch_size_px"]
+    norm = dict(rgb_mean=(0.5, 0.5, 0.5), rgb_std=(0.5, 0.5, 0.5)) if is_beit(w) else {}
     x = prepare_image(image_bgr, max_side_length, use_square_sizing, default_size_px=default_px,
-                      tiling_px=2 * cfg["patch_size_px"])
+                      tiling_px=2 * cfg["patch_size_px"], **norm)
     return forward(w, cfg, x)

@@ -7,7 +7,7 @@ read-only (with an in-memory stub for the absent `cv2`), feed it seeded syntheti
 While doing so it asserts that oracle/dpt_oracle.py reproduces the reference at every stage
 boundary (<= 2e-5 abs on O(1) tensors) - this is what pins the oracle.
 
-usage: PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [--skip-vitl]
+usage: PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [--skip-vitl] [--only-beit]
 """
 
 from __future__ import annotations
@@ -86,13 +86,103 @@ def build(cfg_name, seed):
     return osd, cfg, model, w
 
 
+def gen_beit(report, skip_large):
+    """MiDaS v3.1 BEiT fixtures (reference muggled_dpt/make_beit_dpt.py, v31_beit/*)."""
+    from muggled_dpt.make_beit_dpt import make_beit_dpt_from_midas_v31_state_dict as ref_make_beit
+    from muggled_dpt_amd.synthetic import make_synthetic_beit_state_dict
+    from muggled_dpt_amd import state_dict_conversion_beit as conv
+
+    def build_beit(name, seed):
+        osd = make_synthetic_beit_state_dict(name, seed)
+        cfg_ref, model = ref_make_beit(osd, enable_cache=False, enable_optimizations=True)
+        cfg = conv.get_model_config_from_state_dict(osd)
+        norm = lambda c: {k: (tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in c.items()}  # noqa: E731
+        assert norm(cfg) == norm(cfg_ref), (cfg, cfg_ref)
+        w = flatten_components(conv.convert_state_dict_keys(cfg, osd))
+        ref_keys = {f"{comp}.{k}": list(v.shape) for comp in ("patch_embed", "imgencoder", "reassemble", "fusion", "head")
+                    for k, v in getattr(model, comp).state_dict().items()}
+        assert set(ref_keys) == set(w), set(ref_keys) ^ set(w)
+        for k, shp in ref_keys.items():
+            assert list(w[k].shape) == shp, (k, shp, w[k].shape)
+        return osd, cfg, model, w, ref_keys
+
+    osd, cfg, model, w, ref_keys = build_beit("beit_tiny", 5)
+    with open(os.path.join(GOLD, "beit_tiny_new_keys.json"), "w") as f:
+        json.dump(ref_keys, f, indent=0, sort_keys=True)
+    # base grid (4x4: table used as-is) and two resized grids (4x6, 6x2)
+    save = {}
+    for tag, shape, seed in (("base", (2, 3, 64, 64), 6), ("wide", (2, 3, 64, 96), 7), ("tall", (1, 3, 96, 32), 8)):
+        x = torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+        ref = run_reference(model, x)
+        report[f"beit_tiny_{tag}"] = check_against_oracle(f"beit_tiny_{tag}", ref, w, cfg, x)
+        tok, hw, taps, reasm, fused, depth = ref
+        save.update({f"{tag}_input": x.numpy(), f"{tag}_depth": depth.numpy(), f"{tag}_fused": fused.numpy(),
+                     f"{tag}_patch_tokens": tok.numpy()})
+        save.update({f"{tag}_tap{i}": taps[i].numpy() for i in range(4)})
+        save.update({f"{tag}_reasm{i}": reasm[i].numpy() for i in range(4)})
+    # relative-position bias tensors straight from the reference's encoder ([1,H,N,N]) for three grids
+    enc = model.imgencoder.stages[1].blocks[0].attn.relpos_enc
+    lut = w["imgencoder.stages.1.blocks.0.attn.relpos_enc.ref_bias_lut"]
+    for g in ((4, 4), (4, 6), (6, 2), (8, 8)):
+        with torch.inference_mode():
+            bias = enc._generate_position_bias_lut(g)
+        mine = dpt_oracle.beit_relpos_bias(lut, cfg["base_patch_grid_hw"], g)
+        assert maxdiff(bias, mine) <= 1e-6, (g, maxdiff(bias, mine))
+        save[f"relpos_g{g[0]}x{g[1]}"] = bias.numpy()
+    save["relpos_lut"] = lut.numpy()
+    np.savez_compressed(os.path.join(GOLD, "beit_tiny.npz"), weight_seed=5, **save)
+    # pre-processing: mean = std = 0.5, default 384, tiles of 32
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, size=(300, 420, 3), dtype=np.uint8)
+    prep = {}
+    for tag, kwargs in (("default", {}), ("rect256", dict(max_side_length=256, use_square_sizing=False))):
+        got = model.patch_embed.prepare_image(img, **kwargs)
+        mine = dpt_oracle.prepare_image(img, default_size_px=64, tiling_px=32, rgb_mean=(0.5,) * 3, rgb_std=(0.5,) * 3, **kwargs)
+        assert got.shape == mine.shape and maxdiff(got, mine) <= 1e-5, (tag, got.shape, mine.shape)
+        prep[tag] = got.numpy()
+    np.savez_compressed(os.path.join(GOLD, "beit_prepare_image.npz"), image=img, **prep)
+    try:
+        run_reference(model, torch.randn(1, 3, 48, 48))
+        raise AssertionError("reference accepted an odd patch grid?!")
+    except RuntimeError as e:
+        print("[beit_tiny] odd grid raises in reference:", str(e).splitlines()[0])
+
+    if not skip_large:  # BASELINE.json configs[5]: BEiT-L 384, batch 1
+        osd, cfg, model, w, _ = build_beit("beit_large_384", 0)
+        x = torch.randn(1, 3, 384, 384, generator=torch.Generator().manual_seed(1))
+        ref = run_reference(model, x)
+        report["beit_large_384"] = check_against_oracle("beit_large_384", ref, w, cfg, x)
+        tok, hw, taps, reasm, fused, depth = ref
+        np.savez_compressed(
+            os.path.join(GOLD, "beit_large_384.npz"), weight_seed=0, input_seed=1,
+            weight_checksum=np.array([float(osd["pretrained.model.blocks.3.attn.qkv.weight"].double().sum()),
+                                      float(osd["scratch.refinenet2.out_conv.weight"].double().sum())]),
+            input_checksum=np.array([float(x.double().sum())]),
+            depth_strided=depth[:, ::4, ::4].numpy(), depth_stats=stats(depth),
+            **{f"tap{i}_crop": taps[i][:, :64, :64].numpy() for i in range(4)},
+            **{f"tap{i}_stats": stats(taps[i]) for i in range(4)},
+            **{f"reasm{i}_stats": stats(reasm[i]) for i in range(4)}, fused_stats=stats(fused))
+        print("[beit_large_384] depth stats (min,max,mean,l2):", stats(depth))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-vitl", action="store_true")
+    ap.add_argument("--only-beit", action="store_true", help="regenerate the BEiT fixtures only (report is merged)")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     report = {}
+    if args.only_beit:
+        rp = os.path.join(GOLD, "oracle_vs_reference_report.json")
+        with open(rp) as f:
+            old = json.load(f)
+        gen_beit(report, args.skip_vitl)
+        old["max_abs_err"].update(report)
+        with open(rp, "w") as f:
+            json.dump(old, f, indent=1)
+        print("done ->", GOLD)
+        return
 
     # ------------------------------------------------------------------ 1. tiny config, full tensors
     osd, cfg, model, w = build("tiny", 0)
@@ -208,6 +298,8 @@ def main():
             **{f"tap{i}_stats": stats(taps[i]) for i in range(4)},
             **{f"reasm{i}_stats": stats(reasm[i]) for i in range(4)}, fused_stats=stats(fused))
         print("[vitl504] depth stats (min,max,mean,l2):", stats(depth))
+
+    gen_beit(report, args.skip_vitl)
 
     with open(os.path.join(GOLD, "oracle_vs_reference_report.json"), "w") as f:
         json.dump({"torch": torch.__version__, "tolerance_abs": TOL, "max_abs_err": report}, f, indent=1)
