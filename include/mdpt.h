@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MDPT_ABI_VERSION 1
+#define MDPT_ABI_VERSION 2
 
 /* arithmetic modes (all accumulate in fp32; residual stream, LayerNorm and softmax statistics are fp32) */
 #define MDPT_PREC_BF16 0   /* bf16 MFMA operands - the reference's GPU default dtype (demo_helpers/misc.py:73-77) */
@@ -35,6 +35,7 @@ extern "C" {
 #define MDPT_FAMILY_DAV2 0
 #define MDPT_FAMILY_DAV1 1
 #define MDPT_FAMILY_BEIT 2
+#define MDPT_FAMILY_SWINV2 3
 
 #define MDPT_E_INVALID (-1)    /* bad argument / shape                                  */
 #define MDPT_E_STATE (-2)      /* call order (e.g. forward before finalize)             */
@@ -63,7 +64,15 @@ typedef struct mdpt_config {
                           MDPT_FAMILY_DAV1: Depth-Anything V1 (tapped after each of the last four blocks,
                                             v1_depthanything/image_encoder_model.py:55-61; parameters named imgencoder.blocks.N...)
                           MDPT_FAMILY_BEIT: MiDaS v3.1 BEiT (v31_beit/: relative-position-bias attention with q/v bias, no position
-                                            embedding or out-norm, readout projection in the reassembly, patch 16) */
+                                            embedding or out-norm, readout projection in the reassembly, patch 16)
+                          MDPT_FAMILY_SWINV2: MiDaS v3.1 SwinV2 (v31_swinv2/: 4 stages of shifted-window cosine attention, head dim 32,
+                                            post-norm blocks, patch merging between stages, patch 4). Uses the swin_* fields below;
+                                            features per stage = reassembly_features[], features_per_token = reassembly_features[0] */
+    /* SwinV2 only (make_swinv2_dpt.py:67-79); ignored by the other families */
+    int32_t swin_heads[4];             /* heads_per_stage */
+    int32_t swin_layers[4];            /* layers_per_stage (even: blocks come in plain/shifted pairs, image_encoder_model.py:155-161) */
+    int32_t swin_window_h, swin_window_w;
+    int32_t swin_pretrained_window[4]; /* pretrained_window_sizes_per_stage, 0 = None */
 } mdpt_config;
 
 int mdpt_abi_version(void);

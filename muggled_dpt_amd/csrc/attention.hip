@@ -17,6 +17,13 @@
 //         S^T accumulators come out (keys {0-3, 8-11} + 4*(lane>>5) per 16-key block) and the Vt fragment
 //         is gathered to match with two 8-byte LDS reads - no cross-lane shuffle of P at all.
 // x3 mode: hi/lo bf16 planes for Q, K, V and P (3 MFMAs per product) -> fp32-class accuracy.
+//
+// Template HD = head dim: 64 (DINOv2 / BEiT) or 32 (SwinV2 windows). With HD = 32 a 128-byte LDS row of the K tile holds a
+// PAIR of keys, everything else (DMA chunking, XOR swizzle, fragment reads) is the same code.
+// Template MODE: 0 plain, 1 = BEiT relative-position bias (LUT gather), 2 = SwinV2 window attention: the "batch" is
+// (image, window), scores get the continuous-position bias LUT plus the 0 / -100 shifted-window mask
+// (reference v31_swinv2/components/windowed_attention.py:100-123, :394-439) and output rows are scattered back through the
+// window -> image token map (window reverse + un-roll, :171-260) so the proj GEMM sees tokens in image order.
 
 #include "mdpt_kernels.h"
 #include "mdpt_prof.h"
@@ -46,11 +53,13 @@ __device__ __forceinline__ bf16x8 cat44(bf16x4 a, bf16x4 b) {
 // QB = query blocks of 32 per wave: 2 in bf16 mode (64 queries per wave, 256 per workgroup: every K / Vt fragment read
 // from LDS and every LDS-DMA'd tile feeds twice the MFMAs - the kernel is vector-memory/LDS bound otherwise), 1 in x3
 // mode (register budget: hi+lo planes of Q, K, V and P).
-template <bool X3, int QB, bool BIAS>
+template <bool X3, int QB, int MODE, int HD>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
+    constexpr bool BIAS = MODE != 0;
     constexpr int NPL = X3 ? 2 : 1;           // planes per operand
-    constexpr int TILE = 8192;                // one [64][64] bf16 tile
+    constexpr int TILE = 64 * HD * 2;         // one [64 keys][HD] (or [HD][64 keys]) bf16 tile
     constexpr int STAGE = 2 * NPL * TILE;     // K planes then Vt planes
+    constexpr int KS = HD / 16, DB = HD / 32, CH = HD / 32;  // MFMA k-steps of S, 32-row blocks of O^T, 1 KiB DMA chunks per wave
     constexpr int QPW = 32 * QB, QPB = 4 * QPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -72,18 +81,19 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     }
     const int b = bhi / p.heads, h = bhi - b * p.heads;
     const size_t bh = (size_t)bhi;
+    const int win = MODE == 2 ? b % p.win_nw : 0;  // window index inside its image
     const int q0 = qt * QPB + wave * QPW;
     const bool active = q0 < p.npad;  // tail waves of the last q-tile only help with DMA and barriers
 
     // ---- Q fragments (B operand of S^T = K Q^T): Q[q][d = 16*ks + 8*half .. +8]
-    bf16x8 qh[QB][4], ql[QB][4];
+    bf16x8 qh[QB][KS], ql[QB][KS];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int q = q0 + qb * 32 + l31;
         const int q_ld = q < p.npad ? q : p.npad - 1;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const size_t o = (bh * p.npad + q_ld) * 64 + ks * 16 + half * 8;
+        for (int ks = 0; ks < KS; ++ks) {
+            const size_t o = (bh * p.npad + q_ld) * HD + ks * 16 + half * 8;
             qh[qb][ks] = *(const bf16x8*)(p.q_hi + o);
             if (X3) ql[qb][ks] = *(const bf16x8*)(p.q_lo + o);
         }
@@ -93,34 +103,41 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     //      behind the K/V ring; bias(q,k) = lut[tq[q] - tk[k]] (see beit_relpos_kernel)
     float* lds_lut = (float*)(smem + 2 * STAGE);
     int* lds_tk = (int*)(lds_lut + (BIAS ? p.bias_elen : 0));
-    int tqv[QB];
+    int* lds_reg = lds_tk + (((p.N + 63) >> 6) << 6);  // MODE 2: shifted-window region id of every key
+    int tqv[QB], rqv[QB];
+    const bool masked = MODE == 2 && p.region != nullptr;
     if (BIAS) {
         const float* lut = p.bias_lut + (size_t)h * p.bias_elen;
         for (int i = tid; i < p.bias_elen; i += 256) lds_lut[i] = lut[i];
         const int nk = ((p.N + 63) >> 6) << 6;
         for (int i = tid; i < nk; i += 256) lds_tk[i] = p.tk[i < p.npad ? i : p.npad - 1];
+        if (MODE == 2)
+            for (int i = tid; i < nk; i += 256) lds_reg[i] = masked ? p.region[(size_t)win * p.region_ld + (i < p.N ? i : p.N - 1)] : 0;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             const int q = q0 + qb * 32 + l31;
             tqv[qb] = p.tq[q < p.npad ? q : p.npad - 1];
+            rqv[qb] = masked ? p.region[(size_t)win * p.region_ld + (q < p.N ? q : p.N - 1)] : 0;
         }
     }
 
-    // ---- staging: K tile rows = keys, Vt tile rows = d; 8 chunks of 1 KiB each per plane, 2 per wave
+    // ---- staging: 128-byte LDS rows (K: one key at HD 64, a pair of keys at HD 32; Vt: one d), 1 KiB chunks of 8 rows,
+    //      CH per wave and plane; the XOR swizzle is applied on the SOURCE address (LDS-DMA writes lane-linear)
     const int lrow = lane >> 3, slot = lane & 7;
     const int sw_stage = ((wave & 1) * 4 + (lrow >> 1)) & 7;
-    const int koff = (slot ^ sw_stage) * 8;
+    const int lslot = slot ^ sw_stage;  // logical 16-byte slot this lane fetches
+    const int koff = lslot * 8;
     const int ntiles = (p.N + 63) >> 6;
     auto issue_tile = [&](int tile, int buf) {
         char* s = smem + buf * STAGE;
         const int kv0 = tile * 64;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < CH; ++i) {
             const int c = wave + 4 * i;
-            int krow = kv0 + c * 8 + lrow;
+            int krow = HD == 64 ? kv0 + c * 8 + lrow : kv0 + 2 * (c * 8 + lrow) + (lslot >> 2);
             krow = krow < p.npad ? krow : p.npad - 1;  // rows >= N are masked in the softmax
-            const size_t ko = (bh * p.npad + krow) * 64 + koff;
-            const size_t vo = (bh * 64 + c * 8 + lrow) * p.npadv + kv0 + koff;
+            const size_t ko = (bh * p.npad + krow) * HD + (HD == 64 ? koff : (lslot & 3) * 8);
+            const size_t vo = (bh * HD + c * 8 + lrow) * p.npadv + kv0 + koff;
             glds16(p.k_hi + ko, s + c * 1024);
             if (X3) glds16(p.k_lo + ko, s + TILE + c * 1024);
             glds16(p.vt_hi + vo, s + NPL * TILE + c * 1024);
@@ -129,14 +146,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     };
 
     const int sw_frag = (l31 >> 1) & 7;
-    f32x16 o_acc[QB][2];
+    f32x16 o_acc[QB][DB];
     float m_run[QB], l_run[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         m_run[qb] = -1.0e30f;
         l_run[qb] = 0.0f;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o_acc[qb][db][r] = 0.0f;
     }
@@ -163,8 +180,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int off = (blk * 32 + l31) * 128 + (((ks * 2 + half) ^ sw_frag) << 4);
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = HD == 64 ? (blk * 32 + l31) * 128 + (((ks * 2 + half) ^ sw_frag) << 4)
+                                         : (blk * 16 + (l31 >> 1)) * 128 + ((((l31 & 1) * 4 + ks * 2 + half) ^ ((l31 >> 2) & 7)) << 4);
                 const bf16x8 kh = *(const bf16x8*)(sK + off);
                 bf16x8 kl;
                 if (X3) kl = *(const bf16x8*)(sK + TILE + off);
@@ -188,6 +206,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) s[qb][blk][4 * g + e] += lds_lut[tqv[qb] - tk4[e]];
+                    if (MODE == 2 && masked) {
+                        const i32x4 rk4 = *(const i32x4*)(lds_reg + t * 64 + blk * 32 + 8 * g + 4 * half);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s[qb][blk][4 * g + e] += rqv[qb] != rk4[e] ? -100.0f : 0.0f;
+                    }
                 }
         }
         // key of s[..][blk][r] = t*64 + blk*32 + (r&3) + 8*(r>>2) + 4*half
@@ -227,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             l_run[qb] = l_run[qb] * alpha + psum;
             if (__any(alpha != 1.0f)) {  // after the first tiles the running max rarely moves: skip 32 multiplies
 #pragma unroll
-                for (int db = 0; db < 2; ++db)
+                for (int db = 0; db < DB; ++db)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o_acc[qb][db][r] *= alpha;
             }
@@ -275,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                 }
                 const int kb = blk * 2 + kb2;
 #pragma unroll
-                for (int db = 0; db < 2; ++db) {
+                for (int db = 0; db < DB; ++db) {
                     const int off = (db * 32 + l31) * 128 + (((2 * kb + half) ^ sw_frag) << 4);
                     const bf16x8 vh = *(const bf16x8*)(sV + off);
                     bf16x8 vl;
@@ -299,10 +324,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
         const float inv = 1.0f / l_tot;
         const int q = q0 + qb * 32 + l31;
-        if (q < p.npad) {
-            const size_t orow = ((size_t)b * p.npad + q) * p.F + h * 64;
+        if (MODE == 2 ? q < p.N : q < p.npad) {
+            size_t orow;
+            if (MODE == 2) {  // window reverse + un-roll: row of this window token in its image
+                const int img = b / p.win_nw;
+                orow = ((size_t)img * p.win_nw * p.N + p.rowmap[(size_t)win * p.N + q]) * p.F + h * HD;
+            } else {
+                orow = ((size_t)b * p.npad + q) * p.F + h * HD;
+            }
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     bf16x4 hi4, lo4;
@@ -323,26 +354,32 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 }  // namespace
 
 int mdpt_launch_attention(const AttnParams& p, hipStream_t stream) {
-    if (p.F != p.heads * 64 || (p.npadv & 63) || p.npadv < ((p.N + 63) & ~63) || p.npad < p.N) return (int)hipErrorInvalidValue;
+    const int hd = p.head_dim ? p.head_dim : 64;
+    if ((hd != 64 && hd != 32) || p.F != p.heads * hd || (p.npadv & 63) || p.npadv < ((p.N + 63) & ~63) || p.npad < p.N)
+        return (int)hipErrorInvalidValue;
+    const bool swin = p.rowmap != nullptr;
+    if (swin && (hd != 32 || !p.bias_lut || p.win_nw <= 0 || p.B % p.win_nw)) return (int)hipErrorInvalidValue;
+    if (!swin && hd != 64) return (int)hipErrorInvalidValue;
     // 64 queries per wave (256 per workgroup) when that still gives >= 2 workgroups per CU, else 128-query workgroups
     const long blocks256 = (long)((p.npad + 255) / 256) * p.heads * p.B;
     const bool wide = !p.x3 && blocks256 >= 512;
     const bool bias = p.bias_lut != nullptr;
     const int ntk = ((p.N + 63) / 64) * 64;
-    const size_t extra = bias ? (size_t)p.bias_elen * 4 + (size_t)ntk * 4 : 0;
-    const size_t ring = (size_t)2 * 2 * (p.x3 ? 2 : 1) * 8192;
-    if (ring + extra > 160 * 1024 / 2) {
-        if (ring + extra > 160 * 1024) return (int)hipErrorInvalidValue;  // relative-position table does not fit in LDS
-    }
-    MdptProfScope prof(p.x3 ? (bias ? "attn_kernel<true, 1, true>" : "attn_kernel<true, 1, false>")
-                            : (wide ? (bias ? "attn_kernel<false, 2, true>" : "attn_kernel<false, 2, false>")
-                                    : (bias ? "attn_kernel<false, 1, true>" : "attn_kernel<false, 1, false>")),
-                       4.0 * p.B * p.heads * (double)p.N * p.N * 64.0, stream);
+    const size_t extra = bias ? (size_t)p.bias_elen * 4 + (size_t)ntk * 4 * (swin ? 2 : 1) : 0;
+    const size_t ring = (size_t)2 * 2 * (p.x3 ? 2 : 1) * 64 * hd * 2;
+    if (ring + extra > 160 * 1024) return (int)hipErrorInvalidValue;  // relative-position table does not fit in LDS
+    static const char* const kNames[2][2][3] = {
+        {{"attn_kernel<false, 1, 0, 64>", "attn_kernel<false, 1, 1, 64>", "attn_kernel<false, 1, 2, 32>"},
+         {"attn_kernel<false, 2, 0, 64>", "attn_kernel<false, 2, 1, 64>", "attn_kernel<false, 2, 2, 32>"}},
+        {{"attn_kernel<true, 1, 0, 64>", "attn_kernel<true, 1, 1, 64>", "attn_kernel<true, 1, 2, 32>"},
+         {"attn_kernel<true, 1, 0, 64>", "attn_kernel<true, 1, 1, 64>", "attn_kernel<true, 1, 2, 32>"}}};
+    const int mode = swin ? 2 : (bias ? 1 : 0);
+    MdptProfScope prof(kNames[p.x3 ? 1 : 0][wide ? 1 : 0][mode], 4.0 * p.B * p.heads * (double)p.N * p.N * hd, stream);
     const unsigned lds = (unsigned)(ring + extra);
     const dim3 grid128(((p.npad + 127) / 128) * p.heads * p.B), grid256((unsigned)blocks256), block(256);
-#define ATTN_LAUNCH(X3_, QB_, BIAS_, GRID_)                                                                              \
+#define ATTN_LAUNCH(X3_, QB_, MODE_, HD_, GRID_)                                                                        \
     do {                                                                                                                \
-        auto kern = attn_kernel<X3_, QB_, BIAS_>;                                                                       \
+        auto kern = attn_kernel<X3_, QB_, MODE_, HD_>;                                                                  \
         static bool attr_done = false;                                                                                  \
         if (!attr_done) {                                                                                               \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -352,11 +389,17 @@ int mdpt_launch_attention(const AttnParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(kern, GRID_, block, lds, stream, p);                                                         \
     } while (0)
     if (p.x3) {
-        if (bias) ATTN_LAUNCH(true, 1, true, grid128); else ATTN_LAUNCH(true, 1, false, grid128);
+        if (mode == 2) ATTN_LAUNCH(true, 1, 2, 32, grid128);
+        else if (mode == 1) ATTN_LAUNCH(true, 1, 1, 64, grid128);
+        else ATTN_LAUNCH(true, 1, 0, 64, grid128);
     } else if (wide) {
-        if (bias) ATTN_LAUNCH(false, 2, true, grid256); else ATTN_LAUNCH(false, 2, false, grid256);
+        if (mode == 2) ATTN_LAUNCH(false, 2, 2, 32, grid256);
+        else if (mode == 1) ATTN_LAUNCH(false, 2, 1, 64, grid256);
+        else ATTN_LAUNCH(false, 2, 0, 64, grid256);
     } else {
-        if (bias) ATTN_LAUNCH(false, 1, true, grid128); else ATTN_LAUNCH(false, 1, false, grid128);
+        if (mode == 2) ATTN_LAUNCH(false, 1, 2, 32, grid128);
+        else if (mode == 1) ATTN_LAUNCH(false, 1, 1, 64, grid128);
+        else ATTN_LAUNCH(false, 1, 0, 64, grid128);
     }
 #undef ATTN_LAUNCH
     return (int)hipGetLastError();

@@ -95,6 +95,12 @@ struct Plan {
     size_t fused[2], h1, h1u[2], scratch;
     size_t scratch_floats;
     size_t tokr[2], cbuf, relpos_lut, relpos_tq, relpos_tk;  // BEiT: readout-projected tokens, per-image cls term, bias LUT
+    // SwinV2: stage-0 patch grid, per-stage residual streams (fp32, = the taps), shared GEMM fp32 output, token planes,
+    // window operands, window maps (plain / shifted) and the position-bias LUT
+    struct {
+        int g0h, g0w;
+        size_t resid[4], x, xn[2], q[2], k[2], vt[2], att[2], hb[2], lut, tq, tk, rowmap[2], region[2];
+    } sw;
 };
 
 }  // namespace
@@ -103,6 +109,9 @@ struct mdpt_handle {
     mdpt_config cfg;
     int F, heads, nblocks, bps, P, C, Cp, C2, C2p, Kpatch;
     int hid[4], hidp[4];
+    bool swin;
+    int Pv;  // patch size seen by fusion/head: the finest reassembly map is (4H/Pv) x (4W/Pv); = P except SwinV2 (16)
+    int sH[4], sL[4], swh, sww, spre[4];  // SwinV2: heads / layers per stage, target window, pretrained window sizes (0 = None)
     bool x3;
     int gemm_tile;
     std::vector<WeightSpec> specs;
@@ -165,9 +174,14 @@ std::string blk_name(const mdpt_handle* h, int block) {
 }
 
 inline bool is_beit(const mdpt_handle* h) { return h->cfg.family == MDPT_FAMILY_BEIT; }
-// reference attribute names differ between the families (v2: fusion_model.py:100,138 / v31_beit/fusion_model.py:47,66,...)
-inline const char* rcu_seq(const mdpt_handle* h) { return is_beit(h) ? "conv_seq" : "resconv_seq"; }
-inline const char* proj_seq(const mdpt_handle* h) { return is_beit(h) ? "proj_seq" : "scale_proj_seq"; }
+inline bool is_midas(const mdpt_handle* h) { return h->cfg.family == MDPT_FAMILY_BEIT || h->cfg.family == MDPT_FAMILY_SWINV2; }
+// reference attribute names differ between the families (v2: fusion_model.py:100,138 / v31_beit, v31_swinv2 fusion_model.py)
+inline const char* rcu_seq(const mdpt_handle* h) { return is_midas(h) ? "conv_seq" : "resconv_seq"; }
+inline const char* proj_seq(const mdpt_handle* h) { return is_midas(h) ? "proj_seq" : "scale_proj_seq"; }
+
+int build_inventory_swin_encoder(mdpt_handle* h);
+
+int build_inventory_decoder(mdpt_handle* h);
 
 int build_inventory(mdpt_handle* h) {
     const int F = h->F, P = h->P, C = h->C;
@@ -180,6 +194,10 @@ int build_inventory(mdpt_handle* h) {
     h->add_spec("patch_embed.proj.bias", {F});
     h->add_mat("patch_embed.proj.weight", MDPT_PACK_LINEAR, F, 3 * P * P, F, h->Kpatch, 0);
     h->add_vec("patch_embed.proj.bias", F, F);
+    if (h->swin) {
+        build_inventory_swin_encoder(h);
+        return build_inventory_decoder(h);
+    }
 
     const bool beit = is_beit(h);
     const int nlut = (2 * h->cfg.base_patch_grid_h - 1) * (2 * h->cfg.base_patch_grid_w - 1) + 3;
@@ -225,7 +243,7 @@ int build_inventory(mdpt_handle* h) {
         h->add_mat(p + ".attn.proj.weight", MDPT_PACK_LINEAR, F, F, F, F, 0);
         h->add_mat(p + ".mlp.layers.0.weight", MDPT_PACK_LINEAR, 4 * F, F, 4 * F, F, 0);
         h->add_mat(p + ".mlp.layers.2.weight", MDPT_PACK_LINEAR, F, 4 * F, F, 4 * F, 0);
-        if (beit) h->add_vec(p + ".attn.qkv.bias@beit", 0, 3 * F);  // assembled in finalize: [q_bias, 0, v_bias]
+        if (beit) h->add_vec(p + ".attn.qkv.bias@qv", 0, 3 * F);  // assembled in finalize: [q_bias, 0, v_bias]
         else h->add_vec(p + ".attn.qkv.bias", 3 * F, 3 * F);
         h->add_vec(p + ".attn.proj.bias", F, F);
         h->add_vec(p + ".scale_attn", F, F);
@@ -263,7 +281,12 @@ int build_inventory(mdpt_handle* h) {
         h->add_spec(p + ".fuse_proj.weight", {C, hd, 3, 3});
         h->add_mat(p + ".fuse_proj.weight", MDPT_PACK_CONV3, C, hd, h->Cp, 9 * hp, 3);
     }
+    return build_inventory_decoder(h);
+}
 
+// fusion + head parameters (same structure in every family; attribute names differ, see rcu_seq / proj_seq)
+int build_inventory_decoder(mdpt_handle* h) {
+    const int C = h->C;
     for (int b = 0; b < 4; ++b) {
         char pb[64];
         snprintf(pb, sizeof(pb), "fusion.blocks.%d", b);
@@ -317,8 +340,36 @@ void take_planes(Bump& bump, bool x3, size_t elems, size_t out[2]) {
     out[1] = x3 ? bump.take(elems * 2) : SIZE_MAX;
 }
 
+// reassembly outputs, fusion and head buffers; p.Np / p.gh / p.gw = the "noscale" level (1/Pv of the image)
+void plan_decoder(Bump& bump, const mdpt_handle* h, Plan& p, size_t min_scratch_floats) {
+    const bool x3 = h->x3;
+    const int B = p.B;
+    const size_t px[4] = {(size_t)16 * p.Np, (size_t)4 * p.Np, (size_t)p.Np, (size_t)p.Np / 4};
+    for (int i = 0; i < 4; ++i) {
+        const size_t e = (size_t)B * px[i] * h->Cp;
+        p.r_f32[i] = bump.take(e * 4);
+        take_planes(bump, x3, e, p.r_bf[i]);
+        take_planes(bump, x3, e, p.a1[i]);
+        p.x_f32[i] = bump.take(e * 4);
+        take_planes(bump, x3, e, p.x_bf[i]);
+        take_planes(bump, x3, e, p.b1[i]);
+        take_planes(bump, x3, e, p.b2[i]);
+        p.flo[i] = bump.take(e * 4);
+    }
+    const size_t fpx = (size_t)64 * p.Np;  // (8gh)*(8gw)
+    take_planes(bump, x3, (size_t)B * fpx * h->Cp, p.fused);
+    p.h1 = bump.take((size_t)B * fpx * h->C2p * 4);
+    take_planes(bump, x3, (size_t)B * p.H * p.W * h->C2p, p.h1u);
+    p.scratch_floats = (size_t)B * fpx * h->Cp;
+    if (min_scratch_floats > p.scratch_floats) p.scratch_floats = min_scratch_floats;
+    p.scratch = bump.take(p.scratch_floats * 4);
+}
+
+int make_plan_swin(const mdpt_handle* h, int B, int H, int W, Plan* pl);
+
 int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
     if (B <= 0 || H <= 0 || W <= 0) return fail(MDPT_E_INVALID, "bad batch/size B=%d H=%d W=%d", B, H, W);
+    if (h->swin) return make_plan_swin(h, B, H, W, pl);
     if (H % h->P || W % h->P)
         return fail(MDPT_E_INVALID, "image size %dx%d must be divisible by the patch size %d (reference patch_embed.py:159-163)", H, W, h->P);
     const int gh = H / h->P, gw = W / h->P;
@@ -347,24 +398,7 @@ int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
     take_planes(bump, x3, (size_t)B * px[0] * h->hidp[0], p.u0);
     take_planes(bump, x3, (size_t)B * px[1] * h->hidp[1], p.u1);
     take_planes(bump, x3, (size_t)B * px[3] * h->hidp[3], p.d3);
-    for (int i = 0; i < 4; ++i) {
-        const size_t e = (size_t)B * px[i] * h->Cp;
-        p.r_f32[i] = bump.take(e * 4);
-        take_planes(bump, x3, e, p.r_bf[i]);
-        take_planes(bump, x3, e, p.a1[i]);
-        p.x_f32[i] = bump.take(e * 4);
-        take_planes(bump, x3, e, p.x_bf[i]);
-        take_planes(bump, x3, e, p.b1[i]);
-        take_planes(bump, x3, e, p.b2[i]);
-        p.flo[i] = bump.take(e * 4);
-    }
-    const size_t fpx = (size_t)64 * p.Np;  // (8gh)*(8gw)
-    take_planes(bump, x3, (size_t)B * fpx * h->Cp, p.fused);
-    p.h1 = bump.take((size_t)B * fpx * h->C2p * 4);
-    take_planes(bump, x3, (size_t)B * H * W * h->C2p, p.h1u);
-    p.scratch_floats = (size_t)B * fpx * h->Cp;
-    if (rows * F > p.scratch_floats) p.scratch_floats = rows * F;
-    p.scratch = bump.take(p.scratch_floats * 4);
+    plan_decoder(bump, h, p, rows * F);
     p.tokr[0] = p.tokr[1] = p.cbuf = p.relpos_lut = p.relpos_tq = p.relpos_tk = SIZE_MAX;
     if (is_beit(h)) {
         take_planes(bump, x3, (size_t)B * p.Np * F, p.tokr);
@@ -458,7 +492,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
         {
             GemmParams g = base_params(c, h->M(n + ".attn.qkv.weight"), xn, rows, F);
             g.ekind = MDPT_E_QKV;
-            g.bias = h->V(is_beit(h) ? n + ".attn.qkv.bias@beit" : n + ".attn.qkv.bias");
+            g.bias = h->V(is_beit(h) ? n + ".attn.qkv.bias@qv" : n + ".attn.qkv.bias");
             g.q_hi = q.hi; g.q_lo = q.lo; g.k_hi = k.hi; g.k_lo = k.lo; g.vt_hi = vt.hi; g.vt_lo = vt.lo;
             g.F = F; g.heads = h->heads; g.npad = p.npad; g.npadv = p.npadv; g.qscale = 0.125f;
             CHK(mdpt_launch_gemm(g, c.s));
@@ -675,6 +709,8 @@ int run_head(const Ctx& c, float* depth) {
     return 0;
 }
 
+#include "mdpt_swin.inc"
+
 int make_ctx(mdpt_handle* h, int B, int H, int W, void* ws, size_t ws_bytes, void* stream, Ctx* c) {
     Plan p;
     CHK(make_plan(h, B, H, W, &p));
@@ -697,16 +733,31 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     if (!cfg || !out) return fail(MDPT_E_INVALID, "null argument");
     *out = nullptr;
     if (cfg->is_giant) return fail(MDPT_E_UNSUPPORTED, "ViT-G (SwiGLU MLP) is not built in this version");
+    if (cfg->family < MDPT_FAMILY_DAV2 || cfg->family > MDPT_FAMILY_SWINV2) return fail(MDPT_E_INVALID, "unknown model family %d", cfg->family);
+    const bool swin = cfg->family == MDPT_FAMILY_SWINV2;
     if (cfg->features_per_token <= 0 || cfg->features_per_token % 64)
         return fail(MDPT_E_INVALID, "features_per_token must be a positive multiple of 64, got %d", cfg->features_per_token);
-    if (cfg->num_heads * 64 != cfg->features_per_token)
-        return fail(MDPT_E_UNSUPPORTED, "head dim must be 64 (heads=%d, features=%d)", cfg->num_heads, cfg->features_per_token);
-    if (cfg->num_blocks <= 0 || cfg->num_blocks % 4) return fail(MDPT_E_INVALID, "num_blocks must be a positive multiple of 4, got %d", cfg->num_blocks);
+    if (swin) {
+        if (cfg->patch_size_px != 4) return fail(MDPT_E_UNSUPPORTED, "SwinV2 DPT needs patch_size_px = 4 (head upsample x2 of a 1/2-resolution map), got %d", cfg->patch_size_px);
+        if (cfg->swin_window_h <= 0 || cfg->swin_window_w <= 0) return fail(MDPT_E_INVALID, "bad SwinV2 window size");
+        if (cfg->features_per_token != cfg->reassembly_features[0]) return fail(MDPT_E_INVALID, "SwinV2: features_per_token must equal features_per_stage[0]");
+        for (int i = 0; i < 4; ++i) {
+            if (cfg->reassembly_features[i] <= 0 || cfg->reassembly_features[i] % 64)
+                return fail(MDPT_E_INVALID, "SwinV2 features_per_stage[%d] must be a positive multiple of 64, got %d", i, cfg->reassembly_features[i]);
+            if (cfg->swin_heads[i] * 32 != cfg->reassembly_features[i])
+                return fail(MDPT_E_UNSUPPORTED, "SwinV2 head dim must be 32 (stage %d: heads=%d, features=%d)", i, cfg->swin_heads[i], cfg->reassembly_features[i]);
+            if (cfg->swin_layers[i] <= 0 || cfg->swin_layers[i] % 2) return fail(MDPT_E_INVALID, "SwinV2 layers_per_stage[%d] must be a positive even number", i);
+            if (cfg->swin_pretrained_window[i] < 0) return fail(MDPT_E_INVALID, "bad SwinV2 pretrained window size");
+        }
+    } else {
+        if (cfg->num_heads * 64 != cfg->features_per_token)
+            return fail(MDPT_E_UNSUPPORTED, "head dim must be 64 (heads=%d, features=%d)", cfg->num_heads, cfg->features_per_token);
+        if (cfg->num_blocks <= 0 || cfg->num_blocks % 4) return fail(MDPT_E_INVALID, "num_blocks must be a positive multiple of 4, got %d", cfg->num_blocks);
+    }
     if (cfg->fusion_channels <= 0 || cfg->fusion_channels % 8) return fail(MDPT_E_INVALID, "fusion_channels must be a multiple of 8");
     if (cfg->patch_size_px <= 0 || cfg->patch_size_px % 2) return fail(MDPT_E_INVALID, "patch_size_px must be even (head scale = patch/8)");
     if (cfg->base_patch_grid_h <= 0 || cfg->base_patch_grid_w <= 0) return fail(MDPT_E_INVALID, "bad base patch grid");
     if (cfg->precision != MDPT_PREC_BF16 && cfg->precision != MDPT_PREC_BF16X3) return fail(MDPT_E_INVALID, "unknown precision %d", cfg->precision);
-    if (cfg->family < MDPT_FAMILY_DAV2 || cfg->family > MDPT_FAMILY_BEIT) return fail(MDPT_E_INVALID, "unknown model family %d", cfg->family);
     for (int i = 0; i < 4; ++i)
         if (cfg->reassembly_features[i] <= 0 || cfg->reassembly_features[i] % 4) return fail(MDPT_E_INVALID, "reassembly_features[%d] must be a multiple of 4", i);
     mdpt_handle* h = new mdpt_handle();
@@ -716,6 +767,10 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     h->C2 = h->C / 2; h->C2p = rup(h->C2, 64);
     h->Kpatch = rup(3 * h->P * h->P, 64);
     for (int i = 0; i < 4; ++i) { h->hid[i] = cfg->reassembly_features[i]; h->hidp[i] = rup(h->hid[i], 64); }
+    h->swin = swin;
+    h->Pv = swin ? 16 : h->P;
+    for (int i = 0; i < 4; ++i) { h->sH[i] = cfg->swin_heads[i]; h->sL[i] = cfg->swin_layers[i]; h->spre[i] = cfg->swin_pretrained_window[i]; }
+    h->swh = cfg->swin_window_h; h->sww = cfg->swin_window_w;
     h->x3 = cfg->precision == MDPT_PREC_BF16X3;
     h->gemm_tile = MDPT_TILE_AUTO;
     h->finalized = false;
@@ -792,12 +847,13 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
     }
     for (Vec& v : h->vecs) {
         v.ptr = (float*)(base + v.off);
-        const size_t at = v.src.find(".attn.qkv.bias@beit");
-        if (at != std::string::npos) {  // [q_bias (H*64 = F), zeros(F), v_bias (F)]
+        const size_t at = v.src.find(".attn.qkv.bias@qv");
+        if (at != std::string::npos) {  // [q_bias (heads*d = F), zeros(F), v_bias (F)]: the k projection has no bias
             const std::string blk = v.src.substr(0, at);
+            const int Fq = v.np / 3;
             CHK(hipMemsetAsync(v.ptr, 0, (size_t)v.np * 4, st));
-            CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(blk + ".attn.q_bias")].ptr, v.ptr, h->F, h->F, st));
-            CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(blk + ".attn.v_bias")].ptr, v.ptr + 2 * h->F, h->F, h->F, st));
+            CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(blk + ".attn.q_bias")].ptr, v.ptr, Fq, Fq, st));
+            CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(blk + ".attn.v_bias")].ptr, v.ptr + 2 * Fq, Fq, Fq, st));
             continue;
         }
         CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(v.src)].ptr, v.ptr, v.n, v.np, st));
@@ -826,6 +882,16 @@ int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t B, int32_t H, i
     if (!h || !image_bchw || !depth_bhw) return fail(MDPT_E_INVALID, "null argument");
     Ctx c;
     CHK(make_ctx(h, B, H, W, workspace, workspace_bytes, stream, &c));
+    if (h->swin) {
+        CHK(run_patch_embed_swin(c, (const float*)image_bchw, nullptr));
+        h->last_plan = c.p;
+        h->has_last = true;
+        CHK(run_encoder_swin(c, nullptr));
+        CHK(run_reassemble_swin(c));
+        CHK(run_fusion(c));
+        CHK(run_head(c, (float*)depth_bhw));
+        return 0;
+    }
     CHK(run_patch_embed_fused(c, (const float*)image_bchw));
     h->last_plan = c.p;
     h->has_last = true;
@@ -844,6 +910,13 @@ int mdpt_patch_embed(mdpt_handle* h, const void* image_bchw, int32_t B, int32_t 
         return fail(MDPT_E_INVALID, "image size %dx%d must be divisible by the patch size %d", H, W, h->P);
     // PatchEmbed alone accepts odd grids (the reference only fails later, in fusion): plan with an even-rounded size
     Ctx c;
+    if (h->swin) {
+        CHK(make_ctx(h, B, rup(H, 32), rup(W, 32), workspace, workspace_bytes, stream, &c));
+        c.p.sw.g0h = H / h->P; c.p.sw.g0w = W / h->P;
+        CHK(run_patch_embed_swin(c, (const float*)image_bchw, (float*)tokens_bnf));
+        h->has_last = false;
+        return 0;
+    }
     const int He = rup(H, 2 * h->P), We = rup(W, 2 * h->P);
     CHK(make_ctx(h, B, He, We, workspace, workspace_bytes, stream, &c));
     const int Np = (H / h->P) * (W / h->P);
@@ -864,6 +937,16 @@ int mdpt_encoder(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, 
         if (!stage_out[i]) return fail(MDPT_E_INVALID, "null stage output %d", i);
     if (gh <= 0 || gw <= 0) return fail(MDPT_E_INVALID, "bad grid");
     Ctx c;
+    if (h->swin) {  // tokens = PatchEmbed output [B, gh*gw, F0]; stage s output is [B, (gh>>s)*(gw>>s), F_s]
+        CHK(make_ctx(h, B, gh * h->P, gw * h->P, workspace, workspace_bytes, stream, &c));
+        const size_t n = (size_t)B * gh * gw * h->F;
+        Planes xn = c.pl(c.p.sw.xn);
+        CHK(hipMemcpyAsync(c.at<float>(c.p.sw.resid[0]), tokens_bnf, n * 4, hipMemcpyDeviceToDevice, c.s));
+        CHK(mdpt_launch_f32_to_planes((const float*)tokens_bnf, xn.hi, xn.lo, n, c.s));
+        CHK(run_encoder_swin(c, stage_out));
+        h->has_last = false;
+        return 0;
+    }
     CHK(make_ctx(h, B, rup(gh, 2) * h->P, rup(gw, 2) * h->P, workspace, workspace_bytes, stream, &c));
     // the encoder itself does not need an even grid: re-derive token counts for the true grid
     c.p.gh = gh; c.p.gw = gw; c.p.Np = gh * gw; c.p.N = c.p.Np + 1;
@@ -888,8 +971,20 @@ int mdpt_reassemble(mdpt_handle* h, const void* const stage_in[4], int32_t B, in
     Ctx c;
     CHK(make_ctx(h, B, gh * h->P, gw * h->P, workspace, workspace_bytes, stream, &c));
     const Plan& p = c.p;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i)
         if (!stage_in[i] || !maps_out[i]) return fail(MDPT_E_INVALID, "null stage tensor %d", i);
+    if (h->swin) {  // gh x gw = stage-0 patch grid; maps come out at 1, 1/2, 1/4, 1/8 of it
+        for (int i = 0; i < 4; ++i) {
+            Planes tp = c.pl(p.tap[i]);
+            CHK(mdpt_launch_f32_to_planes((const float*)stage_in[i], tp.hi, tp.lo, (size_t)B * (gh >> i) * (gw >> i) * h->hid[i], c.s));
+        }
+        CHK(run_reassemble_swin(c));
+        for (int i = 0; i < 4; ++i)
+            CHK(mdpt_launch_nhwc_to_nchw(c.at<float>(p.r_f32[i]), nullptr, nullptr, (float*)maps_out[i], B, gh >> i, gw >> i, h->C, h->Cp, c.s));
+        h->has_last = false;
+        return 0;
+    }
+    for (int i = 0; i < 4; ++i) {
         Planes tp = c.pl(p.tap[i]);
         CHK(mdpt_launch_tokens_import((const float*)stage_in[i], tp.hi, tp.lo, B, p.N, p.npad, h->F, c.s));
     }
@@ -905,7 +1000,7 @@ int mdpt_fusion(mdpt_handle* h, const void* const maps_in[4], int32_t B, int32_t
                 size_t workspace_bytes, void* stream) {
     if (!h || !maps_in || !fused_out) return fail(MDPT_E_INVALID, "null argument");
     Ctx c;
-    CHK(make_ctx(h, B, gh * h->P, gw * h->P, workspace, workspace_bytes, stream, &c));
+    CHK(make_ctx(h, B, gh * h->Pv, gw * h->Pv, workspace, workspace_bytes, stream, &c));
     const Plan& p = c.p;
     const int sh[4] = {4 * gh, 2 * gh, gh, gh / 2}, sw[4] = {4 * gw, 2 * gw, gw, gw / 2};
     for (int i = 0; i < 4; ++i) {
@@ -925,7 +1020,7 @@ int mdpt_head(mdpt_handle* h, const void* fused_in, int32_t B, int32_t gh, int32
               size_t workspace_bytes, void* stream) {
     if (!h || !fused_in || !depth_bhw) return fail(MDPT_E_INVALID, "null argument");
     Ctx c;
-    CHK(make_ctx(h, B, gh * h->P, gw * h->P, workspace, workspace_bytes, stream, &c));
+    CHK(make_ctx(h, B, gh * h->Pv, gw * h->Pv, workspace, workspace_bytes, stream, &c));
     Planes fu = c.pl(c.p.fused);
     CHK(mdpt_launch_nchw_to_nhwc((const float*)fused_in, nullptr, fu.hi, fu.lo, 0, B, 8 * gh, 8 * gw, h->C, h->Cp, c.s));
     CHK(run_head(c, (float*)depth_bhw));
@@ -941,7 +1036,10 @@ int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspac
     CHK(check_ws(h, c.p, workspace, workspace_bytes));
     const Plan& p = c.p;
     const int sh[4] = {4 * p.gh, 2 * p.gh, p.gh, p.gh / 2}, sw[4] = {4 * p.gw, 2 * p.gw, p.gw, p.gw / 2};
-    if (which >= 0 && which < 4) {
+    if (which >= 0 && which < 4 && h->swin) {
+        const size_t n = (size_t)p.B * (p.sw.g0h >> which) * (p.sw.g0w >> which) * h->hid[which];
+        CHK(hipMemcpyAsync(out_f32, c.at<float>(p.sw.resid[which]), n * 4, hipMemcpyDeviceToDevice, c.s));
+    } else if (which >= 0 && which < 4) {
         Planes tp = c.pl(p.tap[which]);
         CHK(mdpt_launch_tokens_export(tp.hi, tp.lo, nullptr, (float*)out_f32, p.B, p.N, p.npad, h->F, 0, c.s));
     } else if (which >= 4 && which < 8) {
@@ -978,6 +1076,7 @@ int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_
                     void* stream) {
     if (!h || !name || !out_f32) return fail(MDPT_E_INVALID, "null argument");
     if (!h->has_last) return fail(MDPT_E_STATE, "mdpt_debug_read needs a preceding mdpt_forward");
+    if (h->swin) return fail(MDPT_E_UNSUPPORTED, "mdpt_debug_read: internal buffer names are defined for the ViT families only");
     Ctx c;
     c.h = h; c.p = h->last_plan; c.ws = (char*)workspace; c.s = (hipStream_t)stream;
     CHK(check_ws(h, c.p, workspace, workspace_bytes));

@@ -62,6 +62,10 @@ struct AttnParams {
     int x3;
     // additive relative-position bias (BEiT): per-head extended LUT [heads][bias_elen] fp32, s[q][k] += lut[tq[q] - tk[k]]
     const float* bias_lut; int bias_elen; const int* tq; const int* tk;
+    // SwinV2 window attention (rowmap != null): head_dim 32, B = images * win_nw windows of N tokens each,
+    // rowmap[win_nw*N] = image token of every window token, region[win_nw][region_ld] = shifted-window region ids (null: no mask)
+    int head_dim;  // 0 = 64
+    int win_nw; const int* rowmap; const int* region; int region_ld;
 };
 int mdpt_launch_attention(const AttnParams& p, hipStream_t stream);
 
@@ -114,3 +118,24 @@ int mdpt_launch_beit_relpos(const float* ref_lut, float* ext_lut, int* tq, int* 
                             int N, int ntok_pad, hipStream_t stream);
 int mdpt_beit_relpos_elen(int gh, int gw);
 int mdpt_launch_memset_f32(float* dst, float value, size_t n, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// SwinV2 helpers (swin.hip)
+// ------------------------------------------------------------------------------------------------
+// out = LN_eps(x) (+ add): fp32 rows -> fp32 (may alias add) and/or bf16 hi (+lo)
+int mdpt_launch_ln_res(const float* x, const float* add, const float* gamma, const float* beta, float eps, float* out_f32,
+                       bf16_t* out_hi, bf16_t* out_lo, int rows, int F, hipStream_t stream);
+// window -> image token map (with cyclic shift sh, sw), shifted-window region ids [nW][region_ld], window-local tq / tk terms
+int mdpt_launch_swin_window_map(int* rowmap, int* region, int* tq, int* tk, int gh, int gw, int wh, int ww, int sh, int sw,
+                                int region_ld, int ntok_pad, hipStream_t stream);
+// continuous position bias LUT [heads][(2wh-1)(2ww-1)] = 16*sigmoid(MLP(log-coords)); pretrained = 0 means "None"
+int mdpt_launch_swin_cpb(const float* w1, const float* b1, const float* w2, float* lut, int heads, int hidden, int wh, int ww,
+                         int pretrained, hipStream_t stream);
+// fp32 qkv [B*N, 3F] -> normalised/scaled window operands Q,K [B*nw, heads, npad, 32] and Vt [B*nw, heads, 32, npadv]
+int mdpt_launch_swin_qkv_prep(const float* qkv, const int* rowmap, const float* logit_scale, bf16_t* q_hi, bf16_t* q_lo,
+                              bf16_t* k_hi, bf16_t* k_lo, bf16_t* vt_hi, bf16_t* vt_lo, int B, int N, int nw, int wa, int npad,
+                              int npadv, int heads, hipStream_t stream);
+// fp32 [B,gh,gw,C] -> bf16 rows [B*(gh/2)*(gw/2), 4C] = cat(TL, BL, TR, BR)
+int mdpt_launch_swin_merge_gather(const float* tok, bf16_t* out_hi, bf16_t* out_lo, int B, int gh, int gw, int C,
+                                  hipStream_t stream);
+int mdpt_launch_f32_to_planes(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t n, hipStream_t stream);

@@ -78,11 +78,12 @@ class _Stage(nn.Module):
 class PatchEmbed(_Stage):
     """Image -> patch tokens. reference v2_depthanything/patch_embed.py:23-165."""
 
-    def __init__(self, shapes, patch_size_px: int, default_image_size: int, rgb_mean=RGB_MEAN, rgb_std=RGB_STD):
+    def __init__(self, shapes, patch_size_px: int, default_image_size: int, rgb_mean=RGB_MEAN, rgb_std=RGB_STD,
+                 tiling_patches: int = 2):
         super().__init__("patch_embed", shapes)
         self.patch_size_px = patch_size_px
         self._default_size_px = round(default_image_size)
-        self._tiling_size = round(2 * patch_size_px)  # patch_embed.py:69
+        self._tiling_size = round(tiling_patches * patch_size_px)  # patch_embed.py:69 (SwinV2: 8 patches, v31_swinv2/patch_embed.py:68)
         self.rgb_offset, self.rgb_stdev = tuple(rgb_mean), tuple(rgb_std)
 
     def forward(self, image_tensor_bchw: Tensor) -> tuple[Tensor, tuple[int, int]]:
@@ -144,6 +145,10 @@ class ImageEncoder(_Stage):
         gh, gw = int(patch_grid_hw[0]), int(patch_grid_hw[1])
         b = x.shape[0]
         assert x.shape[1] == gh * gw and x.shape[2] == eng.F, f"tokens {tuple(x.shape)} do not match grid {gh}x{gw}, F={eng.F}"
+        if eng.swin:  # stage s: [B, (gh >> s) * (gw >> s), F_s] (v31_swinv2/image_encoder_model.py:77-98)
+            outs = [torch.empty((b, (gh >> s) * (gw >> s), eng.stage_features[s]), device=x.device, dtype=torch.float32) for s in range(4)]
+            eng.call_checked("mdpt_encoder", x, b, gh, gw, eng.ptr_array(outs), size_hw=(gh * eng.P, gw * eng.P), batch=b)
+            return tuple(eng.as_output(o) for o in outs)
         outs = [torch.empty((b, gh * gw + 1, eng.F), device=x.device, dtype=torch.float32) for _ in range(4)]
         eng.call("mdpt_encoder", x, b, gh, gw, eng.ptr_array(outs), size_hw=((gh + gh % 2) * eng.P, (gw + gw % 2) * eng.P), batch=b)
         return tuple(eng.as_output(o) for o in outs)
@@ -159,8 +164,10 @@ class ReassembleModel(_Stage):
         b = xs[0].shape[0]
         c = eng.C
         sizes = [(4 * gh, 4 * gw), (2 * gh, 2 * gw), (gh, gw), (gh // 2, gw // 2)]
+        if eng.swin:  # patch_grid_hw is the stage-0 grid; maps at 1, 1/2, 1/4, 1/8 of it (v31_swinv2/reassembly_model.py:113-122)
+            sizes = [(gh >> s, gw >> s) for s in range(4)]
         outs = [torch.empty((b, c, sh, sw), device=xs[0].device, dtype=torch.float32) for sh, sw in sizes]
-        eng.call("mdpt_reassemble", eng.ptr_array(xs), b, gh, gw, eng.ptr_array(outs), size_hw=(gh * eng.P, gw * eng.P), batch=b)
+        eng.call_checked("mdpt_reassemble", eng.ptr_array(xs), b, gh, gw, eng.ptr_array(outs), size_hw=(gh * eng.P, gw * eng.P), batch=b)
         return tuple(eng.as_output(o) for o in outs)
 
 
@@ -175,7 +182,7 @@ class FusionModel(_Stage):
             # same failure class as the reference (size mismatch at fusion_model.py:151)
             raise RuntimeError(f"fusion inputs are not scaled x2 relative to each other: {[tuple(x.shape) for x in xs]}")
         out = torch.empty((b, eng.C, 8 * gh, 8 * gw), device=xs[0].device, dtype=torch.float32)
-        eng.call("mdpt_fusion", eng.ptr_array(xs), b, gh, gw, out, size_hw=(gh * eng.P, gw * eng.P), batch=b)
+        eng.call_checked("mdpt_fusion", eng.ptr_array(xs), b, gh, gw, out, size_hw=(gh * eng.Pdec, gw * eng.Pdec), batch=b)
         return eng.as_output(out)
 
 
@@ -187,8 +194,8 @@ class MonocularDepthHead(_Stage):
         x = eng.as_input(imagelike_bchw, 4)
         b, _, fh, fw = x.shape
         gh, gw = fh // 8, fw // 8
-        out = torch.empty((b, gh * eng.P, gw * eng.P), device=x.device, dtype=torch.float32)
-        eng.call("mdpt_head", x, b, gh, gw, out, size_hw=(gh * eng.P, gw * eng.P), batch=b)
+        out = torch.empty((b, gh * eng.Pdec, gw * eng.Pdec), device=x.device, dtype=torch.float32)
+        eng.call_checked("mdpt_head", x, b, gh, gw, out, size_hw=(gh * eng.Pdec, gw * eng.Pdec), batch=b)
         return eng.as_output(out)
 
 
@@ -203,16 +210,29 @@ class _Engine:
         self.lib = native.load()
         self.device, self.dtype = device, dtype
         cfg = model.config
-        self.F, self.C, self.P = cfg["features_per_token"], cfg["fusion_channels"], cfg["patch_size_px"]
+        self.swin = model.family == "swinv2"
         c = native.MdptConfig()
-        c.features_per_token, c.num_heads, c.num_blocks = cfg["features_per_token"], cfg["num_heads"], cfg["num_blocks"]
-        for i in range(4):
-            c.reassembly_features[i] = int(cfg["reassembly_features_list"][i])
+        if self.swin:
+            self.stage_features = [int(v) for v in cfg["features_per_stage"]]
+            self.F, self.C, self.P, self.Pdec = self.stage_features[0], cfg["fusion_channels"], cfg["patch_size_px"], 4 * cfg["patch_size_px"]
+            c.features_per_token, c.num_heads, c.num_blocks = self.F, int(cfg["heads_per_stage"][0]), int(sum(cfg["layers_per_stage"]))
+            for i in range(4):
+                c.reassembly_features[i] = self.stage_features[i]
+                c.swin_heads[i], c.swin_layers[i] = int(cfg["heads_per_stage"][i]), int(cfg["layers_per_stage"][i])
+                pre = cfg["pretrained_window_sizes_per_stage"][i]
+                c.swin_pretrained_window[i] = 0 if pre is None else int(pre)
+            c.swin_window_h, c.swin_window_w = (int(v) for v in cfg["window_size_hw"])
+        else:
+            self.F, self.C, self.P = cfg["features_per_token"], cfg["fusion_channels"], cfg["patch_size_px"]
+            self.Pdec = self.P
+            c.features_per_token, c.num_heads, c.num_blocks = cfg["features_per_token"], cfg["num_heads"], cfg["num_blocks"]
+            for i in range(4):
+                c.reassembly_features[i] = int(cfg["reassembly_features_list"][i])
         c.base_patch_grid_h, c.base_patch_grid_w = (int(v) for v in cfg["base_patch_grid_hw"])
         c.fusion_channels, c.patch_size_px = cfg["fusion_channels"], cfg["patch_size_px"]
         c.is_giant, c.is_metric = int(bool(cfg.get("is_giant", False))), int(bool(cfg.get("is_metric", False)))
         c.precision = native.PREC_BF16X3 if dtype == torch.float32 else native.PREC_BF16
-        c.family = {"v2": native.FAMILY_DAV2, "v1": native.FAMILY_DAV1, "beit": native.FAMILY_BEIT}[model.family]
+        c.family = {"v2": native.FAMILY_DAV2, "v1": native.FAMILY_DAV1, "beit": native.FAMILY_BEIT, "swinv2": native.FAMILY_SWINV2}[model.family]
         self.precision = c.precision
         handle = ctypes.c_void_p()
         native.check(self.lib, self.lib.mdpt_create(ctypes.byref(c), ctypes.byref(handle)))
@@ -288,6 +308,15 @@ class _Engine:
             cargs = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
             native.check(self.lib, getattr(self.lib, fn_name)(self.handle, *cargs, ws_ptr, ws_bytes, stream))
 
+    def call_checked(self, fn_name: str, *args, size_hw, batch):
+        """call(), with the library's grid-shape error surfaced as the RuntimeError the reference raises for such inputs."""
+        try:
+            self.call(fn_name, *args, size_hw=size_hw, batch=batch)
+        except native.MdptError as e:
+            if e.code == native.E_GRID:
+                raise RuntimeError(str(e)) from None
+            raise
+
     def export_tap(self, which: int, out: Tensor, batch: int, size_hw):
         with torch.cuda.device(self.device):
             ws_ptr, ws_bytes = self.workspace(batch, size_hw)
@@ -306,6 +335,9 @@ class DPTModel(nn.Module):
         if family == "beit":
             from .state_dict_conversion_beit import expected_new_keys as beit_keys
             keys = beit_keys(self.config)
+        elif family == "swinv2":
+            from .state_dict_conversion_swinv2 import expected_new_keys as swin_keys
+            keys = swin_keys(self.config)
         else:
             keys = expected_new_keys(self.config, family)
         shapes = _new_key_shapes(self.config, family)
@@ -313,6 +345,8 @@ class DPTModel(nn.Module):
         default_px = self.config["base_patch_grid_hw"][0] * self.config["patch_size_px"]
         if family == "beit":
             self.patch_embed = PatchEmbed(per["patch_embed"], self.config["patch_size_px"], default_px, BEIT_RGB_MEAN, BEIT_RGB_STD)
+        elif family == "swinv2":  # same normalisation as BEiT (v31_swinv2/patch_embed.py:39-40), sizes snap to 8 patches
+            self.patch_embed = PatchEmbed(per["patch_embed"], self.config["patch_size_px"], default_px, BEIT_RGB_MEAN, BEIT_RGB_STD, 8)
         else:
             self.patch_embed = PatchEmbed(per["patch_embed"], self.config["patch_size_px"], default_px)
         self.imgencoder = ImageEncoder("imgencoder", per["imgencoder"])
@@ -389,10 +423,24 @@ class DPTModel(nn.Module):
     def debug_taps(self, batch: int, size_hw: tuple[int, int]) -> dict:
         eng = self._get_engine()
         h, w = size_hw
-        gh, gw = h // eng.P, w // eng.P
-        n = gh * gw + 1
         dev = eng.device
         out = {"stages": [], "reasm": []}
+        if eng.swin:
+            g0h, g0w = h // eng.P, w // eng.P
+            for s in range(4):
+                t = torch.empty((batch, (g0h >> s) * (g0w >> s), eng.stage_features[s]), device=dev, dtype=torch.float32)
+                eng.export_tap(s, t, batch, size_hw)
+                out["stages"].append(t)
+            for s in range(4):
+                t = torch.empty((batch, eng.C, g0h >> s, g0w >> s), device=dev, dtype=torch.float32)
+                eng.export_tap(4 + s, t, batch, size_hw)
+                out["reasm"].append(t)
+            t = torch.empty((batch, eng.C, 2 * g0h, 2 * g0w), device=dev, dtype=torch.float32)
+            eng.export_tap(8, t, batch, size_hw)
+            out["fused"] = t
+            return out
+        gh, gw = h // eng.P, w // eng.P
+        n = gh * gw + 1
         for i in range(4):
             t = torch.empty((batch, n, eng.F), device=dev, dtype=torch.float32)
             eng.export_tap(i, t, batch, size_hw)
@@ -412,6 +460,18 @@ def _new_key_shapes(cfg: dict, family: str = "v2") -> dict[str, tuple]:
     from .synthetic import original_state_dict_shapes
     from .state_dict_conversion import original_to_new_key_table
 
+    if family == "swinv2":
+        from .state_dict_conversion_swinv2 import original_to_new_key_table as swin_table
+        from .synthetic import swinv2_original_state_dict_shapes
+        orig = swinv2_original_state_dict_shapes(cfg)
+        shapes = {}
+        for old, (comp, new) in swin_table(cfg).items():
+            shp = tuple(orig[old])
+            if new.endswith("q_bias") or new.endswith("v_bias"):
+                heads = cfg["heads_per_stage"][int(new.split(".")[1])]
+                shp = (1, heads, 1, shp[0] // heads)
+            shapes[f"{comp}.{new}"] = shp
+        return shapes
     if family == "beit":
         from .state_dict_conversion_beit import original_to_new_key_table as beit_table
         from .synthetic import beit_original_state_dict_shapes

@@ -28,8 +28,10 @@ def make_dpt_from_state_dict(
     if model_type not in known_model_types:
         print("Accepted model types:", *known_model_types, sep="\n")
         raise NotImplementedError(f"Bad model type: {model_type}, no support for this yet!")
-    if model_type not in ("depthanythingv2", "depthanythingv1", "beit"):
-        raise NotImplementedError(f"Model type '{model_type}' is not available on the MI355X path yet (Depth-Anything V1/V2 and BEiT only)")
+    if model_type == "swinv2":
+        from .make_swinv2_dpt import make_swinv2_dpt_from_midas_v31_state_dict as make_swin
+
+        return make_swin(state_dict, enable_cache, enable_optimizations, strict_load)
 
     if model_type == "beit":
         from .make_beit_dpt import make_beit_dpt_from_midas_v31_state_dict as make_beit

@@ -17,14 +17,15 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(CSRC, "libmdpt.so")
-SOURCES = ("gemm.hip", "attention.hip", "elementwise.hip", "mdpt_api.cpp", "mdpt_prof.cpp")
-HEADERS = ("mdpt_kernels.h", "mdpt_prof.h", os.path.join(REPO, "include", "mdpt.h"))
+SOURCES = ("gemm.hip", "attention.hip", "elementwise.hip", "swin.hip", "mdpt_api.cpp", "mdpt_prof.cpp")
+HEADERS = ("mdpt_kernels.h", "mdpt_prof.h", "mdpt_swin.inc", os.path.join(REPO, "include", "mdpt.h"))
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1
 FAMILY_DAV2 = 0
 FAMILY_DAV1 = 1
 FAMILY_BEIT = 2
+FAMILY_SWINV2 = 3
 E_GRID = -7
 
 
@@ -86,6 +87,11 @@ class MdptConfig(ctypes.Structure):
         ("is_metric", ctypes.c_int32),
         ("precision", ctypes.c_int32),
         ("family", ctypes.c_int32),
+        ("swin_heads", ctypes.c_int32 * 4),
+        ("swin_layers", ctypes.c_int32 * 4),
+        ("swin_window_h", ctypes.c_int32),
+        ("swin_window_w", ctypes.c_int32),
+        ("swin_pretrained_window", ctypes.c_int32 * 4),
     ]
 
 
@@ -140,7 +146,7 @@ def load(auto_build: bool = True) -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError here == ABI drift between mdpt.h and the .so
         fn.restype = res
         fn.argtypes = args
-    if lib.mdpt_abi_version() != 1:
+    if lib.mdpt_abi_version() != 2:
         raise RuntimeError("libmdpt ABI version mismatch")
     _LIB = lib
     return lib

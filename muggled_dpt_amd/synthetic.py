@@ -130,6 +130,115 @@ def make_synthetic_beit_state_dict(cfg: dict | str, seed: int = 0) -> dict[str, 
     return sd
 
 
+SWINV2_CONFIGS = {
+    # reference make_swinv2_dpt.py:87-118
+    "swin2_large_384": dict(features_per_stage=[192, 384, 768, 1536], heads_per_stage=[6, 12, 24, 48], layers_per_stage=[2, 2, 18, 2],
+                            base_patch_grid_hw=(96, 96), window_size_hw=(24, 24), pretrained_window_sizes_per_stage=[12, 12, 12, 6],
+                            fusion_channels=256, patch_size_px=4),
+    "swin2_base_384": dict(features_per_stage=[128, 256, 512, 1024], heads_per_stage=[4, 8, 16, 32], layers_per_stage=[2, 2, 18, 2],
+                           base_patch_grid_hw=(96, 96), window_size_hw=(24, 24), pretrained_window_sizes_per_stage=[12, 12, 12, 6],
+                           fusion_channels=256, patch_size_px=4),
+    # not a real model: 64x64 px base image (grid 16 -> 8 -> 4 -> 2), window 4: stages 0/1 shift, stage 2 is one window,
+    # stage 3 shrinks the window to 2x2
+    "swin2_tiny": dict(features_per_stage=[64, 128, 256, 512], heads_per_stage=[2, 4, 8, 16], layers_per_stage=[2, 2, 4, 2],
+                       base_patch_grid_hw=(16, 16), window_size_hw=(4, 4), pretrained_window_sizes_per_stage=[None] * 4,
+                       fusion_channels=32, patch_size_px=4),
+}
+
+
+def swinv2_original_state_dict_shapes(cfg: dict) -> dict[str, tuple]:
+    """Every tensor of a MiDaS v3.1 SwinV2 DPT checkpoint that the reference's converter consumes (+ the attn_mask buffers its
+    config sniffing needs), with its shape."""
+    feats, heads, layers = cfg["features_per_stage"], cfg["heads_per_stage"], cfg["layers_per_stage"]
+    P, C = cfg["patch_size_px"], cfg["fusion_channels"]
+    gh, gw = cfg["base_patch_grid_hw"]
+    wh, ww = cfg["window_size_hw"]
+    s: dict[str, tuple] = {}
+    s["pretrained.model.patch_embed.proj.weight"] = (feats[0], 3, P, P)
+    s["pretrained.model.patch_embed.proj.bias"] = (feats[0],)
+    s["pretrained.model.patch_embed.norm.weight"] = (feats[0],)
+    s["pretrained.model.patch_embed.norm.bias"] = (feats[0],)
+    for st in range(4):
+        F, H = feats[st], heads[st]
+        for l in range(layers[st]):
+            b = f"pretrained.model.layers.{st}.blocks.{l}"
+            if st == 0 and l == 1:  # timm registers the shift mask as a buffer: [num_windows, window_area, window_area]
+                s[f"{b}.attn_mask"] = ((gh // wh) * (gw // ww), wh * ww, wh * ww)
+            s[f"{b}.attn.logit_scale"] = (H, 1, 1)
+            s[f"{b}.attn.q_bias"] = (F,)
+            s[f"{b}.attn.v_bias"] = (F,)
+            s[f"{b}.attn.cpb_mlp.0.weight"] = (512, 2)
+            s[f"{b}.attn.cpb_mlp.0.bias"] = (512,)
+            s[f"{b}.attn.cpb_mlp.2.weight"] = (H, 512)
+            s[f"{b}.attn.qkv.weight"] = (3 * F, F)
+            s[f"{b}.attn.proj.weight"] = (F, F)
+            s[f"{b}.attn.proj.bias"] = (F,)
+            s[f"{b}.norm1.weight"] = (F,)
+            s[f"{b}.norm1.bias"] = (F,)
+            s[f"{b}.mlp.fc1.weight"] = (4 * F, F)
+            s[f"{b}.mlp.fc1.bias"] = (4 * F,)
+            s[f"{b}.mlp.fc2.weight"] = (F, 4 * F)
+            s[f"{b}.mlp.fc2.bias"] = (F,)
+            s[f"{b}.norm2.weight"] = (F,)
+            s[f"{b}.norm2.bias"] = (F,)
+        if st < 3:
+            d = f"pretrained.model.layers.{st}.downsample"
+            s[f"{d}.reduction.weight"] = (feats[st + 1], 4 * F)
+            s[f"{d}.norm.weight"] = (feats[st + 1],)
+            s[f"{d}.norm.bias"] = (feats[st + 1],)
+    for i in range(4):
+        s[f"scratch.layer{i + 1}_rn.weight"] = (C, feats[i], 3, 3)
+    for n in (1, 2, 3, 4):
+        r = f"scratch.refinenet{n}"
+        s[f"{r}.out_conv.weight"] = (C, C, 1, 1)
+        s[f"{r}.out_conv.bias"] = (C,)
+        for unit in ("resConfUnit1", "resConfUnit2"):
+            for conv in ("conv1", "conv2"):
+                s[f"{r}.{unit}.{conv}.weight"] = (C, C, 3, 3)
+                s[f"{r}.{unit}.{conv}.bias"] = (C,)
+    s["scratch.output_conv.0.weight"] = (C // 2, C, 3, 3)
+    s["scratch.output_conv.0.bias"] = (C // 2,)
+    s["scratch.output_conv.2.weight"] = (32, C // 2, 3, 3)
+    s["scratch.output_conv.2.bias"] = (32,)
+    s["scratch.output_conv.4.weight"] = (1, 32, 1, 1)
+    s["scratch.output_conv.4.bias"] = (1,)
+    return s
+
+
+def make_synthetic_swinv2_state_dict(cfg: dict | str, seed: int = 0) -> dict[str, torch.Tensor]:
+    """Seeded fp32 MiDaS-format SwinV2 checkpoint. logit_scale is stored pre-exp as in timm (log of 5..15; the loader clamps at
+    log(100) and exponentiates); the post-norm LayerNorm weights are ~0.3 so the residual stream stays O(1) over 24 blocks."""
+    if isinstance(cfg, str):
+        cfg = SWINV2_CONFIGS[cfg]
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(int(seed))
+    sd: dict[str, torch.Tensor] = {}
+    for key, shape in swinv2_original_state_dict_shapes(cfg).items():
+        if key.endswith("attn_mask"):
+            t = torch.zeros(shape)
+        elif key.endswith("logit_scale"):
+            t = torch.log(5.0 + 10.0 * torch.rand(shape, generator=gen))
+        elif ".blocks." in key and ".norm" in key and key.endswith("weight"):
+            t = 0.3 + 0.05 * torch.randn(shape, generator=gen)
+        elif ".norm" in key and key.endswith("weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=gen)
+        elif key.endswith("cpb_mlp.0.weight"):
+            t = torch.randn(shape, generator=gen)
+        elif key.endswith("cpb_mlp.2.weight"):
+            t = 0.1 * torch.randn(shape, generator=gen)
+        elif key == "scratch.output_conv.4.bias":
+            t = torch.full(shape, 0.5)
+        elif len(shape) >= 2 and key.endswith("weight"):
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            t = torch.randn(shape, generator=gen) * (float(fan_in) ** -0.5)
+        else:
+            t = 0.1 * torch.randn(shape, generator=gen)
+        sd[key] = t.to(torch.float32).contiguous()
+    return sd
+
+
 def original_state_dict_shapes(cfg: dict) -> dict[str, tuple]:
     """Every tensor of an upstream DA-V2 (non-giant) checkpoint, in upstream order, with its shape."""
     F = cfg["features_per_token"]

@@ -72,7 +72,10 @@ def patch_embed(w: dict, image_bchw: torch.Tensor) -> tuple[torch.Tensor, tuple[
     pw = w["patch_embed.proj.weight"]
     y = F.conv2d(image_bchw, pw, w["patch_embed.proj.bias"], stride=pw.shape[-1])
     grid_hw = (int(y.shape[2]), int(y.shape[3]))
-    return y.flatten(2).transpose(1, 2), grid_hw
+    tokens = y.flatten(2).transpose(1, 2)
+    if "patch_embed.norm.weight" in w:  # SwinV2: LayerNorm (default eps 1e-5) on the patch tokens (v31_swinv2/patch_embed.py:76-94)
+        tokens = F.layer_norm(tokens, (tokens.shape[-1],), w["patch_embed.norm.weight"], w["patch_embed.norm.bias"], 1e-5)
+    return tokens, grid_hw
 
 
 def position_embedding(w: dict, grid_hw: tuple[int, int]) -> torch.Tensor:
@@ -238,6 +241,148 @@ def beit_reassemble(w: dict, stage_tokens: list[torch.Tensor], grid_hw: tuple[in
     return outs
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# MiDaS v3.1 SwinV2 family (reference muggled_dpt/v31_swinv2/*)
+
+_SWIN_REASM = ("spatial_noscale", "spatial_downx2", "spatial_downx4", "spatial_downx8")
+
+
+def is_swin(w: dict) -> bool:
+    return "imgencoder.patch_merge_layers.0.reduction.weight" in w
+
+
+def swin_window_and_shift(grid_hw: tuple[int, int], target_hw: tuple[int, int]) -> tuple[tuple[int, int], tuple[int, int]]:
+    """Window / shift sizes for a patch grid: min(target, grid) if it tiles the grid, else the divisor of the grid side in
+    [win/2, 2 win) closest to the grid side; shift = win // 2 unless one window covers the side
+    (components/windowed_attention.py:345-388)."""
+    out_win, out_shift = [], []
+    for patch, targ in zip(grid_hw, target_hw):
+        win = min(targ, patch)
+        if patch % win:
+            divisors = [d for d in range(win // 2, 2 * win) if patch % d == 0]
+            win = min(divisors, key=lambda d: abs(patch - d))
+        out_win.append(win)
+        out_shift.append(0 if patch <= win else win // 2)
+    return tuple(out_win), tuple(out_shift)
+
+
+def swin_partition(x_bhwc: torch.Tensor, win_hw: tuple[int, int]) -> torch.Tensor:
+    """[B,H,W,C] -> [B*nWy*nWx, wh*ww, C], windows row-major, tokens row-major inside a window (:262-289)."""
+    b, h, w, c = x_bhwc.shape
+    wh, ww = win_hw
+    x = x_bhwc.reshape(b, h // wh, wh, w // ww, ww, c).permute(0, 1, 3, 2, 4, 5)
+    return x.reshape(-1, wh * ww, c)
+
+
+def swin_unpartition(win_tokens: torch.Tensor, win_hw: tuple[int, int], bhwc: tuple[int, int, int, int]) -> torch.Tensor:
+    b, h, w, c = bhwc
+    wh, ww = win_hw
+    x = win_tokens.reshape(b, h // wh, w // ww, wh, ww, c).permute(0, 1, 3, 2, 4, 5)
+    return x.reshape(b, h, w, c)
+
+
+def swin_shift_mask(grid_hw, win_hw, shift_hw) -> torch.Tensor:
+    """[nW, 1, wa, wa] additive mask (0 / -100) separating the regions a cyclic shift glues together (:394-439). Built with
+    the same Python slices as the reference: with a zero shift in one dimension, slice(-0, None) covers the whole side."""
+    gh, gw = grid_hw
+    wh, ww = win_hw
+    sh, sw = shift_hw
+    img = torch.zeros((1, gh, gw, 1))
+    cnt = 0
+    for hs in (slice(0, -wh), slice(-wh, -sh), slice(-sh, None)):
+        for ws in (slice(0, -ww), slice(-ww, -sw), slice(-sw, None)):
+            img[:, hs, ws, :] = cnt
+            cnt += 1
+    ids = swin_partition(img, win_hw).reshape(-1, wh * ww)
+    diff = ids.unsqueeze(1) - ids.unsqueeze(2)
+    return torch.where(diff != 0, torch.tensor(-100.0), torch.tensor(0.0)).unsqueeze(1)
+
+
+def swin_cpb_bias(w: dict, pre: str, win_hw, pretrained_window, heads: int) -> torch.Tensor:
+    """[1, heads, wa, wa] continuous position bias: 16 * sigmoid(MLP(2->512->heads)(log-spaced relative offsets)), gathered by
+    the relative position index (components/relative_positional_encoder.py:60-93, :122-188)."""
+    wh, ww = win_hw
+    ys = torch.arange(-(wh - 1), wh, dtype=torch.float32)
+    xs = torch.arange(-(ww - 1), ww, dtype=torch.float32)
+    table = torch.stack(torch.meshgrid([ys, xs], indexing="ij")).permute(1, 2, 0).contiguous().unsqueeze(0)
+    table[..., 0] /= max((wh if pretrained_window is None else pretrained_window) - 1, 1)
+    table[..., 1] /= max((ww if pretrained_window is None else pretrained_window) - 1, 1)
+    table = torch.sign(table) * torch.log2(torch.abs(table * 8) + 1.0) / torch.log2(torch.tensor(8.0))
+    hid = F.relu(F.linear(table, w[f"{pre}.bias_mlp.0.weight"], w[f"{pre}.bias_mlp.0.bias"]))
+    lut = F.linear(hid, w[f"{pre}.bias_mlp.2.weight"]).reshape(-1, heads)
+    iy, ix = torch.meshgrid(torch.arange(wh), torch.arange(ww), indexing="ij")
+    iy, ix = iy.flatten(), ix.flatten()
+    idx = (iy[:, None] - iy[None, :] + wh - 1) * (2 * ww - 1) + (ix[:, None] - ix[None, :] + ww - 1)
+    bias = 16 * torch.sigmoid(lut[idx.reshape(-1)])
+    return bias.reshape(wh * ww, wh * ww, heads).permute(2, 0, 1).unsqueeze(0)
+
+
+def swin_window_attention(w: dict, pre: str, tokens: torch.Tensor, grid_hw, cfg: dict, stage: int, is_shift_block: bool) -> torch.Tensor:
+    """Roll (shift blocks) -> windows -> cosine attention with logit scale, position bias and shift mask -> un-window -> roll
+    back (windowed_attention.py:65-123, :171-260)."""
+    b, n, c = tokens.shape
+    gh, gw = grid_hw
+    heads = cfg["heads_per_stage"][stage]
+    win_hw, shift_hw = swin_window_and_shift(grid_hw, cfg["window_size_hw"])
+    need_shift = is_shift_block and (shift_hw[0] > 0 or shift_hw[1] > 0)
+    img = tokens.reshape(b, gh, gw, c)
+    if need_shift:
+        img = torch.roll(img, shifts=(-shift_hw[0], -shift_hw[1]), dims=(1, 2))
+    win = swin_partition(img, win_hw)
+    p, wa, _ = win.shape
+    qkv = F.linear(win, w[f"{pre}.qkv.weight"]).reshape(p, wa, 3, heads, -1).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] + w[f"{pre}.q_bias"], qkv[1], qkv[2] + w[f"{pre}.v_bias"]
+    att = F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1)
+    att = att * w[f"{pre}.logit_scale"]
+    att = att + swin_cpb_bias(w, f"{pre}.relpos_enc", win_hw, cfg["pretrained_window_sizes_per_stage"][stage], heads)
+    if need_shift:
+        att = att + swin_shift_mask(grid_hw, win_hw, shift_hw).repeat(b, 1, 1, 1)
+    out = (torch.softmax(att, dim=-1) @ v).transpose(1, 2).reshape(p, wa, c)
+    out = F.linear(out, w[f"{pre}.proj.weight"], w[f"{pre}.proj.bias"])
+    img = swin_unpartition(out, win_hw, (b, gh, gw, c))
+    if need_shift:
+        img = torch.roll(img, shifts=shift_hw, dims=(1, 2))
+    return img.reshape(b, n, c)
+
+
+def swin_patch_merge(w: dict, pre: str, tokens: torch.Tensor, grid_hw):
+    """cat(TL, BL, TR, BR) -> Linear(4C -> 2C, no bias) -> LayerNorm(eps 1e-5) (components/patch_merge.py:49-103)."""
+    b, n, c = tokens.shape
+    img = tokens.reshape(b, grid_hw[0], grid_hw[1], c)
+    cat = torch.cat([img[:, 0::2, 0::2], img[:, 1::2, 0::2], img[:, 0::2, 1::2], img[:, 1::2, 1::2]], dim=-1)
+    out_hw = (cat.shape[1], cat.shape[2])
+    x = F.linear(cat.reshape(b, n // 4, 4 * c), w[f"{pre}.reduction.weight"])
+    return F.layer_norm(x, (x.shape[-1],), w[f"{pre}.norm.weight"], w[f"{pre}.norm.bias"], 1e-5), out_hw
+
+
+def swin_image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw) -> list[torch.Tensor]:
+    """4 stages of (plain, shifted) post-norm block pairs with a patch merge between stages; taps = stage outputs
+    (image_encoder_model.py:77-98, :155-161, :213-225)."""
+    tokens, hw, taps = patch_tokens, tuple(grid_hw), []
+    for s in range(4):
+        for l in range(cfg["layers_per_stage"][s]):
+            pre = f"imgencoder.stages.{s}.blocks.{l}"
+            a = swin_window_attention(w, f"{pre}.attn", tokens, hw, cfg, s, is_shift_block=bool(l % 2))
+            tokens = tokens + F.layer_norm(a, (a.shape[-1],), w[f"{pre}.norm1.weight"], w[f"{pre}.norm1.bias"], 1e-5)
+            m = mlp(w, f"{pre}.mlp", tokens)
+            tokens = tokens + F.layer_norm(m, (m.shape[-1],), w[f"{pre}.norm2.weight"], w[f"{pre}.norm2.bias"], 1e-5)
+        taps.append(tokens)
+        if s < 3:
+            tokens, hw = swin_patch_merge(w, f"imgencoder.patch_merge_layers.{s}", tokens, hw)
+    return taps
+
+
+def swin_reassemble(w: dict, stage_tokens: list[torch.Tensor], grid_hw) -> list[torch.Tensor]:
+    """tokens -> BCHW at 1, 1/2, 1/4, 1/8 of the patch grid, 3x3 conv (no bias) to the fusion width
+    (v31_swinv2/reassembly_model.py:113-122)."""
+    outs = []
+    for s, (name, tok) in enumerate(zip(_SWIN_REASM, stage_tokens)):
+        hw = (grid_hw[0] // (2 ** s), grid_hw[1] // (2 ** s))
+        x = tok.transpose(1, 2).unflatten(2, hw)
+        outs.append(F.conv2d(x, w[f"reassemble.{name}.fuse_proj.weight"], None, padding=1))
+    return outs
+
+
 def beit_fusion(w: dict, reasm: list[torch.Tensor]) -> torch.Tensor:
     """Same dataflow as fusion(); parameter names differ (conv_seq / proj_seq, v31_beit/fusion_model.py:95-164)."""
 
@@ -307,7 +452,7 @@ def head(w: dict, cfg: dict, fused: torch.Tensor) -> torch.Tensor:
     """conv3x3(C->C/2) -> bilinear x(patch/8) align_corners -> conv3x3(->32)+ReLU -> conv1x1(->1)+ReLU|Sigmoid
     -> squeeze (head_model.py:67-85, :89-106)."""
     x = F.conv2d(fused, w["head.spatial_upsampler.0.weight"], w["head.spatial_upsampler.0.bias"], padding=1)
-    x = upsample_bilinear_ac(x, cfg["patch_size_px"] / 8)
+    x = upsample_bilinear_ac(x, 2 if is_swin(w) else cfg["patch_size_px"] / 8)  # v31_swinv2/head_model.py:43
     x = F.relu(F.conv2d(x, w["head.proj_1ch.0.weight"], w["head.proj_1ch.0.bias"], padding=1))
     x = F.conv2d(x, w["head.proj_1ch.2.weight"], w["head.proj_1ch.2.bias"])
     x = torch.sigmoid(x) if cfg.get("is_metric", False) else F.relu(x)
@@ -321,7 +466,14 @@ def forward(w: dict, cfg: dict, image_bchw: torch.Tensor, return_stages: bool = 
         if grid_hw[0] % 2 or grid_hw[1] % 2:
             # the reference crashes in fusion (tensor size mismatch, fusion_model.py:151)
             raise RuntimeError(f"patch grid {grid_hw} must be even in both dimensions")
-        if is_beit(w):
+        if is_swin(w):
+            if grid_hw[0] % 8 or grid_hw[1] % 8:
+                # the reference crashes in patch_merge.py:91 (odd grids) or fusion_model.py (sizes not x2 apart)
+                raise RuntimeError(f"patch grid {grid_hw} must be divisible by 8 in both dimensions")
+            taps = swin_image_encoder(w, cfg, tokens, grid_hw)
+            reasm = swin_reassemble(w, taps, grid_hw)
+            fused = beit_fusion(w, reasm)
+        elif is_beit(w):
             taps = beit_image_encoder(w, cfg, tokens, grid_hw)
             reasm = beit_reassemble(w, taps, grid_hw)
             fused = beit_fusion(w, reasm)
@@ -338,7 +490,7 @@ def forward(w: dict, cfg: dict, image_bchw: torch.Tensor, return_stages: bool = 
 def inference(w: dict, cfg: dict, image_bgr, max_side_length=None, use_square_sizing=True) -> torch.Tensor:
     """DPTModel.inference (dpt_model.py:87-109): prepare_image + forward -> [1,H,W]."""
     default_px = cfg["base_patch_grid_hw"][0] * cfg["patch_size_px"]
-    norm = dict(rgb_mean=(0.5, 0.5, 0.5), rgb_std=(0.5, 0.5, 0.5)) if is_beit(w) else {}
-    x = prepare_image(image_bgr, max_side_length, use_square_sizing, default_size_px=default_px,
-                      tiling_px=2 * cfg["patch_size_px"], **norm)
+    norm = dict(rgb_mean=(0.5, 0.5, 0.5), rgb_std=(0.5, 0.5, 0.5)) if (is_beit(w) or is_swin(w)) else {}
+    tiling = (8 if is_swin(w) else 2) * cfg["patch_size_px"]  # v31_swinv2/patch_embed.py:68
+    x = prepare_image(image_bgr, max_side_length, use_square_sizing, default_size_px=default_px, tiling_px=tiling, **norm)
     return forward(w, cfg, x)

@@ -7,7 +7,7 @@ read-only (with an in-memory stub for the absent `cv2`), feed it seeded syntheti
 While doing so it asserts that oracle/dpt_oracle.py reproduces the reference at every stage
 boundary (<= 2e-5 abs on O(1) tensors) - this is what pins the oracle.
 
-usage: PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [--skip-vitl] [--only-beit]
+usage: PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [--skip-vitl] [--only-beit] [--only-swinv2]
 """
 
 from __future__ import annotations
@@ -165,19 +165,110 @@ def gen_beit(report, skip_large):
         print("[beit_large_384] depth stats (min,max,mean,l2):", stats(depth))
 
 
+def gen_swinv2(report, skip_large):
+    """MiDaS v3.1 SwinV2 fixtures (reference muggled_dpt/make_swinv2_dpt.py, v31_swinv2/*)."""
+    from muggled_dpt.make_swinv2_dpt import make_swinv2_dpt_from_midas_v31_state_dict as ref_make_swin
+    from muggled_dpt.v31_swinv2.components.windowed_attention import adjust_window_and_shift_sizes, make_shift_mask
+    from muggled_dpt_amd.synthetic import make_synthetic_swinv2_state_dict
+    from muggled_dpt_amd import state_dict_conversion_swinv2 as conv
+
+    def build_swin(name, seed):
+        osd = make_synthetic_swinv2_state_dict(name, seed)
+        cfg_ref, model = ref_make_swin(osd, enable_cache=False, enable_optimizations=True)
+        cfg = conv.get_model_config_from_state_dict(osd)
+        norm = lambda c: {k: (tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in c.items()}  # noqa: E731
+        assert norm(cfg) == norm(cfg_ref), (cfg, cfg_ref)
+        w = flatten_components(conv.convert_state_dict_keys(cfg, osd))
+        ref_keys = {f"{comp}.{k}": list(v.shape) for comp in ("patch_embed", "imgencoder", "reassemble", "fusion", "head")
+                    for k, v in getattr(model, comp).state_dict().items()}
+        assert set(ref_keys) == set(w), set(ref_keys) ^ set(w)
+        for k, shp in ref_keys.items():
+            assert list(w[k].shape) == shp, (k, shp, w[k].shape)
+            assert maxdiff(w[k], getattr(model, k.split(".")[0]).state_dict()[k.split(".", 1)[1]]) == 0.0, k  # incl. exp'd logit_scale
+        return osd, cfg, model, w, ref_keys
+
+    osd, cfg, model, w, ref_keys = build_swin("swin2_tiny", 6)
+    with open(os.path.join(GOLD, "swin2_tiny_new_keys.json"), "w") as f:
+        json.dump(ref_keys, f, indent=0, sort_keys=True)
+    save = {}
+    # base 64x64 (grid 16: 16 windows of 4x4, shifted), 64x96 (grid 16x24), 96x32 (grid 24x8: stage 3 has a 3x1 grid ->
+    # window (3,1), no shift) - a fresh model per input is not needed: Windowing.resize() re-derives sizes per grid
+    for tag, shape, seed in (("base", (2, 3, 64, 64), 6), ("wide", (2, 3, 64, 96), 7), ("tall", (1, 3, 96, 32), 8)):
+        x = torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+        ref = run_reference(model, x)
+        report[f"swin2_tiny_{tag}"] = check_against_oracle(f"swin2_tiny_{tag}", ref, w, cfg, x)
+        tok, hw, taps, reasm, fused, depth = ref
+        save.update({f"{tag}_input": x.numpy(), f"{tag}_depth": depth.numpy(), f"{tag}_fused": fused.numpy(),
+                     f"{tag}_patch_tokens": tok.numpy()})
+        save.update({f"{tag}_tap{i}": taps[i].numpy() for i in range(4)})
+        save.update({f"{tag}_reasm{i}": reasm[i].numpy() for i in range(4)})
+    # window bookkeeping known answers straight from the reference helpers
+    for grid, targ in (((16, 16), (4, 4)), ((16, 24), (4, 4)), ((3, 1), (4, 4)), ((96, 96), (24, 24)), ((18, 30), (4, 4)), ((12, 12), (24, 24)),
+                       ((40, 24), (24, 24))):
+        win, shift = adjust_window_and_shift_sizes(grid, targ)
+        assert (tuple(win), tuple(shift)) == dpt_oracle.swin_window_and_shift(grid, targ), (grid, targ)
+        save[f"winshift_{grid[0]}x{grid[1]}_t{targ[0]}"] = np.array([*win, *shift])
+    for grid, win, shift in (((8, 8), (4, 4), (2, 2)), ((8, 12), (4, 4), (2, 2)), ((4, 8), (4, 4), (0, 2)), ((6, 2), (3, 2), (1, 0))):
+        mask = make_shift_mask(grid, win, shift)
+        assert maxdiff(mask, dpt_oracle.swin_shift_mask(grid, win, shift)) == 0.0, (grid, win, shift)
+        save[f"mask_{grid[0]}x{grid[1]}_w{win[0]}x{win[1]}_s{shift[0]}x{shift[1]}"] = mask.numpy()
+    enc = model.imgencoder.stages[1].blocks[0].attn.relpos_enc
+    for win in ((4, 4), (3, 1), (2, 6)):
+        with torch.inference_mode():
+            bias = enc._get_position_bias(win)
+        mine = dpt_oracle.swin_cpb_bias(w, "imgencoder.stages.1.blocks.0.attn.relpos_enc", win, None, 4)
+        assert maxdiff(bias, mine) <= 1e-5, (win, maxdiff(bias, mine))
+        save[f"cpb_w{win[0]}x{win[1]}"] = bias.numpy()
+    np.savez_compressed(os.path.join(GOLD, "swin2_tiny.npz"), weight_seed=6, **save)
+    for bad in ((1, 3, 72, 72), (1, 3, 48, 64)):  # grids 18x18 / 12x16: a patch merge meets an odd grid
+        try:
+            run_reference(model, torch.randn(*bad))
+            raise AssertionError("reference accepted a patch grid that is not divisible by 8?!")
+        except RuntimeError as e:
+            print(f"[swin2_tiny] {bad[2]}x{bad[3]} raises in reference:", str(e).splitlines()[0][:100])
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, size=(150, 210, 3), dtype=np.uint8)
+    got = model.patch_embed.prepare_image(img, 128, False)
+    mine = dpt_oracle.prepare_image(img, 128, False, default_size_px=64, tiling_px=32, rgb_mean=(0.5,) * 3, rgb_std=(0.5,) * 3)
+    assert got.shape == mine.shape and maxdiff(got, mine) <= 1e-5
+    save_prep = {"image": img, "rect128": got.numpy()}
+    np.savez_compressed(os.path.join(GOLD, "swin2_prepare_image.npz"), **save_prep)
+
+    if not skip_large:  # BASELINE.json configs[5]: SwinV2-L 384, batch 1
+        osd, cfg, model, w, _ = build_swin("swin2_large_384", 0)
+        x = torch.randn(1, 3, 384, 384, generator=torch.Generator().manual_seed(1))
+        ref = run_reference(model, x)
+        report["swin2_large_384"] = check_against_oracle("swin2_large_384", ref, w, cfg, x)
+        tok, hw, taps, reasm, fused, depth = ref
+        np.savez_compressed(
+            os.path.join(GOLD, "swin2_large_384.npz"), weight_seed=0, input_seed=1,
+            weight_checksum=np.array([float(osd["pretrained.model.layers.2.blocks.3.attn.qkv.weight"].double().sum()),
+                                      float(osd["scratch.refinenet2.out_conv.weight"].double().sum())]),
+            input_checksum=np.array([float(x.double().sum())]),
+            depth_strided=depth[:, ::4, ::4].numpy(), depth_stats=stats(depth),
+            **{f"tap{i}_crop": taps[i][:, :64, :64].numpy() for i in range(4)},
+            **{f"tap{i}_stats": stats(taps[i]) for i in range(4)},
+            **{f"reasm{i}_stats": stats(reasm[i]) for i in range(4)}, fused_stats=stats(fused))
+        print("[swin2_large_384] depth stats (min,max,mean,l2):", stats(depth))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-vitl", action="store_true")
     ap.add_argument("--only-beit", action="store_true", help="regenerate the BEiT fixtures only (report is merged)")
+    ap.add_argument("--only-swinv2", action="store_true", help="regenerate the SwinV2 fixtures only (report is merged)")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     report = {}
-    if args.only_beit:
+    if args.only_beit or args.only_swinv2:
         rp = os.path.join(GOLD, "oracle_vs_reference_report.json")
         with open(rp) as f:
             old = json.load(f)
-        gen_beit(report, args.skip_vitl)
+        if args.only_beit:
+            gen_beit(report, args.skip_vitl)
+        if args.only_swinv2:
+            gen_swinv2(report, args.skip_vitl)
         old["max_abs_err"].update(report)
         with open(rp, "w") as f:
             json.dump(old, f, indent=1)
@@ -300,6 +391,7 @@ def main():
         print("[vitl504] depth stats (min,max,mean,l2):", stats(depth))
 
     gen_beit(report, args.skip_vitl)
+    gen_swinv2(report, args.skip_vitl)
 
     with open(os.path.join(GOLD, "oracle_vs_reference_report.json"), "w") as f:
         json.dump({"torch": torch.__version__, "tolerance_abs": TOL, "max_abs_err": report}, f, indent=1)
