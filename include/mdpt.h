@@ -132,6 +132,25 @@ int mdpt_head(mdpt_handle* h, const void* fused_in, int32_t B, int32_t gh, int32
 int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void* out_chw_f32, int32_t out_h, int32_t out_w,
                        const float rgb_mean[3], const float rgb_std[3], void* stream);
 
+/* Depth post-processing on the device (reference muggled_dpt/demo_helpers/postprocess.py and
+ * run_3dviewer.py:576-590). All buffers are device pointers; `minmax` is a 2-float device buffer {min, max} and
+ * `scratch8` 8 bytes of device scratch - nothing is read back to the host, nothing synchronises.
+ *   mdpt_post_minmax ............ data.min(), data.max() of an fp32 array (normalize_01, postprocess.py:72-73)
+ *   mdpt_post_scale_prediction .. F.interpolate(pred[:, None], size=(out_h, out_w), mode="bilinear") (postprocess.py:22-29);
+ *                                 minmax_out != NULL also reduces min/max of the OUTPUT in the same pass
+ *   mdpt_post_normalize ......... mode MDPT_POST_F32: (x - min) / (max - min) -> fp32            (postprocess.py:74)
+ *                                 mode MDPT_POST_U8:  (255 * norm).byte() -> uint8 (truncation)     (postprocess.py:91)
+ *                                 mode MDPT_POST_U24: round(16777215 * norm) -> BGRA uint8x4, B/G/R = low/mid/high byte,
+ *                                                     alpha 0; lossy != 0 keeps only the high byte (run_3dviewer.py:579-590)
+ *                                 minmax == NULL skips the normalisation (metric models, run_3dviewer.py:577-578) */
+#define MDPT_POST_F32 0
+#define MDPT_POST_U8 1
+#define MDPT_POST_U24 2
+int mdpt_post_minmax(const void* in_f32, size_t count, void* minmax_out, void* scratch8, void* stream);
+int mdpt_post_scale_prediction(const void* in_bhw_f32, int32_t B, int32_t in_h, int32_t in_w, void* out_bhw_f32, int32_t out_h,
+                               int32_t out_w, void* minmax_out, void* scratch8, void* stream);
+int mdpt_post_normalize(const void* in_f32, size_t count, const void* minmax, void* out, int32_t mode, int32_t lossy, void* stream);
+
 /* Stage boundaries of the LAST mdpt_forward on `workspace`, converted to reference layouts (debug / parity taps):
  * which = 0..3 encoder taps [B,N,F]; 4..7 reassembly maps (BCHW); 8 fused map [B,C,8gh,8gw]. */
 int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspace, size_t workspace_bytes, void* stream);

@@ -1065,6 +1065,29 @@ int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void*
     return 0;
 }
 
+// ---- depth post-processing (demo_helpers/postprocess.py, run_3dviewer.py:576-590)
+int mdpt_post_minmax(const void* in_f32, size_t count, void* minmax_out, void* scratch8, void* stream) {
+    if (!in_f32 || !minmax_out || !scratch8 || count == 0) return fail(MDPT_E_INVALID, "null argument / empty input");
+    CHK(mdpt_launch_post_minmax((const float*)in_f32, count, (float*)minmax_out, (unsigned*)scratch8, (hipStream_t)stream));
+    return 0;
+}
+
+int mdpt_post_scale_prediction(const void* in_bhw_f32, int32_t B, int32_t in_h, int32_t in_w, void* out_bhw_f32, int32_t out_h,
+                               int32_t out_w, void* minmax_out, void* scratch8, void* stream) {
+    if (!in_bhw_f32 || !out_bhw_f32 || (minmax_out && !scratch8)) return fail(MDPT_E_INVALID, "null argument");
+    if (B <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) return fail(MDPT_E_INVALID, "bad size %dx%dx%d -> %dx%d", B, in_h, in_w, out_h, out_w);
+    CHK(mdpt_launch_post_scale((const float*)in_bhw_f32, (float*)out_bhw_f32, B, in_h, in_w, out_h, out_w, (float*)minmax_out,
+                               (unsigned*)scratch8, (hipStream_t)stream));
+    return 0;
+}
+
+int mdpt_post_normalize(const void* in_f32, size_t count, const void* minmax, void* out, int32_t mode, int32_t lossy, void* stream) {
+    if (!in_f32 || !out || count == 0) return fail(MDPT_E_INVALID, "null argument / empty input");
+    if (mode < MDPT_POST_F32 || mode > MDPT_POST_U24) return fail(MDPT_E_INVALID, "unknown post-processing mode %d", mode);
+    CHK(mdpt_launch_post_normalize((const float*)in_f32, (const float*)minmax, out, count, mode, lossy, (hipStream_t)stream));
+    return 0;
+}
+
 // ---- test hooks (tests/ only): truncate the encoder after (block, step) and read raw internal buffers as fp32
 int mdpt_debug_set_stop(mdpt_handle* h, int32_t block, int32_t step) {
     if (!h) return fail(MDPT_E_INVALID, "null handle");

@@ -139,3 +139,12 @@ int mdpt_launch_swin_qkv_prep(const float* qkv, const int* rowmap, const float* 
 int mdpt_launch_swin_merge_gather(const float* tok, bf16_t* out_hi, bf16_t* out_lo, int B, int gh, int gw, int C,
                                   hipStream_t stream);
 int mdpt_launch_f32_to_planes(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t n, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// depth post-processing (postprocess.hip); scratch2 = 2 uints of device scratch for the min/max reduction
+// ------------------------------------------------------------------------------------------------
+int mdpt_launch_post_minmax(const float* in, size_t n, float* minmax_out, unsigned* scratch2, hipStream_t stream);
+int mdpt_launch_post_scale(const float* in, float* out, int B, int ih, int iw, int oh, int ow, float* minmax_out,
+                           unsigned* scratch2, hipStream_t stream);
+int mdpt_launch_post_normalize(const float* in, const float* minmax, void* out, size_t n, int mode, int lossy,
+                               hipStream_t stream);

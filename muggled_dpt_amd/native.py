@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(CSRC, "libmdpt.so")
-SOURCES = ("gemm.hip", "attention.hip", "elementwise.hip", "swin.hip", "mdpt_api.cpp", "mdpt_prof.cpp")
+SOURCES = ("gemm.hip", "attention.hip", "elementwise.hip", "swin.hip", "postprocess.hip", "mdpt_api.cpp", "mdpt_prof.cpp")
 HEADERS = ("mdpt_kernels.h", "mdpt_prof.h", "mdpt_swin.inc", os.path.join(REPO, "include", "mdpt.h"))
 
 PREC_BF16 = 0
@@ -27,6 +27,7 @@ FAMILY_DAV1 = 1
 FAMILY_BEIT = 2
 FAMILY_SWINV2 = 3
 E_GRID = -7
+POST_F32, POST_U8, POST_U24 = 0, 1, 2
 
 
 def _hipcc() -> str:
@@ -119,6 +120,9 @@ SYMBOLS = {
     "mdpt_fusion": (ctypes.c_int, [_VP, _VP4, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_head": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_prepare_image": (ctypes.c_int, [_VP, _I, _I, _VP, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _VP]),
+    "mdpt_post_minmax": (ctypes.c_int, [_VP, _SZ, _VP, _VP, _VP]),
+    "mdpt_post_scale_prediction": (ctypes.c_int, [_VP, _I, _I, _I, _VP, _I, _I, _VP, _VP, _VP]),
+    "mdpt_post_normalize": (ctypes.c_int, [_VP, _SZ, _VP, _VP, _I, _I, _VP]),
     "mdpt_export_tap": (ctypes.c_int, [_VP, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_set_gemm_tile": (ctypes.c_int, [_VP, _I]),
     "mdpt_debug_gemm": (ctypes.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _VP]),

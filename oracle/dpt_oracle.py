@@ -494,3 +494,36 @@ def inference(w: dict, cfg: dict, image_bgr, max_side_length=None, use_square_si
     tiling = (8 if is_swin(w) else 2) * cfg["patch_size_px"]  # v31_swinv2/patch_embed.py:68
     x = prepare_image(image_bgr, max_side_length, use_square_sizing, default_size_px=default_px, tiling_px=tiling, **norm)
     return forward(w, cfg, x)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# depth post-processing (reference muggled_dpt/demo_helpers/postprocess.py, run_3dviewer.py:576-590)
+
+
+def scale_prediction(prediction: torch.Tensor, target_wh: tuple[int, int]) -> torch.Tensor:
+    """BxHxW -> Bx(h')x(w') bilinear, align_corners=False, no antialias (postprocess.py:22-29)."""
+    return F.interpolate(prediction.unsqueeze(1), size=(int(target_wh[1]), int(target_wh[0])), mode="bilinear").squeeze(1)
+
+
+def normalize_01(data: torch.Tensor) -> torch.Tensor:
+    """(data - min) / (max - min) (postprocess.py:63-74)."""
+    lo, hi = data.min(), data.max()
+    return (data - lo) / (hi - lo)
+
+
+def convert_to_uint8(depth: torch.Tensor) -> torch.Tensor:
+    """(255 * normalize_01(depth)).byte(): truncation toward zero (postprocess.py:79-91)."""
+    return (255.0 * normalize_01(depth)).byte()
+
+
+def pack_depth_u24(depth: torch.Tensor, is_metric: bool = False, lossy: bool = False) -> torch.Tensor:
+    """round(16777215 * normalize_01(depth)) split over B (low), G (mid), R (high) of a BGRA uint8 image; alpha is filled by the
+    caller's mask (run_3dviewer.py:576-593, MAX_UINT24 :516)."""
+    d = depth if is_metric else normalize_01(depth)
+    q = torch.round(16777215 * d).to(torch.int32).squeeze()
+    out = torch.zeros((*q.shape, 4), dtype=torch.uint8)
+    out[..., 2] = ((q >> 16) & 255).to(torch.uint8)
+    if not lossy:
+        out[..., 1] = ((q >> 8) & 255).to(torch.uint8)
+        out[..., 0] = (q & 255).to(torch.uint8)
+    return out

@@ -165,6 +165,35 @@ def gen_beit(report, skip_large):
         print("[beit_large_384] depth stats (min,max,mean,l2):", stats(depth))
 
 
+def gen_postprocess():
+    """Fixtures from the reference's own post-processing helpers (demo_helpers/postprocess.py) and the 24-bit packing lines of
+    run_3dviewer.py:579-590 (executed verbatim on a seeded depth map)."""
+    from muggled_dpt.demo_helpers.postprocess import convert_to_uint8, normalize_01, scale_prediction
+    g = torch.Generator().manual_seed(11)
+    depth = torch.relu(torch.randn(2, 56, 84, generator=g) * 1.5 + 0.7)  # ReLU-shaped like a model output, incl. exact zeros
+    save = {"depth": depth.numpy()}
+    for tag, wh in (("up", (200, 130)), ("down", (40, 30)), ("same", (84, 56))):
+        s = scale_prediction(depth, wh)
+        assert maxdiff(s, dpt_oracle.scale_prediction(depth, wh)) == 0.0
+        save[f"scaled_{tag}"] = s.numpy()
+        save[f"scaled_{tag}_u8"] = convert_to_uint8(s).numpy()
+        assert torch.equal(convert_to_uint8(s), dpt_oracle.convert_to_uint8(s))
+    n01 = normalize_01(depth[:1])
+    assert maxdiff(n01, dpt_oracle.normalize_01(depth[:1])) == 0.0
+    save["norm01"] = n01.numpy()
+    # run_3dviewer.py:579-590
+    MAX_UINT24 = (2 ** 24) - 1
+    u24 = (torch.round(MAX_UINT24 * n01)).to(dtype=torch.int32).squeeze().cpu().numpy()
+    bgr = np.zeros((*u24.shape[0:2], 4), dtype=np.uint8)
+    bgr[:, :, 2] = np.bitwise_and(np.right_shift(u24, 16).astype(np.uint8), 255)
+    bgr[:, :, 1] = np.bitwise_and(np.right_shift(u24, 8).astype(np.uint8), 255)
+    bgr[:, :, 0] = np.bitwise_and(np.right_shift(u24, 0).astype(np.uint8), 255)
+    assert np.array_equal(bgr, dpt_oracle.pack_depth_u24(depth[:1]).numpy())
+    save["packed_u24"] = bgr
+    np.savez_compressed(os.path.join(GOLD, "postprocess.npz"), **save)
+    print("[postprocess] fixtures written; oracle identical to the reference helpers")
+
+
 def gen_swinv2(report, skip_large):
     """MiDaS v3.1 SwinV2 fixtures (reference muggled_dpt/make_swinv2_dpt.py, v31_swinv2/*)."""
     from muggled_dpt.make_swinv2_dpt import make_swinv2_dpt_from_midas_v31_state_dict as ref_make_swin
@@ -257,10 +286,14 @@ def main():
     ap.add_argument("--skip-vitl", action="store_true")
     ap.add_argument("--only-beit", action="store_true", help="regenerate the BEiT fixtures only (report is merged)")
     ap.add_argument("--only-swinv2", action="store_true", help="regenerate the SwinV2 fixtures only (report is merged)")
+    ap.add_argument("--only-postprocess", action="store_true", help="regenerate the post-processing fixtures only")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     report = {}
+    if args.only_postprocess:
+        gen_postprocess()
+        return
     if args.only_beit or args.only_swinv2:
         rp = os.path.join(GOLD, "oracle_vs_reference_report.json")
         with open(rp) as f:
@@ -392,6 +425,7 @@ def main():
 
     gen_beit(report, args.skip_vitl)
     gen_swinv2(report, args.skip_vitl)
+    gen_postprocess()
 
     with open(os.path.join(GOLD, "oracle_vs_reference_report.json"), "w") as f:
         json.dump({"torch": torch.__version__, "tolerance_abs": TOL, "max_abs_err": report}, f, indent=1)
