@@ -42,7 +42,7 @@ extern "C" {
 #define MDPT_E_MISSING (-3)    /* a weight required by the config was not bound         */
 #define MDPT_E_SHAPE (-4)      /* bound weight has the wrong shape                      */
 #define MDPT_E_WORKSPACE (-5)  /* workspace / packed buffer too small                   */
-#define MDPT_E_UNSUPPORTED (-6)/* config outside this build (e.g. ViT-G SwiGLU)         */
+#define MDPT_E_UNSUPPORTED (-6)/* config outside this build (e.g. head dim != 64)        */
 #define MDPT_E_GRID (-7)       /* odd patch grid: the reference raises RuntimeError at fusion_model.py:151 */
 
 typedef struct mdpt_handle mdpt_handle;
@@ -57,7 +57,7 @@ typedef struct mdpt_config {
     int32_t base_patch_grid_h, base_patch_grid_w;
     int32_t fusion_channels;
     int32_t patch_size_px;
-    int32_t is_giant;  /* must be 0 in this build */
+    int32_t is_giant;  /* ViT-G: SwiGLU FFN instead of the GELU MLP (components/misc_helpers.py:125-185); Depth-Anything V2 only */
     int32_t is_metric; /* sigmoid instead of the final ReLU (head_model.py:84) */
     int32_t precision; /* MDPT_PREC_* */
     int32_t family;    /* MDPT_FAMILY_DAV2: Depth-Anything V2 (encoder tapped after each quarter of the blocks, image_encoder_model.py:88-93)

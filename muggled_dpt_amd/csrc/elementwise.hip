@@ -436,6 +436,26 @@ __global__ __launch_bounds__(256) void beit_relpos_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// ViT-G SwiGLU gate (reference components/misc_helpers.py:182-185): in fp32 [rows, 2h] = (a | b) -> silu(a) * b as
+// bf16 hi (+lo) [rows, hp], columns [h, hp) zero (K padding of the outer GEMM). One thread = 4 columns.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ in, bf16_t* out_hi, bf16_t* out_lo, size_t rows, int h, int hp) {
+    const int cq = hp / 4;
+    const size_t total = rows * cq;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cq) * 4;
+        const size_t r = idx / cq;
+        f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (c < h) {
+            const f32x4 a = *(const f32x4*)(in + r * (size_t)(2 * h) + c), b = *(const f32x4*)(in + r * (size_t)(2 * h) + h + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = a[e] / (1.0f + expf(-a[e])) * b[e];
+        }
+        split_store4(out_hi, out_lo, r * hp + c, y);
+    }
+}
+
 inline int grid_for(size_t total, int block = 256) {
     size_t g = (total + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -458,6 +478,13 @@ int mdpt_launch_layernorm(const float* x, const float* gamma, const float* beta,
     else if (F <= 1536) LN_CASE(6);
     else LN_CASE(8);
 #undef LN_CASE
+    LAUNCH_RET();
+}
+
+int mdpt_launch_swiglu(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t rows, int h, int hp, hipStream_t stream) {
+    if ((h & 3) || (hp & 3) || hp < h) return (int)hipErrorInvalidValue;
+    MdptProfScope prof("swiglu_kernel", 0.0, stream);
+    hipLaunchKernelGGL(swiglu_kernel, dim3(grid_for(rows * (hp / 4))), dim3(256), 0, stream, in, out_hi, out_lo, rows, h, hp);
     LAUNCH_RET();
 }
 

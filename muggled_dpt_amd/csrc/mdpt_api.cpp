@@ -95,6 +95,7 @@ struct Plan {
     size_t fused[2], h1, h1u[2], scratch;
     size_t scratch_floats;
     size_t tokr[2], cbuf, relpos_lut, relpos_tq, relpos_tk;  // BEiT: readout-projected tokens, per-image cls term, bias LUT
+    size_t swi;                                               // ViT-G: fp32 [rows, 2*hidden] output of the doubled inner linear
     // SwinV2: stage-0 patch grid, per-stage residual streams (fp32, = the taps), shared GEMM fp32 output, token planes,
     // window operands, window maps (plain / shifted) and the position-bias LUT
     struct {
@@ -111,6 +112,7 @@ struct mdpt_handle {
     int hid[4], hidp[4];
     bool swin;
     int Pv;  // patch size seen by fusion/head: the finest reassembly map is (4H/Pv) x (4W/Pv); = P except SwinV2 (16)
+    int gh_hidden, gh_hidden_p;  // ViT-G SwiGLU hidden width (and padded to 64), 0 otherwise
     int sH[4], sL[4], swh, sww, spre[4];  // SwinV2: heads / layers per stage, target window, pretrained window sizes (0 = None)
     bool x3;
     int gemm_tile;
@@ -234,21 +236,36 @@ int build_inventory(mdpt_handle* h) {
         h->add_spec(p + ".attn.proj.weight", {F, F});
         h->add_spec(p + ".attn.proj.bias", {F});
         h->add_spec(p + ".scale_attn", {F});
-        h->add_spec(p + ".mlp.layers.0.weight", {4 * F, F});
-        h->add_spec(p + ".mlp.layers.0.bias", {4 * F});
-        h->add_spec(p + ".mlp.layers.2.weight", {F, 4 * F});
-        h->add_spec(p + ".mlp.layers.2.bias", {F});
+        const int sh = h->gh_hidden, shp = h->gh_hidden_p;
+        if (sh) {  // ViT-G: SwiGLU FFN (components/misc_helpers.py:162-168)
+            h->add_spec(p + ".mlp.inner_linear_doubled.weight", {2 * sh, F});
+            h->add_spec(p + ".mlp.inner_linear_doubled.bias", {2 * sh});
+            h->add_spec(p + ".mlp.outer_linear.weight", {F, sh});
+            h->add_spec(p + ".mlp.outer_linear.bias", {F});
+        } else {
+            h->add_spec(p + ".mlp.layers.0.weight", {4 * F, F});
+            h->add_spec(p + ".mlp.layers.0.bias", {4 * F});
+            h->add_spec(p + ".mlp.layers.2.weight", {F, 4 * F});
+            h->add_spec(p + ".mlp.layers.2.bias", {F});
+        }
         h->add_spec(p + ".scale_mlp", {F});
         h->add_mat(p + ".attn.qkv.weight", MDPT_PACK_LINEAR, 3 * F, F, 3 * F, F, 0);
         h->add_mat(p + ".attn.proj.weight", MDPT_PACK_LINEAR, F, F, F, F, 0);
-        h->add_mat(p + ".mlp.layers.0.weight", MDPT_PACK_LINEAR, 4 * F, F, 4 * F, F, 0);
-        h->add_mat(p + ".mlp.layers.2.weight", MDPT_PACK_LINEAR, F, 4 * F, F, 4 * F, 0);
+        if (sh) {
+            h->add_mat(p + ".mlp.inner_linear_doubled.weight", MDPT_PACK_LINEAR, 2 * sh, F, 2 * sh, F, 0);
+            h->add_mat(p + ".mlp.outer_linear.weight", MDPT_PACK_LINEAR, F, sh, F, shp, 0);
+            h->add_vec(p + ".mlp.inner_linear_doubled.bias", 2 * sh, 2 * sh);
+            h->add_vec(p + ".mlp.outer_linear.bias", F, F);
+        } else {
+            h->add_mat(p + ".mlp.layers.0.weight", MDPT_PACK_LINEAR, 4 * F, F, 4 * F, F, 0);
+            h->add_mat(p + ".mlp.layers.2.weight", MDPT_PACK_LINEAR, F, 4 * F, F, 4 * F, 0);
+            h->add_vec(p + ".mlp.layers.0.bias", 4 * F, 4 * F);
+            h->add_vec(p + ".mlp.layers.2.bias", F, F);
+        }
         if (beit) h->add_vec(p + ".attn.qkv.bias@qv", 0, 3 * F);  // assembled in finalize: [q_bias, 0, v_bias]
         else h->add_vec(p + ".attn.qkv.bias", 3 * F, 3 * F);
         h->add_vec(p + ".attn.proj.bias", F, F);
         h->add_vec(p + ".scale_attn", F, F);
-        h->add_vec(p + ".mlp.layers.0.bias", 4 * F, 4 * F);
-        h->add_vec(p + ".mlp.layers.2.bias", F, F);
         h->add_vec(p + ".scale_mlp", F, F);
     }
 
@@ -391,6 +408,7 @@ int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
     take_planes(bump, x3, (size_t)B * h->heads * 64 * p.npadv, p.vt);
     take_planes(bump, x3, rows * F, p.att);
     take_planes(bump, x3, rows * 4 * F, p.hbuf);
+    p.swi = h->gh_hidden ? bump.take(rows * 2 * h->gh_hidden * 4) : SIZE_MAX;
     for (int i = 0; i < 4; ++i) take_planes(bump, x3, rows * F, p.tap[i]);
     p.tapf32 = bump.take(rows * F * 4);
     const size_t px[4] = {(size_t)16 * p.Np, (size_t)4 * p.Np, (size_t)p.Np, (size_t)p.Np / 4};
@@ -524,7 +542,13 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
         DBG_STOP(3);
         CHK(mdpt_launch_layernorm(resid, h->V(n + ".norm2.weight"), h->V(n + ".norm2.bias"), xn.hi, xn.lo, nullptr, rows, F, c.s));
         DBG_STOP(4);
-        {
+        if (h->gh_hidden) {  // ViT-G: (a | b) = x W12^T + b12 ; hidden = silu(a) * b
+            GemmParams g = base_params(c, h->M(n + ".mlp.inner_linear_doubled.weight"), xn, rows, F);
+            g.bias = h->V(n + ".mlp.inner_linear_doubled.bias");
+            g.out_f32 = c.at<float>(p.swi); g.ldc = 2 * h->gh_hidden;
+            CHK(mdpt_launch_gemm(g, c.s));
+            CHK(mdpt_launch_swiglu(c.at<float>(p.swi), hb.hi, hb.lo, (size_t)rows, h->gh_hidden, h->gh_hidden_p, c.s));
+        } else {
             GemmParams g = base_params(c, h->M(n + ".mlp.layers.0.weight"), xn, rows, F);
             g.bias = h->V(n + ".mlp.layers.0.bias");
             g.act = MDPT_ACT_GELU;
@@ -533,8 +557,10 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
         }
         DBG_STOP(5);
         {
-            GemmParams g = base_params(c, h->M(n + ".mlp.layers.2.weight"), hb, rows, 4 * F);
-            g.bias = h->V(n + ".mlp.layers.2.bias");
+            const bool giant = h->gh_hidden != 0;
+            GemmParams g = base_params(c, h->M(giant ? n + ".mlp.outer_linear.weight" : n + ".mlp.layers.2.weight"), hb, rows,
+                                       giant ? h->gh_hidden_p : 4 * F);
+            g.bias = h->V(giant ? n + ".mlp.outer_linear.bias" : n + ".mlp.layers.2.bias");
             g.gamma = h->V(n + ".scale_mlp");
             g.resid = resid; g.out_f32 = resid; g.ldr = F; g.ldc = F;
             CHK(mdpt_launch_gemm(g, c.s));
@@ -732,7 +758,7 @@ const char* mdpt_last_error(void) { return g_err.c_str(); }
 int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     if (!cfg || !out) return fail(MDPT_E_INVALID, "null argument");
     *out = nullptr;
-    if (cfg->is_giant) return fail(MDPT_E_UNSUPPORTED, "ViT-G (SwiGLU MLP) is not built in this version");
+    if (cfg->is_giant && cfg->family != MDPT_FAMILY_DAV2) return fail(MDPT_E_INVALID, "is_giant (SwiGLU MLP) exists for Depth-Anything V2 only");
     if (cfg->family < MDPT_FAMILY_DAV2 || cfg->family > MDPT_FAMILY_SWINV2) return fail(MDPT_E_INVALID, "unknown model family %d", cfg->family);
     const bool swin = cfg->family == MDPT_FAMILY_SWINV2;
     if (cfg->features_per_token <= 0 || cfg->features_per_token % 64)
@@ -769,6 +795,9 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     for (int i = 0; i < 4; ++i) { h->hid[i] = cfg->reassembly_features[i]; h->hidp[i] = rup(h->hid[i], 64); }
     h->swin = swin;
     h->Pv = swin ? 16 : h->P;
+    // components/misc_helpers.py:164-165: 2/3 of the 4x MLP width, rounded up to a multiple of 8
+    h->gh_hidden = cfg->is_giant ? 8 * (((int)((long)(4 * h->F) * 2 / 3) + 7) / 8) : 0;
+    h->gh_hidden_p = rup(h->gh_hidden, 64);
     for (int i = 0; i < 4; ++i) { h->sH[i] = cfg->swin_heads[i]; h->sL[i] = cfg->swin_layers[i]; h->spre[i] = cfg->swin_pretrained_window[i]; }
     h->swh = cfg->swin_window_h; h->sww = cfg->swin_window_w;
     h->x3 = cfg->precision == MDPT_PREC_BF16X3;

@@ -51,8 +51,6 @@ def make_depthanythingv2_dpt(
 ) -> DPTModel:
     """Build an (uninitialised) model from explicit sizes; see muggled_dpt_amd.synthetic.STANDARD_CONFIGS for the
     vit-small/base/large numbers (reference make_depthanythingv2_dpt.py:88-122)."""
-    if is_giant:
-        raise NotImplementedError("ViT-G (SwiGLU MLP) is not supported by the MI355X path yet")
     if not enable_optimizations:
         warnings.warn("enable_optimizations=False: the fused attention kernel never materialises the softmax matrix, so "
                       "attention maps cannot be hooked (reference components/transformer_block.py:101); outputs are identical.")

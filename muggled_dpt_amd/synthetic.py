@@ -19,7 +19,11 @@ STANDARD_CONFIGS = {
                  base_patch_grid_hw=(37, 37), fusion_channels=128, patch_size_px=14),
     "vitl": dict(features_per_token=1024, num_heads=16, num_blocks=24, reassembly_features_list=[256, 512, 1024, 1024],
                  base_patch_grid_hw=(37, 37), fusion_channels=256, patch_size_px=14),
+    "vitg": dict(features_per_token=1536, num_heads=24, num_blocks=40, reassembly_features_list=[1536, 1536, 1536, 1536],
+                 base_patch_grid_hw=(37, 37), fusion_channels=384, patch_size_px=14, is_giant=True),
     # not a real model: small enough for full-tensor golden fixtures (KBs) and fast CPU tests
+    "tiny_giant": dict(features_per_token=128, num_heads=2, num_blocks=4, reassembly_features_list=[16, 32, 64, 64],
+                       base_patch_grid_hw=(5, 5), fusion_channels=32, patch_size_px=14, is_giant=True),  # SwiGLU hidden 344 (not /64)
     "tiny": dict(features_per_token=64, num_heads=1, num_blocks=4, reassembly_features_list=[16, 32, 64, 64],
                  base_patch_grid_hw=(5, 5), fusion_channels=32, patch_size_px=14),
 }
@@ -239,6 +243,11 @@ def make_synthetic_swinv2_state_dict(cfg: dict | str, seed: int = 0) -> dict[str
     return sd
 
 
+def swiglu_hidden(features_per_token: int, ratio: float = 4) -> int:
+    """Hidden width of the ViT-G SwiGLU FFN: 2/3 of the MLP width rounded up to 8 (components/misc_helpers.py:164-165)."""
+    return 8 * ((int(int(ratio * features_per_token) * 2 / 3) + 7) // 8)
+
+
 def original_state_dict_shapes(cfg: dict) -> dict[str, tuple]:
     """Every tensor of an upstream DA-V2 (non-giant) checkpoint, in upstream order, with its shape."""
     F = cfg["features_per_token"]
@@ -263,10 +272,17 @@ def original_state_dict_shapes(cfg: dict) -> dict[str, tuple]:
         shapes[f"{b}.ls1.gamma"] = (F,)
         shapes[f"{b}.norm2.weight"] = (F,)
         shapes[f"{b}.norm2.bias"] = (F,)
-        shapes[f"{b}.mlp.fc1.weight"] = (4 * F, F)
-        shapes[f"{b}.mlp.fc1.bias"] = (4 * F,)
-        shapes[f"{b}.mlp.fc2.weight"] = (F, 4 * F)
-        shapes[f"{b}.mlp.fc2.bias"] = (F,)
+        if cfg.get("is_giant", False):  # SwiGLU FFN (reference components/misc_helpers.py:162-168)
+            shid = swiglu_hidden(F)
+            shapes[f"{b}.mlp.w12.weight"] = (2 * shid, F)
+            shapes[f"{b}.mlp.w12.bias"] = (2 * shid,)
+            shapes[f"{b}.mlp.w3.weight"] = (F, shid)
+            shapes[f"{b}.mlp.w3.bias"] = (F,)
+        else:
+            shapes[f"{b}.mlp.fc1.weight"] = (4 * F, F)
+            shapes[f"{b}.mlp.fc1.bias"] = (4 * F,)
+            shapes[f"{b}.mlp.fc2.weight"] = (F, 4 * F)
+            shapes[f"{b}.mlp.fc2.bias"] = (F,)
         shapes[f"{b}.ls2.gamma"] = (F,)
     shapes["pretrained.norm.weight"] = (F,)
     shapes["pretrained.norm.bias"] = (F,)

@@ -106,7 +106,11 @@ def attention(w: dict, pre: str, x: torch.Tensor, num_heads: int) -> torch.Tenso
 
 
 def mlp(w: dict, pre: str, x: torch.Tensor) -> torch.Tensor:
-    """Linear(F->4F) -> exact (erf) GELU -> Linear(4F->F) (components/misc_helpers.py:88-120)."""
+    """Linear(F->4F) -> exact (erf) GELU -> Linear(4F->F) (components/misc_helpers.py:88-120); ViT-G: SwiGLU FFN,
+    Linear(F->2h) split in halves (a, b) -> silu(a) * b -> Linear(h->F) (:170-185)."""
+    if f"{pre}.inner_linear_doubled.weight" in w:
+        a, b = F.linear(x, w[f"{pre}.inner_linear_doubled.weight"], w[f"{pre}.inner_linear_doubled.bias"]).chunk(2, dim=-1)
+        return F.linear(F.silu(a) * b, w[f"{pre}.outer_linear.weight"], w[f"{pre}.outer_linear.bias"])
     h = F.gelu(F.linear(x, w[f"{pre}.layers.0.weight"], w[f"{pre}.layers.0.bias"]))
     return F.linear(h, w[f"{pre}.layers.2.weight"], w[f"{pre}.layers.2.bias"])
 

@@ -45,13 +45,13 @@ def test_create_validates_config(lib):
     h = ctypes.c_void_p()
     assert lib.mdpt_create(ctypes.byref(_cfg()), ctypes.byref(h)) == 0
     lib.mdpt_destroy(h)
-    for bad in (dict(features_per_token=1000), dict(num_heads=8), dict(num_blocks=10), dict(is_giant=True), dict(patch_size_px=15)):
+    for bad in (dict(features_per_token=1000), dict(num_heads=8), dict(num_blocks=10), dict(patch_size_px=15)):
         rc = lib.mdpt_create(ctypes.byref(_cfg(**bad)), ctypes.byref(h))
         assert rc < 0 and lib.mdpt_last_error(), bad
     assert lib.mdpt_create(ctypes.byref(_cfg(precision=7)), ctypes.byref(h)) == -1
 
 
-@pytest.mark.parametrize("name", ["tiny", "vits", "vitl"])
+@pytest.mark.parametrize("name", ["tiny", "vits", "vitl", "vitg", "tiny_giant"])
 def test_parameter_inventory_uses_reference_key_names(lib, name):
     h = ctypes.c_void_p()
     assert lib.mdpt_create(ctypes.byref(_cfg(name)), ctypes.byref(h)) == 0

@@ -242,3 +242,31 @@ def test_make_dpt_from_state_dict_file_roundtrip(tmp_path):
     assert cfg2["features_per_token"] == 64 and cfg2["enable_cache"] is True
     x = seeded_input((1, 3, 56, 56), 9)
     assert rel_err(model.to("cuda")(x.to("cuda")).cpu(), _oracle().forward(w, cfg, x)) <= REL_TOL_X3
+
+
+@pytest.mark.parametrize("dtype,tol", MODES)
+def test_vit_giant_swiglu_ffn(golden_dir, dtype, tol):
+    """§8(f) row 3: is_giant checkpoints (mlp.w12 / mlp.w3 -> SwiGLU FFN, hidden width 344 here: exercises the K padding of the
+    outer GEMM) vs a fixture generated from the reference."""
+    from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+    from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict
+    g = np.load(os.path.join(golden_dir, "tiny_giant.npz"))
+    cfg, model = make_depthanythingv2_dpt_from_original_state_dict(make_synthetic_original_state_dict("tiny_giant", int(g["weight_seed"])))
+    assert cfg["is_giant"] is True and "stages.0.blocks.0.mlp.inner_linear_doubled.weight" in model.imgencoder.state_dict()
+    model = model.to("cuda", dtype)
+    y = model(torch.from_numpy(g["input"]).to("cuda", dtype))
+    taps = model.debug_taps(2, (56, 84))
+    for i in range(4):
+        assert rel_err(taps["stages"][i].cpu(), torch.from_numpy(g[f"tap{i}"])) <= tol, f"tap{i}"
+    assert rel_err(taps["fused"].cpu(), torch.from_numpy(g["fused"])) <= tol
+    assert rel_err(y.float().cpu(), torch.from_numpy(g["depth"])) <= (tol if dtype == torch.float32 else 2 * tol)
+
+
+def test_vit_giant_full_width_runs():
+    """The real ViT-G sizes (F=1536, 24 heads, 40 blocks, SwiGLU hidden 4096, C=384) at 504x504, bf16: finite, non-trivial output
+    and equal to the batch-1 result (CPU oracle at this size takes minutes, so only properties are checked here)."""
+    model, cfg, w = _model("vitg", torch.bfloat16)
+    x = seeded_input((2, 3, 504, 504), 2).to("cuda", torch.bfloat16)
+    y = model(x)
+    assert tuple(y.shape) == (2, 504, 504) and torch.isfinite(y.float()).all() and float(y.float().max()) > 0
+    assert torch.equal(y[1:], model(x[1:]))

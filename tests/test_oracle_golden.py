@@ -133,3 +133,18 @@ def test_depth_anything_v1_last_four_block_taps(golden_dir):
         _close(st["stages"][i], g[f"tap{i}"])
     _close(st["fused"], g["fused"])
     _close(depth, g["depth"])
+
+
+def test_vit_giant_swiglu_oracle(golden_dir):
+    from muggled_dpt_amd.state_dict_conversion import convert_state_dict_keys, flatten_components, get_model_config_from_state_dict
+    from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict, swiglu_hidden
+    g = np.load(os.path.join(golden_dir, "tiny_giant.npz"))
+    osd = make_synthetic_original_state_dict("tiny_giant", int(g["weight_seed"]))
+    cfg = get_model_config_from_state_dict(osd)
+    assert cfg["is_giant"] is True and swiglu_hidden(128) == 344 and swiglu_hidden(1536) == 4096
+    assert osd["pretrained.blocks.0.mlp.w12.weight"].shape == (688, 128)
+    w = flatten_components(convert_state_dict_keys(cfg, osd))
+    depth, st = dpt_oracle.forward(w, cfg, torch.from_numpy(g["input"]), return_stages=True)
+    assert float((depth - torch.from_numpy(g["depth"])).abs().max()) <= ATOL
+    for i in range(4):
+        assert float((st["stages"][i] - torch.from_numpy(g[f"tap{i}"])).abs().max()) <= ATOL

@@ -355,6 +355,20 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "tiny_v1.npz"), weight_seed=3, num_blocks=8, input=x1.numpy(), depth=ref1[5].numpy(),
                         fused=ref1[4].numpy(), **{f"tap{i}": ref1[2][i].numpy() for i in range(4)})
 
+    # ------------------------------------------------------------------ 1c. ViT-G style SwiGLU FFN (is_giant), toy width
+    osdg = make_synthetic_original_state_dict("tiny_giant", 4)
+    cfg_refg, modelg = make_depthanythingv2_dpt_from_original_state_dict(osdg, enable_cache=False, enable_optimizations=True)
+    cfgg = get_model_config_from_state_dict(osdg)
+    assert cfgg["is_giant"] and cfg_refg["is_giant"]
+    wg = flatten_components(convert_state_dict_keys(cfgg, osdg))
+    ref_keysg = {f"{comp}.{k}" for comp in ("patch_embed", "imgencoder", "reassemble", "fusion", "head") for k in getattr(modelg, comp).state_dict()}
+    assert ref_keysg == set(wg), ref_keysg ^ set(wg)
+    xg = torch.randn(2, 3, 56, 84, generator=torch.Generator().manual_seed(5))
+    refg = run_reference(modelg, xg)
+    report["tiny_giant"] = check_against_oracle("tiny_giant", refg, wg, cfgg, xg)
+    np.savez_compressed(os.path.join(GOLD, "tiny_giant.npz"), weight_seed=4, input=xg.numpy(), depth=refg[5].numpy(), fused=refg[4].numpy(),
+                        **{f"tap{i}": refg[2][i].numpy() for i in range(4)})
+
     # ------------------------------------------------------------------ 2. position embedding resize
     base = w["imgencoder.posenc.base_patch_embedding"]
     pos = {}
