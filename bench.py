@@ -147,7 +147,7 @@ def main():
             line["path_tflops"] = round(value * gflop / 1e3, 2)
             line["path_frac_of_mfma_peak"] = round(value * gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
         if prof and prof["kernels"]:
-            gemms = [k for k in prof["kernels"] if k["gflop"] > 0 and k["name"].startswith("gemm_kernel")]
+            gemms = [k for k in prof["kernels"] if k["gflop"] > 0 and k["name"].startswith("gemm")]
             dom = max(gemms, key=lambda k: k["total_ms"]) if gemms else prof["kernels"][0]
             line["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": dom["name"],
