@@ -183,16 +183,18 @@ __global__ __launch_bounds__(256) void zero_vt_pad_kernel(bf16_t* vt_hi, bf16_t*
 
 // ---------------------------------------------------------------------------------------------------
 // bilinear resize, align_corners=True (components/misc_helpers.py:39-42): src = dst*(in-1)/(out-1).
-// NHWC fp32 in -> bf16 hi(/lo) and/or fp32 out. One thread = 4 channels of one output pixel.
+// NHWC fp32 in -> bf16 hi(/lo) and/or fp32 out. One thread = CPT (4 or 8) channels of one output pixel: a CU retires
+// about one store instruction per 64 cycles whatever its width, so the bf16 output wants 16-byte (8-channel) stores.
 // ---------------------------------------------------------------------------------------------------
+template <int CPT>
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, bf16_t* out_hi, bf16_t* out_lo,
                                                        float* out_f32, int B, int Hi, int Wi, int Ho, int Wo, int C) {
-    const int cq = C / 4;
+    const int cq = C / CPT;
     const size_t total = (size_t)B * Ho * Wo * cq;
     const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.0f;
     const float sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.0f;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % cq) * 4;
+        const int c = (int)(idx % cq) * CPT;
         const size_t pix = idx / cq;
         const int x = (int)(pix % Wo);
         const int y = (int)((pix / Wo) % Ho);
@@ -202,14 +204,37 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
         const int y1 = y0 + (y0 < Hi - 1), x1 = x0 + (x0 < Wi - 1);
         const float ly = fy - (float)y0, lx = fx - (float)x0;
         const float* base = in + (size_t)b * Hi * Wi * C + c;
-        const f32x4 v00 = *(const f32x4*)(base + ((size_t)y0 * Wi + x0) * C);
-        const f32x4 v01 = *(const f32x4*)(base + ((size_t)y0 * Wi + x1) * C);
-        const f32x4 v10 = *(const f32x4*)(base + ((size_t)y1 * Wi + x0) * C);
-        const f32x4 v11 = *(const f32x4*)(base + ((size_t)y1 * Wi + x1) * C);
-        const f32x4 v = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
         const size_t o = pix * C + c;
-        if (out_hi) split_store4(out_hi, out_lo, o, v);
-        if (out_f32) *(f32x4*)(out_f32 + o) = v;
+        f32x4 v[CPT / 4];
+#pragma unroll
+        for (int q = 0; q < CPT / 4; ++q) {
+            const f32x4 v00 = *(const f32x4*)(base + ((size_t)y0 * Wi + x0) * C + 4 * q);
+            const f32x4 v01 = *(const f32x4*)(base + ((size_t)y0 * Wi + x1) * C + 4 * q);
+            const f32x4 v10 = *(const f32x4*)(base + ((size_t)y1 * Wi + x0) * C + 4 * q);
+            const f32x4 v11 = *(const f32x4*)(base + ((size_t)y1 * Wi + x1) * C + 4 * q);
+            v[q] = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+            if (out_f32) *(f32x4*)(out_f32 + o + 4 * q) = v[q];
+        }
+        if (out_hi) {
+            if (CPT == 8) {
+                bf16x4 h0, h1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h0[e] = (__bf16)v[0][e]; h1[e] = (__bf16)v[CPT / 4 - 1][e]; }
+                typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+                bf16x8_t h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h[e] = h0[e]; h[e + 4] = h1[e]; }
+                *(bf16x8_t*)(out_hi + o) = h;
+                if (out_lo) {
+                    bf16x8_t l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { l[e] = (__bf16)(v[0][e] - (float)h0[e]); l[e + 4] = (__bf16)(v[CPT / 4 - 1][e] - (float)h1[e]); }
+                    *(bf16x8_t*)(out_lo + o) = l;
+                }
+            } else {
+                split_store4(out_hi, out_lo, o, v[0]);
+            }
+        }
     }
 }
 
@@ -521,7 +546,10 @@ int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float*
     if (C & 3) return (int)hipErrorInvalidValue;
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
     MdptProfScope prof("upsample_kernel", 0.0, stream);
-    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, stream, in, out_hi, out_lo, out_f32, B, Hi, Wi, Ho, Wo, C);
+    if ((C & 7) == 0 && out_hi)
+        hipLaunchKernelGGL(upsample_kernel<8>, dim3(grid_for(total / 2)), dim3(256), 0, stream, in, out_hi, out_lo, out_f32, B, Hi, Wi, Ho, Wo, C);
+    else
+        hipLaunchKernelGGL(upsample_kernel<4>, dim3(grid_for(total)), dim3(256), 0, stream, in, out_hi, out_lo, out_f32, B, Hi, Wi, Ho, Wo, C);
     LAUNCH_RET();
 }
 

@@ -519,6 +519,120 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
 // re-staged ONE phase later, which is safe because the reading phase retires its 4 B reads (issued first, order pinned)
 // with lgkmcnt(8) BEFORE its first barrier.
 // ------------------------------------------------------------------------------------------------------------
+// Direct (register -> global) epilogues of the 8-phase kernel for tiles computed with SWAPPED MFMA operands
+// (acc = mfma(B frag, A frag)): a lane then owns, for output row m = 16-row block + (lane & 15), four CONSECUTIVE columns
+// n = 16-col block + 4*(lane >> 4) + r - fp32 values go out as 16-byte vectors straight from the accumulators, and a bf16
+// result gets its 8-column / 16-byte vectors by one v_permlane16_swap per register pair between lanes l and l^16
+// (even 16-lane rows collect block j = 0, odd rows block j = 1). No LDS round trip. Everything is unrolled over the 128
+// accumulator registers, so only the three hot epilogues of the encoder get this form (small code, no per-row feature
+// branches); every other combination runs the plain operand order + the LDS-strip epilogue:
+//   DM_BF16  : out_hi(/lo) = act(acc + bias)                    (fc1 + GELU; plain bf16 outputs)
+//   DM_RESID : out_f32 = resid + gamma * (acc + bias), fp32      (attention proj, fc2: in-place residual update)
+//   DM_QK    : Q (pre-scaled) / K head-major bf16(/lo)            (QKV tiles without V columns)
+enum { DM_NONE = 0, DM_BF16 = 1, DM_RESID = 2, DM_QK = 3 };
+
+template <int MODE>
+__device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc)[2][2][4][2], int m0, int n0, int grp, int wc, int lane) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const int l15 = lane & 15, lh = lane >> 4;
+    const bool x3 = MODE == DM_QK ? p.q_lo != nullptr : p.out_lo != nullptr;
+    const bool gelu = MODE == DM_BF16 && p.act == MDPT_ACT_GELU;
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn) {
+        const int nq = n0 + qn * 128 + wc * 32;
+        const int n8 = nq + (lh & 1) * 16 + (lh >> 1) * 8;  // first of the 8 columns this lane stores as bf16
+        // per-column constants of this lane's two 4-column groups (clamped: out-of-range columns are never stored)
+        f32x4 bias[2], gam[2];
+        int ncol[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            ncol[j] = nq + j * 16 + 4 * lh;
+            const int nc = ncol[j] < p.N ? ncol[j] : p.N - 4;
+            bias[j] = p.bias ? *(const f32x4*)(p.bias + nc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (MODE == DM_RESID) gam[j] = *(const f32x4*)(p.gamma + nc);
+            if (MODE == DM_QK && ncol[j] < p.F) gam[j] = f32x4{p.qscale, p.qscale, p.qscale, p.qscale};
+            else if (MODE == DM_QK) gam[j] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+        }
+        // QKV: destination of this lane's 8-column group (head-major planes)
+        bf16_t* qk_hi = nullptr;
+        bf16_t* qk_lo = nullptr;
+        int qk_h = 0, qk_d = 0;
+        if (MODE == DM_QK) {
+            const int which = n8 >= p.F;
+            const int f = n8 - which * p.F;
+            qk_h = f >> 6; qk_d = f & 63;
+            qk_hi = which ? p.k_hi : p.q_hi;
+            qk_lo = which ? p.k_lo : p.q_lo;
+        }
+#pragma unroll
+        for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + qm * 128 + grp * 64 + i * 16 + l15;
+                const bool mok = m < p.M;
+                f32x4 v[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    v[j] = acc[qm][qn][i][j] + bias[j];
+                    if (MODE == DM_RESID) {
+                        if (mok && ncol[j] < p.N) {
+                            float* rp = p.out_f32 + (size_t)m * p.ldc + ncol[j];  // == resid row (in place), ldr == ldc checked by the caller
+                            *(f32x4*)rp = v[j] * gam[j] + *(const f32x4*)(p.resid + (size_t)m * p.ldr + ncol[j]);
+                        }
+                    } else if (MODE == DM_QK) {
+                        v[j] *= gam[j];
+                    } else if (gelu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[j][e] = gelu_erf(v[j][e]);
+                    } else if (p.act == MDPT_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[j][e] = fmaxf(v[j][e], 0.0f);
+                    }
+                }
+                if (MODE == DM_RESID) continue;
+                // ---- bf16 result: pack pairs, exchange halves with lane ^ 16, one 16-byte store (two in x3 mode)
+                unsigned hw_[2][2], lw_[2][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int w2 = 0; w2 < 2; ++w2) {
+                        const f32x2 pp = {v[j][2 * w2], v[j][2 * w2 + 1]};
+                        const bf16x2 hh = __builtin_convertvector(pp, bf16x2);
+                        hw_[j][w2] = __builtin_bit_cast(unsigned, hh);
+                        const f32x2 rr = pp - __builtin_convertvector(hh, f32x2);
+                        lw_[j][w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                    }
+                unsigned ph[4], pl[4];
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2) {
+                    auto r = __builtin_amdgcn_permlane16_swap(hw_[0][w2], hw_[1][w2], false, false);
+                    ph[w2] = r[0];
+                    ph[w2 + 2] = r[1];
+                    if (x3) {
+                        auto rl = __builtin_amdgcn_permlane16_swap(lw_[0][w2], lw_[1][w2], false, false);
+                        pl[w2] = rl[0];
+                        pl[w2 + 2] = rl[1];
+                    }
+                }
+                if (!mok || n8 >= p.N) continue;
+                size_t o;
+                bf16_t *oh, *ol;
+                if (MODE == DM_BF16) {
+                    o = (size_t)m * p.ldc + n8;
+                    oh = p.out_hi; ol = p.out_lo;
+                } else {
+                    const int b = m / p.npad, tk = m - b * p.npad;
+                    o = ((size_t)(b * p.heads + qk_h) * p.npad + tk) * 64 + qk_d;
+                    oh = qk_hi; ol = qk_lo;
+                }
+                *(u32x4*)(oh + o) = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                if (x3) *(u32x4*)(ol + o) = u32x4{pl[0], pl[1], pl[2], pl[3]};
+            }
+    }
+}
+
 template <int AMODE>
 struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i covers rows 8c..8c+7; half h = chunks i in {2h, 2h+1}
     static constexpr int A_BYTES = 256 * 128;
@@ -618,18 +732,15 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
     }
 };
 
-template <int AMODE, int EKIND>
-__global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
+template <int AMODE, int EKIND, bool SW>
+__device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, const int dmode, const int m0, const int n0,
+                                           const unsigned long long t_start) {
     constexpr int A_BYTES = 256 * 128, BUF = 2 * A_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wc = wave & 3;
-    unsigned long long t_start = 0, t_first = 0, t_loop = 0;
-    if (p.dbg_times) t_start = memtime_now();
-
-    int m0, n0;
-    tile_coords((p.N + 255) / 256, 256, 256, m0, n0);
+    unsigned long long t_first = 0, t_loop = 0;
+    constexpr bool swapped = SW;
     HalfStager<AMODE> st;
     st.init(p, m0, n0, wave, lane);
 
@@ -671,7 +782,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                              \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
-                    acc[QM_][QN_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kk], FB_[j][kk], acc[QM_][QN_][i][j], 0, 0, 0); \
+                    acc[QM_][QN_][i][j] = swapped ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB_[j][kk], fa[i][kk], acc[QM_][QN_][i][j], 0, 0, 0) \
+                                                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kk], FB_[j][kk], acc[QM_][QN_][i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                                \
     } while (0)
 #define WAIT_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory")
@@ -739,6 +851,19 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
 #undef LOAD_B
 #undef MFMA_Q
     if (p.dbg_times) t_loop = memtime_now();
+    if constexpr (SW) {
+        if (EKIND == MDPT_E_QKV) epilogue_direct<DM_QK>(p, acc, m0, n0, grp, wc, lane);
+        else if (dmode == DM_BF16) epilogue_direct<DM_BF16>(p, acc, m0, n0, grp, wc, lane);
+        else epilogue_direct<DM_RESID>(p, acc, m0, n0, grp, wc, lane);
+        if (p.dbg_times && tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned long long* d = p.dbg_times + (size_t)blockIdx.x * 6;
+            d[0] = t_start; d[1] = t_first; d[2] = t_loop; d[3] = memtime_now();
+            d[4] = __builtin_amdgcn_s_getreg(20 << 0 | 0 << 6 | 3 << 11);
+            d[5] = __builtin_amdgcn_s_getreg(4 << 0 | 0 << 6 | 31 << 11);
+        }
+        return;
+    }
     __syncthreads();  // every wave is done reading the ring: reuse it as epilogue staging
 
     // ---- epilogue: per quadrant two [32][32] blocks through the wave-private strip (C layout of the 16x16 MFMA:
@@ -770,6 +895,32 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
 #undef BAR
 #undef WAIT_LGKM
 #undef WAIT_VM
+
+template <int AMODE, int EKIND>
+__global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long t_start = 0;
+    if (p.dbg_times) t_start = memtime_now();
+    int m0, n0;
+    tile_coords((p.N + 255) / 256, 256, 256, m0, n0);
+    // operand order of the MFMAs (workgroup-uniform, two separate instantiations of the body): swapped -> accumulators hold
+    // 4 consecutive COLUMNS per lane and one of the direct epilogues applies; plain order (4 consecutive ROWS per lane) +
+    // LDS strip for every other epilogue and for QKV tiles that contain V columns (written transposed, token-contiguous)
+    int dmode = DM_NONE;
+    if (EKIND == MDPT_E_GENERIC) {
+        const bool plain = !p.up_src && !p.bias_img_stride;
+        if (plain && p.out_hi && !p.out_f32 && !p.gamma && !p.resid && !p.relu_bf16) dmode = DM_BF16;
+        else if (plain && p.out_f32 && !p.out_hi && p.gamma && p.resid && p.bias && p.act == MDPT_ACT_NONE && p.ldr == p.ldc) dmode = DM_RESID;
+    } else if (EKIND == MDPT_E_QKV && n0 + 256 <= 2 * p.F) {
+        dmode = DM_QK;
+    }
+    if (EKIND == MDPT_E_GENERIC || EKIND == MDPT_E_QKV) {
+        if (dmode != DM_NONE) gemm8_body<AMODE, EKIND, true>(p, smem, dmode, m0, n0, t_start);
+        else gemm8_body<AMODE, EKIND, false>(p, smem, dmode, m0, n0, t_start);
+    } else {
+        gemm8_body<AMODE, EKIND, false>(p, smem, dmode, m0, n0, t_start);
+    }
+}
 
 template <int AMODE, int EKIND>
 int launch_pp(const GemmParams& p, hipStream_t stream) {

@@ -10,8 +10,9 @@ from muggled_dpt_amd import native
 
 lib = native.load()
 stream = torch.cuda.current_stream().cuda_stream
-N, K, tile = 1024, 1024, 2
-for M in (256, 2048, 8192, 16384, 41728):
+N, K = 1024, 1024
+tile = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+for M in (256, 16384, 41728):
     a = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)
     w = (torch.rand(N, K, device="cuda") * 2 - 1).to(torch.bfloat16)
     out = torch.empty(M, N, device="cuda", dtype=torch.float32)
