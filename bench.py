@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-launch HIP events in the timed region")
+    ap.add_argument("--no-split", action="store_true", help="disable the two-stream half-batch split inside mdpt_forward")
     args = ap.parse_args()
 
     rank, world, local_rank = init_distributed()
@@ -94,6 +95,9 @@ def main():
     model = model.to(dev, dtype)
     if args.tile:
         model.set_gemm_tile(args.tile)
+    if args.no_split:
+        from muggled_dpt_amd import native as _native
+        _native.check(_native.load(), _native.load().mdpt_set_batch_split(model._get_engine().handle, 0))
     x_cpu = torch.randn(args.batch, 3, args.size, args.size, generator=torch.Generator().manual_seed(1 + rank))
     x = x_cpu.to(dev).to(dtype)
     dp = DataParallelDepth(model, rank, world)
@@ -141,7 +145,7 @@ def main():
                                    f"{args.batch}/GPU, {args.precision} MFMA operands + fp32 accumulate, mdpt_forward via C ABI"
                                    + (", RCCL all-gather of depth maps" if world > 1 else ""),
                        "global_batch": world * args.batch, "tensor_hw": [args.size, args.size], "parallelism": f"dp{world}",
-                       "gemm_tile": args.tile},
+                       "gemm_tile": args.tile, "batch_split": not args.no_split},
         }
         if gflop:
             line["path_tflops"] = round(value * gflop / 1e3, 2)

@@ -126,6 +126,12 @@ int mdpt_fusion(mdpt_handle* h, const void* const maps_in[4], int32_t B, int32_t
 int mdpt_head(mdpt_handle* h, const void* fused_in, int32_t B, int32_t gh, int32_t gw, void* depth_bhw, void* workspace,
               size_t workspace_bytes, void* stream);
 
+/* Batches of at least `min_batch` images (default 8; 0 = never) are run by mdpt_forward as two half batches, one on the caller's
+ * stream and one on an internal side stream (event fork / join, no host synchronisation): the halves' kernels overlap and fill
+ * each other's partially occupied last round of tiles. Results are bit-identical to the unsplit run. mdpt_workspace_bytes
+ * accounts for the split. */
+int mdpt_set_batch_split(mdpt_handle* h, int32_t min_batch);
+
 /* PatchEmbed.prepare_image (v2_depthanything/patch_embed.py:103-145): uint8 [in_h,in_w,3] BGR on the device ->
  * fp32 [3,out_h,out_w] RGB, antialiased-bilinear resized exactly like F.interpolate(..., antialias=True) and normalised with the
  * given per-channel mean/std (ImageNet values for Depth-Anything, 0.5/0.5 for BEiT). The caller picks out_h/out_w with the reference's size rule (multiples of 2*patch). */

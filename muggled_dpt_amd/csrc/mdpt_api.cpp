@@ -130,6 +130,16 @@ struct mdpt_handle {
     Plan last_plan;
     bool has_last;
     int dbg_block, dbg_step;  // test hook: stop the encoder after (block, step); -1 = off
+    // batch split: batches >= split_min run as two halves on the caller's stream and an internal side stream (fork / join with
+    // events, no host sync) so that one half's kernels fill the tile-quantisation tails and epilogue phases of the other's
+    int split_min;
+    hipStream_t side_stream;
+    hipEvent_t ev_fork, ev_join;
+    ~mdpt_handle() {
+        if (side_stream) hipStreamDestroy(side_stream);
+        if (ev_fork) hipEventDestroy(ev_fork);
+        if (ev_join) hipEventDestroy(ev_join);
+    }
 
     void add_spec(const std::string& name, std::initializer_list<int64_t> shape) {
         WeightSpec s;
@@ -806,6 +816,9 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     h->has_last = false;
     h->zero_page = nullptr;
     h->dbg_block = h->dbg_step = -1;
+    h->split_min = 8;
+    h->side_stream = nullptr;
+    h->ev_fork = h->ev_join = nullptr;
     build_inventory(h);
     *out = h;
     return 0;
@@ -897,6 +910,18 @@ int mdpt_workspace_bytes(const mdpt_handle* h, int32_t B, int32_t H, int32_t W, 
     Plan p;
     CHK(make_plan(h, B, H, W, &p));
     *bytes = p.total;
+    if (h->split_min > 0 && B >= h->split_min && B >= 2) {  // two half-batch plans side by side (mdpt_forward)
+        Plan p0, p1;
+        CHK(make_plan(h, B / 2, H, W, &p0));
+        CHK(make_plan(h, B - B / 2, H, W, &p1));
+        if (rup256(p0.total) + p1.total > *bytes) *bytes = rup256(p0.total) + p1.total;
+    }
+    return 0;
+}
+
+int mdpt_set_batch_split(mdpt_handle* h, int32_t min_batch) {
+    if (!h || min_batch < 0) return fail(MDPT_E_INVALID, "bad argument");
+    h->split_min = min_batch == 1 ? 2 : min_batch;
     return 0;
 }
 
@@ -906,11 +931,45 @@ int mdpt_set_gemm_tile(mdpt_handle* h, int32_t tile) {
     return 0;
 }
 
+static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, void* depth_bhw);
+
 int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t B, int32_t H, int32_t W, void* depth_bhw, void* workspace,
                  size_t workspace_bytes, void* stream) {
     if (!h || !image_bchw || !depth_bhw) return fail(MDPT_E_INVALID, "null argument");
+    if (h->split_min > 0 && B >= h->split_min && B >= 2 && h->dbg_block < 0) {
+        // two half batches, one on the caller's stream, one on the side stream; joined before returning to the caller's stream
+        const int B0 = B / 2, B1 = B - B0;
+        Plan p0, p1;
+        CHK(make_plan(h, B0, H, W, &p0));
+        CHK(make_plan(h, B1, H, W, &p1));
+        CHK(check_ws(h, p0, workspace, workspace_bytes));
+        const size_t off1 = rup256(p0.total);
+        if (workspace_bytes < off1 + p1.total) return fail(MDPT_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", off1 + p1.total, workspace_bytes);
+        if (!h->side_stream) {
+            CHK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+            CHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            CHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
+        hipStream_t s0 = (hipStream_t)stream;
+        CHK(hipEventRecord(h->ev_fork, s0));
+        CHK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+        Ctx c0, c1;
+        c0.h = h; c0.p = p0; c0.ws = (char*)workspace; c0.s = s0;
+        c1.h = h; c1.p = p1; c1.ws = (char*)workspace + off1; c1.s = h->side_stream;
+        const size_t in_stride = (size_t)3 * H * W * 4, out_stride = (size_t)H * W * 4;
+        CHK(forward_one(h, c0, image_bchw, depth_bhw));
+        CHK(forward_one(h, c1, (const char*)image_bchw + in_stride * B0, (char*)depth_bhw + out_stride * B0));
+        CHK(hipEventRecord(h->ev_join, h->side_stream));
+        CHK(hipStreamWaitEvent(s0, h->ev_join, 0));
+        h->has_last = false;  // taps live in two half-batch plans: mdpt_export_tap is for unsplit (small) batches
+        return 0;
+    }
     Ctx c;
     CHK(make_ctx(h, B, H, W, workspace, workspace_bytes, stream, &c));
+    return forward_one(h, c, image_bchw, depth_bhw);
+}
+
+static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, void* depth_bhw) {
     if (h->swin) {
         CHK(run_patch_embed_swin(c, (const float*)image_bchw, nullptr));
         h->last_plan = c.p;
