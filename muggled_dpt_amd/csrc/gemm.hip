@@ -968,7 +968,7 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
         // per CU, finer tile quantisation). The 256x128x32 3-deep-ring variant is kept selectable but never won.
         const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-        const bool big = p.N % 256 == 0 && (tiles256 >= 512 || (tiles256 >= 256 && p.K >= 2048));
+        const bool big = p.N % 256 == 0 && tiles256 >= 200;  // >= ~0.8 rounds of 256x256 tiles (measured: 8-phase wins from there)
         // small problems (batch 1): 128x128 tiles would leave most of the 256 CUs idle -> 64x64 tiles
         // the 8-phase schedule of the 256x256 tile beats the lockstep one on every measured shape (+11..23 %); it walks K in
         // pairs of 64-deep tiles, the lockstep kernel takes the odd counts
