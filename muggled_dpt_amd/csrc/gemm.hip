@@ -963,16 +963,15 @@ template <int AMODE, int EKIND>
 int launch_tile(const GemmParams& p, hipStream_t stream) {
     int tile = p.tile;
     if (tile == MDPT_TILE_AUTO) {
-        // measured on MI355X (tests/gpu_gemm_bench.py, M = 41728): 256x256x64 wins whenever there are >= 2 rounds of
-        // big tiles or the K loop is deep enough to amortise its ~17k-cycle epilogue; otherwise 128x128x64 (2 workgroups
-        // per CU, finer tile quantisation). The 256x128x32 3-deep-ring variant is kept selectable but never won.
+        // measured on MI355X, kernel alone on the GPU (tests/gpu_gemm_tile_sweep.py): the 8-phase 256x256 tile wins from ~140
+        // tiles (0.55 rounds; one tile takes ~25 us at K = 1024 whatever the count), 64x64 tiles win the latency race while
+        // there are <= ~330 128x128 tiles, 128x128 (2 workgroups per CU) in between. When the other half batch runs on a second
+        // stream (throughput_mode) idle CUs are not wasted, so the tile with the best CU-time per flop - the big one - is taken
+        // much earlier.
         const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-        const bool big = p.N % 256 == 0 && tiles256 >= 200;  // >= ~0.8 rounds of 256x256 tiles (measured: 8-phase wins from there)
-        // small problems (batch 1): 128x128 tiles would leave most of the 256 CUs idle -> 64x64 tiles
-        // the 8-phase schedule of the 256x256 tile beats the lockstep one on every measured shape (+11..23 %); it walks K in
-        // pairs of 64-deep tiles, the lockstep kernel takes the odd counts
-        tile = big ? MDPT_TILE_PP256 : (tiles128 < 384 ? MDPT_TILE_64x64 : MDPT_TILE_128x128);
+        const bool big = p.N % 256 == 0 && tiles256 >= (p.throughput_mode ? 24 : 140);
+        tile = big ? MDPT_TILE_PP256 : (tiles128 <= 330 ? MDPT_TILE_64x64 : MDPT_TILE_128x128);
     }
     if (tile == MDPT_TILE_64x64) return launch_cfg<64, 64, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);
     if (tile == MDPT_TILE_PP256 && (((p.K / 64) * p.npass) & 1) == 0) return launch_pp<AMODE, EKIND>(p, stream);

@@ -444,6 +444,7 @@ struct Ctx {
     Plan p;
     char* ws;
     hipStream_t s;
+    bool split = false;  // this context is one half of a two-stream batch split
     template <class T> T* at(size_t off) const { return off == SIZE_MAX ? nullptr : (T*)(ws + off); }
     Planes pl(const size_t o[2]) const {
         Planes r;
@@ -462,6 +463,7 @@ GemmParams base_params(const Ctx& c, const Mat& w, Planes a, int M, int lda) {
     g.npass = c.h->x3 ? 3 : 1;
     g.zero_page = c.h->zero_page;
     g.amode = MDPT_A_DENSE; g.ekind = MDPT_E_GENERIC; g.tile = c.h->gemm_tile;
+    g.throughput_mode = c.split ? 1 : 0;
     g.ldc = w.Np; g.ldr = w.Np;
     return g;
 }
@@ -954,8 +956,8 @@ int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t B, int32_t H, i
         CHK(hipEventRecord(h->ev_fork, s0));
         CHK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
         Ctx c0, c1;
-        c0.h = h; c0.p = p0; c0.ws = (char*)workspace; c0.s = s0;
-        c1.h = h; c1.p = p1; c1.ws = (char*)workspace + off1; c1.s = h->side_stream;
+        c0.h = h; c0.p = p0; c0.ws = (char*)workspace; c0.s = s0; c0.split = true;
+        c1.h = h; c1.p = p1; c1.ws = (char*)workspace + off1; c1.s = h->side_stream; c1.split = true;
         const size_t in_stride = (size_t)3 * H * W * 4, out_stride = (size_t)H * W * 4;
         CHK(forward_one(h, c0, image_bchw, depth_bhw));
         CHK(forward_one(h, c1, (const char*)image_bchw + in_stride * B0, (char*)depth_bhw + out_stride * B0));

@@ -46,6 +46,7 @@ struct GemmParams {
     // E_HEAD: N == 32: depth[m] = final( sum_n relu(acc+bias[n]) * head_w[n] + head_b )
     const float* head_w; const float* head_b; int head_sigmoid; float* head_out;
     // test hook: per-workgroup phase timestamps (s_memtime): [start, first barrier passed, main loop done, epilogue done]
+    int throughput_mode;  // 1: another stream runs the other half batch concurrently -> pick tiles by CU-time efficiency, not latency
     unsigned long long* dbg_times;
 };
 
