@@ -133,12 +133,12 @@ def main():
             # roofline, time the same steps once more with the split off (every kernel alone on the GPU, same stream events).
             handle = model._get_engine().handle
             native.check(lib, lib.mdpt_set_batch_split(handle, 0))
-            with torch.inference_mode():
-                dp.forward_shard(x)
+            with torch.inference_mode():  # local forward only (no collective: the other ranks are not in this pass)
+                model(x)
                 torch.cuda.synchronize()
                 lib.mdpt_profile_enable(1)
                 for _ in range(args.steps):
-                    dp.forward_shard(x)
+                    model(x)
                 torch.cuda.synchronize()
             buf = ctypes.create_string_buffer(1 << 16)
             if lib.mdpt_profile_report(buf, len(buf)) == 0:
