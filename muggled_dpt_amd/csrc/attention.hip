@@ -332,20 +332,42 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             } else {
                 orow = ((size_t)b * p.npad + q) * p.F + h * HD;
             }
+            // 16-byte stores (a CU retires about one store instruction per 64 cycles whatever its width): this lane owns
+            // d = 8g + 4*half + 0..3 for g = 0..3; one v_permlane32_swap per packed register pair hands the lower lane the
+            // whole d = 8g .. 8g+7 run of the even g and the upper lane that of the odd g
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
 #pragma unroll
             for (int db = 0; db < DB; ++db)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 hi4, lo4;
+                for (int gp = 0; gp < 2; ++gp) {
+                    unsigned hx[2][2], lx[2][2];  // [g parity][packed pair]
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = o_acc[qb][db][g * 4 + e] * inv;
-                        hi4[e] = (__bf16)v;
-                        if (X3) lo4[e] = (__bf16)(v - (float)hi4[e]);
+                    for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                        for (int w2 = 0; w2 < 2; ++w2) {
+                            const f32x2 pp = {o_acc[qb][db][(2 * gp + gi) * 4 + 2 * w2] * inv, o_acc[qb][db][(2 * gp + gi) * 4 + 2 * w2 + 1] * inv};
+                            const bf16x2 hh = __builtin_convertvector(pp, bf16x2);
+                            hx[gi][w2] = __builtin_bit_cast(unsigned, hh);
+                            if (X3) {
+                                const f32x2 rr = pp - __builtin_convertvector(hh, f32x2);
+                                lx[gi][w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                            }
+                        }
+                    unsigned oh[4], ol[4];
+#pragma unroll
+                    for (int w2 = 0; w2 < 2; ++w2) {
+                        auto r = __builtin_amdgcn_permlane32_swap(hx[0][w2], hx[1][w2], false, false);
+                        oh[w2] = r[0];
+                        oh[w2 + 2] = r[1];
+                        if (X3) {
+                            auto rl = __builtin_amdgcn_permlane32_swap(lx[0][w2], lx[1][w2], false, false);
+                            ol[w2] = rl[0];
+                            ol[w2 + 2] = rl[1];
+                        }
                     }
-                    const size_t o = orow + db * 32 + 8 * g + 4 * half;
-                    *(bf16x4*)(p.out_hi + o) = hi4;
-                    if (X3) *(bf16x4*)(p.out_lo + o) = lo4;
+                    const size_t o = orow + db * 32 + 8 * (2 * gp + half);
+                    *(u32x4s*)(p.out_hi + o) = u32x4s{oh[0], oh[1], oh[2], oh[3]};
+                    if (X3) *(u32x4s*)(p.out_lo + o) = u32x4s{ol[0], ol[1], ol[2], ol[3]};
                 }
         }
     }
