@@ -170,13 +170,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         const char* sV = sK + NPL * TILE;
 
         // ---- S^T[key][query] for 2 blocks of 32 keys x QB blocks of 32 queries
+        // The first MFMA of every accumulator takes a constant-zero C operand (an inline constant in the instruction) instead of
+        // a zeroed register block: the kernel is VALU-bound and clearing 64 registers per tile costs 32 v_mov_b64
         f32x16 s[QB][2];
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[qb][blk][r] = 0.0f;
+        const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -189,10 +186,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
                     if (X3) {
-                        s[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[qb][ks], s[qb][blk], 0, 0, 0);
+                        s[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[qb][ks], ks == 0 ? zero16 : s[qb][blk], 0, 0, 0);
                         s[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[qb][ks], s[qb][blk], 0, 0, 0);
+                        s[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[qb][ks], s[qb][blk], 0, 0, 0);
+                    } else {
+                        s[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[qb][ks], ks == 0 ? zero16 : s[qb][blk], 0, 0, 0);
                     }
-                    s[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[qb][ks], s[qb][blk], 0, 0, 0);
                 }
             }
         if (BIAS) {
@@ -240,15 +239,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kLog2e);
             const float mb = m_new * kLog2e;
             m_run[qb] = m_new;
-            float psum = 0.0f;
+            f32x2 psum2 = {0.0f, 0.0f};
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(s[qb][blk][r] * kLog2e - mb);
-                    s[qb][blk][r] = e;
-                    psum += e;
+                for (int r = 0; r < 16; r += 2) {
+                    const float e0 = __builtin_amdgcn_exp2f(s[qb][blk][r] * kLog2e - mb);
+                    const float e1 = __builtin_amdgcn_exp2f(s[qb][blk][r + 1] * kLog2e - mb);
+                    s[qb][blk][r] = e0;
+                    s[qb][blk][r + 1] = e1;
+                    psum2 += f32x2{e0, e1};  // one v_pk_add_f32 per pair
                 }
+            const float psum = psum2[0] + psum2[1];
             l_run[qb] = l_run[qb] * alpha + psum;
             if (__any(alpha != 1.0f)) {  // after the first tiles the running max rarely moves: skip 32 multiplies
 #pragma unroll
