@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void zero_vt_pad_kernel(bf16_t* vt_hi, bf16_t*
 template <int CPT>
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, bf16_t* out_hi, bf16_t* out_lo,
                                                        float* out_f32, int B, int Hi, int Wi, int Ho, int Wo, int C) {
+#pragma clang fp contract(off)  // the direct and the tiled kernel must round identically (batch-size independent bits)
     const int cq = C / CPT;
     const size_t total = (size_t)B * Ho * Wo * cq;
     const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.0f;
@@ -234,6 +235,73 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
             } else {
                 split_store4(out_hi, out_lo, o, v[0]);
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-tiled form for the big maps (fp32 NHWC in, bf16 hi(/lo) out): a workgroup owns an 8x8 block of OUTPUT pixels, stages the
+// (at most 7x7) source patch they interpolate from once in LDS and reads its four neighbours per pixel from there. The direct
+// kernel issues four 16-byte global loads per 8-byte result and tops out at ~2.5 TB/s on the vector-memory path; here the
+// source is read from global once (x1.2-1.7 halo), so the kernel is limited by the unavoidable HBM bytes.
+// Same arithmetic, same operation order as upsample_kernel (bit-identical results).
+// ---------------------------------------------------------------------------------------------------
+template <int C8>  // channels / 8 (lanes per pixel): 32 -> C = 256, 16 -> C = 128
+__global__ __launch_bounds__(256) void upsample_tiled_kernel(const float* __restrict__ in, bf16_t* out_hi, bf16_t* out_lo, int B, int Hi,
+                                                             int Wi, int Ho, int Wo) {
+#pragma clang fp contract(off)
+    constexpr int C = C8 * 8, TS = 8, PS = 7;  // tile side, max patch side
+    extern __shared__ __attribute__((aligned(16))) float patch[];  // [PS*PS][C]
+    const int tiles_x = (Wo + TS - 1) / TS, tiles_y = (Ho + TS - 1) / TS;
+    const int bt = blockIdx.x;
+    const int tx = bt % tiles_x, ty = (bt / tiles_x) % tiles_y, b = bt / (tiles_x * tiles_y);
+    const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.0f;
+    const float sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.0f;
+    const int oy0 = ty * TS, ox0 = tx * TS;
+    const int oy1 = min(oy0 + TS, Ho) - 1, ox1 = min(ox0 + TS, Wo) - 1;
+    const int py0 = (int)(sy * (float)oy0), px0 = (int)(sx * (float)ox0);      // first source row / column of the patch
+    const int py1 = min((int)(sy * (float)oy1) + 1, Hi - 1), px1 = min((int)(sx * (float)ox1) + 1, Wi - 1);
+    const int ph = py1 - py0 + 1, pw = px1 - px0 + 1;                           // <= PS (checked by the launcher's scale test)
+    // ---- stage the patch: one 16-byte vector per thread and step, channel-contiguous (coalesced 1 KiB / 512 B rows)
+    const float* src = in + (size_t)b * Hi * Wi * C;
+    constexpr int V = C / 4;  // float4 per pixel
+    for (int i = threadIdx.x; i < ph * pw * V; i += 256) {
+        const int v = i % V, pp = i / V;
+        const int yy = pp / pw, xx = pp - yy * pw;
+        *(f32x4*)(patch + (size_t)(yy * PS + xx) * C + 4 * v) = *(const f32x4*)(src + ((size_t)(py0 + yy) * Wi + (px0 + xx)) * C + 4 * v);
+    }
+    __syncthreads();
+    // ---- 8 channels per thread, C8 lanes per output pixel, 256 / C8 pixels per pass
+    const int lane_c = (threadIdx.x % C8) * 8, lp = threadIdx.x / C8;
+    constexpr int PPP = 256 / C8;
+    for (int pix = lp; pix < TS * TS; pix += PPP) {
+        const int y = oy0 + pix / TS, x = ox0 + pix % TS;
+        if (y >= Ho || x >= Wo) continue;
+        const float fy = sy * (float)y, fx = sx * (float)x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hi - 1), x1 = x0 + (x0 < Wi - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* p00 = patch + (size_t)((y0 - py0) * PS + (x0 - px0)) * C + lane_c;
+        const float* p01 = patch + (size_t)((y0 - py0) * PS + (x1 - px0)) * C + lane_c;
+        const float* p10 = patch + (size_t)((y1 - py0) * PS + (x0 - px0)) * C + lane_c;
+        const float* p11 = patch + (size_t)((y1 - py0) * PS + (x1 - px0)) * C + lane_c;
+        f32x4 v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x4 v00 = *(const f32x4*)(p00 + 4 * q), v01 = *(const f32x4*)(p01 + 4 * q);
+            const f32x4 v10 = *(const f32x4*)(p10 + 4 * q), v11 = *(const f32x4*)(p11 + 4 * q);
+            v[q] = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+        }
+        const size_t o = (((size_t)b * Ho + y) * Wo + x) * C + lane_c;
+        typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+        bf16x8_t h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v[0][e]; h[e + 4] = (__bf16)v[1][e]; }
+        *(bf16x8_t*)(out_hi + o) = h;
+        if (out_lo) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { l[e] = (__bf16)(v[0][e] - (float)h[e]); l[e + 4] = (__bf16)(v[1][e] - (float)h[e + 4]); }
+            *(bf16x8_t*)(out_lo + o) = l;
         }
     }
 }
@@ -546,6 +614,24 @@ int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float*
     if (C & 3) return (int)hipErrorInvalidValue;
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
     MdptProfScope prof("upsample_kernel", 0.0, stream);
+    // big bf16 outputs with 128 / 256 channels and a source span of at most 7 pixels per 8 output pixels (scale >= ~1.2): tiled
+    const bool span_ok = (long)7 * (Hi - 1) <= (long)5 * (Ho - 1) && (long)7 * (Wi - 1) <= (long)5 * (Wo - 1);
+    if (out_hi && !out_f32 && (C == 256 || C == 128) && span_ok && (size_t)B * Ho * Wo >= 65536) {
+        const int tiles = B * ((Ho + 7) / 8) * ((Wo + 7) / 8);
+        const size_t lds = (size_t)49 * C * 4;
+        if (C == 256) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                hipError_t e = hipFuncSetAttribute((const void*)upsample_tiled_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                if (e != hipSuccess) return (int)e;
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(upsample_tiled_kernel<32>, dim3(tiles), dim3(256), lds, stream, in, out_hi, out_lo, B, Hi, Wi, Ho, Wo);
+        } else {
+            hipLaunchKernelGGL(upsample_tiled_kernel<16>, dim3(tiles), dim3(256), lds, stream, in, out_hi, out_lo, B, Hi, Wi, Ho, Wo);
+        }
+        LAUNCH_RET();
+    }
     if ((C & 7) == 0 && out_hi)
         hipLaunchKernelGGL(upsample_kernel<8>, dim3(grid_for(total / 2)), dim3(256), 0, stream, in, out_hi, out_lo, out_f32, B, Hi, Wi, Ho, Wo, C);
     else
