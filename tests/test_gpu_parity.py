@@ -270,3 +270,28 @@ def test_vit_giant_full_width_runs():
     y = model(x)
     assert tuple(y.shape) == (2, 504, 504) and torch.isfinite(y.float()).all() and float(y.float().max()) > 0
     assert torch.equal(y[1:], model(x[1:]))
+
+
+def test_batch_split_under_hipgraph_capture_and_toggle():
+    """mdpt_forward splits batches >= 8 over the caller's stream and an internal side stream (event fork / join). The split must
+    (a) not change a single bit, (b) be capturable into a hipGraph (cross-stream events are legal in stream capture)."""
+    from muggled_dpt_amd import native
+    model, cfg, w = _model("vits", torch.bfloat16)
+    x = seeded_input((8, 3, 252, 252), 17).to("cuda", torch.bfloat16)
+    y_split = model(x)
+    eng = model._get_engine()
+    native.check(eng.lib, eng.lib.mdpt_set_batch_split(eng.handle, 0))
+    y_plain = model(x)
+    native.check(eng.lib, eng.lib.mdpt_set_batch_split(eng.handle, 8))
+    assert torch.equal(y_split, y_plain)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        model(x)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        y_graph = model(x)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y_graph, y_plain)
