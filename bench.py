@@ -169,11 +169,20 @@ def main():
             line["path_tflops"] = round(value * gflop / 1e3, 2)
             line["path_frac_of_mfma_peak"] = round(value * gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
         if prof and prof["kernels"]:
+            def hbm_traffic(kernel_name):
+                """HBM bytes per launch of `kernel_name` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this
+                exact workload, corrected per MI355X_MICROARCH.md: profiles/r01_hbm_traffic.md). bench.py cannot run PMC passes itself."""
+                path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+                if args.model != "vitl" or args.batch != 32 or args.size != 504 or args.precision != "bf16" or not os.path.exists(path):
+                    return None
+                rec = json.load(open(path)).get(kernel_name)
+                return None if rec is None else int((rec["fetch_mb_per_launch"] + rec["write_mb_per_launch"]) * 1e6)
+
             def roof(pr, how):
                 gemms = [k for k in pr["kernels"] if k["gflop"] > 0 and k["name"].startswith("gemm")]
                 dom = max(gemms, key=lambda k: k["total_ms"]) if gemms else pr["kernels"][0]
                 return {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": dom["name"],
+                        "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic(dom["name"]), "kernel": dom["name"],
                         "launches": dom["launches"], "avg_us": dom["avg_us"],
                         "gflop_per_launch": round(dom["gflop"] / dom["launches"], 3), "measured": how}
             if prof_alone and prof_alone["kernels"]:
