@@ -302,6 +302,15 @@ def swin_shift_mask(grid_hw, win_hw, shift_hw) -> torch.Tensor:
     return torch.where(diff != 0, torch.tensor(-100.0), torch.tensor(0.0)).unsqueeze(1)
 
 
+def swin_relative_position_index(win_hw) -> torch.Tensor:
+    """[wa, wa] index into the (2wh-1)(2ww-1) offset table: (yi - yj + wh - 1) * (2ww - 1) + (xi - xj + ww - 1)
+    (components/relative_positional_encoder.py:193-283; worked 2x3 example at :270-275)."""
+    wh, ww = win_hw
+    iy, ix = torch.meshgrid(torch.arange(wh), torch.arange(ww), indexing="ij")
+    iy, ix = iy.flatten(), ix.flatten()
+    return (iy[:, None] - iy[None, :] + wh - 1) * (2 * ww - 1) + (ix[:, None] - ix[None, :] + ww - 1)
+
+
 def swin_cpb_bias(w: dict, pre: str, win_hw, pretrained_window, heads: int) -> torch.Tensor:
     """[1, heads, wa, wa] continuous position bias: 16 * sigmoid(MLP(2->512->heads)(log-spaced relative offsets)), gathered by
     the relative position index (components/relative_positional_encoder.py:60-93, :122-188)."""
@@ -314,9 +323,7 @@ def swin_cpb_bias(w: dict, pre: str, win_hw, pretrained_window, heads: int) -> t
     table = torch.sign(table) * torch.log2(torch.abs(table * 8) + 1.0) / torch.log2(torch.tensor(8.0))
     hid = F.relu(F.linear(table, w[f"{pre}.bias_mlp.0.weight"], w[f"{pre}.bias_mlp.0.bias"]))
     lut = F.linear(hid, w[f"{pre}.bias_mlp.2.weight"]).reshape(-1, heads)
-    iy, ix = torch.meshgrid(torch.arange(wh), torch.arange(ww), indexing="ij")
-    iy, ix = iy.flatten(), ix.flatten()
-    idx = (iy[:, None] - iy[None, :] + wh - 1) * (2 * ww - 1) + (ix[:, None] - ix[None, :] + ww - 1)
+    idx = swin_relative_position_index(win_hw)
     bias = 16 * torch.sigmoid(lut[idx.reshape(-1)])
     return bias.reshape(wh * ww, wh * ww, heads).permute(2, 0, 1).unsqueeze(0)
 

@@ -126,3 +126,23 @@ def test_beit_large_fixture_is_self_consistent(golden_dir):
     g = np.load(os.path.join(golden_dir, "beit_large_384.npz"))
     assert g["depth_strided"].shape == (1, 96, 96) and g["depth_stats"][1] > 0
     assert stats(torch.from_numpy(g["tap0_crop"])).shape == (4,)
+
+
+def test_relative_position_index_matches_the_reference_docstring_example():
+    """The only known-answer data the reference itself carries for this path: the worked 2x3-grid example in
+    v31_beit/components/relative_positional_encoder.py:229-236 (cls row / column / corner = 15 / 16 / 17)."""
+    want = torch.tensor([[17, 15, 15, 15, 15, 15, 15],
+                         [16, 7, 6, 5, 2, 1, 0],
+                         [16, 8, 7, 6, 3, 2, 1],
+                         [16, 9, 8, 7, 4, 3, 2],
+                         [16, 12, 11, 10, 7, 6, 5],
+                         [16, 13, 12, 11, 8, 7, 6],
+                         [16, 14, 13, 12, 9, 8, 7]])
+    assert torch.equal(dpt_oracle.beit_relative_position_index((2, 3)), want)
+    # the device kernels use bias = lut[tq[q] - tk[k]] with tq = (y + gh - 1)(2gw - 1) + x + gw - 1, tk = y (2gw - 1) + x
+    # (beit_relpos_kernel in csrc/elementwise.hip): the same decomposition reproduces the token-token block
+    gh, gw = 2, 3
+    ys, xs = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+    tq = ((ys + gh - 1) * (2 * gw - 1) + xs + gw - 1).flatten()
+    tk = (ys * (2 * gw - 1) + xs).flatten()
+    assert torch.equal(tq[:, None] - tk[None, :], want[1:, 1:])

@@ -147,3 +147,17 @@ def test_make_dpt_routes_swinv2(tmp_path):
     assert model.family == "swinv2" and cfg["window_size_hw"] == (4, 4) and cfg["base_patch_grid_hw"] == (16, 16)
     assert model.patch_embed._tiling_size == 32 and model.patch_embed._default_size_px == 64
     assert hasattr(model.reassemble, "spatial_downx8") and hasattr(model.imgencoder, "patch_merge_layers")
+
+
+def test_relative_position_index_matches_the_reference_docstring_example():
+    """Worked 2x3-window example of v31_swinv2/components/relative_positional_encoder.py:262-275: shifted/scaled y offsets plus
+    shifted x offsets (the two matrices printed there) sum to the index."""
+    ypart = torch.tensor([[5, 5, 5, 0, 0, 0]] * 3 + [[10, 10, 10, 5, 5, 5]] * 3)
+    xpart = torch.tensor([[2, 1, 0, 2, 1, 0], [3, 2, 1, 3, 2, 1], [4, 3, 2, 4, 3, 2]] * 2)
+    assert torch.equal(dpt_oracle.swin_relative_position_index((2, 3)), ypart + xpart)
+    # decomposition used on the device (swin_window_map_kernel in csrc/swin.hip): index = tq[i] - tk[j]
+    wh, ww = 2, 3
+    iy, ix = torch.meshgrid(torch.arange(wh), torch.arange(ww), indexing="ij")
+    tq = ((iy + wh - 1) * (2 * ww - 1) + ix + ww - 1).flatten()
+    tk = (iy * (2 * ww - 1) + ix).flatten()
+    assert torch.equal(tq[:, None] - tk[None, :], ypart + xpart)
