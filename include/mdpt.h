@@ -122,6 +122,11 @@ int mdpt_reassemble(mdpt_handle* h, const void* const stage_in[4], int32_t B, in
 /* FusionModel.forward (fusion_model.py:55-80): the 4 maps above -> [B,C,8gh,8gw] */
 int mdpt_fusion(mdpt_handle* h, const void* const maps_in[4], int32_t B, int32_t gh, int32_t gw, void* fused_out, void* workspace,
                 size_t workspace_bytes, void* stream);
+/* FusionModel.blocks[index].forward (fusion_model.py:89-114 top-most block, :148-154 regular blocks; called one by one by
+ * experiments/fusion_scaling.py:330-334): reassembly map [B,C,sh,sw] (+ the previous block's output [B,C,sh,sw]; NULL for index 3,
+ * the top-most block) -> [B,C,2sh,2sw]. */
+int mdpt_fusion_block(mdpt_handle* h, int32_t index, const void* reasm_in, const void* prior_in, int32_t B, int32_t sh, int32_t sw,
+                      void* out, void* workspace, size_t workspace_bytes, void* stream);
 /* MonocularDepthHead.forward (head_model.py:89-106): [B,C,8gh,8gw] -> [B, gh*P, gw*P] */
 int mdpt_head(mdpt_handle* h, const void* fused_in, int32_t B, int32_t gh, int32_t gw, void* depth_bhw, void* workspace,
               size_t workspace_bytes, void* stream);

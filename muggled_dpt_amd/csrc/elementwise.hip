@@ -344,6 +344,10 @@ __global__ __launch_bounds__(256) void memset_f32_kernel(float* dst, float value
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) dst[idx] = value;
 }
 
+__global__ __launch_bounds__(256) void add_f32_kernel(float* dst, const float* __restrict__ src, size_t n) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) dst[idx] += src[idx];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // layout conversion (stage-level API and debug taps; not on the fused forward path)
 // ---------------------------------------------------------------------------------------------------
@@ -654,6 +658,12 @@ int mdpt_launch_pad_copy_f32(const float* src, float* dst, int n, int np, hipStr
 int mdpt_launch_memset_f32(float* dst, float value, size_t n, hipStream_t stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(memset_f32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dst, value, n);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_add_f32(float* dst, const float* src, size_t n, hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dst, src, n);
     LAUNCH_RET();
 }
 

@@ -1106,6 +1106,62 @@ int mdpt_fusion(mdpt_handle* h, const void* const maps_in[4], int32_t B, int32_t
     return 0;
 }
 
+// FusionModel.blocks[index] on its own (reference fusion_model.py:89-114 top-most block, :148-154 regular block; used by
+// experiments/fusion_scaling.py:330-334): reasm_in [B,C,sh,sw] (+ prior_in [B,C,sh,sw], the previous block's output; must be NULL for
+// index 3) -> out [B,C,2sh,2sw].
+int mdpt_fusion_block(mdpt_handle* h, int32_t index, const void* reasm_in, const void* prior_in, int32_t B, int32_t sh, int32_t sw,
+                      void* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !reasm_in || !out) return fail(MDPT_E_INVALID, "null argument");
+    if (index < 0 || index > 3) return fail(MDPT_E_INVALID, "fusion block index %d out of range", index);
+    if ((index == 3) != (prior_in == nullptr))
+        return fail(MDPT_E_INVALID, "fusion block %d takes %s", index, index == 3 ? "one input (top-most block)" : "two inputs (reassembly map, previous fusion output)");
+    // level `index` has spatial size (4, 2, 1, 1/2) x the virtual patch grid
+    int gh, gw;
+    if (index == 3) { gh = 2 * sh; gw = 2 * sw; }
+    else {
+        const int f = 4 >> index;
+        if (sh % f || sw % f) return fail(MDPT_E_INVALID, "fusion block %d input %dx%d is not a multiple of %d", index, sh, sw, f);
+        gh = sh / f; gw = sw / f;
+    }
+    Ctx c;
+    CHK(make_ctx(h, B, gh * h->Pv, gw * h->Pv, workspace, workspace_bytes, stream, &c));
+    const Plan& p = c.p;
+    const int i = index;
+    char pb[64];
+    snprintf(pb, sizeof(pb), "fusion.blocks.%d", i);
+    const std::string blk = pb;
+    const size_t elems = (size_t)B * sh * sw * h->Cp;
+    Planes rb = c.pl(p.r_bf[i]);
+    CHK(mdpt_launch_nchw_to_nhwc((const float*)reasm_in, c.at<float>(p.r_f32[i]), rb.hi, rb.lo, 1, B, sh, sw, h->C, h->Cp, c.s));
+    const float* x_f32 = c.at<float>(p.r_f32[i]);
+    Planes x_bf = rb;
+    if (i != 3) {
+        // skip term of the reassembly RCU plus the previous fusion output: (r + prior), added in the second conv's epilogue
+        float* skip = c.at<float>(p.scratch);
+        CHK(mdpt_launch_nchw_to_nhwc((const float*)prior_in, skip, nullptr, nullptr, 0, B, sh, sw, h->C, h->Cp, c.s));
+        CHK(mdpt_launch_add_f32(skip, c.at<float>(p.r_f32[i]), elems, c.s));
+        Planes a1 = c.pl(p.a1[i]);
+        CHK(rcu_conv(c, blk + ".conv_reassembly." + rcu_seq(h) + ".1", rb, sh, sw, nullptr, nullptr, 0, 0, nullptr, a1, 1));
+        x_bf = c.pl(p.x_bf[i]);
+        CHK(rcu_conv(c, blk + ".conv_reassembly." + rcu_seq(h) + ".3", a1, sh, sw, skip, nullptr, 0, 0, c.at<float>(p.x_f32[i]), x_bf, 1));
+        x_f32 = c.at<float>(p.x_f32[i]);
+    }
+    Planes b1 = c.pl(p.b1[i]), b2 = c.pl(p.b2[i]);
+    CHK(rcu_conv(c, blk + "." + proj_seq(h) + ".0." + rcu_seq(h) + ".1", x_bf, sh, sw, nullptr, nullptr, 0, 0, nullptr, b1, 1));
+    CHK(rcu_conv(c, blk + "." + proj_seq(h) + ".0." + rcu_seq(h) + ".3", b1, sh, sw, x_f32, nullptr, 0, 0, nullptr, b2, 0));
+    {
+        GemmParams g = base_params(c, h->M(blk + "." + proj_seq(h) + ".2.weight"), b2, B * sh * sw, h->Cp);
+        g.bias = h->V(blk + "." + proj_seq(h) + ".2.bias");
+        g.out_f32 = c.at<float>(p.flo[i]); g.ldc = h->Cp;
+        CHK(mdpt_launch_gemm(g, c.s));
+    }
+    float* tmp = c.at<float>(p.scratch);
+    CHK(mdpt_launch_upsample(c.at<float>(p.flo[i]), nullptr, nullptr, tmp, B, sh, sw, 2 * sh, 2 * sw, h->Cp, c.s));
+    CHK(mdpt_launch_nhwc_to_nchw(tmp, nullptr, nullptr, (float*)out, B, 2 * sh, 2 * sw, h->C, h->Cp, c.s));
+    h->has_last = false;
+    return 0;
+}
+
 int mdpt_head(mdpt_handle* h, const void* fused_in, int32_t B, int32_t gh, int32_t gw, void* depth_bhw, void* workspace,
               size_t workspace_bytes, void* stream) {
     if (!h || !fused_in || !depth_bhw) return fail(MDPT_E_INVALID, "null argument");

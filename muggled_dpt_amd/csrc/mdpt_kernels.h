@@ -119,6 +119,7 @@ int mdpt_launch_beit_relpos(const float* ref_lut, float* ext_lut, int* tq, int* 
                             int N, int ntok_pad, hipStream_t stream);
 int mdpt_beit_relpos_elen(int gh, int gw);
 int mdpt_launch_memset_f32(float* dst, float value, size_t n, hipStream_t stream);
+int mdpt_launch_add_f32(float* dst, const float* src, size_t n, hipStream_t stream);  // dst += src
 // ViT-G SwiGLU gate: fp32 [rows, 2h] -> silu(first half) * second half as bf16 hi (+lo) [rows, hp] (pad columns zero)
 int mdpt_launch_swiglu(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t rows, int h, int hp, hipStream_t stream);
 

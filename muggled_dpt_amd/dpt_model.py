@@ -41,6 +41,16 @@ class _Node(nn.Module):
     def forward(self, *args, **kwargs):  # pragma: no cover - containers are not callable
         raise RuntimeError("parameter container, not a callable layer")
 
+    # numeric children behave like the reference's nn.ModuleList / nn.Sequential (model.fusion.blocks[2], len(...), iteration)
+    def __getitem__(self, idx):
+        return getattr(self, str(int(idx) if int(idx) >= 0 else len(self) + int(idx)))
+
+    def __len__(self):
+        return sum(1 for name in self._modules if name.isdigit())
+
+    def __iter__(self):
+        return iter(getattr(self, str(i)) for i in range(len(self)))
+
 
 def _register_tree(root: nn.Module, shapes: dict[str, tuple]) -> None:
     for key, shape in shapes.items():
@@ -171,8 +181,38 @@ class ReassembleModel(_Stage):
         return tuple(eng.as_output(o) for o in outs)
 
 
+class _FusionBlock(_Node):
+    """One fusion block, callable on its own like the reference's FusionBlock / TopMostFusionBlock (fusion_model.py:89-154):
+    blocks[3](downx2_map) ; blocks[i](reassembly_map, previous_fusion_map) -> map at twice the resolution."""
+
+    def forward(self, reassembly_feature_map: Tensor, previous_fusion_feature_map: Tensor | None = None) -> Tensor:
+        fusion = self.__dict__["_fusion"]
+        idx = self.__dict__["_idx"]
+        eng = fusion._engine()
+        x = eng.as_input(reassembly_feature_map, 4)
+        b, _, sh, sw = x.shape
+        if (previous_fusion_feature_map is None) != (idx == 3):
+            raise TypeError(f"fusion block {idx} takes {'one input' if idx == 3 else 'two inputs'}")
+        prior = None if previous_fusion_feature_map is None else eng.as_input(previous_fusion_feature_map, 4)
+        if prior is not None and prior.shape != x.shape:
+            raise RuntimeError(f"The size of tensor a {tuple(x.shape)} must match the size of tensor b {tuple(prior.shape)}")
+        out = torch.empty((b, eng.C, 2 * sh, 2 * sw), device=x.device, dtype=torch.float32)
+        gh, gw = (2 * sh, 2 * sw) if idx == 3 else (sh // (4 >> idx), sw // (4 >> idx))
+        eng.call_checked("mdpt_fusion_block", idx, x, prior, b, sh, sw, out,
+                         size_hw=(gh * eng.Pdec, gw * eng.Pdec), batch=b)
+        return eng.as_output(out)
+
+
 class FusionModel(_Stage):
     """RefineNet-style coarse-to-fine fusion. reference v2_depthanything/fusion_model.py:20-220."""
+
+    def __init__(self, component, shapes):
+        super().__init__(component, shapes)
+        for i in range(4):  # make blocks[i] callable: same parameters, same names, class swapped on the container node
+            blk = getattr(self.blocks, str(i))
+            blk.__class__ = _FusionBlock
+            blk.__dict__["_idx"] = i
+            blk.__dict__["_fusion"] = self
 
     def forward(self, upx4_featuremap, upx2_featuremap, noscale_featuremap, downx2_featuremap):
         eng = self._engine()

@@ -295,3 +295,26 @@ def test_batch_split_under_hipgraph_capture_and_toggle():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(y_graph, y_plain)
+
+
+@pytest.mark.parametrize("dtype,tol", MODES)
+def test_fusion_blocks_are_callable_one_by_one(golden_dir, dtype, tol):
+    """experiments/fusion_scaling.py:330-334 drives model.fusion.blocks[i] directly: blocks[3](r4), blocks[i](r_i, previous)."""
+    g = np.load(os.path.join(golden_dir, "tiny_full.npz"))
+    model, cfg, w = _model("tiny", dtype)
+    orc = _oracle()
+    reasm = [torch.from_numpy(g[f"reasm{i}"]) for i in range(4)]
+    dev = [r.to("cuda", dtype) for r in reasm]
+    assert len(model.fusion.blocks) == 4 and model.fusion.blocks[-1] is model.fusion.blocks[3]
+    prev_ref, prev = None, None
+    for i in (3, 2, 1, 0):
+        ref = orc.fusion_block(w, i, reasm[i], prev_ref)
+        out = model.fusion.blocks[i](dev[i]) if i == 3 else model.fusion.blocks[i](dev[i], prev)
+        assert out.dtype == dtype and tuple(out.shape) == tuple(ref.shape)
+        assert rel_err(out.float().cpu(), ref) <= tol, f"block {i}"
+        prev_ref, prev = ref, ref.to("cuda", dtype)  # feed the exact previous map so errors do not compound
+    assert rel_err(prev_ref, torch.from_numpy(g["fused"])) <= 1e-5
+    with pytest.raises(TypeError):
+        model.fusion.blocks[3](dev[3], dev[3])
+    with pytest.raises(TypeError):
+        model.fusion.blocks[1](dev[1])
