@@ -12,7 +12,13 @@
 //     depth-to-space | fused 32->1 depth head)
 //   * the tile shape.
 //
-// Structure (per workgroup): BMxBNx64 tiles, 64-lane waves each owning a (BM/WM)x(BN/WN) sub-tile of
+// Two main-loop families (picked per problem by launch_tile):
+//   * gemm8_kernel: 256x256x64 tiles, 8 waves in two groups staggered by one barrier, 16x16x32 MFMA quadrants, half-tile DMA
+//     prefetch with a counted vmcnt, direct register->global epilogues for the hot encoder shapes - the big-problem kernel
+//     (see its own header further down);
+//   * gemm_kernel ("lockstep"): BMxBNx64 tiles for small / narrow problems and odd K-tile counts, described next.
+//
+// Lockstep structure (per workgroup): BMxBNx64 tiles, 64-lane waves each owning a (BM/WM)x(BN/WN) sub-tile of
 // 32x32x16 bf16 MFMAs. Operand tiles go HBM -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4, 1 KiB
 // per wave-instruction, no VGPR round trip) into a 2-deep ring; one barrier per K-step (the DMA for
 // step t+1 is in flight while step t computes). The LDS image is row-major [row][64 k] (128-B rows) with
