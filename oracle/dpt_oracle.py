@@ -9,7 +9,7 @@ module, and only as the *checker*. The product path (muggled_dpt_amd) never rout
 
 Parity pinning: the reference ships no tests or golden vectors ("parity unpinned" by the
 reference itself). This oracle is instead pinned to the *imported reference*
-(torch 2.10 CPU fp32): `tools/gen_golden.py` (run in the build container, where
+(torch 2.10 CPU fp32): `tests/golden/gen_golden.py` (run in the build container, where
 /root/reference exists) asserts oracle == reference to <= 2e-5 at every stage boundary and
 writes `tests/golden/*.npz`; `tests/test_oracle_golden.py` re-checks the oracle against those
 committed fixtures on any machine.

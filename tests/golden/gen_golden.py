@@ -7,7 +7,7 @@ read-only (with an in-memory stub for the absent `cv2`), feed it seeded syntheti
 While doing so it asserts that oracle/dpt_oracle.py reproduces the reference at every stage
 boundary (<= 2e-5 abs on O(1) tensors) - this is what pins the oracle.
 
-usage: PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [--skip-vitl] [--only-beit] [--only-swinv2]
+usage: PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py [--skip-vitl] [--only-beit] [--only-swinv2]
 """
 
 from __future__ import annotations
@@ -21,7 +21,7 @@ import types
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference"
 sys.dont_write_bytecode = True
 sys.path.insert(0, REPO)

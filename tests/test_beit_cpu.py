@@ -1,4 +1,4 @@
-"""CPU side of the MiDaS v3.1 BEiT family: oracle vs the fixtures generated from the reference (tools/gen_golden.py),
+"""CPU side of the MiDaS v3.1 BEiT family: oracle vs the fixtures generated from the reference (tests/golden/gen_golden.py),
 checkpoint conversion contract, C-ABI inventory. No GPU compute."""
 import ctypes
 import json

@@ -180,7 +180,7 @@ def test_vits_1036_matches_oracle():
 
 def test_prepare_image_kernel_vs_golden(golden_dir):
     """mdpt_prepare_image (HIP antialiased bilinear + BGR->RGB + normalise) against outputs of the reference's
-    prepare_image_bgr (tools/gen_golden.py): same shapes (518->504 snapping, aspect-ratio mode, 1036, upscaling) and values."""
+    prepare_image_bgr (tests/golden/gen_golden.py): same shapes (518->504 snapping, aspect-ratio mode, 1036, upscaling) and values."""
     from tests.helpers import stats
     g = np.load(os.path.join(golden_dir, "prepare_image.npz"))
     model, _, _ = _model("vits", torch.float32)

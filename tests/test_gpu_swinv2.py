@@ -1,4 +1,4 @@
-"""MiDaS v3.1 SwinV2 family on the HIP path vs the fixtures generated from the reference (tools/gen_golden.py) and the
+"""MiDaS v3.1 SwinV2 family on the HIP path vs the fixtures generated from the reference (tests/golden/gen_golden.py) and the
 oracle. Run with `pytest -m gpu` on an MI355X. Tolerances as in test_gpu_parity.py."""
 import os
 

@@ -1,6 +1,6 @@
 """The oracle (oracle/dpt_oracle.py) against the committed golden fixtures.
 
-The fixtures were produced by tools/gen_golden.py from the imported reference
+The fixtures were produced by tests/golden/gen_golden.py from the imported reference
 (torch 2.10 CPU fp32); these tests run anywhere (no /root/reference needed).
 Tolerance: 5e-5 absolute on O(1..10) tensors - fp32 noise of the reference against
 itself across thread counts / layouts is 2-5e-6.
