@@ -1296,7 +1296,8 @@ int mdpt_debug_gemm(const void* a_bf16, const void* w_bf16, void* out_f32, void*
     g.A_hi = (const bf16_t*)a_bf16; g.W_hi = (const bf16_t*)w_bf16;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.npass = 1;
     g.zero_page = (const bf16_t*)w_bf16;
-    g.amode = MDPT_A_DENSE; g.ekind = MDPT_E_GENERIC; g.tile = tile;
+    g.amode = MDPT_A_DENSE; g.ekind = MDPT_E_GENERIC; g.tile = tile & 255;
+    g.act = (tile >> 8) & 3;  // bits 8-9 of `tile`: epilogue activation (MDPT_ACT_*), for epilogue-cost measurements
     g.out_f32 = (float*)out_f32; g.out_hi = (bf16_t*)out_bf16; g.ldc = N; g.ldr = N;
     g.dbg_times = (unsigned long long*)dbg_times;
     for (int i = 0; i < iters; ++i) CHK(mdpt_launch_gemm(g, (hipStream_t)stream));
