@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(CSRC, "libmdpt.so")
 SOURCES = ("gemm.hip", "attention.hip", "elementwise.hip", "swin.hip", "postprocess.hip", "mdpt_api.cpp", "mdpt_prof.cpp")
 HEADERS = ("mdpt_kernels.h", "mdpt_prof.h", "mdpt_swin.inc", os.path.join(REPO, "include", "mdpt.h"))
 
+ABI_VERSION = 2  # MDPT_ABI_VERSION in include/mdpt.h
 PREC_BF16 = 0
 PREC_BF16X3 = 1
 FAMILY_DAV2 = 0
@@ -152,7 +153,7 @@ def load(auto_build: bool = True) -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError here == ABI drift between mdpt.h and the .so
         fn.restype = res
         fn.argtypes = args
-    if lib.mdpt_abi_version() != 2:
+    if lib.mdpt_abi_version() != ABI_VERSION:
         raise RuntimeError("libmdpt ABI version mismatch")
     _LIB = lib
     return lib

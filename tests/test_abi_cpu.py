@@ -115,3 +115,11 @@ def test_make_dpt_routes_v1_and_v2_by_file_name(tmp_path):
         make_dpt_from_state_dict(p1, model_type="swinv2")
     with pytest.raises(NotImplementedError):
         make_dpt_from_state_dict(p1, model_type="nonsense")
+
+
+def test_graft_entry_build_check_matches_header_abi_version():
+    """__graft_entry__.build() asserts the library's ABI version: keep native.ABI_VERSION and include/mdpt.h in step."""
+    header = open(os.path.join(REPO, "include", "mdpt.h")).read()
+    assert int(re.search(r"#define MDPT_ABI_VERSION (\d+)", header).group(1)) == native.ABI_VERSION == native.load().mdpt_abi_version()
+    src = open(os.path.join(REPO, "__graft_entry__.py")).read()
+    assert "native.ABI_VERSION" in src
