@@ -122,6 +122,12 @@ int mdpt_reassemble(mdpt_handle* h, const void* const stage_in[4], int32_t B, in
 /* FusionModel.forward (fusion_model.py:55-80): the 4 maps above -> [B,C,8gh,8gw] */
 int mdpt_fusion(mdpt_handle* h, const void* const maps_in[4], int32_t B, int32_t gh, int32_t gw, void* fused_out, void* workspace,
                 size_t workspace_bytes, void* stream);
+/* mdpt_encoder plus the explicit attention weights of selected blocks: what the reference's non-optimised attention exposes through its
+ * nn.Softmax module (enable_optimizations=False, v2_depthanything/components/transformer_block.py:101,126-131; hooked by
+ * experiments/attention_visualization.py:325-332). attn_out has num_blocks entries; every non-NULL entry receives that block's
+ * softmax(q k^T / sqrt(d) [+ relative-position bias]) as fp32 [B, heads, N, N] (N = 1 + gh*gw). ViT / BEiT families. */
+int mdpt_encoder_probe(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, int32_t gw, void* const stage_out[4],
+                       void* const* attn_out, void* workspace, size_t workspace_bytes, void* stream);
 /* FusionModel.blocks[index].forward (fusion_model.py:89-114 top-most block, :148-154 regular blocks; called one by one by
  * experiments/fusion_scaling.py:330-334): reassembly map [B,C,sh,sw] (+ the previous block's output [B,C,sh,sw]; NULL for index 3,
  * the top-most block) -> [B,C,2sh,2sw]. */

@@ -375,6 +375,57 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Attention-weight dump (diagnostic, not on the hot path): softmax(q k^T (+ relative-position bias)) of ONE block as an
+// explicit [B, H, N, N] fp32 tensor - what the reference exposes through its nn.Softmax module when enable_optimizations is
+// False (v2_depthanything/components/transformer_block.py:101,126-131; experiments/attention_visualization.py:325-332).
+// One workgroup per (batch*head, query row); operands are the Q (pre-scaled) / K planes the fused kernel consumes.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_weights_kernel(const bf16_t* __restrict__ q_hi, const bf16_t* __restrict__ q_lo,
+                                                           const bf16_t* __restrict__ k_hi, const bf16_t* __restrict__ k_lo,
+                                                           const float* __restrict__ bias_lut, int bias_elen, const int* tq, const int* tk,
+                                                           float* __restrict__ out, int heads, int N, int npad) {
+    extern __shared__ float sc[];  // [N] scores, then 8 floats of reduction scratch
+    const int row = blockIdx.x, bh = blockIdx.y, h = bh % heads, tid = threadIdx.x;
+    float q[64];
+    const bf16_t* qp = q_hi + ((size_t)bh * npad + row) * 64;
+    const bf16_t* qlp = q_lo ? q_lo + ((size_t)bh * npad + row) * 64 : nullptr;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) q[d] = (float)qp[d] + (qlp ? (float)qlp[d] : 0.0f);
+    const float* lut = bias_lut ? bias_lut + (size_t)h * bias_elen : nullptr;
+    const int tqr = lut ? tq[row] : 0;
+    float lmax = -3.0e38f;
+    for (int key = tid; key < N; key += 256) {
+        const bf16_t* kp = k_hi + ((size_t)bh * npad + key) * 64;
+        const bf16_t* klp = k_lo ? k_lo + ((size_t)bh * npad + key) * 64 : nullptr;
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) s += q[d] * ((float)kp[d] + (klp ? (float)klp[d] : 0.0f));
+        if (lut) s += lut[tqr - tk[key]];
+        sc[key] = s;
+        lmax = fmaxf(lmax, s);
+    }
+    float* red = sc + N;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if ((tid & 63) == 0) red[tid >> 6] = lmax;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float lsum = 0.0f;
+    for (int key = tid; key < N; key += 256) {
+        const float e = __expf(sc[key] - m);
+        sc[key] = e;
+        lsum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = lsum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    float* op = out + ((size_t)bh * N + row) * N;
+    for (int key = tid; key < N; key += 256) op[key] = sc[key] * inv;
+}
+
 }  // namespace
 
 int mdpt_launch_attention(const AttnParams& p, hipStream_t stream) {
@@ -426,5 +477,14 @@ int mdpt_launch_attention(const AttnParams& p, hipStream_t stream) {
         else ATTN_LAUNCH(false, 1, 0, 64, grid128);
     }
 #undef ATTN_LAUNCH
+    return (int)hipGetLastError();
+}
+
+int mdpt_launch_attn_weights(const AttnParams& p, float* out_bhnn, hipStream_t stream) {
+    if ((p.head_dim && p.head_dim != 64) || p.rowmap) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)(p.N + 8) * 4;
+    if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_weights_kernel, dim3(p.N, p.B * p.heads), dim3(256), lds, stream, p.q_hi, p.q_lo, p.k_hi, p.k_lo, p.bias_lut,
+                       p.bias_elen, p.tq, p.tk, out_bhnn, p.heads, p.N, p.npad);
     return (int)hipGetLastError();
 }

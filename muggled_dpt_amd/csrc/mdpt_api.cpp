@@ -445,6 +445,7 @@ struct Ctx {
     char* ws;
     hipStream_t s;
     bool split = false;  // this context is one half of a two-stream batch split
+    void* const* attn_dump = nullptr;  // per block: where to write softmax(q k^T) as fp32 [B,H,N,N] (null entries: skip)
     template <class T> T* at(size_t off) const { return off == SIZE_MAX ? nullptr : (T*)(ws + off); }
     Planes pl(const size_t o[2]) const {
         Planes r;
@@ -541,6 +542,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
                 a.bias_lut = c.at<float>(p.relpos_lut); a.bias_elen = mdpt_beit_relpos_elen(p.gh, p.gw);
                 a.tq = c.at<int>(p.relpos_tq); a.tk = c.at<int>(p.relpos_tk);
             }
+            if (c.attn_dump && c.attn_dump[b]) CHK(mdpt_launch_attn_weights(a, (float*)c.attn_dump[b], c.s));
             CHK(mdpt_launch_attention(a, c.s));
         }
         DBG_STOP(2);
@@ -1042,6 +1044,35 @@ int mdpt_encoder(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, 
     c.p.gh = gh; c.p.gw = gw; c.p.Np = gh * gw; c.p.N = c.p.Np + 1;
     if (rup(c.p.N, 8) > c.p.npad) return fail(MDPT_E_INVALID, "internal: plan too small");
     c.p.npad = rup(c.p.N, 8); c.p.npadv = rup(c.p.N, 64);
+    if (is_beit(h)) {
+        CHK(mdpt_launch_memset_f32(c.at<float>(c.p.pos), 0.0f, (size_t)c.p.Np * h->F, c.s));
+    } else {
+        CHK(run_pos(c));
+    }
+    CHK(mdpt_launch_init_tokens(c.at<float>(c.p.resid), h->V("imgencoder.cls_token"), is_beit(h) ? nullptr : h->V("imgencoder.posenc.cls_embedding"),
+                                B, c.p.N, c.p.npad, h->F, c.s));
+    CHK(mdpt_launch_tokens_to_resid((const float*)tokens_bnf, c.at<float>(c.p.pos), c.at<float>(c.p.resid), B, c.p.Np, c.p.npad, h->F, c.s));
+    CHK(run_encoder(c, stage_out));
+    h->has_last = false;
+    return 0;
+}
+
+// mdpt_encoder + explicit attention weights of selected blocks (enable_optimizations=False semantics of the reference: the
+// nn.Softmax output of every block is observable, experiments/attention_visualization.py:325-332). attn_out has num_blocks
+// entries; a non-null entry receives that block's softmax(q k^T / sqrt(d) [+ bias]) as fp32 [B, heads, N, N].
+int mdpt_encoder_probe(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, int32_t gw, void* const stage_out[4],
+                       void* const* attn_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !tokens_bnf || !stage_out || !attn_out) return fail(MDPT_E_INVALID, "null argument");
+    if (h->swin) return fail(MDPT_E_UNSUPPORTED, "attention-weight dumps are implemented for the ViT / BEiT encoders (head dim 64) only");
+    for (int i = 0; i < 4; ++i)
+        if (!stage_out[i]) return fail(MDPT_E_INVALID, "null stage output %d", i);
+    if (gh <= 0 || gw <= 0) return fail(MDPT_E_INVALID, "bad grid");
+    Ctx c;
+    CHK(make_ctx(h, B, rup(gh, 2) * h->P, rup(gw, 2) * h->P, workspace, workspace_bytes, stream, &c));
+    c.p.gh = gh; c.p.gw = gw; c.p.Np = gh * gw; c.p.N = c.p.Np + 1;
+    if (rup(c.p.N, 8) > c.p.npad) return fail(MDPT_E_INVALID, "internal: plan too small");
+    c.p.npad = rup(c.p.N, 8); c.p.npadv = rup(c.p.N, 64);
+    c.attn_dump = attn_out;
     if (is_beit(h)) {
         CHK(mdpt_launch_memset_f32(c.at<float>(c.p.pos), 0.0f, (size_t)c.p.Np * h->F, c.s));
     } else {

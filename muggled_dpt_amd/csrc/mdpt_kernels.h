@@ -69,6 +69,8 @@ struct AttnParams {
     int win_nw; const int* rowmap; const int* region; int region_ld;
 };
 int mdpt_launch_attention(const AttnParams& p, hipStream_t stream);
+// diagnostic: explicit softmax(q k^T + bias) as fp32 [B, heads, N, N] from the same Q / K planes (head dim 64 families)
+int mdpt_launch_attn_weights(const AttnParams& p, float* out_bhnn, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // bandwidth-bound helpers

@@ -52,6 +52,16 @@ class _Node(nn.Module):
         return iter(getattr(self, str(i)) for i in range(len(self)))
 
 
+class _SoftmaxProbe(nn.Softmax):
+    """Stand-in for the nn.Softmax module of the reference's non-optimised attention (transformer_block.py:101): the fused HIP
+    kernel never materialises the softmax matrix, but when a forward hook is registered here (the way
+    demo_helpers/model_capture.py:54-59 captures attention maps) the encoder dumps this block's [B, heads, N, N] weights with a
+    dedicated kernel (mdpt_encoder_probe) and passes them through this module so the hook fires with them as output."""
+
+    def forward(self, attention_weights: Tensor) -> Tensor:
+        return attention_weights
+
+
 def _register_tree(root: nn.Module, shapes: dict[str, tuple]) -> None:
     for key, shape in shapes.items():
         parts = key.split(".")
@@ -155,6 +165,19 @@ class ImageEncoder(_Stage):
         gh, gw = int(patch_grid_hw[0]), int(patch_grid_hw[1])
         b = x.shape[0]
         assert x.shape[1] == gh * gw and x.shape[2] == eng.F, f"tokens {tuple(x.shape)} do not match grid {gh}x{gw}, F={eng.F}"
+        probes = self.__dict__.get("_softmax_probes") or []
+        hooked = [i for i, pr in enumerate(probes) if len(pr._forward_hooks) > 0]
+        if hooked:  # enable_optimizations=False + hooks on the softmax modules: same encoder pass, plus weight dumps
+            n = gh * gw + 1
+            heads = eng.F // 64
+            outs = [torch.empty((b, n, eng.F), device=x.device, dtype=torch.float32) for _ in range(4)]
+            dumps = {i: torch.empty((b, heads, n, n), device=x.device, dtype=torch.float32) for i in hooked}
+            arr = (ctypes.c_void_p * len(probes))(*[dumps[i].data_ptr() if i in dumps else None for i in range(len(probes))])
+            eng.call("mdpt_encoder_probe", x, b, gh, gw, eng.ptr_array(outs), arr,
+                     size_hw=((gh + gh % 2) * eng.P, (gw + gw % 2) * eng.P), batch=b)
+            for i in hooked:
+                probes[i](eng.as_output(dumps[i]))  # fires the registered forward hooks with the weights as module output
+            return tuple(eng.as_output(o) for o in outs)
         if eng.swin:  # stage s: [B, (gh >> s) * (gw >> s), F_s] (v31_swinv2/image_encoder_model.py:77-98)
             outs = [torch.empty((b, (gh >> s) * (gw >> s), eng.stage_features[s]), device=x.device, dtype=torch.float32) for s in range(4)]
             eng.call_checked("mdpt_encoder", x, b, gh, gw, eng.ptr_array(outs), size_hw=(gh * eng.P, gw * eng.P), batch=b)
@@ -395,6 +418,16 @@ class DPTModel(nn.Module):
         self.head = MonocularDepthHead("head", per["head"])
         for comp in COMPONENTS:
             getattr(self, comp).__dict__["_owner"] = self
+        # enable_optimizations=False: every block gets an `attn.softmax` module that hooks can observe (reference Attention class,
+        # components/transformer_block.py:79-136). The arithmetic path is the same fused kernel either way.
+        if self.config.get("enable_optimizations", True) is False and family in ("v2", "v1", "beit"):
+            probes = []
+            bps = max(1, self.config["num_blocks"] // 4)
+            for blk in range(self.config["num_blocks"]):
+                node = self.imgencoder.blocks[blk] if family == "v1" else self.imgencoder.stages[blk // bps].blocks[blk % bps]
+                node.attn.add_module("softmax", _SoftmaxProbe(dim=-1))
+                probes.append(node.attn.softmax)
+            self.imgencoder.__dict__["_softmax_probes"] = probes
         self.__dict__["_engine_obj"] = None
         self.__dict__["_gemm_tile"] = 0
         self.eval()  # inference only (dpt_model.py:57)
@@ -424,6 +457,11 @@ class DPTModel(nn.Module):
     # ---- reference API
     def forward(self, image_rgb_normalized_bchw: Tensor) -> Tensor:
         """[B,3,H,W] normalised RGB -> inverse depth [B,H,W] (dpt_model.py:61-83), one fused C-ABI call."""
+        probes = self.imgencoder.__dict__.get("_softmax_probes") or []
+        if any(len(pr._forward_hooks) > 0 for pr in probes):
+            # somebody is listening on the attention softmax modules: go stage by stage so the encoder can dump the weights
+            tokens, hw = self.patch_embed(image_rgb_normalized_bchw)
+            return self.head(self.fusion(*self.reassemble(*self.imgencoder(tokens, hw), hw)))
         eng = self._get_engine()
         x = eng.as_input(image_rgb_normalized_bchw, 4)
         b, c, h, w = x.shape

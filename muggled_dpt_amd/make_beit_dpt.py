@@ -33,6 +33,7 @@ def make_beit_dpt(
     fusion_channels: int = 256,
     patch_size_px: int = 16,
     enable_cache: bool = False,
+    enable_optimizations: bool = True,
     **unused_kwargs,
 ) -> DPTModel:
     """Standard sizes: muggled_dpt_amd.synthetic.BEIT_CONFIGS (reference make_beit_dpt.py:86-113). `enable_cache` is accepted for
@@ -47,6 +48,7 @@ def make_beit_dpt(
         "fusion_channels": int(fusion_channels),
         "patch_size_px": int(patch_size_px),
         "enable_cache": bool(enable_cache),
+        "enable_optimizations": bool(enable_optimizations),  # False: hookable attn.softmax modules (see DPTModel.__init__)
     }
     if int(features_per_token) != 64 * int(num_heads):
         raise NotImplementedError("the MI355X attention kernel supports head dim 64 only")

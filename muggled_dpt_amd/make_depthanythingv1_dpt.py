@@ -39,8 +39,6 @@ def make_depthanythingv1_dpt(
     enable_optimizations: bool = True,
 ) -> DPTModel:
     """Standard configs are the vit-small/base/large rows of muggled_dpt_amd.synthetic.STANDARD_CONFIGS."""
-    if not enable_optimizations:
-        warnings.warn("enable_optimizations=False: the fused attention kernel never materialises the softmax matrix; outputs are identical.")
     config = {
         "features_per_token": int(features_per_token),
         "num_heads": int(num_heads),

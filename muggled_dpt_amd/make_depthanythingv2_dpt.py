@@ -3,7 +3,6 @@ muggled_dpt/make_depthanythingv2_dpt.py (:24-61 and :67-138), building the libmd
 
 from __future__ import annotations
 
-import warnings
 
 from .dpt_model import DPTModel
 from .state_dict_conversion import (COMPONENTS, convert_state_dict_keys, get_model_config_from_state_dict,
@@ -51,9 +50,8 @@ def make_depthanythingv2_dpt(
 ) -> DPTModel:
     """Build an (uninitialised) model from explicit sizes; see muggled_dpt_amd.synthetic.STANDARD_CONFIGS for the
     vit-small/base/large numbers (reference make_depthanythingv2_dpt.py:88-122)."""
-    if not enable_optimizations:
-        warnings.warn("enable_optimizations=False: the fused attention kernel never materialises the softmax matrix, so "
-                      "attention maps cannot be hooked (reference components/transformer_block.py:101); outputs are identical.")
+    # enable_optimizations=False: every block grows an `attn.softmax` module; forward hooks on it receive the [B, heads, N, N]
+    # attention weights (dumped by mdpt_encoder_probe), like the reference's non-optimised Attention (transformer_block.py:101)
     # enable_cache: position embeddings are recomputed per call by a ~10 us kernel; accepted for API compatibility
     config = {
         "features_per_token": int(features_per_token),

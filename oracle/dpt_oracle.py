@@ -93,14 +93,17 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torc
     return F.layer_norm(x, (x.shape[-1],), weight, bias, LN_EPS)
 
 
-def attention(w: dict, pre: str, x: torch.Tensor, num_heads: int) -> torch.Tensor:
+def attention(w: dict, pre: str, x: torch.Tensor, num_heads: int, capture: list | None = None) -> torch.Tensor:
     """qkv Linear -> per-head softmax(q k^T / sqrt(d)) v -> proj Linear
-    (components/transformer_block.py:105-136 / :154-170; both forms are the same math)."""
+    (components/transformer_block.py:105-136 / :154-170; both forms are the same math). `capture` collects the
+    [B, heads, N, N] softmax output, i.e. what a forward hook on the non-optimised form's nn.Softmax (:101, :131) sees."""
     b, n, c = x.shape
     d = c // num_heads
     qkv = F.linear(x, w[f"{pre}.qkv.weight"], w[f"{pre}.qkv.bias"]).reshape(b, n, 3, num_heads, d).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     att = torch.softmax((q * d**-0.5) @ k.transpose(-2, -1), dim=-1)
+    if capture is not None:
+        capture.append(att)
     y = (att @ v).transpose(1, 2).reshape(b, n, c)
     return F.linear(y, w[f"{pre}.proj.weight"], w[f"{pre}.proj.bias"])
 
@@ -115,15 +118,15 @@ def mlp(w: dict, pre: str, x: torch.Tensor) -> torch.Tensor:
     return F.linear(h, w[f"{pre}.layers.2.weight"], w[f"{pre}.layers.2.bias"])
 
 
-def transformer_block(w: dict, pre: str, x: torch.Tensor, num_heads: int) -> torch.Tensor:
+def transformer_block(w: dict, pre: str, x: torch.Tensor, num_heads: int, capture: list | None = None) -> torch.Tensor:
     """Pre-norm block with layer-scale: t + g1*attn(LN1 t); u + g2*mlp(LN2 u) (transformer_block.py:53-65)."""
-    a = attention(w, f"{pre}.attn", layernorm(x, w[f"{pre}.norm1.weight"], w[f"{pre}.norm1.bias"]), num_heads)
+    a = attention(w, f"{pre}.attn", layernorm(x, w[f"{pre}.norm1.weight"], w[f"{pre}.norm1.bias"]), num_heads, capture)
     x = x + w[f"{pre}.scale_attn"] * a
     m = mlp(w, f"{pre}.mlp", layernorm(x, w[f"{pre}.norm2.weight"], w[f"{pre}.norm2.bias"]))
     return x + w[f"{pre}.scale_mlp"] * m
 
 
-def image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple[int, int]) -> list[torch.Tensor]:
+def image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple[int, int], capture: list | None = None) -> list[torch.Tensor]:
     """+pos-embed, prepend cls(+cls_embedding), 4 stages of round(num_blocks/4) blocks, shared out-norm on
     each stage output (image_encoder_model.py:80-94, :69, :136-147; position_encoder.py:55-76)."""
     b = patch_tokens.shape[0]
@@ -135,14 +138,14 @@ def image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple
         # (v1_depthanything/image_encoder_model.py:55-61)
         n = cfg["num_blocks"]
         for i in range(n):
-            tokens = transformer_block(w, f"imgencoder.blocks.{i}", tokens, cfg["num_heads"])
+            tokens = transformer_block(w, f"imgencoder.blocks.{i}", tokens, cfg["num_heads"], capture)
             if i >= n - 4:
                 taps.append(tokens)
     else:
         per_stage = int(round(cfg["num_blocks"] / 4))
         for s in range(4):
             for i in range(per_stage):
-                tokens = transformer_block(w, f"imgencoder.stages.{s}.blocks.{i}", tokens, cfg["num_heads"])
+                tokens = transformer_block(w, f"imgencoder.stages.{s}.blocks.{i}", tokens, cfg["num_heads"], capture)
             taps.append(tokens)
     return [layernorm(t, w["imgencoder.outnorm.weight"], w["imgencoder.outnorm.bias"]) for t in taps]
 
@@ -190,7 +193,7 @@ def beit_relpos_bias(lut: torch.Tensor, base_grid_hw: tuple[int, int], grid_hw: 
     return full[idx.reshape(-1)].reshape(n, n, heads).permute(2, 0, 1).unsqueeze(0)
 
 
-def beit_attention(w: dict, pre: str, x: torch.Tensor, cfg: dict, grid_hw: tuple[int, int]) -> torch.Tensor:
+def beit_attention(w: dict, pre: str, x: torch.Tensor, cfg: dict, grid_hw: tuple[int, int], capture: list | None = None) -> torch.Tensor:
     """qkv Linear without bias, +q_bias / +v_bias (k has none), softmax(q k^T / sqrt(d) + relpos) v, proj
     (image_encoder_model.py:331-356)."""
     b, n, c = x.shape
@@ -199,11 +202,14 @@ def beit_attention(w: dict, pre: str, x: torch.Tensor, cfg: dict, grid_hw: tuple
     q, k, v = qkv[0] + w[f"{pre}.q_bias"], qkv[1], qkv[2] + w[f"{pre}.v_bias"]
     att = (q * (c // heads) ** -0.5) @ k.transpose(-2, -1)
     att = att + beit_relpos_bias(w[f"{pre}.relpos_enc.ref_bias_lut"], cfg["base_patch_grid_hw"], grid_hw)
-    y = (torch.softmax(att, dim=-1) @ v).transpose(1, 2).reshape(b, n, c)
+    att = torch.softmax(att, dim=-1)
+    if capture is not None:
+        capture.append(att)
+    y = (att @ v).transpose(1, 2).reshape(b, n, c)
     return F.linear(y, w[f"{pre}.proj.weight"], w[f"{pre}.proj.bias"])
 
 
-def beit_image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple[int, int]) -> list[torch.Tensor]:
+def beit_image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple[int, int], capture: list | None = None) -> list[torch.Tensor]:
     """cls ++ patch tokens (no absolute position embedding), 4 stages, raw stage outputs are the taps (no out-norm)
     (image_encoder_model.py:80-99, block :241-251)."""
     tokens = torch.cat((w["imgencoder.cls_token"].expand(patch_tokens.shape[0], -1, -1), patch_tokens), dim=1)
@@ -212,7 +218,7 @@ def beit_image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: 
     for s in range(4):
         for i in range(per_stage):
             pre = f"imgencoder.stages.{s}.blocks.{i}"
-            a = beit_attention(w, f"{pre}.attn", layernorm(tokens, w[f"{pre}.norm1.weight"], w[f"{pre}.norm1.bias"]), cfg, grid_hw)
+            a = beit_attention(w, f"{pre}.attn", layernorm(tokens, w[f"{pre}.norm1.weight"], w[f"{pre}.norm1.bias"]), cfg, grid_hw, capture)
             tokens = tokens + w[f"{pre}.scale_attn"] * a
             m = mlp(w, f"{pre}.mlp", layernorm(tokens, w[f"{pre}.norm2.weight"], w[f"{pre}.norm2.bias"]))
             tokens = tokens + w[f"{pre}.scale_mlp"] * m

@@ -123,3 +123,31 @@ def test_graft_entry_build_check_matches_header_abi_version():
     assert int(re.search(r"#define MDPT_ABI_VERSION (\d+)", header).group(1)) == native.ABI_VERSION == native.load().mdpt_abi_version()
     src = open(os.path.join(REPO, "__graft_entry__.py")).read()
     assert "native.ABI_VERSION" in src
+
+
+def test_enable_optimizations_false_adds_hookable_softmax_modules_only():
+    """reference components/transformer_block.py:79-136: the non-optimised attention owns an nn.Softmax that tooling hooks
+    (demo_helpers/model_capture.py:54-59). Here they are parameter-free probe modules, one per block, in block order."""
+    import torch.nn as nn
+    import muggled_dpt_amd as mda
+    from muggled_dpt_amd.synthetic import make_synthetic_beit_state_dict
+    from tests.helpers import synthetic_model
+    osd, _, _ = synthetic_model("tiny", 0)
+    cfg, slow = mda.make_depthanythingv2_dpt_from_original_state_dict(osd, enable_optimizations=False)
+    _, fast = mda.make_depthanythingv2_dpt_from_original_state_dict(osd)
+    names = [n for n, m in slow.named_modules() if isinstance(m, nn.Softmax)]
+    assert names == [f"imgencoder.stages.{b}.blocks.0.attn.softmax" for b in range(cfg["num_blocks"])]
+    assert not any(isinstance(m, nn.Softmax) for m in fast.modules())
+    assert list(slow.state_dict()) == list(fast.state_dict())
+    bcfg, beit = mda.make_beit_dpt_from_midas_v31_state_dict(make_synthetic_beit_state_dict("beit_tiny", 1), enable_optimizations=False)
+    assert sum(isinstance(m, nn.Softmax) for m in beit.modules()) == bcfg["num_blocks"]
+    # the oracle's capture hands back one [B, heads, N, N] row-stochastic matrix per block
+    import torch
+    from oracle import dpt_oracle as orc
+    from muggled_dpt_amd.state_dict_conversion import convert_state_dict_keys, flatten_components
+    w = flatten_components(convert_state_dict_keys(cfg, osd))
+    tokens, grid = orc.patch_embed(w, torch.randn(1, 3, 56, 56, generator=torch.Generator().manual_seed(0)))
+    cap = []
+    orc.image_encoder(w, cfg, tokens, grid, capture=cap)
+    assert len(cap) == cfg["num_blocks"] and tuple(cap[0].shape) == (1, cfg["num_heads"], 17, 17)
+    assert float((cap[-1].sum(-1) - 1).abs().max()) < 1e-5
