@@ -537,68 +537,150 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
 //   DM_QK    : Q (pre-scaled) / K head-major bf16(/lo)            (QKV tiles without V columns)
 enum { DM_NONE = 0, DM_BF16 = 1, DM_RESID = 2, DM_QK = 3 };
 
-template <int MODE>
+// Everything that selects code is a template parameter (MODE, X3 = hi+lo output planes, ACT) and every memory access is a raw
+// buffer op whose out-of-range lanes (tail rows: offset beyond num_records; tail columns: offset forced to ~0) are dropped by
+// the hardware bounds check. No divergent branch means hipcc can count vmcnt: with `if (row < M) store` every store sat in its
+// own basic block behind an `s_waitcnt vmcnt(0)`, i.e. each store waited for the previous one's write acknowledgement
+// (measured: 520 cycles per store, 33-42k cycles for the in-place residual form whose loads waited the same way).
+// Row addresses advance by uniform strides; DM_RESID reads back exactly the 16-byte groups it writes, group g+1's loads are
+// issued ahead of group g's stores.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)(bytes < 0xFFFFFFF0ull ? bytes : 0xFFFFFFF0ull), 0x00020000);
+}
+
+template <int MODE, bool X3, int ACT>
 __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc)[2][2][4][2], int m0, int n0, int grp, int wc, int lane) {
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
     const int l15 = lane & 15, lh = lane >> 4;
-    const bool x3 = MODE == DM_QK ? p.q_lo != nullptr : p.out_lo != nullptr;
-    const bool gelu = MODE == DM_BF16 && p.act == MDPT_ACT_GELU;
+    const int rows_here = p.M - m0 < 256 ? p.M - m0 : 256;  // valid rows of this tile (tail tile: fewer)
+
+    if (MODE == DM_RESID) {
+        // in-place residual update; descriptor over this tile's rows (base = row m0), byte offsets inside it
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(p.out_f32 + (size_t)m0 * p.ldc, (size_t)rows_here * p.ldc * 4);
+        const unsigned row_b = (unsigned)p.ldc * 4u;
+        f32x4 bias[2][2], gam[2][2];
+        unsigned col_off[2][2];
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nc = n0 + qn * 128 + wc * 32 + j * 16 + 4 * lh;
+                const int ncl = nc < p.N ? nc : p.N - 4;
+                bias[qn][j] = *(const f32x4*)(p.bias + ncl);
+                gam[qn][j] = *(const f32x4*)(p.gamma + ncl);
+                col_off[qn][j] = nc < p.N ? (unsigned)nc * 4u : OOB;
+            }
+        auto row_off = [&](int g, int i) { return (unsigned)((g >> 1) * 128 + grp * 64 + i * 16 + l15) * row_b; };  // group g = 2 qm + qn
+        // vmcnt retires in order, so a wait for loads that were issued after a store also waits for that store's write
+        // acknowledgement (~2 us). Order: loads of groups 0,1 -> results 0,1 computed in registers -> loads of groups 2,3
+        // (into the registers the finished accumulators free) -> stores 0,1 -> wait for loads 2,3 only -> stores 2,3.
+        u32x4 old[4][4][2];
+        f32x4 res[2][4][2];
+        auto load_group = [&](int g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned c = col_off[g & 1][j];
+                    old[g][i][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, c == OOB ? OOB : row_off(g, i) + c, 0, 0);
+                }
+        };
+        auto value = [&](int g, int i, int j) {
+            return (acc[g >> 1][g & 1][i][j] + bias[g & 1][j]) * gam[g & 1][j] + __builtin_bit_cast(f32x4, old[g][i][j]);
+        };
+        auto store = [&](int g, int i, int j, f32x4 v) {
+            const unsigned c = col_off[g & 1][j];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, c == OOB ? OOB : row_off(g, i) + c, 0, 0);
+        };
+        load_group(0);
+        load_group(1);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) res[g][i][j] = value(g, i, j);
+        load_group(2);
+        load_group(3);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) store(g, i, j, res[g][i][j]);
+#pragma unroll
+        for (int g = 2; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) store(g, i, j, value(g, i, j));
+        return;
+    }
+
+    // ---- bf16 outputs
+    __amdgpu_buffer_rsrc_t rs_hi, rs_lo;
+    if (MODE == DM_BF16) {
+        rs_hi = tile_rsrc(p.out_hi + (size_t)m0 * p.ldc, (size_t)rows_here * p.ldc * 2);
+        rs_lo = tile_rsrc(X3 ? p.out_lo + (size_t)m0 * p.ldc : p.out_hi, X3 ? (size_t)rows_here * p.ldc * 2 : 0);
+    }
+    // per-column constants of this lane's 4-column groups, both column halves loaded before the first store (a wait placed
+    // after a store would also wait for that store's acknowledgement)
+    f32x4 bias_q[2][2], gam_q[2][2];
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ncol = n0 + qn * 128 + wc * 32 + j * 16 + 4 * lh;
+            const int nc = ncol < p.N ? ncol : p.N - 4;  // clamped: out-of-range columns are never stored
+            bias_q[qn][j] = p.bias ? *(const f32x4*)(p.bias + nc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (MODE == DM_QK && ncol < p.F) gam_q[qn][j] = f32x4{p.qscale, p.qscale, p.qscale, p.qscale};
+            else if (MODE == DM_QK) gam_q[qn][j] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+        }
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn) {
         const int nq = n0 + qn * 128 + wc * 32;
         const int n8 = nq + (lh & 1) * 16 + (lh >> 1) * 8;  // first of the 8 columns this lane stores as bf16
-        // per-column constants of this lane's two 4-column groups (clamped: out-of-range columns are never stored)
-        f32x4 bias[2], gam[2];
-        int ncol[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            ncol[j] = nq + j * 16 + 4 * lh;
-            const int nc = ncol[j] < p.N ? ncol[j] : p.N - 4;
-            bias[j] = p.bias ? *(const f32x4*)(p.bias + nc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (MODE == DM_RESID) gam[j] = *(const f32x4*)(p.gamma + nc);
-            if (MODE == DM_QK && ncol[j] < p.F) gam[j] = f32x4{p.qscale, p.qscale, p.qscale, p.qscale};
-            else if (MODE == DM_QK) gam[j] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
-        }
-        // QKV: destination of this lane's 8-column group (head-major planes)
-        bf16_t* qk_hi = nullptr;
-        bf16_t* qk_lo = nullptr;
+        const f32x4(&bias)[2] = bias_q[qn];
+        const f32x4(&gam)[2] = gam_q[qn];
+        // QKV: this wave's 32 columns lie in one of the Q / K planes (F is a multiple of 64): wave-uniform descriptor
         int qk_h = 0, qk_d = 0;
         if (MODE == DM_QK) {
-            const int which = n8 >= p.F;
-            const int f = n8 - which * p.F;
-            qk_h = f >> 6; qk_d = f & 63;
-            qk_hi = which ? p.k_hi : p.q_hi;
-            qk_lo = which ? p.k_lo : p.q_lo;
+            const int which = __builtin_amdgcn_readfirstlane(nq >= p.F);
+            const int fcol = n8 - which * p.F;
+            qk_h = fcol >> 6; qk_d = fcol & 63;
+            const size_t plane = (size_t)p.M * p.F * 2;  // [B, heads, npad, 64] bf16 (M = B * npad); < 4 GiB checked by the caller
+            rs_hi = tile_rsrc(which ? p.k_hi : p.q_hi, plane);
+            rs_lo = tile_rsrc(X3 ? (which ? p.k_lo : p.q_lo) : p.q_hi, X3 ? plane : 0);
         }
+        const bool nok = n8 < p.N;
 #pragma unroll
-        for (int qm = 0; qm < 2; ++qm)
+        for (int qm = 0; qm < 2; ++qm) {
+            const int rfirst = qm * 128 + grp * 64 + l15;  // tile-local row of block i is rfirst + 16 i
+            int qb = 0, qt = 0;
+            if (MODE == DM_QK) {
+                qb = (m0 + rfirst) / p.npad;
+                qt = m0 + rfirst - qb * p.npad;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int m = m0 + qm * 128 + grp * 64 + i * 16 + l15;
-                const bool mok = m < p.M;
                 f32x4 v[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     v[j] = acc[qm][qn][i][j] + bias[j];
-                    if (MODE == DM_RESID) {
-                        if (mok && ncol[j] < p.N) {
-                            float* rp = p.out_f32 + (size_t)m * p.ldc + ncol[j];  // == resid row (in place), ldr == ldc checked by the caller
-                            *(f32x4*)rp = v[j] * gam[j] + *(const f32x4*)(p.resid + (size_t)m * p.ldr + ncol[j]);
-                        }
-                    } else if (MODE == DM_QK) {
+                    if (MODE == DM_QK) {
                         v[j] *= gam[j];
-                    } else if (gelu) {
+                    } else if (ACT == MDPT_ACT_GELU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[j][e] = gelu_erf(v[j][e]);
-                    } else if (p.act == MDPT_ACT_RELU) {
+                    } else if (ACT == MDPT_ACT_RELU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[j][e] = fmaxf(v[j][e], 0.0f);
                     }
                 }
-                if (MODE == DM_RESID) continue;
-                // ---- bf16 result: pack pairs, exchange halves with lane ^ 16, one 16-byte store (two in x3 mode)
+                // pack pairs, exchange halves with lane ^ 16, one 16-byte store (two in x3 mode)
                 unsigned hw_[2][2], lw_[2][2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -607,8 +689,10 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc
                         const f32x2 pp = {v[j][2 * w2], v[j][2 * w2 + 1]};
                         const bf16x2 hh = __builtin_convertvector(pp, bf16x2);
                         hw_[j][w2] = __builtin_bit_cast(unsigned, hh);
-                        const f32x2 rr = pp - __builtin_convertvector(hh, f32x2);
-                        lw_[j][w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                        if (X3) {
+                            const f32x2 rr = pp - __builtin_convertvector(hh, f32x2);
+                            lw_[j][w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                        }
                     }
                 unsigned ph[4], pl[4];
 #pragma unroll
@@ -616,26 +700,28 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc
                     auto r = __builtin_amdgcn_permlane16_swap(hw_[0][w2], hw_[1][w2], false, false);
                     ph[w2] = r[0];
                     ph[w2 + 2] = r[1];
-                    if (x3) {
+                    if (X3) {
                         auto rl = __builtin_amdgcn_permlane16_swap(lw_[0][w2], lw_[1][w2], false, false);
                         pl[w2] = rl[0];
                         pl[w2 + 2] = rl[1];
                     }
                 }
-                if (!mok || n8 >= p.N) continue;
-                size_t o;
-                bf16_t *oh, *ol;
+                unsigned off;
                 if (MODE == DM_BF16) {
-                    o = (size_t)m * p.ldc + n8;
-                    oh = p.out_hi; ol = p.out_lo;
+                    off = ((unsigned)(rfirst + 16 * i) * (unsigned)p.ldc + (unsigned)n8) * 2u;  // rows >= M lie beyond num_records
+                    if (!nok) off = OOB;
                 } else {
-                    const int b = m / p.npad, tk = m - b * p.npad;
-                    o = ((size_t)(b * p.heads + qk_h) * p.npad + tk) * 64 + qk_d;
-                    oh = qk_hi; ol = qk_lo;
+                    off = (unsigned)((((size_t)(qb * p.heads + qk_h) * p.npad + qt) * 64 + qk_d) * 2);
+                    if (!nok || m0 + rfirst + 16 * i >= p.M) off = OOB;
                 }
-                *(u32x4*)(oh + o) = u32x4{ph[0], ph[1], ph[2], ph[3]};
-                if (x3) *(u32x4*)(ol + o) = u32x4{pl[0], pl[1], pl[2], pl[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{ph[0], ph[1], ph[2], ph[3]}, rs_hi, off, 0, 0);
+                if (X3) __builtin_amdgcn_raw_buffer_store_b128(u32x4{pl[0], pl[1], pl[2], pl[3]}, rs_lo, off, 0, 0);
+                if (MODE == DM_QK) {  // next row block: token + 16, rolling over into the next image
+                    qt += 16;
+                    while (qt >= p.npad) { qt -= p.npad; ++qb; }
+                }
             }
+        }
     }
 }
 
@@ -858,14 +944,28 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
 #undef MFMA_Q
     if (p.dbg_times) t_loop = memtime_now();
     if constexpr (SW) {
-        if (EKIND == MDPT_E_QKV) epilogue_direct<DM_QK>(p, acc, m0, n0, grp, wc, lane);
-        else if (dmode == DM_BF16) epilogue_direct<DM_BF16>(p, acc, m0, n0, grp, wc, lane);
-        else epilogue_direct<DM_RESID>(p, acc, m0, n0, grp, wc, lane);
+        if (EKIND == MDPT_E_QKV) {
+            if (p.q_lo) epilogue_direct<DM_QK, true, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+            else epilogue_direct<DM_QK, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+        } else if (dmode == DM_BF16) {
+            const int sel = (p.out_lo ? 3 : 0) + (p.act == MDPT_ACT_GELU ? 2 : p.act == MDPT_ACT_RELU ? 1 : 0);
+            switch (sel) {
+                case 0: epilogue_direct<DM_BF16, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane); break;
+                case 1: epilogue_direct<DM_BF16, false, MDPT_ACT_RELU>(p, acc, m0, n0, grp, wc, lane); break;
+                case 2: epilogue_direct<DM_BF16, false, MDPT_ACT_GELU>(p, acc, m0, n0, grp, wc, lane); break;
+                case 3: epilogue_direct<DM_BF16, true, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane); break;
+                case 4: epilogue_direct<DM_BF16, true, MDPT_ACT_RELU>(p, acc, m0, n0, grp, wc, lane); break;
+                default: epilogue_direct<DM_BF16, true, MDPT_ACT_GELU>(p, acc, m0, n0, grp, wc, lane); break;
+            }
+        } else {
+            epilogue_direct<DM_RESID, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+        }
         if (p.dbg_times && tid == 0) {
+            const unsigned long long t_issued = memtime_now();  // all of this wave's stores issued, none waited for
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned long long* d = p.dbg_times + (size_t)blockIdx.x * 6;
             d[0] = t_start; d[1] = t_first; d[2] = t_loop; d[3] = memtime_now();
-            d[4] = __builtin_amdgcn_s_getreg(20 << 0 | 0 << 6 | 3 << 11);
+            d[4] = t_issued;
             d[5] = __builtin_amdgcn_s_getreg(4 << 0 | 0 << 6 | 31 << 11);
         }
         return;
@@ -915,9 +1015,10 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
     int dmode = DM_NONE;
     if (EKIND == MDPT_E_GENERIC) {
         const bool plain = !p.up_src && !p.bias_img_stride;
-        if (plain && p.out_hi && !p.out_f32 && !p.gamma && !p.resid && !p.relu_bf16) dmode = DM_BF16;
-        else if (plain && p.out_f32 && !p.out_hi && p.gamma && p.resid && p.bias && p.act == MDPT_ACT_NONE && p.ldr == p.ldc) dmode = DM_RESID;
-    } else if (EKIND == MDPT_E_QKV && n0 + 256 <= 2 * p.F) {
+        const bool fits = (size_t)256 * p.ldc * 4 < 0xFFFFFFF0ull;  // tile-local byte offsets of the buffer ops are 32-bit
+        if (plain && fits && p.out_hi && !p.out_f32 && !p.gamma && !p.resid && !p.relu_bf16) dmode = DM_BF16;
+        else if (plain && fits && p.out_f32 && !p.out_hi && p.gamma && p.resid && p.resid == p.out_f32 && p.bias && p.act == MDPT_ACT_NONE && p.ldr == p.ldc) dmode = DM_RESID;
+    } else if (EKIND == MDPT_E_QKV && n0 + 256 <= 2 * p.F && (size_t)p.M * p.F * 2 < 0xFFFFFFF0ull) {
         dmode = DM_QK;
     }
     if (EKIND == MDPT_E_GENERIC || EKIND == MDPT_E_QKV) {

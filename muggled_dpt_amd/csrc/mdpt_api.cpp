@@ -1331,6 +1331,10 @@ int mdpt_debug_gemm(const void* a_bf16, const void* w_bf16, void* out_f32, void*
     g.act = (tile >> 8) & 3;  // bits 8-9 of `tile`: epilogue activation (MDPT_ACT_*), for epilogue-cost measurements
     g.out_f32 = (float*)out_f32; g.out_hi = (bf16_t*)out_bf16; g.ldc = N; g.ldr = N;
     g.dbg_times = (unsigned long long*)dbg_times;
+    if ((tile >> 10) & 1) {  // bit 10: in-place residual epilogue (proj / fc2 form); bias and gamma are read from the out_bf16 buffer
+        if (!out_f32 || !out_bf16) return fail(MDPT_E_INVALID, "residual mode needs both output buffers");
+        g.bias = (const float*)out_bf16; g.gamma = (const float*)out_bf16 + N; g.resid = (const float*)out_f32; g.out_hi = nullptr;
+    }
     for (int i = 0; i < iters; ++i) CHK(mdpt_launch_gemm(g, (hipStream_t)stream));
     return 0;
 }

@@ -17,16 +17,20 @@ for M in (256, 16384, 41728):
     w = (torch.rand(N, K, device="cuda") * 2 - 1).to(torch.bfloat16)
     out = torch.empty(M, N, device="cuda", dtype=torch.float32)
     outb = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    for mode in ("f32", "bf16"):
+    for mode in ("f32", "bf16", "gelu", "resid"):
         nblk = ((M + 255) // 256) * (N // 256)
         dbg = torch.zeros(nblk * 6 + nblk * 16, dtype=torch.int64, device="cuda")
-        o32 = out.data_ptr() if mode == "f32" else None
-        o16 = outb.data_ptr() if mode == "bf16" else None
-        native.check(lib, lib.mdpt_debug_gemm(a.data_ptr(), w.data_ptr(), o32, o16, M, N, K, tile, 2, stream, None))
+        o32 = out.data_ptr() if mode in ("f32", "resid") else None
+        o16 = outb.data_ptr() if mode in ("bf16", "gelu", "resid") else None
+        tl = tile | (2 << 8 if mode == "gelu" else 0) | (1 << 10 if mode == "resid" else 0)
+        if mode == "resid":
+            outb.zero_(); out.zero_()
+        native.check(lib, lib.mdpt_debug_gemm(a.data_ptr(), w.data_ptr(), o32, o16, M, N, K, tl, 2, stream, None))
         torch.cuda.synchronize()
-        native.check(lib, lib.mdpt_debug_gemm(a.data_ptr(), w.data_ptr(), o32, o16, M, N, K, tile, 1, stream, dbg.data_ptr()))
+        native.check(lib, lib.mdpt_debug_gemm(a.data_ptr(), w.data_ptr(), o32, o16, M, N, K, tl, 1, stream, dbg.data_ptr()))
         torch.cuda.synchronize()
         d = dbg.cpu().numpy().astype(np.int64)[:nblk * 6].reshape(nblk, 6)
         pro, loop, epi = (d[:, 1] - d[:, 0]), (d[:, 2] - d[:, 1]), (d[:, 3] - d[:, 2])
+        issue = d[:, 4] - d[:, 2]
         print(f"M={M:6d} blocks={nblk:4d} out={mode:4s}: prologue {pro.mean():7.0f}  loop/kstep {loop.mean()/16:6.0f}  epilogue mean {epi.mean():7.0f} "
-              f"p10 {np.percentile(epi,10):6.0f} p50 {np.percentile(epi,50):6.0f} p90 {np.percentile(epi,90):6.0f}", flush=True)
+              f"p10 {np.percentile(epi,10):6.0f} p50 {np.percentile(epi,50):6.0f} p90 {np.percentile(epi,90):6.0f}  (issue-only, wave 0: {issue.mean():7.0f})", flush=True)
