@@ -948,7 +948,7 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
             if (p.q_lo) epilogue_direct<DM_QK, true, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
             else epilogue_direct<DM_QK, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
         } else if (dmode == DM_BF16) {
-            const int sel = (p.out_lo ? 3 : 0) + (p.act == MDPT_ACT_GELU ? 2 : p.act == MDPT_ACT_RELU ? 1 : 0);
+            const int sel = (p.out_lo ? 3 : 0) + (p.act == MDPT_ACT_GELU ? 2 : (p.act == MDPT_ACT_RELU || p.relu_bf16) ? 1 : 0);
             switch (sel) {
                 case 0: epilogue_direct<DM_BF16, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane); break;
                 case 1: epilogue_direct<DM_BF16, false, MDPT_ACT_RELU>(p, acc, m0, n0, grp, wc, lane); break;
@@ -1002,37 +1002,40 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
 #undef WAIT_LGKM
 #undef WAIT_VM
 
-template <int AMODE, int EKIND>
+// Operand order of the MFMAs: swapped -> accumulators hold 4 consecutive COLUMNS per lane and one of the direct epilogues
+// applies; plain order (4 consecutive ROWS per lane) + LDS strip for every other epilogue. For the generic epilogue the choice is
+// a property of the launch and is made on the host (DMODE template parameter: one main loop + one epilogue per kernel keeps the
+// register allocation of the 256-VGPR loop predictable); QKV launches decide per tile (tiles that contain V columns are written
+// transposed, token-contiguous, through the strip).
+__host__ __device__ inline int generic_direct_mode(const GemmParams& p) {
+    const bool plain = !p.up_src && !p.bias_img_stride;
+    const bool fits = (size_t)256 * p.ldc * 4 < 0xFFFFFFF0ull;  // tile-local byte offsets of the buffer ops are 32-bit
+    // relu_bf16 without an fp32 copy is just a ReLU activation (first conv of every residual conv unit)
+    if (plain && fits && p.out_hi && !p.out_f32 && !p.gamma && !p.resid && !(p.relu_bf16 && p.act != MDPT_ACT_NONE)) return DM_BF16;
+    if (plain && fits && p.out_f32 && !p.out_hi && p.gamma && p.resid && p.resid == p.out_f32 && p.bias && p.act == MDPT_ACT_NONE && p.ldr == p.ldc)
+        return DM_RESID;
+    return DM_NONE;
+}
+
+template <int AMODE, int EKIND, int DMODE>
 __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long t_start = 0;
     if (p.dbg_times) t_start = memtime_now();
     int m0, n0;
     tile_coords((p.N + 255) / 256, 256, 256, m0, n0);
-    // operand order of the MFMAs (workgroup-uniform, two separate instantiations of the body): swapped -> accumulators hold
-    // 4 consecutive COLUMNS per lane and one of the direct epilogues applies; plain order (4 consecutive ROWS per lane) +
-    // LDS strip for every other epilogue and for QKV tiles that contain V columns (written transposed, token-contiguous)
-    int dmode = DM_NONE;
-    if (EKIND == MDPT_E_GENERIC) {
-        const bool plain = !p.up_src && !p.bias_img_stride;
-        const bool fits = (size_t)256 * p.ldc * 4 < 0xFFFFFFF0ull;  // tile-local byte offsets of the buffer ops are 32-bit
-        if (plain && fits && p.out_hi && !p.out_f32 && !p.gamma && !p.resid && !p.relu_bf16) dmode = DM_BF16;
-        else if (plain && fits && p.out_f32 && !p.out_hi && p.gamma && p.resid && p.resid == p.out_f32 && p.bias && p.act == MDPT_ACT_NONE && p.ldr == p.ldc) dmode = DM_RESID;
-    } else if (EKIND == MDPT_E_QKV && n0 + 256 <= 2 * p.F && (size_t)p.M * p.F * 2 < 0xFFFFFFF0ull) {
-        dmode = DM_QK;
-    }
-    if (EKIND == MDPT_E_GENERIC || EKIND == MDPT_E_QKV) {
-        if (dmode != DM_NONE) gemm8_body<AMODE, EKIND, true>(p, smem, dmode, m0, n0, t_start);
-        else gemm8_body<AMODE, EKIND, false>(p, smem, dmode, m0, n0, t_start);
+    if (EKIND == MDPT_E_QKV) {
+        if (n0 + 256 <= 2 * p.F && (size_t)p.M * p.F * 2 < 0xFFFFFFF0ull) gemm8_body<AMODE, EKIND, true>(p, smem, DM_QK, m0, n0, t_start);
+        else gemm8_body<AMODE, EKIND, false>(p, smem, DM_NONE, m0, n0, t_start);
     } else {
-        gemm8_body<AMODE, EKIND, false>(p, smem, dmode, m0, n0, t_start);
+        gemm8_body<AMODE, EKIND, DMODE != DM_NONE>(p, smem, DMODE, m0, n0, t_start);
     }
 }
 
-template <int AMODE, int EKIND>
-int launch_pp(const GemmParams& p, hipStream_t stream) {
+template <int AMODE, int EKIND, int DMODE>
+int launch_pp_mode(const GemmParams& p, hipStream_t stream) {
     constexpr unsigned LDS = 2 * 65536;
-    auto kern = gemm8_kernel<AMODE, EKIND>;
+    auto kern = gemm8_kernel<AMODE, EKIND, DMODE>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1041,10 +1044,24 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
     }
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     static char prof_name[64] = "";
-    if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "gemm8_kernel<%d, %d>", AMODE, EKIND);
+    if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "gemm8_kernel<%d, %d, %d>", AMODE, EKIND, DMODE);
     MdptProfScope prof(prof_name, 2.0 * p.M * p.N * p.K, stream);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, p);
     return (int)hipGetLastError();
+}
+
+template <int AMODE, int EKIND>
+int launch_pp(const GemmParams& p, hipStream_t stream) {
+    if constexpr (EKIND == MDPT_E_GENERIC) {
+        const int dmode = generic_direct_mode(p);
+        if (dmode == DM_BF16) return launch_pp_mode<AMODE, EKIND, DM_BF16>(p, stream);
+        if (dmode == DM_RESID) return launch_pp_mode<AMODE, EKIND, DM_RESID>(p, stream);
+        return launch_pp_mode<AMODE, EKIND, DM_NONE>(p, stream);
+    } else if constexpr (EKIND == MDPT_E_QKV) {
+        return launch_pp_mode<AMODE, EKIND, DM_QK>(p, stream);
+    } else {
+        return launch_pp_mode<AMODE, EKIND, DM_NONE>(p, stream);
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int NST, int MINW, int AMODE, int EKIND>
