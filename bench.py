@@ -57,11 +57,36 @@ def cpu_baseline(model_name: str, size: int, x_cpu: torch.Tensor, gpu_out: torch
     out = {"value": round(n_img / dt, 4), "unit": "depth-maps/s", "cores": threads, "kind": "port",
            "sample": f"{n_img} images of the same workload, batch 1, fp32, torch {torch.__version__} CPU, {threads} threads "
                      f"(os.cpu_count()={os.cpu_count()})"}
-    err = None
-    if gpu_out is not None:
-        d = (gpu_out[:1].double().cpu() - ref.double()).abs().max()
-        err = {"max_abs": float(d), "rel_to_max": float(d / ref.double().abs().max())}
-    return out, err
+    return out, error_vs(ref, gpu_out), ref
+
+
+def error_vs(ref: torch.Tensor, gpu_out: torch.Tensor | None):
+    """The north-star error figure of image 0: max|y - y_cpu| and the same relative to max|y_cpu|."""
+    if gpu_out is None:
+        return None
+    d = (gpu_out[:1].double().cpu() - ref.double()).abs().max()
+    return {"max_abs": float(d), "rel_to_max": float(d / ref.double().abs().max())}
+
+
+def fp32_class_leg(args, dev, x_cpu, ref):
+    """The same workload in the bf16x3 mode (hi + lo bf16 operand planes, 3 MFMA passes, fp32 accumulate): the mode that meets the
+    north star's 1e-3 relative tolerance. Reported beside the headline bf16 number, never instead of it."""
+    osd = make_synthetic_original_state_dict(args.model, 0)
+    _, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
+    del osd
+    model = model.to(dev, torch.float32)
+    x = x_cpu.to(dev)
+    steps = max(2, min(args.steps, 5))
+    with torch.inference_mode():
+        y = model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y = model(x)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"value": round(args.batch * steps / dt, 3), "unit": "depth-maps/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "dtype": "bf16x3 (hi/lo split bf16 MFMA operands, 3 passes, fp32 accumulate)", "error_vs_cpu_fp32": error_vs(ref, y.float())}
 
 
 def main():
@@ -196,9 +221,12 @@ def main():
         else:
             line["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
-            base, err = cpu_baseline(args.model, args.size, x_cpu, y.float())
+            base, err, ref = cpu_baseline(args.model, args.size, x_cpu, y.float())
             line["cpu_baseline"] = base
             line["error_vs_cpu_fp32"] = err
+            if args.precision == "bf16":
+                del y
+                line["fp32_class_mode"] = fp32_class_leg(args, dev, x_cpu, ref)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

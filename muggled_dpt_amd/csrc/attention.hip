@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             } else {
                 orow = ((size_t)b * p.npad + q) * p.F + h * HD;
             }
-            // 16-byte stores (a CU retires about one store instruction per 64 cycles whatever its width): this lane owns
+            // 16-byte stores (fewest store instructions for the bytes moved): this lane owns
             // d = 8g + 4*half + 0..3 for g = 0..3; one v_permlane32_swap per packed register pair hands the lower lane the
             // whole d = 8g .. 8g+7 run of the even g and the upper lane that of the odd g
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;

@@ -217,14 +217,27 @@ __device__ __forceinline__ void tile_coords(int tiles_n, int BM, int BN, int& m0
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    if (tiles_n >= 8 && (tiles_n & 3) == 0) {
+        // wide outputs (fc1: 16 column tiles, QKV: 12): row-major order makes the 32 concurrent tiles of an XCD cover 2 row
+        // blocks x ALL columns, i.e. the whole weight matrix (8 MB for fc1, twice the 4 MB L2) is re-streamed for every pair
+        // of row blocks (measured 969 MB fetched per fc1 launch vs 93 MB algorithmic). Walk 4-column panels instead: the
+        // panel's weights (2 MB at K = 1024) stay in L2 while the row blocks stream past once per panel.
+        const int tiles_m = nwg / tiles_n, per_panel = tiles_m * 4;
+        const int panel = swz / per_panel, r = swz - panel * per_panel;
+        m0 = (r >> 2) * BM;
+        n0 = (panel * 4 + (r & 3)) * BN;
+        return;
+    }
     m0 = (swz / tiles_n) * BM;
     n0 = (swz % tiles_n) * BN;
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // Epilogue shared by both main-loop variants: per 32-row block, accumulators -> wave-private LDS strip [32][WTN] fp32
-// -> row-major vectors. A CU retires roughly one wave store instruction per ~66 cycles whatever its width (measured),
-// so every store is 16 bytes per lane: each lane owns 8 consecutive columns (one bf16x8 store, two fp32x4 stores).
+// -> row-major vectors. The vector-memory path moves 64 B/clk per CU and a store instruction costs about the same address
+// processing whatever its width, so every store is 16 bytes per lane: each lane owns 8 consecutive columns (one bf16x8 store,
+// two fp32x4 stores). Stores here sit behind per-lane bounds checks (divergent branches), which makes hipcc wait for every
+// store's acknowledgement before the next one (see epilogue_direct for the branch-free form used on the big GEMMs).
 // ------------------------------------------------------------------------------------------------------------
 // One [32 rows][WTN cols] fp32 block, already transposed into the wave-private LDS `strip`, -> global memory.
 template <int WTN, int EKIND>

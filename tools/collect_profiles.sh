@@ -1,0 +1,24 @@
+#!/bin/bash
+# Runs ON the MI355X box (through gpurun): the rocprofv3 passes whose summaries are committed under profiles/.
+#   1. kernel trace + stats of the default bench command (two-stream batch split) and of `--no-split`
+#   2. PMC passes (separate runs, --kernel-trace only): FETCH_SIZE, WRITE_SIZE -> HBM traffic per launch
+# Output: gpurun_out/profiles_<tag>/ ; copy what is to be judged into profiles/.
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/split" -- python "$R/bench.py" --steps 10 --warmup 3 > "$OUT/bench_under_rocprof.json" 2> "$OUT/split.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/nosplit" -- python "$R/bench.py" --no-split --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_nosplit_under_rocprof.json" 2> "$OUT/nosplit.log"
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -- python "$R/bench.py" --no-split --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> "$OUT/pmc_$C.log"
+done
+for d in split nosplit; do
+  f=$(find "$OUT/$d" -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp "$f" "$OUT/${d}_kernel_stats.csv"
+done
+python "$R/tools/summarize_pmc.py" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/hbm_traffic" > "$OUT/hbm_traffic.log" 2>&1
+# the raw per-dispatch traces are large; keep the summaries only
+rm -rf "$OUT/split" "$OUT/nosplit" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE"
+ls -la "$OUT"
