@@ -548,7 +548,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
 //   DM_BF16  : out_hi(/lo) = act(acc + bias)                    (fc1 + GELU; plain bf16 outputs)
 //   DM_RESID : out_f32 = resid + gamma * (acc + bias), fp32      (attention proj, fc2: in-place residual update)
 //   DM_QK    : Q (pre-scaled) / K head-major bf16(/lo)            (QKV tiles without V columns)
-enum { DM_NONE = 0, DM_BF16 = 1, DM_RESID = 2, DM_QK = 3 };
+//   DM_VT    : V transposed, token-contiguous (epilogue_direct_vt: PLAIN operand order, a lane owns 4 consecutive tokens)
+enum { DM_NONE = 0, DM_BF16 = 1, DM_RESID = 2, DM_QK = 3, DM_VT = 4 };
 
 // Everything that selects code is a template parameter (MODE, X3 = hi+lo output planes, ACT) and every memory access is a raw
 // buffer op whose out-of-range lanes (tail rows: offset beyond num_records; tail columns: offset forced to ~0) are dropped by
@@ -733,6 +734,77 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc
                     qt += 16;
                     while (qt >= p.npad) { qt -= p.npad; ++qb; }
                 }
+            }
+        }
+    }
+}
+
+// V columns of the QKV GEMM, written transposed: Vt[(b, h, d)][token]. With the PLAIN MFMA operand order a lane owns 4 consecutive
+// rows (tokens 4*(lane>>4) .. +3 of a 16-row block) of one column, i.e. 8 bytes of a Vt row; v_permlane16_swap between the two
+// 16-column blocks of the quadrant gives lanes (lane>>4) = 0,1 the 8 tokens 0-7 of a column of block 0 / block 1 and lanes 2,3
+// the tokens 8-15: one 16-byte store per lane and row block, no LDS. Same arithmetic as the strip path (bias add, hi/lo split).
+template <bool X3>
+__device__ __forceinline__ void epilogue_direct_vt(const GemmParams& p, f32x4 (&acc)[2][2][4][2], int m0, int n0, int grp, int wc, int lane) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const int l15 = lane & 15, lh = lane >> 4;
+    const size_t plane = (size_t)(p.M / p.npad) * p.F * p.npadv * 2;  // [B, heads, 64, npadv] bf16; < 4 GiB checked by the caller
+    const __amdgpu_buffer_rsrc_t rs_hi = tile_rsrc(p.vt_hi, plane);
+    const __amdgpu_buffer_rsrc_t rs_lo = tile_rsrc(X3 ? p.vt_lo : p.vt_hi, X3 ? plane : 0);
+    float bias_q[2][2];
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + qn * 128 + wc * 32 + j * 16 + l15;
+            bias_q[qn][j] = p.bias[n < p.N ? n : p.N - 1];
+        }
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn) {
+        const int ncol = n0 + qn * 128 + wc * 32 + (lh & 1) * 16 + l15;  // the column this lane stores after the swap
+        const int fcol = ncol - 2 * p.F, hh = fcol >> 6, dd = fcol & 63;
+        const bool nok = ncol < p.N;
+#pragma unroll
+        for (int qm = 0; qm < 2; ++qm) {
+            const int mfirst = m0 + qm * 128 + grp * 64 + (lh >> 1) * 8;  // first of this lane's 8 tokens in row block 0
+            int qb = mfirst / p.npad, qt = mfirst - qb * p.npad;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned hw_[2][2], lw_[2][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 v = acc[qm][qn][i][j] + bias_q[qn][j];
+#pragma unroll
+                    for (int w2 = 0; w2 < 2; ++w2) {
+                        const f32x2 pp = {v[2 * w2], v[2 * w2 + 1]};
+                        const bf16x2 hb = __builtin_convertvector(pp, bf16x2);
+                        hw_[j][w2] = __builtin_bit_cast(unsigned, hb);
+                        if (X3) {
+                            const f32x2 rr = pp - __builtin_convertvector(hb, f32x2);
+                            lw_[j][w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                        }
+                    }
+                }
+                unsigned ph[4], pl[4];
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2) {
+                    auto r = __builtin_amdgcn_permlane16_swap(hw_[0][w2], hw_[1][w2], false, false);
+                    ph[w2] = r[0];
+                    ph[w2 + 2] = r[1];
+                    if (X3) {
+                        auto rl = __builtin_amdgcn_permlane16_swap(lw_[0][w2], lw_[1][w2], false, false);
+                        pl[w2] = rl[0];
+                        pl[w2 + 2] = rl[1];
+                    }
+                }
+                unsigned off = (unsigned)((((size_t)(qb * p.heads + hh) * 64 + dd) * p.npadv + qt) * 2);
+                if (!nok || mfirst + 16 * i >= p.M) off = OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{ph[0], ph[1], ph[2], ph[3]}, rs_hi, off, 0, 0);
+                if (X3) __builtin_amdgcn_raw_buffer_store_b128(u32x4{pl[0], pl[1], pl[2], pl[3]}, rs_lo, off, 0, 0);
+                qt += 16;
+                while (qt >= p.npad) { qt -= p.npad; ++qb; }
             }
         }
     }
@@ -983,6 +1055,16 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
         }
         return;
     }
+    if (EKIND == MDPT_E_QKV && dmode == DM_VT) {
+        if (p.vt_lo) epilogue_direct_vt<true>(p, acc, m0, n0, grp, wc, lane);
+        else epilogue_direct_vt<false>(p, acc, m0, n0, grp, wc, lane);
+        if (p.dbg_times && tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned long long* d = p.dbg_times + (size_t)blockIdx.x * 6;
+            d[0] = t_start; d[1] = t_first; d[2] = t_loop; d[3] = memtime_now(); d[4] = d[3]; d[5] = 0;
+        }
+        return;
+    }
     __syncthreads();  // every wave is done reading the ring: reuse it as epilogue staging
 
     // ---- epilogue: per quadrant two [32][32] blocks through the wave-private strip (C layout of the 16x16 MFMA:
@@ -1038,7 +1120,11 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
     int m0, n0;
     tile_coords((p.N + 255) / 256, 256, 256, m0, n0);
     if (EKIND == MDPT_E_QKV) {
+        // per tile: Q / K columns only -> swapped order + head-major direct epilogue; V columns only -> plain order + transposed
+        // direct epilogue; a tile that straddles 2F (odd head counts) or planes beyond 32-bit offsets -> plain order + LDS strip
         if (n0 + 256 <= 2 * p.F && (size_t)p.M * p.F * 2 < 0xFFFFFFF0ull) gemm8_body<AMODE, EKIND, true>(p, smem, DM_QK, m0, n0, t_start);
+        else if (n0 >= 2 * p.F && n0 + 256 <= p.N && (size_t)(p.M / p.npad) * p.F * p.npadv * 2 < 0xFFFFFFF0ull)
+            gemm8_body<AMODE, EKIND, false>(p, smem, DM_VT, m0, n0, t_start);
         else gemm8_body<AMODE, EKIND, false>(p, smem, DM_NONE, m0, n0, t_start);
     } else {
         gemm8_body<AMODE, EKIND, DMODE != DM_NONE>(p, smem, DMODE, m0, n0, t_start);
