@@ -1,0 +1,34 @@
+"""The RCCL side of the data-parallel path on the hardware that is available to the test tier (one GPU): a one-rank "nccl" process group
+must initialise on the box and carry DataParallelDepth's collective. The world-size-2 semantics are covered on CPU with gloo
+(tests/test_parallel.py); the 8-GPU run is the driver's. `pytest -m gpu`."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from muggled_dpt_amd.parallel import init_distributed, all_gather_maps, DataParallelDepth
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+x = torch.randn(4, 56, 56, device="cuda").to(torch.bfloat16)
+out = torch.empty_like(x)
+dist.all_gather_into_tensor(out, x)          # the exact collective DataParallelDepth issues (RCCL all-gather on this GPU)
+torch.cuda.synchronize()
+assert torch.equal(out, x)
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK", torch.cuda.nccl.version())
+""" % REPO
+
+
+def test_rccl_backend_initialises_and_allgathers_on_this_box():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
