@@ -112,6 +112,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:  # one process per node checks / builds libmdpt.so, the others load the finished file
+        if local_rank == 0:
+            native.load()
+        dist.barrier()
     dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
 
     osd = make_synthetic_original_state_dict(args.model, 0)

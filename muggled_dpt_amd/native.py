@@ -55,8 +55,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
              "-Wno-unused-result"]
     objs = []
 
+    # objects and the linked library go through pid-unique names and an atomic rename: several processes (one per GPU) may find
+    # the library stale at the same time
+    tag = f".{os.getpid()}"
+
     def compile_one(src: str) -> str:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + tag + ".o")
         cmd = [hipcc, *flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -67,8 +71,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    tmp = LIB_PATH + ".tmp"
+    tmp = LIB_PATH + tag + ".tmp"
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp, "-ldl"], capture_output=True, text=True)
+    for obj in objs:
+        final = obj[: -len(tag + ".o")] + ".o"
+        os.replace(obj, final)  # keep the objects (incremental relinks by hand, disassembly)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     os.replace(tmp, LIB_PATH)
