@@ -609,8 +609,17 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc
             const unsigned c = col_off[g & 1][j];
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, c == OOB ? OOB : row_off(g, i) + c, 0, 0);
         };
+        // test hook (dbg_times): wave 0 stamps [epilogue start, loads 0,1 issued, loads 0,1 landed, loads 2,3 + stores 0,1 issued,
+        // loads 2,3 landed, all stores issued] behind the 6 per-workgroup slots of every workgroup
+        unsigned long long* stamp = p.dbg_times && threadIdx.x == 0 ? p.dbg_times + (size_t)gridDim.x * 6 + (size_t)blockIdx.x * 16 : nullptr;
+        if (stamp) stamp[0] = memtime_now();
         load_group(0);
         load_group(1);
+        if (p.dbg_times) {
+            if (stamp) stamp[1] = memtime_now();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (stamp) stamp[2] = memtime_now();
+        }
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -625,12 +634,18 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) store(g, i, j, res[g][i][j]);
+        if (p.dbg_times) {
+            if (stamp) stamp[3] = memtime_now();
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (stamp) stamp[4] = memtime_now();
+        }
 #pragma unroll
         for (int g = 2; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) store(g, i, j, value(g, i, j));
+        if (stamp) stamp[5] = memtime_now();
         return;
     }
 

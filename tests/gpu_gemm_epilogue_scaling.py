@@ -32,5 +32,10 @@ for M in (256, 16384, 41728):
         d = dbg.cpu().numpy().astype(np.int64)[:nblk * 6].reshape(nblk, 6)
         pro, loop, epi = (d[:, 1] - d[:, 0]), (d[:, 2] - d[:, 1]), (d[:, 3] - d[:, 2])
         issue = d[:, 4] - d[:, 2]
+        if mode == "resid":
+            e = dbg.cpu().numpy().astype(np.int64)[nblk * 6:].reshape(nblk, 16)
+            st = e[:, 1:6] - e[:, 0:5]
+            print("      resid phases (wave 0 mean): issue L01 %5.0f | wait L01 %5.0f | compute + issue L23,S01 %5.0f | wait L23 %5.0f | compute + issue S23 %5.0f"
+                  % tuple(st.mean(axis=0)), flush=True)
         print(f"M={M:6d} blocks={nblk:4d} out={mode:4s}: prologue {pro.mean():7.0f}  loop/kstep {loop.mean()/16:6.0f}  epilogue mean {epi.mean():7.0f} "
               f"p10 {np.percentile(epi,10):6.0f} p50 {np.percentile(epi,50):6.0f} p90 {np.percentile(epi,90):6.0f}  (issue-only, wave 0: {issue.mean():7.0f})", flush=True)
