@@ -1,0 +1,40 @@
+"""Code-generation guard (no GPU needed: hipcc cross-compiles gfx950): the 8-phase GEMM main loop and the attention kernel run at the
+256-VGPR occupancy limit, where a few extra live values turn into scratch spills inside the loop (measured: -6 % end to end, 2x on the
+residual epilogue). Compile the kernels to ISA text and require ScratchSize == 0 for every hot kernel."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(REPO, "muggled_dpt_amd", "csrc")
+
+
+def _kernel_stats(src, tmp_path):
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("hipcc not available")
+    out = str(tmp_path / (src + ".s"))
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(REPO, "include"), "-I", CSRC, "-x", "hip",
+                        "--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    stats, name = {}, None
+    for line in open(out):
+        m = re.match(r"^(_Z\S+):\s", line)
+        if m:
+            name = m.group(1)
+        m = re.match(r"^; (NumVgprs|ScratchSize): (\d+)", line)
+        if m and name:
+            stats.setdefault(name, {})[m.group(1)] = int(m.group(2))
+    return stats
+
+
+@pytest.mark.parametrize("src,pattern", [("gemm.hip", "gemm8_kernel"), ("attention.hip", "attn_kernel")])
+def test_hot_kernels_do_not_spill(tmp_path, src, pattern):
+    stats = {k: v for k, v in _kernel_stats(src, tmp_path).items() if pattern in k}
+    assert len(stats) >= 6, sorted(stats)
+    for name, s in stats.items():
+        assert s["ScratchSize"] == 0, f"{name} spills {s['ScratchSize']} bytes of scratch per lane ({s['NumVgprs']} VGPRs)"
+        assert s["NumVgprs"] <= 256
