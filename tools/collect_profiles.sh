@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON the MI355X box (through gpurun): the rocprofv3 passes whose summaries are committed under profiles/.
 #   1. kernel trace + stats of the default bench command (two-stream batch split) and of `--no-split`
-#   2. PMC passes (separate runs, --kernel-trace only): FETCH_SIZE, WRITE_SIZE -> HBM traffic per launch
+#   2. PMC passes (separate runs, --kernel-trace only): FETCH_SIZE, WRITE_SIZE -> HBM traffic per launch; SQ wave-state counters
 # Output: gpurun_out/profiles_<tag>/ ; copy what is to be judged into profiles/.
 set -u
 TAG=${1:-r01}
@@ -14,11 +14,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/nosplit" -- python
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -- python "$R/bench.py" --no-split --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> "$OUT/pmc_$C.log"
 done
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS \
+  --kernel-trace --output-format csv -d "$OUT/pmc_SQ" -- python "$R/bench.py" --no-split --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> "$OUT/pmc_SQ.log"
+python "$R/tools/summarize_sq.py" "$OUT/pmc_SQ" "$OUT/sq_counters.md" > "$OUT/sq_counters.log" 2>&1
 for d in split nosplit; do
   f=$(find "$OUT/$d" -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${d}_kernel_stats.csv"
 done
 python "$R/tools/summarize_pmc.py" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/hbm_traffic" > "$OUT/hbm_traffic.log" 2>&1
 # the raw per-dispatch traces are large; keep the summaries only
-rm -rf "$OUT/split" "$OUT/nosplit" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE"
+rm -rf "$OUT/split" "$OUT/nosplit" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ"
 ls -la "$OUT"
