@@ -548,8 +548,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
 //   DM_BF16  : out_hi(/lo) = act(acc + bias)                    (fc1 + GELU; plain bf16 outputs)
 //   DM_RESID : out_f32 = resid + gamma * (acc + bias), fp32      (attention proj, fc2: in-place residual update)
 //   DM_QK    : Q (pre-scaled) / K head-major bf16(/lo)            (QKV tiles without V columns)
+//   DM_F32   : out_f32 = acc + bias, fp32                          (1x1 projections, SwinV2 QKV / proj / fc2, SwiGLU inner linear)
 //   DM_VT    : V transposed, token-contiguous (epilogue_direct_vt: PLAIN operand order, a lane owns 4 consecutive tokens)
-enum { DM_NONE = 0, DM_BF16 = 1, DM_RESID = 2, DM_QK = 3, DM_VT = 4 };
+enum { DM_NONE = 0, DM_BF16 = 1, DM_RESID = 2, DM_QK = 3, DM_VT = 4, DM_F32 = 5 };
 
 // Everything that selects code is a template parameter (MODE, X3 = hi+lo output planes, ACT) and every memory access is a raw
 // buffer op whose out-of-range lanes (tail rows: offset beyond num_records; tail columns: offset forced to ~0) are dropped by
@@ -571,6 +572,33 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc
     const int l15 = lane & 15, lh = lane >> 4;
     const int rows_here = p.M - m0 < 256 ? p.M - m0 : 256;  // valid rows of this tile (tail tile: fewer)
 
+    if (MODE == DM_F32) {
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(p.out_f32 + (size_t)m0 * p.ldc, (size_t)rows_here * p.ldc * 4);
+        const unsigned row_b = (unsigned)p.ldc * 4u;
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn) {
+            f32x4 bias[2];
+            unsigned col_off[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nc = n0 + qn * 128 + wc * 32 + j * 16 + 4 * lh;
+                bias[j] = p.bias ? *(const f32x4*)(p.bias + (nc < p.N ? nc : p.N - 4)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                col_off[j] = nc < p.N ? (unsigned)nc * 4u : OOB;
+            }
+#pragma unroll
+            for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned row = (unsigned)(qm * 128 + grp * 64 + i * 16 + l15) * row_b;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x4 v = acc[qm][qn][i][j] + bias[j];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, col_off[j] == OOB ? OOB : row + col_off[j], 0, 0);
+                    }
+                }
+        }
+        return;
+    }
     if (MODE == DM_RESID) {
         // in-place residual update; descriptor over this tile's rows (base = row m0), byte offsets inside it
         const __amdgpu_buffer_rsrc_t rs = tile_rsrc(p.out_f32 + (size_t)m0 * p.ldc, (size_t)rows_here * p.ldc * 4);
@@ -1057,6 +1085,8 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
                 case 4: epilogue_direct<DM_BF16, true, MDPT_ACT_RELU>(p, acc, m0, n0, grp, wc, lane); break;
                 default: epilogue_direct<DM_BF16, true, MDPT_ACT_GELU>(p, acc, m0, n0, grp, wc, lane); break;
             }
+        } else if (dmode == DM_F32) {
+            epilogue_direct<DM_F32, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
         } else {
             epilogue_direct<DM_RESID, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
         }
@@ -1124,6 +1154,7 @@ __host__ __device__ inline int generic_direct_mode(const GemmParams& p) {
     if (plain && fits && p.out_hi && !p.out_f32 && !p.gamma && !p.resid && !(p.relu_bf16 && p.act != MDPT_ACT_NONE)) return DM_BF16;
     if (plain && fits && p.out_f32 && !p.out_hi && p.gamma && p.resid && p.resid == p.out_f32 && p.bias && p.act == MDPT_ACT_NONE && p.ldr == p.ldc)
         return DM_RESID;
+    if (plain && fits && p.out_f32 && !p.out_hi && !p.gamma && !p.resid && p.act == MDPT_ACT_NONE && !p.relu_bf16) return DM_F32;
     return DM_NONE;
 }
 
@@ -1170,6 +1201,7 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
         const int dmode = generic_direct_mode(p);
         if (dmode == DM_BF16) return launch_pp_mode<AMODE, EKIND, DM_BF16>(p, stream);
         if (dmode == DM_RESID) return launch_pp_mode<AMODE, EKIND, DM_RESID>(p, stream);
+        if (dmode == DM_F32) return launch_pp_mode<AMODE, EKIND, DM_F32>(p, stream);
         return launch_pp_mode<AMODE, EKIND, DM_NONE>(p, stream);
     } else if constexpr (EKIND == MDPT_E_QKV) {
         return launch_pp_mode<AMODE, EKIND, DM_QK>(p, stream);
