@@ -137,6 +137,13 @@ int mdpt_launch_swin_window_map(int* rowmap, int* region, int* tq, int* tk, int 
 // continuous position bias LUT [heads][(2wh-1)(2ww-1)] = 16*sigmoid(MLP(log-coords)); pretrained = 0 means "None"
 int mdpt_launch_swin_cpb(const float* w1, const float* b1, const float* w2, float* lut, int heads, int hidden, int wh, int ww,
                          int pretrained, hipStream_t stream);
+// the same for every block of the encoder in ONE launch (the LUTs depend on weights and window sizes only, not on activations)
+struct SwinCpbBatch {
+    const float* w1[32]; const float* b1[32]; const float* w2[32]; float* lut[32];
+    int heads[32], wh[32], ww[32], pre[32];
+    int n, hidden;
+};
+int mdpt_launch_swin_cpb_batch(const SwinCpbBatch& b, hipStream_t stream);
 // fp32 qkv [B*N, 3F] -> normalised/scaled window operands Q,K [B*nw, heads, npad, 32] and Vt [B*nw, heads, 32, npadv]
 int mdpt_launch_swin_qkv_prep(const float* qkv, const int* rowmap, const float* logit_scale, bf16_t* q_hi, bf16_t* q_lo,
                               bf16_t* k_hi, bf16_t* k_lo, bf16_t* vt_hi, bf16_t* vt_lo, int B, int N, int nw, int wa, int npad,

@@ -11,6 +11,7 @@
 // All are coalesced streaming kernels; the matmuls around them run in gemm.hip / attention.hip.
 
 #include "mdpt_kernels.h"
+#include <algorithm>
 #include "mdpt_prof.h"
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -129,11 +130,12 @@ __global__ __launch_bounds__(256) void swin_window_map_kernel(int* rowmap, int* 
 // with c = sign(v) * log2(|8 v| + 1) / log2(8), v = offset / max(divider - 1, 1), divider = pretrained window size if given
 // else the current window size (relative_positional_encoder.py:122-150, :79-84).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void swin_cpb_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
-                                                       float* __restrict__ lut, int heads, int hidden, int wh, int ww, int pre) {
+__device__ __forceinline__ void swin_cpb_body(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                              float* __restrict__ lut, int heads, int hidden, int wh, int ww, int pre) {
     extern __shared__ float hid[];
     const int rw = 2 * ww - 1, R = (2 * wh - 1) * rw;
     const int e = blockIdx.x;
+    if (e >= R) return;  // batched launch: the grid covers the largest window
     const int dy = e / rw - (wh - 1), dx = e % rw - (ww - 1);
     const float div_h = (float)max((pre > 0 ? pre : wh) - 1, 1), div_w = (float)max((pre > 0 ? pre : ww) - 1, 1);
     float cy = (float)dy / div_h, cx = (float)dx / div_w;
@@ -149,6 +151,16 @@ __global__ __launch_bounds__(256) void swin_cpb_kernel(const float* __restrict__
         acc = wave_sum(acc);
         if (lane == 0) lut[(size_t)h * R + e] = 16.0f / (1.0f + expf(-acc));
     }
+}
+
+__global__ __launch_bounds__(256) void swin_cpb_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                       float* __restrict__ lut, int heads, int hidden, int wh, int ww, int pre) {
+    swin_cpb_body(w1, b1, w2, lut, heads, hidden, wh, ww, pre);
+}
+
+__global__ __launch_bounds__(256) void swin_cpb_batch_kernel(const SwinCpbBatch b) {
+    const int l = blockIdx.y;
+    swin_cpb_body(b.w1[l], b.b1[l], b.w2[l], b.lut[l], b.heads[l], b.hidden, b.wh[l], b.ww[l], b.pre[l]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -279,6 +291,15 @@ int mdpt_launch_swin_cpb(const float* w1, const float* b1, const float* w2, floa
     const int R = (2 * wh - 1) * (2 * ww - 1);
     MdptProfScope prof("swin_cpb_kernel", 0.0, stream);
     hipLaunchKernelGGL(swin_cpb_kernel, dim3(R), dim3(256), (size_t)hidden * 4, stream, w1, b1, w2, lut, heads, hidden, wh, ww, pretrained);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_swin_cpb_batch(const SwinCpbBatch& b, hipStream_t stream) {
+    if (b.n < 1 || b.n > 32) return (int)hipErrorInvalidValue;
+    int rmax = 0;
+    for (int l = 0; l < b.n; ++l) rmax = std::max(rmax, (2 * b.wh[l] - 1) * (2 * b.ww[l] - 1));
+    MdptProfScope prof("swin_cpb_batch_kernel", 0.0, stream);
+    hipLaunchKernelGGL(swin_cpb_batch_kernel, dim3(rmax, b.n), dim3(256), (size_t)b.hidden * 4, stream, b);
     LAUNCH_RET();
 }
 
