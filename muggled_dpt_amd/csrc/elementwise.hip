@@ -489,8 +489,8 @@ __global__ __launch_bounds__(256) void prepare_image_kernel(const unsigned char*
 // with the three cls cases mapped onto constant regions: tq[cls] = R+T, tk[cls] = -(R+T+1):
 //     [R, R+T] = cls->token value, [R+T+1, 2R+T] = token->cls value, [2R+2T+1] = cls->cls   (R=(2gh-1)(2gw-1), T=(gh-1)(2gw-1)+gw-1)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void beit_relpos_kernel(const float* __restrict__ ref, float* __restrict__ ext, int* tq, int* tk,
-                                                          int heads, int Gh, int Gw, int gh, int gw, int N, int ntok_pad) {
+__device__ __forceinline__ void beit_relpos_body(const float* __restrict__ ref, float* __restrict__ ext, int* tq, int* tk,
+                                                 int heads, int Gh, int Gw, int gh, int gw, int N, int ntok_pad) {
     const int rh = 2 * gh - 1, rw = 2 * gw - 1, Rh = 2 * Gh - 1, Rw = 2 * Gw - 1;
     const int R = rh * rw, T = (gh - 1) * rw + gw - 1, Rref = Rh * Rw;
     const int elen = 2 * R + 2 * T + 2;
@@ -531,6 +531,17 @@ __global__ __launch_bounds__(256) void beit_relpos_kernel(const float* __restric
         }
         ext[idx] = v;
     }
+}
+
+__global__ __launch_bounds__(256) void beit_relpos_kernel(const float* __restrict__ ref, float* __restrict__ ext, int* tq, int* tk,
+                                                          int heads, int Gh, int Gw, int gh, int gw, int N, int ntok_pad) {
+    beit_relpos_body(ref, ext, tq, tk, heads, Gh, Gw, gh, gw, N, ntok_pad);
+}
+
+// every block's table in one launch (blockIdx.y = block): the tables depend on the learned LUTs and the grid only
+__global__ __launch_bounds__(256) void beit_relpos_batch_kernel(const BeitRelposBatch b) {
+    const int l = blockIdx.y;
+    beit_relpos_body(b.ref[l], b.ext0 + (size_t)l * b.ext_stride, b.tq, b.tk, b.heads, b.Gh, b.Gw, b.gh, b.gw, b.N, l == 0 ? b.ntok_pad : 0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -707,6 +718,14 @@ int mdpt_launch_prepare_image(const unsigned char* bgr, float* out, int ih, int 
 int mdpt_beit_relpos_elen(int gh, int gw) {
     const int rw = 2 * gw - 1, R = (2 * gh - 1) * rw, T = (gh - 1) * rw + gw - 1;
     return 2 * R + 2 * T + 2;
+}
+
+int mdpt_launch_beit_relpos_batch(const BeitRelposBatch& b, hipStream_t stream) {
+    if (b.n < 1 || b.n > 32) return (int)hipErrorInvalidValue;
+    const size_t total = (size_t)b.heads * mdpt_beit_relpos_elen(b.gh, b.gw);
+    const size_t work = total > (size_t)b.ntok_pad ? total : (size_t)b.ntok_pad;
+    hipLaunchKernelGGL(beit_relpos_batch_kernel, dim3(grid_for(work), b.n), dim3(256), 0, stream, b);
+    LAUNCH_RET();
 }
 
 int mdpt_launch_beit_relpos(const float* ref_lut, float* ext_lut, int* tq, int* tk, int heads, int Gh, int Gw, int gh, int gw, int N,

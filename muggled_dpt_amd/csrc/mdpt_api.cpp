@@ -431,7 +431,7 @@ int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
     if (is_beit(h)) {
         take_planes(bump, x3, (size_t)B * p.Np * F, p.tokr);
         p.cbuf = bump.take((size_t)B * F * 4);
-        p.relpos_lut = bump.take((size_t)h->heads * mdpt_beit_relpos_elen(gh, gw) * 4);
+        p.relpos_lut = bump.take((size_t)h->heads * mdpt_beit_relpos_elen(gh, gw) * 4 * (h->nblocks <= 32 ? h->nblocks : 1));  // one table per block
         p.relpos_tq = bump.take((size_t)p.npadv * 4);
         p.relpos_tk = bump.take((size_t)p.npadv * 4);
     }
@@ -516,6 +516,18 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
     Planes xn = c.pl(p.xn), q = c.pl(p.q), k = c.pl(p.k), vt = c.pl(p.vt), att = c.pl(p.att), hb = c.pl(p.hbuf);
     CHK(mdpt_launch_zero_vt_pad(vt.hi, vt.lo, p.B * h->heads * 64, p.N, p.npadv, c.s));
 #define DBG_STOP(step) if (h->dbg_block == b && h->dbg_step == (step)) return 0
+    const size_t relpos_stride = is_beit(h) ? (size_t)h->heads * mdpt_beit_relpos_elen(p.gh, p.gw) : 0;
+    const bool relpos_batched = is_beit(h) && h->nblocks <= 32;
+    if (relpos_batched) {  // every block's relative-position table, resized to the current grid: one launch per forward
+        BeitRelposBatch rb;
+        memset(&rb, 0, sizeof(rb));
+        for (int b = 0; b < h->nblocks; ++b) rb.ref[b] = h->V(blk_name(h, b) + ".attn.relpos_enc.ref_bias_lut");
+        rb.ext0 = c.at<float>(p.relpos_lut); rb.ext_stride = relpos_stride;
+        rb.tq = c.at<int>(p.relpos_tq); rb.tk = c.at<int>(p.relpos_tk);
+        rb.n = h->nblocks; rb.heads = h->heads; rb.Gh = h->cfg.base_patch_grid_h; rb.Gw = h->cfg.base_patch_grid_w;
+        rb.gh = p.gh; rb.gw = p.gw; rb.N = p.N; rb.ntok_pad = p.npadv;
+        CHK(mdpt_launch_beit_relpos_batch(rb, c.s));
+    }
     for (int b = 0; b < h->nblocks; ++b) {
         const std::string n = blk_name(h, b);
         CHK(mdpt_launch_layernorm(resid, h->V(n + ".norm1.weight"), h->V(n + ".norm1.bias"), xn.hi, xn.lo, nullptr, rows, F, c.s));
@@ -535,11 +547,12 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             a.q_hi = q.hi; a.q_lo = q.lo; a.k_hi = k.hi; a.k_lo = k.lo; a.vt_hi = vt.hi; a.vt_lo = vt.lo;
             a.out_hi = att.hi; a.out_lo = att.lo;
             a.B = p.B; a.heads = h->heads; a.N = p.N; a.npad = p.npad; a.npadv = p.npadv; a.F = F; a.x3 = h->x3;
-            if (is_beit(h)) {  // this layer's relative-position table, resized to the current grid (tiny kernel)
-                CHK(mdpt_launch_beit_relpos(h->V(n + ".attn.relpos_enc.ref_bias_lut"), c.at<float>(p.relpos_lut), c.at<int>(p.relpos_tq),
-                                            c.at<int>(p.relpos_tk), h->heads, h->cfg.base_patch_grid_h, h->cfg.base_patch_grid_w, p.gh, p.gw,
-                                            p.N, p.npadv, c.s));
-                a.bias_lut = c.at<float>(p.relpos_lut); a.bias_elen = mdpt_beit_relpos_elen(p.gh, p.gw);
+            if (is_beit(h)) {
+                float* lut_b = c.at<float>(p.relpos_lut) + (relpos_batched ? (size_t)b * relpos_stride : 0);
+                if (!relpos_batched)  // more than 32 blocks: this layer's table on its own (tiny kernel)
+                    CHK(mdpt_launch_beit_relpos(h->V(n + ".attn.relpos_enc.ref_bias_lut"), lut_b, c.at<int>(p.relpos_tq), c.at<int>(p.relpos_tk),
+                                                h->heads, h->cfg.base_patch_grid_h, h->cfg.base_patch_grid_w, p.gh, p.gw, p.N, p.npadv, c.s));
+                a.bias_lut = lut_b; a.bias_elen = mdpt_beit_relpos_elen(p.gh, p.gw);
                 a.tq = c.at<int>(p.relpos_tq); a.tk = c.at<int>(p.relpos_tk);
             }
             if (c.attn_dump && c.attn_dump[b]) CHK(mdpt_launch_attn_weights(a, (float*)c.attn_dump[b], c.s));

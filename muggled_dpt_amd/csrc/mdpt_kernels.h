@@ -120,6 +120,12 @@ int mdpt_launch_prepare_image(const unsigned char* bgr, float* out, int ih, int 
 int mdpt_launch_beit_relpos(const float* ref_lut, float* ext_lut, int* tq, int* tk, int heads, int Gh, int Gw, int gh, int gw,
                             int N, int ntok_pad, hipStream_t stream);
 int mdpt_beit_relpos_elen(int gh, int gw);
+struct BeitRelposBatch {
+    const float* ref[32]; float* ext0; size_t ext_stride;  // block l writes ext0 + l * ext_stride (elements)
+    int* tq; int* tk;
+    int n, heads, Gh, Gw, gh, gw, N, ntok_pad;
+};
+int mdpt_launch_beit_relpos_batch(const BeitRelposBatch& b, hipStream_t stream);
 int mdpt_launch_memset_f32(float* dst, float value, size_t n, hipStream_t stream);
 int mdpt_launch_add_f32(float* dst, const float* src, size_t n, hipStream_t stream);  // dst += src
 // ViT-G SwiGLU gate: fp32 [rows, 2h] -> silu(first half) * second half as bf16 hi (+lo) [rows, hp] (pad columns zero)
