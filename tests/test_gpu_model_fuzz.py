@@ -1,0 +1,48 @@
+"""Randomised small Depth-Anything-V2 configurations (widths, head counts incl. odd ones, block counts, reassembly widths, fusion channels,
+rectangular grids, batch sizes) through the whole HIP path vs the CPU oracle, fp32-class mode at the north-star tolerance and bf16 mode at
+its own. Odd head counts make QKV tiles straddle the Q|K|V boundaries; widths that are not multiples of 64/256 exercise every padding rule.
+`pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    rng = np.random.default_rng(20260928)
+    out = []
+    for k in range(10):
+        heads = int(rng.integers(1, 9))                      # 1..8 heads of 64
+        F = 64 * heads
+        blocks = int(rng.choice([4, 8]))
+        feats = [int(16 * rng.integers(1, 9)) for _ in range(4)]
+        C = int(rng.choice([32, 48, 64, 96]))
+        gh, gw = int(2 * rng.integers(1, 8)), int(2 * rng.integers(1, 8))
+        B = int(rng.integers(1, 6))
+        giant = bool(k % 5 == 4)
+        out.append((dict(features_per_token=F, num_heads=heads, num_blocks=blocks, reassembly_features_list=feats,
+                         base_patch_grid_hw=(5, 5), fusion_channels=C, patch_size_px=14, is_giant=giant), (gh, gw), B, k))
+    return out
+
+
+@pytest.mark.parametrize("cfg,grid,B,seed", _cases(), ids=lambda v: None)
+def test_random_configurations_match_the_oracle(cfg, grid, B, seed):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+    from muggled_dpt_amd.state_dict_conversion import convert_state_dict_keys, flatten_components, get_model_config_from_state_dict
+    from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict
+    from oracle import dpt_oracle
+    osd = make_synthetic_original_state_dict(cfg, seed)
+    c = get_model_config_from_state_dict(osd)
+    w = flatten_components(convert_state_dict_keys(c, osd))
+    x = torch.randn(B, 3, grid[0] * 14, grid[1] * 14, generator=torch.Generator().manual_seed(100 + seed))
+    ref = dpt_oracle.forward(w, c, x)
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 4e-2)):
+        _, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
+        y = model.to("cuda", dtype)(x.to("cuda", dtype))
+        assert tuple(y.shape) == tuple(ref.shape)
+        e = rel_err(y.float().cpu(), ref)
+        assert e <= tol, f"{cfg} grid {grid} B={B} {dtype}: rel err {e:.3e} > {tol}"
