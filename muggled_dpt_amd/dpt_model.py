@@ -353,9 +353,9 @@ class _Engine:
     def workspace(self, batch: int, size_hw: tuple[int, int]) -> tuple[int, int]:
         key = (batch, int(size_hw[0]), int(size_hw[1]))
         ws = self._workspaces.get(key)
-        if ws is None:
-            nbytes = ctypes.c_size_t()
-            native.check(self.lib, self.lib.mdpt_workspace_bytes(self.handle, batch, key[1], key[2], ctypes.byref(nbytes)))
+        nbytes = ctypes.c_size_t()  # asked every call (host-side arithmetic only): settings such as the batch split change the need
+        native.check(self.lib, self.lib.mdpt_workspace_bytes(self.handle, batch, key[1], key[2], ctypes.byref(nbytes)))
+        if ws is None or ws.numel() < nbytes.value + 256:
             if len(self._workspaces) >= 2:
                 self._workspaces.clear()
             ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
