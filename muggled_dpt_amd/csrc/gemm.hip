@@ -1245,6 +1245,9 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
         const bool cols_ok = (ncol - p.N) * 4 <= ncol;
         const bool big = cols_ok && tiles256 >= (p.throughput_mode ? 24 : 140);
         tile = big ? MDPT_TILE_PP256 : (tiles128 <= 330 ? MDPT_TILE_64x64 : MDPT_TILE_128x128);
+        // narrow outputs with many rows (64-channel decoder convs of the small models): a 128-wide tile would spend half of its
+        // MFMAs on padding columns. 128x64, four waves stacked in M: ViT-S B=32 +8.4 %
+        if (!big && tiles128 > 330 && p.N <= 64) return launch_cfg<128, 64, 4, 1, 64, 2, 2, AMODE, EKIND>(p, stream);
     }
     if (tile == MDPT_TILE_64x64) return launch_cfg<64, 64, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);
     if (tile == MDPT_TILE_PP256 && (((p.K / 64) * p.npass) & 1) == 0) return launch_pp<AMODE, EKIND>(p, stream);
