@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
 // source is read from global once (x1.2-1.7 halo), so the kernel is limited by the unavoidable HBM bytes.
 // Same arithmetic, same operation order as upsample_kernel (bit-identical results).
 // ---------------------------------------------------------------------------------------------------
-template <int C8>  // channels / 8 (lanes per pixel): 32 -> C = 256, 16 -> C = 128
+template <int C8>  // channels / 8 (lanes per pixel): 32 -> C = 256, 16 -> C = 128, 8 -> C = 64
 __global__ __launch_bounds__(256) void upsample_tiled_kernel(const float* __restrict__ in, bf16_t* out_hi, bf16_t* out_lo, int B, int Hi,
                                                              int Wi, int Ho, int Wo) {
 #pragma clang fp contract(off)
@@ -629,9 +629,9 @@ int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float*
     if (C & 3) return (int)hipErrorInvalidValue;
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
     MdptProfScope prof("upsample_kernel", 0.0, stream);
-    // big bf16 outputs with 128 / 256 channels and a source span of at most 7 pixels per 8 output pixels (scale >= ~1.2): tiled
+    // big bf16 outputs with 64 / 128 / 256 channels and a source span of at most 7 pixels per 8 output pixels (scale >= ~1.2): tiled
     const bool span_ok = (long)7 * (Hi - 1) <= (long)5 * (Ho - 1) && (long)7 * (Wi - 1) <= (long)5 * (Wo - 1);
-    if (out_hi && !out_f32 && (C == 256 || C == 128) && span_ok && (size_t)B * Ho * Wo >= 65536) {
+    if (out_hi && !out_f32 && (C == 256 || C == 128 || C == 64) && span_ok && (size_t)B * Ho * Wo >= 65536) {
         const int tiles = B * ((Ho + 7) / 8) * ((Wo + 7) / 8);
         const size_t lds = (size_t)49 * C * 4;
         if (C == 256) {
@@ -642,8 +642,10 @@ int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float*
                 attr_done = true;
             }
             hipLaunchKernelGGL(upsample_tiled_kernel<32>, dim3(tiles), dim3(256), lds, stream, in, out_hi, out_lo, B, Hi, Wi, Ho, Wo);
-        } else {
+        } else if (C == 128) {
             hipLaunchKernelGGL(upsample_tiled_kernel<16>, dim3(tiles), dim3(256), lds, stream, in, out_hi, out_lo, B, Hi, Wi, Ho, Wo);
+        } else {
+            hipLaunchKernelGGL(upsample_tiled_kernel<8>, dim3(tiles), dim3(256), lds, stream, in, out_hi, out_lo, B, Hi, Wi, Ho, Wo);
         }
         LAUNCH_RET();
     }
