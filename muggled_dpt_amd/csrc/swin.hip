@@ -130,26 +130,45 @@ __global__ __launch_bounds__(256) void swin_window_map_kernel(int* rowmap, int* 
 // with c = sign(v) * log2(|8 v| + 1) / log2(8), v = offset / max(divider - 1, 1), divider = pretrained window size if given
 // else the current window size (relative_positional_encoder.py:122-150, :79-84).
 // ---------------------------------------------------------------------------------------------------
+constexpr int kCpbPos = 8;  // table positions per workgroup: 53k one-position workgroups were dispatch-rate bound (0.55 ms per forward)
+
 __device__ __forceinline__ void swin_cpb_body(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                               float* __restrict__ lut, int heads, int hidden, int wh, int ww, int pre) {
-    extern __shared__ float hid[];
+    extern __shared__ float hid[];  // [kCpbPos][hidden]
+    __shared__ float coord[kCpbPos][2];
     const int rw = 2 * ww - 1, R = (2 * wh - 1) * rw;
-    const int e = blockIdx.x;
-    if (e >= R) return;  // batched launch: the grid covers the largest window
-    const int dy = e / rw - (wh - 1), dx = e % rw - (ww - 1);
-    const float div_h = (float)max((pre > 0 ? pre : wh) - 1, 1), div_w = (float)max((pre > 0 ? pre : ww) - 1, 1);
-    float cy = (float)dy / div_h, cx = (float)dx / div_w;
-    const float sy = cy > 0.0f ? 1.0f : (cy < 0.0f ? -1.0f : 0.0f), sx = cx > 0.0f ? 1.0f : (cx < 0.0f ? -1.0f : 0.0f);
-    cy = sy * (log2f(fabsf(cy * 8.0f) + 1.0f) / 3.0f);
-    cx = sx * (log2f(fabsf(cx * 8.0f) + 1.0f) / 3.0f);
-    for (int j = threadIdx.x; j < hidden; j += blockDim.x) hid[j] = fmaxf(w1[2 * j] * cy + w1[2 * j + 1] * cx + b1[j], 0.0f);
+    const int e0 = blockIdx.x * kCpbPos;
+    if (e0 >= R) return;  // batched launch: the grid covers the largest window
+    if (threadIdx.x < kCpbPos) {
+        const int e = min(e0 + (int)threadIdx.x, R - 1);
+        const int dy = e / rw - (wh - 1), dx = e % rw - (ww - 1);
+        const float div_h = (float)max((pre > 0 ? pre : wh) - 1, 1), div_w = (float)max((pre > 0 ? pre : ww) - 1, 1);
+        float cy = (float)dy / div_h, cx = (float)dx / div_w;
+        const float sy = cy > 0.0f ? 1.0f : (cy < 0.0f ? -1.0f : 0.0f), sx = cx > 0.0f ? 1.0f : (cx < 0.0f ? -1.0f : 0.0f);
+        coord[threadIdx.x][0] = sy * (log2f(fabsf(cy * 8.0f) + 1.0f) / 3.0f);
+        coord[threadIdx.x][1] = sx * (log2f(fabsf(cx * 8.0f) + 1.0f) / 3.0f);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < kCpbPos * hidden; idx += blockDim.x) {
+        const int q = idx / hidden, j = idx - q * hidden;
+        hid[idx] = fmaxf(w1[2 * j] * coord[q][0] + w1[2 * j + 1] * coord[q][1] + b1[j], 0.0f);
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int h = wave; h < heads; h += 4) {
-        float acc = 0.0f;
-        for (int j = lane; j < hidden; j += 64) acc += w2[(size_t)h * hidden + j] * hid[j];
-        acc = wave_sum(acc);
-        if (lane == 0) lut[(size_t)h * R + e] = 16.0f / (1.0f + expf(-acc));
+        float acc[kCpbPos];
+#pragma unroll
+        for (int q = 0; q < kCpbPos; ++q) acc[q] = 0.0f;
+        for (int j = lane; j < hidden; j += 64) {
+            const float w = w2[(size_t)h * hidden + j];
+#pragma unroll
+            for (int q = 0; q < kCpbPos; ++q) acc[q] += w * hid[q * hidden + j];
+        }
+#pragma unroll
+        for (int q = 0; q < kCpbPos; ++q) {
+            const float s = wave_sum(acc[q]);
+            if (lane == 0 && e0 + q < R) lut[(size_t)h * R + e0 + q] = 16.0f / (1.0f + expf(-s));
+        }
     }
 }
 
@@ -290,7 +309,8 @@ int mdpt_launch_swin_cpb(const float* w1, const float* b1, const float* w2, floa
                          hipStream_t stream) {
     const int R = (2 * wh - 1) * (2 * ww - 1);
     MdptProfScope prof("swin_cpb_kernel", 0.0, stream);
-    hipLaunchKernelGGL(swin_cpb_kernel, dim3(R), dim3(256), (size_t)hidden * 4, stream, w1, b1, w2, lut, heads, hidden, wh, ww, pretrained);
+    hipLaunchKernelGGL(swin_cpb_kernel, dim3((R + kCpbPos - 1) / kCpbPos), dim3(256), (size_t)kCpbPos * hidden * 4, stream, w1, b1, w2, lut, heads,
+                       hidden, wh, ww, pretrained);
     LAUNCH_RET();
 }
 
@@ -299,7 +319,7 @@ int mdpt_launch_swin_cpb_batch(const SwinCpbBatch& b, hipStream_t stream) {
     int rmax = 0;
     for (int l = 0; l < b.n; ++l) rmax = std::max(rmax, (2 * b.wh[l] - 1) * (2 * b.ww[l] - 1));
     MdptProfScope prof("swin_cpb_batch_kernel", 0.0, stream);
-    hipLaunchKernelGGL(swin_cpb_batch_kernel, dim3(rmax, b.n), dim3(256), (size_t)b.hidden * 4, stream, b);
+    hipLaunchKernelGGL(swin_cpb_batch_kernel, dim3((rmax + kCpbPos - 1) / kCpbPos, b.n), dim3(256), (size_t)kCpbPos * b.hidden * 4, stream, b);
     LAUNCH_RET();
 }
 
