@@ -143,6 +143,13 @@ int mdpt_head(mdpt_handle* h, const void* fused_in, int32_t B, int32_t gh, int32
  * accounts for the split. */
 int mdpt_set_batch_split(mdpt_handle* h, int32_t min_batch);
 
+/* Latency mode (default off). Off: every image's result is bit-identical whatever batch it is part of (the kernels that run do
+ * not depend on the batch size in any way that changes the arithmetic). On: launches that are too small to fill the GPU (batch 1 of
+ * the small models) may use forms that change the summation order - today the attention kernel splits the key loop over the four
+ * waves of a workgroup and merges the partial softmax states (ViT-S, batch 1: +13 %) - so results can differ in the last bit from
+ * the batch-invariant form. Accuracy against the fp32 oracle is unchanged. */
+int mdpt_set_latency_mode(mdpt_handle* h, int32_t on);
+
 /* PatchEmbed.prepare_image (v2_depthanything/patch_embed.py:103-145): uint8 [in_h,in_w,3] BGR on the device ->
  * fp32 [3,out_h,out_w] RGB, antialiased-bilinear resized exactly like F.interpolate(..., antialias=True) and normalised with the
  * given per-channel mean/std (ImageNet values for Depth-Anything, 0.5/0.5 for BEiT). The caller picks out_h/out_w with the reference's size rule (multiples of 2*patch). */

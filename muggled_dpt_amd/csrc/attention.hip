@@ -53,14 +53,18 @@ __device__ __forceinline__ bf16x8 cat44(bf16x4 a, bf16x4 b) {
 // QB = query blocks of 32 per wave: 2 in bf16 mode (64 queries per wave, 256 per workgroup: every K / Vt fragment read
 // from LDS and every LDS-DMA'd tile feeds twice the MFMAs - the kernel is vector-memory/LDS bound otherwise), 1 in x3
 // mode (register budget: hi+lo planes of Q, K, V and P).
-template <bool X3, int QB, int MODE, int HD>
+// SPLIT (latency form for small launches, e.g. batch 1): the four waves of a workgroup share ONE block of 32*QB queries and each
+// takes every fourth key tile (private K/V ring per wave, no barrier in the loop); the partial (m, l, O) states are merged through
+// LDS at the end. A launch that cannot fill the GPU anyway finishes in a quarter of the key-loop time.
+template <bool X3, int QB, int MODE, int HD, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     constexpr bool BIAS = MODE != 0;
     constexpr int NPL = X3 ? 2 : 1;           // planes per operand
     constexpr int TILE = 64 * HD * 2;         // one [64 keys][HD] (or [HD][64 keys]) bf16 tile
     constexpr int STAGE = 2 * NPL * TILE;     // K planes then Vt planes
     constexpr int KS = HD / 16, DB = HD / 32, CH = HD / 32;  // MFMA k-steps of S, 32-row blocks of O^T, 1 KiB DMA chunks per wave
-    constexpr int QPW = 32 * QB, QPB = 4 * QPW;
+    constexpr int QPW = 32 * QB, QPB = SPLIT ? QPW : 4 * QPW;
+    constexpr int RINGS = SPLIT ? 4 : 1;  // private ring per wave in the split form
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         // A last q-tile with a single active wave (N = 1297: 17 queries) holds a workgroup slot for a full pass over K/V while three
         // of its waves idle. Dispatch those tiles LAST, together: their lone waves then run without a partner on their SIMDs
         // (the rounds before them are made of full tiles only).
-        const bool tail_last = nq > 1 && p.npad - (nq - 1) * QPB <= QPW && p.tail_last;
+        const bool tail_last = !SPLIT && nq > 1 && p.npad - (nq - 1) * QPB <= QPW && p.tail_last;
         if (tail_last) {
             const int per_xcd = nbh >> 3, full = per_xcd * (nq - 1);
             if (slot < full) {
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const int b = bhi / p.heads, h = bhi - b * p.heads;
     const size_t bh = (size_t)bhi;
     const int win = MODE == 2 ? b % p.win_nw : 0;  // window index inside its image
-    const int q0 = qt * QPB + wave * QPW;
+    const int q0 = SPLIT ? qt * QPB : qt * QPB + wave * QPW;
     const bool active = q0 < p.npad;  // tail waves of the last q-tile only help with DMA and barriers
 
     // ---- Q fragments (B operand of S^T = K Q^T): Q[q][d = 16*ks + 8*half .. +8]
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 
     // ---- BEiT relative position bias: this head's resized table (ext LUT) and the per-key index terms live in LDS
     //      behind the K/V ring; bias(q,k) = lut[tq[q] - tk[k]] (see beit_relpos_kernel)
-    float* lds_lut = (float*)(smem + 2 * STAGE);
+    float* lds_lut = (float*)(smem + RINGS * 2 * STAGE);
     int* lds_tk = (int*)(lds_lut + (BIAS ? p.bias_elen : 0));
     int* lds_reg = lds_tk + (((p.N + 63) >> 6) << 6);  // MODE 2: shifted-window region id of every key
     int tqv[QB], rqv[QB];
@@ -139,16 +143,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     // ---- staging: 128-byte LDS rows (K: one key at HD 64, a pair of keys at HD 32; Vt: one d), 1 KiB chunks of 8 rows,
     //      CH per wave and plane; the XOR swizzle is applied on the SOURCE address (LDS-DMA writes lane-linear)
     const int lrow = lane >> 3, slot = lane & 7;
-    const int sw_stage = ((wave & 1) * 4 + (lrow >> 1)) & 7;
-    const int lslot = slot ^ sw_stage;  // logical 16-byte slot this lane fetches
-    const int koff = lslot * 8;
     const int ntiles = (p.N + 63) >> 6;
+    char* const ring = smem + (SPLIT ? wave * 2 * STAGE : 0);
     auto issue_tile = [&](int tile, int buf) {
-        char* s = smem + buf * STAGE;
+        char* s = ring + buf * STAGE;
         const int kv0 = tile * 64;
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int c = wave + 4 * i;
+        for (int i = 0; i < (SPLIT ? 4 * CH : CH); ++i) {
+            const int c = SPLIT ? i : wave + 4 * i;                   // 1 KiB chunk = 8 LDS rows
+            const int sw_stage = ((c & 1) * 4 + (lrow >> 1)) & 7;     // key(row) = (row >> 1) & 7 of row c*8 + lrow
+            const int lslot = slot ^ sw_stage;                        // logical 16-byte slot this lane fetches
+            const int koff = lslot * 8;
             int krow = HD == 64 ? kv0 + c * 8 + lrow : kv0 + 2 * (c * 8 + lrow) + (lslot >> 2);
             krow = krow < p.npad ? krow : p.npad - 1;  // rows >= N are masked in the softmax
             const size_t ko = (bh * p.npad + krow) * HD + (HD == 64 ? koff : (lslot & 3) * 8);
@@ -173,15 +178,25 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             for (int r = 0; r < 16; ++r) o_acc[qb][db][r] = 0.0f;
     }
 
-    issue_tile(0, 0);
-    for (int t = 0; t < ntiles; ++t) {
+    if (SPLIT) {
+        if (BIAS) __syncthreads();  // the bias tables were staged by all 256 threads
+        if (wave < ntiles) issue_tile(wave, 0);
+    } else {
+        issue_tile(0, 0);
+    }
+    for (int t = SPLIT ? wave : 0, it = 0; t < ntiles; t += SPLIT ? 4 : 1, ++it) {
         // LDS-DMA completion is tracked by vmcnt; hipcc does NOT reliably wait for it before the barrier
         // (observed: only lgkmcnt(0) in this loop -> rare stale K/V tiles). Wait explicitly, then publish.
+        // Split form: the ring is private to the wave, its own covering vmcnt is all a wave needs to read what it fetched.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < ntiles) issue_tile(t + 1, (t + 1) & 1);
+        if (!SPLIT) __syncthreads();
+        if (SPLIT) {
+            if (t + 4 < ntiles) issue_tile(t + 4, (it + 1) & 1);
+        } else {
+            if (t + 1 < ntiles) issue_tile(t + 1, (t + 1) & 1);
+        }
         if (!active) continue;
-        const char* sK = smem + (t & 1) * STAGE;
+        const char* sK = ring + ((SPLIT ? it : t) & 1) * STAGE;
         const char* sV = sK + NPL * TILE;
 
         // ---- S^T[key][query] for 2 blocks of 32 keys x QB blocks of 32 queries
@@ -334,6 +349,43 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             }
     }
 
+    if (SPLIT) {
+        // ---- merge the four partial softmax states: waves 1-3 park (m, l, O) in LDS (the rings are dead), wave 0 folds them in
+        constexpr int NREG = QB * (2 + DB * 16);
+        __syncthreads();
+        float* park = (float*)smem;  // [3][NREG][64]
+        if (wave > 0) {
+            float* dst = park + (size_t)(wave - 1) * NREG * 64 + lane;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                dst[(qb * (2 + DB * 16) + 0) * 64] = m_run[qb];
+                dst[(qb * (2 + DB * 16) + 1) * 64] = l_run[qb];
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[(qb * (2 + DB * 16) + 2 + db * 16 + r) * 64] = o_acc[qb][db][r];
+            }
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const float* src = park + (size_t)w * NREG * 64 + lane;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float m_w = src[(qb * (2 + DB * 16) + 0) * 64], l_w = src[(qb * (2 + DB * 16) + 1) * 64];
+                const float m_new = fmaxf(m_run[qb], m_w);
+                const float a = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kLog2e), bsc = __builtin_amdgcn_exp2f((m_w - m_new) * kLog2e);
+                m_run[qb] = m_new;
+                l_run[qb] = l_run[qb] * a + l_w * bsc;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        o_acc[qb][db][r] = o_acc[qb][db][r] * a + src[(qb * (2 + DB * 16) + 2 + db * 16 + r) * 64] * bsc;
+            }
+        }
+    }
     // ---- normalise and store: o_acc[qb][db][r] = O[q][d = 32db + (r&3) + 8(r>>2) + 4half]
     if (!active) return;
 #pragma unroll
@@ -458,6 +510,36 @@ int mdpt_launch_attention(const AttnParams& p, hipStream_t stream) {
     const size_t extra = bias ? (size_t)p.bias_elen * 4 + (size_t)ntk * 4 * (swin ? 2 : 1) : 0;
     const size_t ring = (size_t)2 * 2 * (p.x3 ? 2 : 1) * 64 * hd * 2;
     if (ring + extra > 160 * 1024) return (int)hipErrorInvalidValue;  // relative-position table does not fit in LDS
+    // latency form (opt-in, mdpt_set_latency_mode: the merge changes the summation order): a launch of at most ~one workgroup per CU
+    // even at 32 queries per workgroup (batch 1 of the small models) splits the key loop over the four waves instead (bf16 only: four
+    // private rings of the x3 operand planes do not fit)
+    const long blocks32 = (long)((p.npad + 31) / 32) * p.heads * p.B;
+    if (p.allow_split_kv && !swin && !p.x3 && blocks32 <= 320 && 4 * ring + extra <= 160 * 1024) {
+        AttnParams ps = p;
+        ps.tail_last = 0;
+        const unsigned lds_s = (unsigned)(4 * ring + extra);
+        MdptProfScope prof_s(bias ? "attn_kernel<false, 1, 1, 64, split>" : "attn_kernel<false, 1, 0, 64, split>",
+                             4.0 * p.B * p.heads * (double)p.N * p.N * hd, stream);
+        static bool attr0 = false, attr1 = false;
+        if (bias) {
+            auto kern = attn_kernel<false, 1, 1, 64, true>;
+            if (!attr1) {
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return (int)e;
+                attr1 = true;
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks32), dim3(256), lds_s, stream, ps);
+        } else {
+            auto kern = attn_kernel<false, 1, 0, 64, true>;
+            if (!attr0) {
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return (int)e;
+                attr0 = true;
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks32), dim3(256), lds_s, stream, ps);
+        }
+        return (int)hipGetLastError();
+    }
     static const char* const kNames[2][2][3] = {
         {{"attn_kernel<false, 1, 0, 64>", "attn_kernel<false, 1, 1, 64>", "attn_kernel<false, 1, 2, 32>"},
          {"attn_kernel<false, 2, 0, 64>", "attn_kernel<false, 2, 1, 64>", "attn_kernel<false, 2, 2, 32>"}},

@@ -133,6 +133,7 @@ struct mdpt_handle {
     // batch split: batches >= split_min run as two halves on the caller's stream and an internal side stream (fork / join with
     // events, no host sync) so that one half's kernels fill the tile-quantisation tails and epilogue phases of the other's
     int split_min;
+    int latency_mode;  // mdpt_set_latency_mode: small launches may use summation orders that are not batch-invariant
     hipStream_t side_stream;
     hipEvent_t ev_fork, ev_join;
     ~mdpt_handle() {
@@ -547,6 +548,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             a.q_hi = q.hi; a.q_lo = q.lo; a.k_hi = k.hi; a.k_lo = k.lo; a.vt_hi = vt.hi; a.vt_lo = vt.lo;
             a.out_hi = att.hi; a.out_lo = att.lo;
             a.B = p.B; a.heads = h->heads; a.N = p.N; a.npad = p.npad; a.npadv = p.npadv; a.F = F; a.x3 = h->x3;
+            a.allow_split_kv = h->latency_mode;
             if (is_beit(h)) {
                 float* lut_b = c.at<float>(p.relpos_lut) + (relpos_batched ? (size_t)b * relpos_stride : 0);
                 if (!relpos_batched)  // more than 32 blocks: this layer's table on its own (tiny kernel)
@@ -939,6 +941,12 @@ int mdpt_workspace_bytes(const mdpt_handle* h, int32_t B, int32_t H, int32_t W, 
 int mdpt_set_batch_split(mdpt_handle* h, int32_t min_batch) {
     if (!h || min_batch < 0) return fail(MDPT_E_INVALID, "bad argument");
     h->split_min = min_batch == 1 ? 2 : min_batch;
+    return 0;
+}
+
+int mdpt_set_latency_mode(mdpt_handle* h, int32_t on) {
+    if (!h) return fail(MDPT_E_INVALID, "null handle");
+    h->latency_mode = on ? 1 : 0;
     return 0;
 }
 

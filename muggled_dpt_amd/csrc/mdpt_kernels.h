@@ -67,6 +67,7 @@ struct AttnParams {
     // rowmap[win_nw*N] = image token of every window token, region[win_nw][region_ld] = shifted-window region ids (null: no mask)
     int head_dim;  // 0 = 64
     int win_nw; const int* rowmap; const int* region; int region_ld;
+    int allow_split_kv;  // latency mode: small launches may split the key loop over the waves (not batch-invariant in the last bit)
     int tail_last;  // set by the launcher: dispatch nearly empty last q-tiles after all full ones
 };
 int mdpt_launch_attention(const AttnParams& p, hipStream_t stream);

@@ -304,6 +304,8 @@ class _Engine:
         tile = model.__dict__.get("_gemm_tile", 0)
         if tile:
             native.check(self.lib, self.lib.mdpt_set_gemm_tile(self.handle, tile))
+        if model.__dict__.get("_latency_mode", False):
+            native.check(self.lib, self.lib.mdpt_set_latency_mode(self.handle, 1))
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             keep = []
@@ -453,6 +455,14 @@ class DPTModel(nn.Module):
         """Benchmark knob: 0 auto, 1 = 128x128, 2 = 256x256 GEMM tiles."""
         self.__dict__["_gemm_tile"] = int(tile)
         self._invalidate()
+
+    def set_latency_mode(self, on: bool = True) -> None:
+        """Off (default): an image's result does not depend on the batch it is part of, bit for bit. On: launches too small to fill the
+        GPU (batch 1 of the small models) may use faster forms whose summation order differs (mdpt_set_latency_mode)."""
+        self.__dict__["_latency_mode"] = bool(on)
+        eng = self.__dict__.get("_engine_obj")
+        if eng is not None:
+            native.check(eng.lib, eng.lib.mdpt_set_latency_mode(eng.handle, int(bool(on))))
 
     # ---- reference API
     def forward(self, image_rgb_normalized_bchw: Tensor) -> Tensor:

@@ -136,6 +136,7 @@ SYMBOLS = {
     "mdpt_export_tap": (ctypes.c_int, [_VP, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_set_gemm_tile": (ctypes.c_int, [_VP, _I]),
     "mdpt_set_batch_split": (ctypes.c_int, [_VP, _I]),
+    "mdpt_set_latency_mode": (ctypes.c_int, [_VP, _I]),
     "mdpt_debug_gemm": (ctypes.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _VP]),
     "mdpt_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "mdpt_profile_report": (ctypes.c_int, [ctypes.c_char_p, _SZ]),

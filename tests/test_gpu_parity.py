@@ -330,3 +330,19 @@ def test_float16_model_dtype_runs_on_the_bf16_path():
     assert rel_err(y.float().cpu(), _oracle().forward(w, cfg, x)) <= REL_TOL_BF16
     tok, hw = model.patch_embed(x.to("cuda", torch.float16))
     assert tok.dtype == torch.float16 and tuple(hw) == (4, 6)
+
+
+def test_latency_mode_split_kv_attention_matches_the_oracle():
+    """mdpt_set_latency_mode: small launches split the key loop of the attention kernel over the four waves of a workgroup (partial
+    softmax states merged through LDS). Same accuracy against the oracle; bits may differ from the batch-invariant default form."""
+    for name, shape in (("tiny", (2, 3, 56, 84)), ("vits", (1, 3, 504, 504))):
+        model, cfg, w = _model(name, torch.bfloat16)
+        x = seeded_input(shape, 21)
+        ref = _oracle().forward(w, cfg, x)
+        y_default = model(x.to("cuda", torch.bfloat16))
+        model.set_latency_mode(True)
+        y_fast = model(x.to("cuda", torch.bfloat16))
+        assert rel_err(y_fast.float().cpu(), ref) <= REL_TOL_BF16
+        assert rel_err(y_fast.float().cpu(), y_default.float().cpu()) <= REL_TOL_BF16
+        model.set_latency_mode(False)
+        assert torch.equal(model(x.to("cuda", torch.bfloat16)), y_default)  # and back: the default form is reproduced exactly

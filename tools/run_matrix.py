@@ -108,6 +108,11 @@ def main():
                         sec_g = timeit(g.replay, 100)
                         ok = bool(torch.equal(yg, model(x)))
                         row.update({"graph_ms": round(sec_g * 1e3, 3), "graph_maps_per_s": round(1 / sec_g, 2), "graph_bitwise_equal": ok})
+                        # opt-in latency mode (mdpt_set_latency_mode): summation orders that are not batch-invariant in the last bit
+                        model.set_latency_mode(True)
+                        sec_l = timeit(lambda: model(x), 50)
+                        model.set_latency_mode(False)
+                        row.update({"latency_mode_ms": round(sec_l * 1e3, 3), "latency_mode_maps_per_s": round(1 / sec_l, 2)})
                     if batch == 32 and size == 504 and tag == "bf16":
                         xh = torch.randn(batch, 3, size, size, dtype=dtype).pin_memory()
                         sec_h = timeit(lambda: model(xh.to("cuda", non_blocking=True)), 10)
