@@ -116,3 +116,19 @@ def test_beit_512_batch_is_independent_of_batch_composition():
     for i in range(3):
         assert torch.equal(y[i:i + 1], model(x[i:i + 1])), i
     assert torch.isfinite(y.float()).all() and float(y.float().max()) > 0
+
+
+def test_beit_latency_mode_split_kv_with_relpos_bias(golden_dir):
+    """Opt-in latency mode on the relative-position-bias attention (LUT + per-key terms staged next to four private K/V rings)."""
+    g = np.load(os.path.join(golden_dir, "beit_tiny.npz"))
+    model, cfg, w = _build("beit_tiny", int(g["weight_seed"]), torch.bfloat16)
+    x = torch.from_numpy(g["input_base"]) if "input_base" in g.files else seeded_input((2, 3, 64, 96), 9)
+    from oracle import dpt_oracle
+    ref = dpt_oracle.forward(w, cfg, x)
+    y_default = model(x.to("cuda", torch.bfloat16))
+    model.set_latency_mode(True)
+    y_fast = model(x.to("cuda", torch.bfloat16))
+    assert rel_err(y_fast.float().cpu(), ref) <= REL_TOL_BF16
+    assert rel_err(y_fast.float().cpu(), y_default.float().cpu()) <= REL_TOL_BF16
+    model.set_latency_mode(False)
+    assert torch.equal(model(x.to("cuda", torch.bfloat16)), y_default)
