@@ -287,19 +287,46 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const float*
             return;
         }
 
-        for (int pr = 0; pr < 32 / RPP; ++pr) {
-            const int row = pr * RPP + erow;
-            const int m = mbase + row, n = nbase + ecol;
-            if (m >= p.M || n >= p.N) continue;
-            f32x4 v[2];
-            v[0] = *(const f32x4*)(strip + row * WTN + ecol);
-            v[1] = *(const f32x4*)(strip + row * WTN + ecol + 4);
-
-            if (EKIND == MDPT_E_GENERIC) {
+        if (EKIND == MDPT_E_GENERIC) {
+            // Every global load of the block is issued before the first use (bias / layer scale once per column group, the residual
+            // of all passes up front, addresses clamped for out-of-range lanes): one memory round trip per block instead of one per
+            // feature and pass - these epilogues dominate the short-K tiles of the small-batch path. Arithmetic order unchanged.
+            constexpr int NP = 32 / RPP;
+            const int n = nbase + ecol;
+            const bool nvalid = n < p.N;
+            const int nc = nvalid ? n : 0;
+            const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 bia[2] = {zero4, zero4}, gam[2] = {zero4, zero4};
+            if (p.bias && !p.bias_img_stride) { bia[0] = *(const f32x4*)(p.bias + nc); bia[1] = *(const f32x4*)(p.bias + nc + 4); }
+            if (p.gamma) { gam[0] = *(const f32x4*)(p.gamma + nc); gam[1] = *(const f32x4*)(p.gamma + nc + 4); }
+            f32x4 res[NP][2], bim[NP][2];
+#pragma unroll
+            for (int pr = 0; pr < NP; ++pr) {
+                const int mq = mbase + pr * RPP + erow;
+                const int mc = mq < p.M ? mq : p.M - 1;
+                res[pr][0] = res[pr][1] = bim[pr][0] = bim[pr][1] = zero4;
+                if (p.resid) {
+                    const float* rp = p.resid + (size_t)mc * p.ldr + nc;
+                    res[pr][0] = *(const f32x4*)rp;
+                    res[pr][1] = *(const f32x4*)(rp + 4);
+                }
+                if (p.bias && p.bias_img_stride) {
+                    const float* bp = p.bias + nc + (size_t)(mc / p.tok_np) * p.bias_img_stride;
+                    bim[pr][0] = *(const f32x4*)bp;
+                    bim[pr][1] = *(const f32x4*)(bp + 4);
+                }
+            }
+#pragma unroll
+            for (int pr = 0; pr < NP; ++pr) {
+                const int row = pr * RPP + erow;
+                const int m = mbase + row;
+                if (m >= p.M || !nvalid) continue;
+                f32x4 v[2];
+                v[0] = *(const f32x4*)(strip + row * WTN + ecol);
+                v[1] = *(const f32x4*)(strip + row * WTN + ecol + 4);
                 if (p.bias) {
-                    const float* bp = p.bias + n + (p.bias_img_stride ? (size_t)(m / p.tok_np) * p.bias_img_stride : 0);
-                    v[0] += *(const f32x4*)bp;
-                    v[1] += *(const f32x4*)(bp + 4);
+                    v[0] += p.bias_img_stride ? bim[pr][0] : bia[0];
+                    v[1] += p.bias_img_stride ? bim[pr][1] : bia[1];
                 }
                 if (p.act == MDPT_ACT_GELU) {
 #pragma unroll
@@ -308,12 +335,8 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const float*
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[0][e] = fmaxf(v[0][e], 0.0f); v[1][e] = fmaxf(v[1][e], 0.0f); }
                 }
-                if (p.gamma) { v[0] *= *(const f32x4*)(p.gamma + n); v[1] *= *(const f32x4*)(p.gamma + n + 4); }
-                if (p.resid) {
-                    const float* rp = p.resid + (size_t)m * p.ldr + n;
-                    v[0] += *(const f32x4*)rp;
-                    v[1] += *(const f32x4*)(rp + 4);
-                }
+                if (p.gamma) { v[0] *= gam[0]; v[1] *= gam[1]; }
+                if (p.resid) { v[0] += res[pr][0]; v[1] += res[pr][1]; }
                 if (p.up_src) {
                     // + bilinear x2 (align_corners=True) of the previous fusion level (fusion_model.py:151,178)
                     const int hw = p.Ho * p.Wo;
@@ -343,7 +366,19 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const float*
                     }
                     split_store8(p.out_hi, p.out_lo, o, v[0], v[1]);
                 }
-            } else if (EKIND == MDPT_E_QKV) {
+            }
+            return;
+        }
+
+        for (int pr = 0; pr < 32 / RPP; ++pr) {
+            const int row = pr * RPP + erow;
+            const int m = mbase + row, n = nbase + ecol;
+            if (m >= p.M || n >= p.N) continue;
+            f32x4 v[2];
+            v[0] = *(const f32x4*)(strip + row * WTN + ecol);
+            v[1] = *(const f32x4*)(strip + row * WTN + ecol + 4);
+
+            if (EKIND == MDPT_E_QKV) {
                 // Q (pre-scaled by 1/sqrt(d), exact power of two) and K, head-major [B,H,npad,64]
                 v[0] += *(const f32x4*)(p.bias + n);
                 v[1] += *(const f32x4*)(p.bias + n + 4);
