@@ -46,3 +46,37 @@ def test_random_configurations_match_the_oracle(cfg, grid, B, seed):
         assert tuple(y.shape) == tuple(ref.shape)
         e = rel_err(y.float().cpu(), ref)
         assert e <= tol, f"{cfg} grid {grid} B={B} {dtype}: rel err {e:.3e} > {tol}"
+
+
+def _beit_cases():
+    rng = np.random.default_rng(77)
+    out = []
+    for k in range(6):
+        heads = int(rng.integers(1, 7))
+        base = int(rng.choice([4, 6, 8]))
+        out.append((dict(features_per_token=64 * heads, num_heads=heads, num_blocks=int(rng.choice([4, 8])),
+                         reassembly_features_list=[int(16 * rng.integers(1, 7)) for _ in range(4)], base_patch_grid_hw=(base, base),
+                         fusion_channels=int(rng.choice([32, 64])), patch_size_px=16),
+                    (int(2 * rng.integers(1, 7)), int(2 * rng.integers(1, 7))), int(rng.integers(1, 4)), k))
+    return out
+
+
+@pytest.mark.parametrize("cfg,grid,B,seed", _beit_cases(), ids=lambda v: None)
+def test_random_beit_configurations_match_the_oracle(cfg, grid, B, seed):
+    """MiDaS v3.1 BEiT: random widths / head counts / base grids (the learned relative-position table is resized to every grid)."""
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from muggled_dpt_amd import make_beit_dpt_from_midas_v31_state_dict
+    from muggled_dpt_amd import state_dict_conversion_beit as conv
+    from muggled_dpt_amd.state_dict_conversion import flatten_components
+    from muggled_dpt_amd.synthetic import make_synthetic_beit_state_dict
+    from oracle import dpt_oracle
+    osd = make_synthetic_beit_state_dict(cfg, seed)
+    c, _ = make_beit_dpt_from_midas_v31_state_dict(osd)
+    w = flatten_components(conv.convert_state_dict_keys(c, osd))
+    x = torch.randn(B, 3, grid[0] * 16, grid[1] * 16, generator=torch.Generator().manual_seed(200 + seed))
+    ref = dpt_oracle.forward(w, c, x)
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 4e-2)):
+        _, model = make_beit_dpt_from_midas_v31_state_dict(osd)
+        y = model.to("cuda", dtype)(x.to("cuda", dtype))
+        e = rel_err(y.float().cpu(), ref)
+        assert e <= tol, f"{cfg} grid {grid} B={B} {dtype}: rel err {e:.3e} > {tol}"
