@@ -397,9 +397,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             size_t orow;
             if (MODE == 2) {  // window reverse + un-roll: row of this window token in its image
                 const int img = b / p.win_nw;
-                orow = ((size_t)img * p.win_nw * p.N + p.rowmap[(size_t)win * p.N + q]) * p.F + h * HD;
+                orow = ((size_t)img * p.win_nw * p.N + p.rowmap[(size_t)win * p.N + q]) * (p.out_ld ? p.out_ld : p.F) + h * HD;
             } else {
-                orow = ((size_t)b * p.npad + q) * p.F + h * HD;
+                orow = ((size_t)b * p.npad + q) * (p.out_ld ? p.out_ld : p.F) + h * HD;
             }
             // 16-byte stores (fewest store instructions for the bytes moved): this lane owns
             // d = 8g + 4*half + 0..3 for g = 0..3; one v_permlane32_swap per packed register pair hands the lower lane the

@@ -790,15 +790,16 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     if (cfg->is_giant && cfg->family != MDPT_FAMILY_DAV2) return fail(MDPT_E_INVALID, "is_giant (SwiGLU MLP) exists for Depth-Anything V2 only");
     if (cfg->family < MDPT_FAMILY_DAV2 || cfg->family > MDPT_FAMILY_SWINV2) return fail(MDPT_E_INVALID, "unknown model family %d", cfg->family);
     const bool swin = cfg->family == MDPT_FAMILY_SWINV2;
-    if (cfg->features_per_token <= 0 || cfg->features_per_token % 64)
-        return fail(MDPT_E_INVALID, "features_per_token must be a positive multiple of 64, got %d", cfg->features_per_token);
+    if (cfg->features_per_token <= 0 || cfg->features_per_token % (swin ? 32 : 64))
+        return fail(MDPT_E_INVALID, "features_per_token must be a positive multiple of %d, got %d", swin ? 32 : 64, cfg->features_per_token);
     if (swin) {
         if (cfg->patch_size_px != 4) return fail(MDPT_E_UNSUPPORTED, "SwinV2 DPT needs patch_size_px = 4 (head upsample x2 of a 1/2-resolution map), got %d", cfg->patch_size_px);
         if (cfg->swin_window_h <= 0 || cfg->swin_window_w <= 0) return fail(MDPT_E_INVALID, "bad SwinV2 window size");
         if (cfg->features_per_token != cfg->reassembly_features[0]) return fail(MDPT_E_INVALID, "SwinV2: features_per_token must equal features_per_stage[0]");
         for (int i = 0; i < 4; ++i) {
-            if (cfg->reassembly_features[i] <= 0 || cfg->reassembly_features[i] % 64)
-                return fail(MDPT_E_INVALID, "SwinV2 features_per_stage[%d] must be a positive multiple of 64, got %d", i, cfg->reassembly_features[i]);
+            // swin2_tiny_256 has a 96-wide first stage (3 heads of 32): operand planes are padded to a multiple of 64 columns
+            if (cfg->reassembly_features[i] <= 0 || cfg->reassembly_features[i] % 32)
+                return fail(MDPT_E_INVALID, "SwinV2 features_per_stage[%d] must be a positive multiple of 32, got %d", i, cfg->reassembly_features[i]);
             if (cfg->swin_heads[i] * 32 != cfg->reassembly_features[i])
                 return fail(MDPT_E_UNSUPPORTED, "SwinV2 head dim must be 32 (stage %d: heads=%d, features=%d)", i, cfg->swin_heads[i], cfg->reassembly_features[i]);
             if (cfg->swin_layers[i] <= 0 || cfg->swin_layers[i] % 2) return fail(MDPT_E_INVALID, "SwinV2 layers_per_stage[%d] must be a positive even number", i);
@@ -1055,7 +1056,8 @@ int mdpt_encoder(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, 
         const size_t n = (size_t)B * gh * gw * h->F;
         Planes xn = c.pl(c.p.sw.xn);
         CHK(hipMemcpyAsync(c.at<float>(c.p.sw.resid[0]), tokens_bnf, n * 4, hipMemcpyDeviceToDevice, c.s));
-        CHK(mdpt_launch_f32_to_planes((const float*)tokens_bnf, xn.hi, xn.lo, n, c.s));
+        CHK(swin_zero_pad_planes(c, B * gh * gw));
+        CHK(mdpt_launch_f32_to_planes((const float*)tokens_bnf, xn.hi, xn.lo, (size_t)B * gh * gw, h->F, rup(h->F, 64), c.s));
         CHK(run_encoder_swin(c, stage_out));
         h->has_last = false;
         return 0;
@@ -1118,7 +1120,8 @@ int mdpt_reassemble(mdpt_handle* h, const void* const stage_in[4], int32_t B, in
     if (h->swin) {  // gh x gw = stage-0 patch grid; maps come out at 1, 1/2, 1/4, 1/8 of it
         for (int i = 0; i < 4; ++i) {
             Planes tp = c.pl(p.tap[i]);
-            CHK(mdpt_launch_f32_to_planes((const float*)stage_in[i], tp.hi, tp.lo, (size_t)B * (gh >> i) * (gw >> i) * h->hid[i], c.s));
+            if (i == 0) CHK(swin_zero_pad_planes(c, B * gh * gw));
+            CHK(mdpt_launch_f32_to_planes((const float*)stage_in[i], tp.hi, tp.lo, (size_t)B * (gh >> i) * (gw >> i), h->hid[i], h->hidp[i], c.s));
         }
         CHK(run_reassemble_swin(c));
         for (int i = 0; i < 4; ++i)

@@ -67,6 +67,7 @@ struct AttnParams {
     // rowmap[win_nw*N] = image token of every window token, region[win_nw][region_ld] = shifted-window region ids (null: no mask)
     int head_dim;  // 0 = 64
     int win_nw; const int* rowmap; const int* region; int region_ld;
+    int out_ld;          // row stride of out_hi / out_lo in elements (0 = F); pad columns are the caller's
     int allow_split_kv;  // latency mode: small launches may split the key loop over the waves (not batch-invariant in the last bit)
     int tail_last;  // set by the launcher: dispatch nearly empty last q-tiles after all full ones
 };
@@ -138,7 +139,7 @@ int mdpt_launch_swiglu(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t r
 // ------------------------------------------------------------------------------------------------
 // out = LN_eps(x) (+ add): fp32 rows -> fp32 (may alias add) and/or bf16 hi (+lo)
 int mdpt_launch_ln_res(const float* x, const float* add, const float* gamma, const float* beta, float eps, float* out_f32,
-                       bf16_t* out_hi, bf16_t* out_lo, int rows, int F, hipStream_t stream);
+                       bf16_t* out_hi, bf16_t* out_lo, int rows, int F, hipStream_t stream, int ld_planes = 0);
 // window -> image token map (with cyclic shift sh, sw), shifted-window region ids [nW][region_ld], window-local tq / tk terms
 int mdpt_launch_swin_window_map(int* rowmap, int* region, int* tq, int* tk, int gh, int gw, int wh, int ww, int sh, int sw,
                                 int region_ld, int ntok_pad, hipStream_t stream);
@@ -159,7 +160,7 @@ int mdpt_launch_swin_qkv_prep(const float* qkv, const int* rowmap, const float* 
 // fp32 [B,gh,gw,C] -> bf16 rows [B*(gh/2)*(gw/2), 4C] = cat(TL, BL, TR, BR)
 int mdpt_launch_swin_merge_gather(const float* tok, bf16_t* out_hi, bf16_t* out_lo, int B, int gh, int gw, int C,
                                   hipStream_t stream);
-int mdpt_launch_f32_to_planes(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t n, hipStream_t stream);
+int mdpt_launch_f32_to_planes(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t rows, int F, int ld, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // depth post-processing (postprocess.hip); scratch2 = 2 uints of device scratch for the min/max reduction

@@ -49,7 +49,8 @@ inline int grid_for(size_t total, int block = 256) {
 template <int NV>
 __global__ __launch_bounds__(256) void ln_res_kernel(const float* __restrict__ x, const float* add, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, float* out_f32, bf16_t* out_hi,
-                                                     bf16_t* out_lo, int rows, int F) {
+                                                     bf16_t* out_lo, int rows, int F, int ldp) {
+    // ldp = row stride of the bf16 planes (>= F; pad columns are zeroed once per forward by the caller, never written here)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void ln_res_kernel(const float* __restrict__ x
                 for (int e = 0; e < 4; ++e) y[e] += a[e];
             }
             if (out_f32) *(f32x4*)(out_f32 + o) = y;
-            if (out_hi) split_store4(out_hi, out_lo, o, y);
+            if (out_hi) split_store4(out_hi, out_lo, (size_t)row * ldp + c, y);
         }
     }
 }
@@ -271,9 +272,13 @@ __global__ __launch_bounds__(256) void swin_merge_gather_kernel(const float* __r
 }
 
 // fp32 -> bf16 hi (+lo) planes, flat
-__global__ __launch_bounds__(256) void f32_to_planes_kernel(const float* __restrict__ in, bf16_t* out_hi, bf16_t* out_lo, size_t n4) {
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * blockDim.x)
-        split_store4(out_hi, out_lo, idx * 4, *(const f32x4*)(in + idx * 4));
+__global__ __launch_bounds__(256) void f32_to_planes_kernel(const float* __restrict__ in, bf16_t* out_hi, bf16_t* out_lo, size_t n4, int F4,
+                                                            int ld) {
+    // rows of F4 float4 each -> planes with row stride ld (elements); ld == 4 * F4: plain contiguous conversion
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = idx / F4, c4 = idx - row * F4;
+        split_store4(out_hi, out_lo, row * ld + c4 * 4, *(const f32x4*)(in + idx * 4));
+    }
 }
 
 }  // namespace
@@ -281,12 +286,13 @@ __global__ __launch_bounds__(256) void f32_to_planes_kernel(const float* __restr
 #define LAUNCH_RET() return (int)hipGetLastError()
 
 int mdpt_launch_ln_res(const float* x, const float* add, const float* gamma, const float* beta, float eps, float* out_f32, bf16_t* out_hi,
-                       bf16_t* out_lo, int rows, int F, hipStream_t stream) {
-    if ((F & 3) || F > 2048) return (int)hipErrorInvalidValue;
+                       bf16_t* out_lo, int rows, int F, hipStream_t stream, int ld_planes) {
+    if (ld_planes <= 0) ld_planes = F;
+    if ((F & 3) || F > 2048 || ld_planes < F || (ld_planes & 3)) return (int)hipErrorInvalidValue;
     if (rows <= 0) return 0;
     MdptProfScope prof("ln_res_kernel", 0.0, stream);
     const dim3 grid((rows + 3) / 4), block(256);
-#define LN_CASE(NV) hipLaunchKernelGGL(ln_res_kernel<NV>, grid, block, 0, stream, x, add, gamma, beta, eps, out_f32, out_hi, out_lo, rows, F)
+#define LN_CASE(NV) hipLaunchKernelGGL(ln_res_kernel<NV>, grid, block, 0, stream, x, add, gamma, beta, eps, out_f32, out_hi, out_lo, rows, F, ld_planes)
     if (F <= 256) LN_CASE(1);
     else if (F <= 512) LN_CASE(2);
     else if (F <= 1024) LN_CASE(4);
@@ -342,8 +348,9 @@ int mdpt_launch_swin_merge_gather(const float* tok, bf16_t* out_hi, bf16_t* out_
     LAUNCH_RET();
 }
 
-int mdpt_launch_f32_to_planes(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t n, hipStream_t stream) {
-    if (n & 3) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(f32_to_planes_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, in, out_hi, out_lo, n / 4);
+int mdpt_launch_f32_to_planes(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t rows, int F, int ld, hipStream_t stream) {
+    if ((F & 3) || ld < F || (ld & 3)) return (int)hipErrorInvalidValue;
+    const size_t n4 = rows * (size_t)(F / 4);
+    hipLaunchKernelGGL(f32_to_planes_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, in, out_hi, out_lo, n4, F / 4, ld);
     LAUNCH_RET();
 }

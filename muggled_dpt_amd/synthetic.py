@@ -142,6 +142,10 @@ SWINV2_CONFIGS = {
     "swin2_base_384": dict(features_per_stage=[128, 256, 512, 1024], heads_per_stage=[4, 8, 16, 32], layers_per_stage=[2, 2, 18, 2],
                            base_patch_grid_hw=(96, 96), window_size_hw=(24, 24), pretrained_window_sizes_per_stage=[12, 12, 12, 6],
                            fusion_channels=256, patch_size_px=4),
+    # the smallest MiDaS v3.1 SwinV2: a 96-wide first stage (3 heads of 32) - operand planes padded to 128 columns on the device
+    "swin2_tiny_256": dict(features_per_stage=[96, 192, 384, 768], heads_per_stage=[3, 6, 12, 24], layers_per_stage=[2, 2, 6, 2],
+                           base_patch_grid_hw=(64, 64), window_size_hw=(16, 16), pretrained_window_sizes_per_stage=[16, 16, 16, 8],
+                           fusion_channels=256, patch_size_px=4),
     # not a real model: 64x64 px base image (grid 16 -> 8 -> 4 -> 2), window 4: stages 0/1 shift, stage 2 is one window,
     # stage 3 shrinks the window to 2x2
     "swin2_tiny": dict(features_per_stage=[64, 128, 256, 512], heads_per_stage=[2, 4, 8, 16], layers_per_stage=[2, 2, 4, 2],

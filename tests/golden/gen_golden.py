@@ -194,7 +194,7 @@ def gen_postprocess():
     print("[postprocess] fixtures written; oracle identical to the reference helpers")
 
 
-def gen_swinv2(report, skip_large):
+def gen_swinv2(report, skip_large, only_tiny256=False):
     """MiDaS v3.1 SwinV2 fixtures (reference muggled_dpt/make_swinv2_dpt.py, v31_swinv2/*)."""
     from muggled_dpt.make_swinv2_dpt import make_swinv2_dpt_from_midas_v31_state_dict as ref_make_swin
     from muggled_dpt.v31_swinv2.components.windowed_attention import adjust_window_and_shift_sizes, make_shift_mask
@@ -215,6 +215,24 @@ def gen_swinv2(report, skip_large):
             assert list(w[k].shape) == shp, (k, shp, w[k].shape)
             assert maxdiff(w[k], getattr(model, k.split(".")[0]).state_dict()[k.split(".", 1)[1]]) == 0.0, k  # incl. exp'd logit_scale
         return osd, cfg, model, w, ref_keys
+
+    # reference make_swinv2_dpt.py:107-115 (swin2_tiny_256): first stage 96 wide
+    osd, cfg, model, w, _ = build_swin("swin2_tiny_256", 3)
+    x = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(4))
+    ref = run_reference(model, x)
+    report["swin2_tiny_256"] = check_against_oracle("swin2_tiny_256", ref, w, cfg, x)
+    tok, hw, taps, reasm, fused, depth = ref
+    np.savez_compressed(
+        os.path.join(GOLD, "swin2_tiny_256.npz"), weight_seed=3, input_seed=4,
+        weight_checksum=np.array([float(osd["pretrained.model.layers.0.blocks.1.attn.qkv.weight"].double().sum())]),
+        input_checksum=np.array([float(x.double().sum())]),
+        depth_strided=depth[:, ::4, ::4].numpy(), depth_stats=stats(depth),
+        **{f"tap{i}_crop": taps[i][:, :64, :64].numpy() for i in range(4)},
+        **{f"tap{i}_stats": stats(taps[i]) for i in range(4)},
+        **{f"reasm{i}_stats": stats(reasm[i]) for i in range(4)}, fused_stats=stats(fused))
+    print("[swin2_tiny_256] depth stats (min,max,mean,l2):", stats(depth))
+    if only_tiny256:
+        return
 
     osd, cfg, model, w, ref_keys = build_swin("swin2_tiny", 6)
     with open(os.path.join(GOLD, "swin2_tiny_new_keys.json"), "w") as f:
@@ -287,6 +305,7 @@ def main():
     ap.add_argument("--only-beit", action="store_true", help="regenerate the BEiT fixtures only (report is merged)")
     ap.add_argument("--only-swinv2", action="store_true", help="regenerate the SwinV2 fixtures only (report is merged)")
     ap.add_argument("--only-postprocess", action="store_true", help="regenerate the post-processing fixtures only")
+    ap.add_argument("--only-swin-tiny256", action="store_true", help="generate the swin2_tiny_256 fixture only (report is merged)")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -294,7 +313,7 @@ def main():
     if args.only_postprocess:
         gen_postprocess()
         return
-    if args.only_beit or args.only_swinv2:
+    if args.only_beit or args.only_swinv2 or args.only_swin_tiny256:
         rp = os.path.join(GOLD, "oracle_vs_reference_report.json")
         with open(rp) as f:
             old = json.load(f)
@@ -302,6 +321,8 @@ def main():
             gen_beit(report, args.skip_vitl)
         if args.only_swinv2:
             gen_swinv2(report, args.skip_vitl)
+        if args.only_swin_tiny256:
+            gen_swinv2(report, True, only_tiny256=True)
         old["max_abs_err"].update(report)
         with open(rp, "w") as f:
             json.dump(old, f, indent=1)

@@ -80,3 +80,41 @@ def test_random_beit_configurations_match_the_oracle(cfg, grid, B, seed):
         y = model.to("cuda", dtype)(x.to("cuda", dtype))
         e = rel_err(y.float().cpu(), ref)
         assert e <= tol, f"{cfg} grid {grid} B={B} {dtype}: rel err {e:.3e} > {tol}"
+
+
+def _swin_cases():
+    rng = np.random.default_rng(99)
+    out = []
+    for k in range(5):
+        h0 = int(rng.integers(1, 4))                      # heads of stage 0 (head dim 32), doubling per stage
+        feats = [32 * h0 * (1 << s) for s in range(4)]
+        win = int(rng.choice([4, 8]))
+        base = int(rng.choice([16, 32]))
+        pre = [None] * 4 if k % 2 == 0 else [win, win, win, max(win // 2, 1)]
+        gh, gw = int(8 * rng.integers(1, 5)), int(8 * rng.integers(1, 5))
+        out.append((dict(features_per_stage=feats, heads_per_stage=[h0 * (1 << s) for s in range(4)], layers_per_stage=[2, 2, int(rng.choice([2, 4])), 2],
+                         base_patch_grid_hw=(base, base), window_size_hw=(win, win), pretrained_window_sizes_per_stage=pre,
+                         fusion_channels=int(rng.choice([32, 64])), patch_size_px=4), (gh, gw), int(rng.integers(1, 4)), k))
+    return out
+
+
+@pytest.mark.parametrize("cfg,grid,B,seed", _swin_cases(), ids=lambda v: None)
+def test_random_swinv2_configurations_match_the_oracle(cfg, grid, B, seed):
+    """MiDaS v3.1 SwinV2: random widths / head counts / window sizes / pretrained-window settings on rectangular grids (windows are
+    re-fitted and shifts re-derived per stage and grid)."""
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from muggled_dpt_amd import make_swinv2_dpt_from_midas_v31_state_dict
+    from muggled_dpt_amd import state_dict_conversion_swinv2 as conv
+    from muggled_dpt_amd.state_dict_conversion import flatten_components
+    from muggled_dpt_amd.synthetic import make_synthetic_swinv2_state_dict
+    from oracle import dpt_oracle
+    osd = make_synthetic_swinv2_state_dict(cfg, seed)
+    c, _ = make_swinv2_dpt_from_midas_v31_state_dict(osd)
+    w = flatten_components(conv.convert_state_dict_keys(c, osd))
+    x = torch.randn(B, 3, grid[0] * 4, grid[1] * 4, generator=torch.Generator().manual_seed(300 + seed))
+    ref = dpt_oracle.forward(w, c, x)
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 8e-2)):  # cosine attention at logit scale ~10 amplifies bf16 noise on tiny maps
+        _, model = make_swinv2_dpt_from_midas_v31_state_dict(osd)
+        y = model.to("cuda", dtype)(x.to("cuda", dtype))
+        e = rel_err(y.float().cpu(), ref)
+        assert e <= tol, f"{cfg} grid {grid} B={B} {dtype}: rel err {e:.3e} > {tol}"

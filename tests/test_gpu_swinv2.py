@@ -133,3 +133,31 @@ def test_swin_batch_is_independent_of_batch_composition():
     for i in range(3):
         assert torch.equal(y[i:i + 1], model(x[i:i + 1])), i
     assert torch.isfinite(y.float()).all() and float(y.float().max()) > 0
+
+
+@pytest.mark.parametrize("dtype,tol", MODES)
+def test_swin_tiny_256_vs_golden_fixture(golden_dir, dtype, tol):
+    """The smallest MiDaS v3.1 SwinV2 (reference make_swinv2_dpt.py:107-115): 96-wide first stage, 3 heads - bf16 operand planes of that
+    stage are padded to 128 columns on the device. Fixture generated from the reference (tests/golden/gen_golden.py --only-swin-tiny256)."""
+    from muggled_dpt_amd.synthetic import make_synthetic_swinv2_state_dict
+    g = np.load(os.path.join(golden_dir, "swin2_tiny_256.npz"))
+    osd = make_synthetic_swinv2_state_dict("swin2_tiny_256", int(g["weight_seed"]))
+    np.testing.assert_allclose(float(osd["pretrained.model.layers.0.blocks.1.attn.qkv.weight"].double().sum()), g["weight_checksum"][0], rtol=1e-9)
+    del osd
+    model, cfg, w = _build("swin2_tiny_256", int(g["weight_seed"]), dtype)
+    x = seeded_input((2, 3, 256, 256), int(g["input_seed"]))
+    np.testing.assert_allclose(float(x.double().sum()), g["input_checksum"][0], rtol=1e-9)
+    y = model(x.to("cuda", dtype)).float().cpu()
+    ref = torch.from_numpy(g["depth_strided"])
+    assert float((y[:, ::4, ::4].double() - ref.double()).abs().max() / ref.abs().max()) <= tol
+    taps = model.debug_taps(2, (256, 256))
+    for i in range(4):
+        crop = torch.from_numpy(g[f"tap{i}_crop"])
+        scale = float(g[f"tap{i}_stats"][1] - g[f"tap{i}_stats"][0])
+        assert float((taps["stages"][i][:, :64, :64].cpu() - crop).abs().max()) / scale <= tol, f"tap{i}"
+    if dtype == torch.float32:
+        np.testing.assert_allclose(stats(y)[3], g["depth_stats"][3], rtol=1e-3)
+    # stage-by-stage entry points carry the padded planes too (tokens -> encoder -> reassemble)
+    tok, hw = model.patch_embed(x[:1].to("cuda", dtype))
+    maps = model.reassemble(*model.imgencoder(tok, hw), hw)
+    assert rel_err(model.head(model.fusion(*maps)).float().cpu(), y[:1]) <= (1e-5 if dtype == torch.float32 else tol)

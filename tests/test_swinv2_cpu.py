@@ -161,3 +161,37 @@ def test_relative_position_index_matches_the_reference_docstring_example():
     tq = ((iy + wh - 1) * (2 * ww - 1) + ix + ww - 1).flatten()
     tk = (iy * (2 * ww - 1) + ix).flatten()
     assert torch.equal(tq[:, None] - tk[None, :], ypart + xpart)
+
+
+def test_swin2_tiny_256_oracle_vs_reference_fixture_and_abi(golden_dir):
+    """swin2_tiny_256 (96-wide first stage): the oracle reproduces the reference fixture; the C ABI accepts widths that are multiples
+    of 32 (head dim) and still rejects others."""
+    import numpy as np
+    from oracle import dpt_oracle
+    from muggled_dpt_amd.synthetic import make_synthetic_swinv2_state_dict
+    from muggled_dpt_amd.state_dict_conversion import flatten_components
+    g = np.load(os.path.join(golden_dir, "swin2_tiny_256.npz"))
+    osd = make_synthetic_swinv2_state_dict("swin2_tiny_256", int(g["weight_seed"]))
+    cfg = conv.get_model_config_from_state_dict(osd)
+    assert list(cfg["features_per_stage"]) == [96, 192, 384, 768] and list(cfg["heads_per_stage"]) == [3, 6, 12, 24]
+    w = flatten_components(conv.convert_state_dict_keys(cfg, osd))
+    x = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(int(g["input_seed"])))
+    y = dpt_oracle.forward(w, cfg, x)
+    assert float((y[:, ::4, ::4] - torch.from_numpy(g["depth_strided"])).abs().max()) <= 1e-5
+    lib = native.load()
+    s = native.MdptConfig()
+    c = SWINV2_CONFIGS["swin2_tiny_256"]
+    s.features_per_token, s.num_heads, s.num_blocks = 96, 3, sum(c["layers_per_stage"])
+    for i in range(4):
+        s.reassembly_features[i] = c["features_per_stage"][i]
+        s.swin_heads[i], s.swin_layers[i] = c["heads_per_stage"][i], c["layers_per_stage"][i]
+        s.swin_pretrained_window[i] = c["pretrained_window_sizes_per_stage"][i]
+    s.swin_window_h, s.swin_window_w = c["window_size_hw"]
+    s.base_patch_grid_h, s.base_patch_grid_w = c["base_patch_grid_hw"]
+    s.fusion_channels, s.patch_size_px, s.precision, s.family = 256, 4, native.PREC_BF16, native.FAMILY_SWINV2
+    h = ctypes.c_void_p()
+    assert lib.mdpt_create(ctypes.byref(s), ctypes.byref(h)) == 0, lib.mdpt_last_error()
+    lib.mdpt_destroy(h)
+    s.features_per_token = s.reassembly_features[0] = 80
+    s.swin_heads[0] = 2
+    assert lib.mdpt_create(ctypes.byref(s), ctypes.byref(h)) < 0
