@@ -346,3 +346,21 @@ def test_latency_mode_split_kv_attention_matches_the_oracle():
         assert rel_err(y_fast.float().cpu(), y_default.float().cpu()) <= REL_TOL_BF16
         model.set_latency_mode(False)
         assert torch.equal(model(x.to("cuda", torch.bfloat16)), y_default)  # and back: the default form is reproduced exactly
+
+
+def test_prepare_image_kernel_on_random_sizes_vs_oracle():
+    """The HIP antialiased resize against the oracle (= F.interpolate(antialias=True), pinned to the reference) on random image sizes,
+    aspect ratios, target sides and both sizing modes: strong down-scales (wide triangle filters), up-scales, 1-pixel-wide borders."""
+    model, _, _ = _model("tiny", torch.float32)
+    orc = _oracle()
+    rng = np.random.default_rng(123)
+    for k in range(24):
+        h, w = int(rng.integers(9, 900)), int(rng.integers(9, 900))
+        side = [None, int(rng.integers(28, 700))][int(rng.integers(0, 2))]
+        square = bool(rng.integers(0, 2))
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        got = model.prepare_image_bgr(img, side, square)
+        want = orc.prepare_image(img, side, square, default_size_px=model.patch_embed._default_size_px)
+        assert got.is_cuda and tuple(got.shape) == tuple(want.shape), (h, w, side, square, tuple(got.shape), tuple(want.shape))
+        err = float((got.cpu() - want).abs().max())
+        assert err <= 3e-5, f"{h}x{w} side={side} square={square}: max abs err {err:.2e}"

@@ -71,3 +71,23 @@ def test_hip_postprocess_on_model_output_and_negative_values():
     assert torch.equal(u8.cpu(), dpt_oracle.convert_to_uint8(x)) and int(u8.max()) == 255 and int(u8.min()) == 0
     xb = x.cuda().to(torch.bfloat16)
     assert postprocess.normalize_01(xb).dtype == torch.bfloat16 and postprocess.scale_prediction(xb, (100, 50)).shape == (3, 50, 100)
+
+
+@pytest.mark.gpu
+def test_hip_postprocess_on_random_shapes_vs_oracle():
+    """Random map sizes / batch sizes / target sizes (strong up- and down-scales, 1-pixel targets excluded as in the demos):
+    resize within fp32 noise, integer conversions exact given identical inputs."""
+    from muggled_dpt_amd import postprocess
+    rng = np.random.default_rng(5)
+    for k in range(16):
+        b, h, w = int(rng.integers(1, 4)), int(rng.integers(2, 300)), int(rng.integers(2, 300))
+        tw, th = int(rng.integers(2, 700)), int(rng.integers(2, 700))
+        x = torch.from_numpy(rng.standard_normal((b, h, w), dtype=np.float32) * float(rng.uniform(0.1, 50)) + float(rng.uniform(-5, 5)))
+        s = postprocess.scale_prediction(x.cuda(), (tw, th))
+        ref = dpt_oracle.scale_prediction(x, (tw, th))
+        assert tuple(s.shape) == tuple(ref.shape) == (b, th, tw)
+        scale = float(x.abs().max())
+        assert float((s.cpu() - ref).abs().max()) <= 4e-6 * scale, (b, h, w, tw, th)
+        assert torch.equal(postprocess.normalize_01(x.cuda()).cpu(), dpt_oracle.normalize_01(x))
+        assert torch.equal(postprocess.convert_to_uint8(x.cuda()).cpu(), dpt_oracle.convert_to_uint8(x))
+        assert torch.equal(postprocess.pack_depth_u24(x[:1].cuda()).cpu(), dpt_oracle.pack_depth_u24(x[:1]))
