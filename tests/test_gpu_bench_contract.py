@@ -1,0 +1,34 @@
+"""bench.py's output contract (one JSON line; metric/config of BASELINE.json; roofline and cpu_baseline objects). `pytest -m gpu`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["unit"] == "depth-maps/s"
+    assert "workload" in d["config"] and "vitl" in d["config"]["workload"] and "batch 32" in d["config"]["workload"]
+    assert abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-3
+    roof = d["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0.05 < roof["frac"] < 1.0
+    assert roof["traffic"] is None or roof["traffic"] > 1e8
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["unit"] == "depth-maps/s" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
+    assert d["error_vs_cpu_fp32"]["rel_to_max"] < 3e-2
+    assert d["fp32_class_mode"]["error_vs_cpu_fp32"]["rel_to_max"] < 1e-3 and d["fp32_class_mode"]["value"] > 0
