@@ -34,30 +34,35 @@ def test_rccl_backend_initialises_and_allgathers_on_this_box():
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_c_abi_allgather_wrapper_on_a_one_rank_communicator():
-    """mdpt_allgather_f32 (the ncclAllGather wrapper for non-torch hosts): communicator created straight from librccl with ctypes."""
-    import ctypes
-    import torch
-    from muggled_dpt_amd import native
-    assert torch.cuda.is_available()
-    lib = native.load()
-    rccl = None
-    for name in ("librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
-        try:
-            rccl = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
-            break
-        except OSError:
-            continue
-    assert rccl is not None, "librccl.so not found"
-    comm = ctypes.c_void_p()
-    devs = (ctypes.c_int * 1)(0)
-    assert rccl.ncclCommInitAll(ctypes.byref(comm), 1, devs) == 0
+WRAPPER_SCRIPT = r"""
+import ctypes, sys, torch
+sys.path.insert(0, %r)
+from muggled_dpt_amd import native
+lib = native.load()
+rccl = None
+for name in ("librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
     try:
-        x = torch.randn(3, 56, 84, device="cuda")
-        out = torch.empty_like(x)
-        stream = torch.cuda.current_stream().cuda_stream
-        native.check(lib, lib.mdpt_allgather_f32(comm, x.data_ptr(), out.data_ptr(), x.numel(), stream))
-        torch.cuda.synchronize()
-        assert torch.equal(out, x)
-    finally:
-        rccl.ncclCommDestroy(comm)
+        rccl = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+        break
+    except OSError:
+        continue
+assert rccl is not None, "librccl.so not found"
+comm = ctypes.c_void_p()
+devs = (ctypes.c_int * 1)(0)
+assert rccl.ncclCommInitAll(ctypes.byref(comm), 1, devs) == 0
+x = torch.randn(3, 56, 84, device="cuda")
+out = torch.empty_like(x)
+native.check(lib, lib.mdpt_allgather_f32(comm, x.data_ptr(), out.data_ptr(), x.numel(), torch.cuda.current_stream().cuda_stream))
+torch.cuda.synchronize()
+assert torch.equal(out, x)
+rccl.ncclCommDestroy(comm)
+print("WRAPPER_OK")
+""" % REPO
+
+
+def test_c_abi_allgather_wrapper_on_a_one_rank_communicator():
+    """mdpt_allgather_f32 (the ncclAllGather wrapper for non-torch hosts): communicator created straight from librccl with ctypes
+    (in a child process: RCCL prints a version banner at exit)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", WRAPPER_SCRIPT], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "WRAPPER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
