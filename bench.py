@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Headline benchmark: depth-maps/sec of the Depth-Anything-V2 ViT-L DPT path on MI355X.
+"""Headline benchmark: depth-maps/sec of the DPT path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                          # BASELINE configs[2]: DA-V2 ViT-L, 518x518 (-> 504), batch 32, bf16
+    python bench.py --precision bf16x3 --steps 20                          # the same workload in the mode that meets the 1e-3 tolerance
+    python bench.py --size 1036 --batch 8                                  # the other north-star size (1036x1036, 5477 tokens)
+    python bench.py --model beitl   (or swinl)                             # BASELINE configs[4]: MiDaS v3.1 BEiT-L / SwinV2-L, 384x384, batch 16
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
 
 One "step" = one pass of the hot path (mdpt_forward through the C ABI) over one batch of synthetic images per GPU,
-followed (N>1) by the RCCL all-gather of the depth maps. Workload = BASELINE.json configs[2]/[3]:
+followed (N>1) by the RCCL all-gather of the depth maps. Default workload = BASELINE.json configs[2]/[3]:
 ViT-L, "518x518" images (= 504x504 model tensor, the reference's own size snapping), bf16 MFMA with fp32 accumulate,
 batch 32 per GPU (weak scaling: global batch 32*N), seeded synthetic weights and inputs already resident in HBM.
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
@@ -25,27 +28,64 @@ import torch.distributed as dist
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict, native  # noqa: E402
+from muggled_dpt_amd import native  # noqa: E402
 from muggled_dpt_amd.parallel import DataParallelDepth, init_distributed  # noqa: E402
-from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict  # noqa: E402
 
-# algorithmic GFLOP per depth map (2 FLOP/MAC), SURVEY §8(d) / BASELINE.md §4
+# algorithmic GFLOP per depth map of the reference graph (2 FLOP/MAC), SURVEY §8(d) / BASELINE.md §4
 GFLOP_PER_MAP = {("vitl", 504): 1224.9, ("vitl", 532): 1385.8, ("vitl", 1036): 7424.0,
-                 ("vits", 504): 107.3, ("vits", 532): 123.5, ("vits", 1036): 875.2}
+                 ("vits", 504): 107.3, ("vits", 532): 123.5, ("vits", 1036): 875.2,
+                 ("beitl", 384): 516.4, ("swinl", 384): 343.7}
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+FAMILY = {"vitl": "Depth-Anything-V2 ViT-L", "vits": "Depth-Anything-V2 ViT-S", "vitb": "Depth-Anything-V2 ViT-B",
+          "beitl": "MiDaS v3.1 BEiT-L-384", "swinl": "MiDaS v3.1 SwinV2-L-384"}
+SYNTH_NAME = {"beitl": "beit_large_384", "swinl": "swin2_large_384"}
 
 
-def cpu_baseline(model_name: str, size: int, x_cpu: torch.Tensor, gpu_out: torch.Tensor | None):
-    """Oracle (CPU restatement of the reference, kind="port") timed on this box's host cores on a bounded sample."""
+def make_model_and_weights(name: str, want_weights: bool = False):
+    """(model on CPU, (cfg, flat weight dict) for the oracle or None). Seeded synthetic checkpoints in the ORIGINAL key layout go
+    through the same factories a real .pth would (make_*_dpt_from_*_state_dict)."""
+    from muggled_dpt_amd.state_dict_conversion import flatten_components
+    if name == "beitl":
+        from muggled_dpt_amd import make_beit_dpt_from_midas_v31_state_dict as make
+        from muggled_dpt_amd import state_dict_conversion_beit as conv
+        from muggled_dpt_amd.synthetic import make_synthetic_beit_state_dict as synth
+        osd = synth(SYNTH_NAME[name], 0)
+    elif name == "swinl":
+        from muggled_dpt_amd import make_swinv2_dpt_from_midas_v31_state_dict as make
+        from muggled_dpt_amd import state_dict_conversion_swinv2 as conv
+        from muggled_dpt_amd.synthetic import make_synthetic_swinv2_state_dict as synth
+        osd = synth(SYNTH_NAME[name], 0)
+    else:
+        from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict as make
+        from muggled_dpt_amd import state_dict_conversion as conv
+        from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict as synth
+        osd = synth(name, 0)
+    cfg, model = make(osd)
+    ow = None
+    if want_weights:
+        ocfg = conv.get_model_config_from_state_dict(osd) if hasattr(conv, "get_model_config_from_state_dict") and name not in SYNTH_NAME else cfg
+        ow = (ocfg, flatten_components(conv.convert_state_dict_keys(ocfg, osd)))
+    return model, ow
+
+
+def cpu_name() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(args, x_cpu: torch.Tensor, gpu_out: torch.Tensor | None):
+    """Oracle (CPU restatement of the reference, kind="port") timed on this box's host cores on a bounded sample (~10-30 s)."""
     from oracle import dpt_oracle
-    from muggled_dpt_amd.state_dict_conversion import convert_state_dict_keys, flatten_components, get_model_config_from_state_dict
 
     threads = max(1, (os.cpu_count() or 2) // 2)  # the reference's own policy (demo_helpers/misc.py:161-166)
     torch.set_num_threads(threads)
-    osd = make_synthetic_original_state_dict(model_name, 0)
-    cfg = get_model_config_from_state_dict(osd)
-    w = flatten_components(convert_state_dict_keys(cfg, osd))
-    n_img = 2 if model_name == "vitl" else 8
+    _, (cfg, w) = make_model_and_weights(args.model, want_weights=True)
+    n_img = 8 if args.model == "vits" else (1 if args.size > 600 else 2)
     dpt_oracle.forward(w, cfg, x_cpu[:1])  # warm-up (thread pool, oneDNN primitive caches)
     t0 = time.perf_counter()
     ref = None
@@ -54,9 +94,10 @@ def cpu_baseline(model_name: str, size: int, x_cpu: torch.Tensor, gpu_out: torch
         if i == 0:
             ref = y
     dt = time.perf_counter() - t0
-    out = {"value": round(n_img / dt, 4), "unit": "depth-maps/s", "cores": threads, "kind": "port",
-           "sample": f"{n_img} images of the same workload, batch 1, fp32, torch {torch.__version__} CPU, {threads} threads "
-                     f"(os.cpu_count()={os.cpu_count()})"}
+    out = {"value": round(n_img / dt, 4), "unit": "depth-maps/s", "cores": threads, "kind": "port", "cpu": cpu_name(),
+           "sample": f"{n_img} images of the same workload one at a time (batch 1: the reference's run_image.py path), fp32, torch {torch.__version__} CPU, "
+                     f"{threads} threads = os.cpu_count()//2 (the reference's thread policy; os.cpu_count()={os.cpu_count()}; all-cores and batch-8 arms: "
+                     f"profiles/r01_cpu_baseline.md - the container's CPU quota makes more threads slower)"}
     return out, error_vs(ref, gpu_out), ref
 
 
@@ -68,15 +109,60 @@ def error_vs(ref: torch.Tensor, gpu_out: torch.Tensor | None):
     return {"max_abs": float(d), "rel_to_max": float(d / ref.double().abs().max())}
 
 
-def fp32_class_leg(args, dev, x_cpu, ref):
+def hbm_traffic(args, kernel_name: str):
+    """HBM bytes per launch of `kernel_name` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this exact workload,
+    corrected per MI355X_MICROARCH.md; tools/collect_profiles.sh + tools/summarize_pmc.py). bench.py cannot run PMC passes itself, so the
+    summary is stamped with a hash of the kernel sources it was taken on and is reported only while that hash still matches (else null)."""
+    if args.model != "vitl" or args.batch != 32 or args.size != 504 or args.precision != "bf16":
+        return None
+    sha = native.source_hash()
+    for tag in ("r02", "r01"):
+        path = os.path.join(REPO, "profiles", f"{tag}_hbm_traffic.json")
+        if not os.path.exists(path):
+            continue
+        rows = json.load(open(path))
+        if rows.get("_meta", {}).get("csrc_sha") != sha:
+            continue
+        rec = rows.get(kernel_name)
+        return None if rec is None else int((rec["fetch_mb_per_launch"] + rec["write_mb_per_launch"]) * 1e6)
+    return None
+
+
+def roofline(args, pr, how):
+    """Dominant GEMM kernel (by accumulated time) of a profiler report. `gflop` in the report is ALGORITHMIC (2 M N K, one pass); in the
+    bf16x3 mode every product runs as three MFMA passes, so the executed-MFMA fraction is three times the algorithmic one."""
+    gemms = [k for k in pr["kernels"] if k["gflop"] > 0 and k["name"].startswith("gemm")]
+    dom = max(gemms, key=lambda k: k["total_ms"]) if gemms else pr["kernels"][0]
+    r = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+         "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic(args, dom["name"]), "kernel": dom["name"],
+         "launches": dom["launches"], "avg_us": dom["avg_us"], "gflop_per_launch": round(dom["gflop"] / dom["launches"], 3), "measured": how}
+    if args.precision == "bf16x3":
+        r["executed_mfma_tflops"] = round(3 * dom["tflops"], 2)
+        r["executed_mfma_frac"] = round(3 * dom["tflops"] / PEAK_BF16_TFLOPS, 4)
+        r["note"] = "achieved/frac are algorithmic (one product per MAC); the x3 mode executes three bf16 MFMA passes per product"
+    return r
+
+
+def profile_pass(lib, fn, steps):
+    torch.cuda.synchronize()
+    lib.mdpt_profile_enable(1)
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    buf = ctypes.create_string_buffer(1 << 16)
+    prof = json.loads(buf.value.decode()) if lib.mdpt_profile_report(buf, len(buf)) == 0 else None
+    lib.mdpt_profile_enable(0)
+    return prof
+
+
+def fp32_class_leg(args, dev, x_cpu, ref, lib):
     """The same workload in the bf16x3 mode (hi + lo bf16 operand planes, 3 MFMA passes, fp32 accumulate): the mode that meets the
-    north star's 1e-3 relative tolerance. Reported beside the headline bf16 number, never instead of it."""
-    osd = make_synthetic_original_state_dict(args.model, 0)
-    _, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
-    del osd
+    north star's 1e-3 relative tolerance. Reported beside the headline bf16 number, never instead of it; `bench.py --precision bf16x3`
+    is the same measurement as a first-class run (full step count)."""
+    model, _ = make_model_and_weights(args.model)
     model = model.to(dev, torch.float32)
     x = x_cpu.to(dev)
-    steps = max(2, min(args.steps, 5))
+    steps = max(2, min(args.steps, 10))
     with torch.inference_mode():
         y = model(x)
         torch.cuda.synchronize()
@@ -85,8 +171,16 @@ def fp32_class_leg(args, dev, x_cpu, ref):
             y = model(x)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    return {"value": round(args.batch * steps / dt, 3), "unit": "depth-maps/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-            "dtype": "bf16x3 (hi/lo split bf16 MFMA operands, 3 passes, fp32 accumulate)", "error_vs_cpu_fp32": error_vs(ref, y.float())}
+        handle = model._get_engine().handle
+        native.check(lib, lib.mdpt_set_batch_split(handle, 0))
+        model(x)
+        prof = profile_pass(lib, lambda: model(x), 2)
+    sub = argparse.Namespace(**{**vars(args), "precision": "bf16x3"})
+    out = {"value": round(args.batch * steps / dt, 3), "unit": "depth-maps/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "dtype": "bf16x3 (hi/lo split bf16 MFMA operands, 3 passes, fp32 accumulate)", "error_vs_cpu_fp32": error_vs(ref, y.float())}
+    if prof and prof["kernels"]:
+        out["roofline"] = roofline(sub, prof, "HIP events, batch split off, 2 steps")
+    return out
 
 
 def main():
@@ -94,15 +188,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="vitl", choices=["vitl", "vits"])
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--size", type=int, default=504, help="model tensor side (a 518x518 image is processed at 504)")
+    ap.add_argument("--model", default="vitl", choices=sorted(FAMILY))
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: 32; 8 at --size 1036; 16 for beitl / swinl)")
+    ap.add_argument("--size", type=int, default=0, help="model tensor side (default 504 = what a 518x518 image is processed at; 384 for beitl / swinl)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-launch HIP events in the timed region")
     ap.add_argument("--no-split", action="store_true", help="disable the two-stream half-batch split inside mdpt_forward")
     args = ap.parse_args()
+    midas = args.model in SYNTH_NAME
+    if not args.size:
+        args.size = 384 if midas else 504
+    if not args.batch:
+        args.batch = 16 if midas else (8 if args.size > 600 else 32)
 
     rank, world, local_rank = init_distributed()
     if args.gpus != world:
@@ -118,19 +217,16 @@ def main():
         dist.barrier()
     dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
 
-    osd = make_synthetic_original_state_dict(args.model, 0)
-    _, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
-    del osd
+    model, _ = make_model_and_weights(args.model)
     model = model.to(dev, dtype)
+    lib = native.load()
     if args.tile:
         model.set_gemm_tile(args.tile)
     if args.no_split:
-        from muggled_dpt_amd import native as _native
-        _native.check(_native.load(), _native.load().mdpt_set_batch_split(model._get_engine().handle, 0))
+        native.check(lib, lib.mdpt_set_batch_split(model._get_engine().handle, 0))
     x_cpu = torch.randn(args.batch, 3, args.size, args.size, generator=torch.Generator().manual_seed(1 + rank))
     x = x_cpu.to(dev).to(dtype)
     dp = DataParallelDepth(model, rank, world)
-    lib = native.load()
 
     def barrier():
         if world > 1:
@@ -164,15 +260,7 @@ def main():
             native.check(lib, lib.mdpt_set_batch_split(handle, 0))
             with torch.inference_mode():  # local forward only (no collective: the other ranks are not in this pass)
                 model(x)
-                torch.cuda.synchronize()
-                lib.mdpt_profile_enable(1)
-                for _ in range(args.steps):
-                    model(x)
-                torch.cuda.synchronize()
-            buf = ctypes.create_string_buffer(1 << 16)
-            if lib.mdpt_profile_report(buf, len(buf)) == 0:
-                prof_alone = json.loads(buf.value.decode())
-            lib.mdpt_profile_enable(0)
+                prof_alone = profile_pass(lib, lambda: model(x), args.steps)
             native.check(lib, lib.mdpt_set_batch_split(handle, 8))
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -183,12 +271,13 @@ def main():
         maps = world * args.batch * args.steps
         value = maps / elapsed
         gflop = GFLOP_PER_MAP.get((args.model, args.size))
+        img = {504: "518x518 (504x504 model tensor)", 1036: "1036x1036"}.get(args.size, f"{args.size}x{args.size}")
         line = {
-            "metric": "depth-maps/sec @518x518 (504x504 model tensor), DA-V2 %s" % {"vitl": "ViT-L", "vits": "ViT-S"}[args.model],
+            "metric": f"depth-maps/sec @{img}, {FAMILY[args.model]}",
             "value": round(value, 3), "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16x3(fp32-class)", "data": "synthetic",
-            "config": {"workload": f"Depth-Anything-V2 {args.model}, 518x518 image -> {args.size}x{args.size} tensor, batch "
+            "config": {"workload": f"{FAMILY[args.model]} ({args.model}), {'518x518 image -> ' if args.size == 504 else ''}{args.size}x{args.size} tensor, batch "
                                    f"{args.batch}/GPU, {args.precision} MFMA operands + fp32 accumulate, mdpt_forward via C ABI"
                                    + (", RCCL all-gather of depth maps" if world > 1 else ""),
                        "global_batch": world * args.batch, "tensor_hw": [args.size, args.size], "parallelism": f"dp{world}",
@@ -198,39 +287,25 @@ def main():
             line["path_tflops"] = round(value * gflop / 1e3, 2)
             line["path_frac_of_mfma_peak"] = round(value * gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
         if prof and prof["kernels"]:
-            def hbm_traffic(kernel_name):
-                """HBM bytes per launch of `kernel_name` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this
-                exact workload, corrected per MI355X_MICROARCH.md: profiles/r01_hbm_traffic.md). bench.py cannot run PMC passes itself."""
-                path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
-                if args.model != "vitl" or args.batch != 32 or args.size != 504 or args.precision != "bf16" or not os.path.exists(path):
-                    return None
-                rec = json.load(open(path)).get(kernel_name)
-                return None if rec is None else int((rec["fetch_mb_per_launch"] + rec["write_mb_per_launch"]) * 1e6)
-
-            def roof(pr, how):
-                gemms = [k for k in pr["kernels"] if k["gflop"] > 0 and k["name"].startswith("gemm")]
-                dom = max(gemms, key=lambda k: k["total_ms"]) if gemms else pr["kernels"][0]
-                return {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic(dom["name"]), "kernel": dom["name"],
-                        "launches": dom["launches"], "avg_us": dom["avg_us"],
-                        "gflop_per_launch": round(dom["gflop"] / dom["launches"], 3), "measured": how}
             if prof_alone and prof_alone["kernels"]:
-                line["roofline"] = roof(prof_alone, "HIP events, second pass of the same steps with the batch split off (kernel alone on the GPU; "
-                                                    "`bench.py --no-split` + rocprofv3 reproduce it)")
-                line["roofline_in_timed_region"] = roof(prof, "HIP events in the timed region: two half-batch kernels overlap, durations include sharing")
+                line["roofline"] = roofline(args, prof_alone, "HIP events, second pass of the same steps with the batch split off (kernel alone on the GPU; "
+                                                              "`bench.py --no-split` + rocprofv3 reproduce it)")
+                line["roofline_in_timed_region"] = roofline(args, prof, "HIP events in the timed region: two half-batch kernels overlap, durations include sharing")
+                shares = prof_alone
             else:
-                line["roofline"] = roof(prof, "HIP events in the timed region")
-            tot = sum(k["total_ms"] for k in prof["kernels"])
-            line["kernel_time_share"] = {k["name"]: round(k["total_ms"] / tot, 4) for k in prof["kernels"][:12]}
+                line["roofline"] = roofline(args, prof, "HIP events in the timed region")
+                shares = prof
+            tot = sum(k["total_ms"] for k in shares["kernels"])
+            line["kernel_time_share"] = {k["name"]: round(k["total_ms"] / tot, 4) for k in shares["kernels"][:12]}
         else:
             line["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
-            base, err, ref = cpu_baseline(args.model, args.size, x_cpu, y.float())
+            base, err, ref = cpu_baseline(args, x_cpu, y.float())
             line["cpu_baseline"] = base
             line["error_vs_cpu_fp32"] = err
             if args.precision == "bf16":
                 del y
-                line["fp32_class_mode"] = fp32_class_leg(args, dev, x_cpu, ref)
+                line["fp32_class_mode"] = fp32_class_leg(args, dev, x_cpu, ref, lib)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

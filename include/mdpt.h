@@ -152,9 +152,13 @@ int mdpt_set_latency_mode(mdpt_handle* h, int32_t on);
 
 /* PatchEmbed.prepare_image (v2_depthanything/patch_embed.py:103-145): uint8 [in_h,in_w,3] BGR on the device ->
  * fp32 [3,out_h,out_w] RGB, antialiased-bilinear resized exactly like F.interpolate(..., antialias=True) and normalised with the
- * given per-channel mean/std (ImageNet values for Depth-Anything, 0.5/0.5 for BEiT). The caller picks out_h/out_w with the reference's size rule (multiples of 2*patch). */
+ * given per-channel mean/std (ImageNet values for Depth-Anything, 0.5/0.5 for BEiT). The caller picks out_h/out_w with the reference's size rule (multiples of 2*patch).
+ * `interpolation` = the reference's interpolation_mode argument (patch_embed.py:108,141): bilinear (its default) or bicubic; torch itself
+ * rejects antialias=True for every other mode, and so does this entry point (MDPT_E_UNSUPPORTED). */
+#define MDPT_INTERP_BILINEAR 0
+#define MDPT_INTERP_BICUBIC 1
 int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void* out_chw_f32, int32_t out_h, int32_t out_w,
-                       const float rgb_mean[3], const float rgb_std[3], void* stream);
+                       const float rgb_mean[3], const float rgb_std[3], int32_t interpolation, void* stream);
 
 /* Depth post-processing on the device (reference muggled_dpt/demo_helpers/postprocess.py and
  * run_3dviewer.py:576-590). All buffers are device pointers; `minmax` is a 2-float device buffer {min, max} and

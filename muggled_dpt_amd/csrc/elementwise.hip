@@ -434,11 +434,26 @@ __global__ __launch_bounds__(256) void tokens_to_resid_kernel(const float* __res
 // antialias=True, align_corners=False)) and normalised ((v/255) - mean) / std. The antialias filter is the
 // separable triangle filter of aten's _upsample_bilinear2d_aa: per output index i, scale = in/out,
 // support = max(scale, 1), centre = scale*(i+0.5), taps j in [floor(centre-support+0.5), floor(centre+support+0.5))
-// clipped to the image, weight = max(0, 1 - |(j - centre + 0.5) / max(scale,1)|), normalised to sum 1.
+// clipped to the image, weight = max(0, 1 - |(j - centre + 0.5) / max(scale,1)|), normalised to sum 1. mode="bicubic" is the same
+// machinery with the cubic filter (support 2*max(scale,1)).
 // One thread per output pixel (all 3 channels): rows of weights are recomputed per pixel (<= ~2*scale+2 taps).
 // ---------------------------------------------------------------------------------------------------
+// INTERP 0 = bilinear (triangle filter, support 1), 1 = bicubic (Keys cubic with a = -0.5, support 2: aten's _upsample_bicubic2d_aa;
+// its weights go negative, so outputs may over/undershoot the 0..255 range exactly like the reference's).
+template <int INTERP>
+__device__ __forceinline__ float aa_filter(float x) {
+    x = fabsf(x);
+    if (INTERP == 0) return fmaxf(0.0f, 1.0f - x);
+    const float a = -0.5f;
+    if (x < 1.0f) return ((a + 2.0f) * x - (a + 3.0f)) * x * x + 1.0f;
+    if (x < 2.0f) return (((x - 5.0f) * x + 8.0f) * x - 4.0f) * a;
+    return 0.0f;
+}
+
+template <int INTERP>
 __device__ __forceinline__ void aa_span(int i, float scale, int in_size, int& lo, int& n, float& center, float& invscale) {
-    const float support = scale >= 1.0f ? scale : 1.0f;
+    const float half_taps = INTERP == 0 ? 1.0f : 2.0f;  // interp_size / 2
+    const float support = scale >= 1.0f ? half_taps * scale : half_taps;
     invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
     center = scale * ((float)i + 0.5f);
     lo = max((int)(center - support + 0.5f), 0);
@@ -446,6 +461,7 @@ __device__ __forceinline__ void aa_span(int i, float scale, int in_size, int& lo
     n = hi - lo;
 }
 
+template <int INTERP>
 __global__ __launch_bounds__(256) void prepare_image_kernel(const unsigned char* __restrict__ bgr, float* __restrict__ out, int ih,
                                                             int iw, int oh, int ow, float m0, float m1, float m2, float s0,
                                                             float s1, float s2) {
@@ -455,18 +471,18 @@ __global__ __launch_bounds__(256) void prepare_image_kernel(const unsigned char*
     const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
     int ylo, yn, xlo, xn;
     float yc, yinv, xc, xinv;
-    aa_span(oy, sy, ih, ylo, yn, yc, yinv);
-    aa_span(ox, sx, iw, xlo, xn, xc, xinv);
+    aa_span<INTERP>(oy, sy, ih, ylo, yn, yc, yinv);
+    aa_span<INTERP>(ox, sx, iw, xlo, xn, xc, xinv);
     float wxs = 0.0f, wys = 0.0f;
-    for (int j = 0; j < xn; ++j) wxs += fmaxf(0.0f, 1.0f - fabsf(((float)(j + xlo) - xc + 0.5f) * xinv));
-    for (int j = 0; j < yn; ++j) wys += fmaxf(0.0f, 1.0f - fabsf(((float)(j + ylo) - yc + 0.5f) * yinv));
+    for (int j = 0; j < xn; ++j) wxs += aa_filter<INTERP>(((float)(j + xlo) - xc + 0.5f) * xinv);
+    for (int j = 0; j < yn; ++j) wys += aa_filter<INTERP>(((float)(j + ylo) - yc + 0.5f) * yinv);
     float acc_b = 0.0f, acc_g = 0.0f, acc_r = 0.0f;
     for (int a = 0; a < yn; ++a) {
-        const float wy = fmaxf(0.0f, 1.0f - fabsf(((float)(a + ylo) - yc + 0.5f) * yinv)) / wys;
+        const float wy = aa_filter<INTERP>(((float)(a + ylo) - yc + 0.5f) * yinv) / wys;
         const unsigned char* row = bgr + ((size_t)(ylo + a) * iw + xlo) * 3;
         float rb = 0.0f, rg = 0.0f, rr = 0.0f;  // horizontal pass first (like the reference's separable CPU kernel)
         for (int c = 0; c < xn; ++c) {
-            const float wx = fmaxf(0.0f, 1.0f - fabsf(((float)(c + xlo) - xc + 0.5f) * xinv)) / wxs;
+            const float wx = aa_filter<INTERP>(((float)(c + xlo) - xc + 0.5f) * xinv) / wxs;
             rb += wx * (float)row[c * 3 + 0];
             rg += wx * (float)row[c * 3 + 1];
             rr += wx * (float)row[c * 3 + 2];
@@ -709,11 +725,15 @@ int mdpt_launch_tokens_to_resid(const float* tokens, const float* pos, float* re
 }
 
 int mdpt_launch_prepare_image(const unsigned char* bgr, float* out, int ih, int iw, int oh, int ow, const float mean[3],
-                              const float inv_std[3], hipStream_t stream) {
-    if (ih <= 0 || iw <= 0 || oh <= 0 || ow <= 0) return (int)hipErrorInvalidValue;
+                              const float inv_std[3], int interp, hipStream_t stream) {
+    if (ih <= 0 || iw <= 0 || oh <= 0 || ow <= 0 || (interp != 0 && interp != 1)) return (int)hipErrorInvalidValue;
     MdptProfScope prof("prepare_image_kernel", 0.0, stream);
-    hipLaunchKernelGGL(prepare_image_kernel, dim3((oh * ow + 255) / 256), dim3(256), 0, stream, bgr, out, ih, iw, oh, ow, mean[0], mean[1],
-                       mean[2], inv_std[0], inv_std[1], inv_std[2]);
+    if (interp == 0)
+        hipLaunchKernelGGL(prepare_image_kernel<0>, dim3((oh * ow + 255) / 256), dim3(256), 0, stream, bgr, out, ih, iw, oh, ow, mean[0], mean[1],
+                           mean[2], inv_std[0], inv_std[1], inv_std[2]);
+    else
+        hipLaunchKernelGGL(prepare_image_kernel<1>, dim3((oh * ow + 255) / 256), dim3(256), 0, stream, bgr, out, ih, iw, oh, ow, mean[0], mean[1],
+                           mean[2], inv_std[0], inv_std[1], inv_std[2]);
     LAUNCH_RET();
 }
 

@@ -1258,11 +1258,13 @@ int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspac
 
 // ---- PatchEmbed.prepare_image (reference v2_depthanything/patch_embed.py:103-145): resize + BGR->RGB + normalise on the GPU
 int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void* out_chw_f32, int32_t out_h, int32_t out_w,
-                       const float rgb_mean[3], const float rgb_std[3], void* stream) {
+                       const float rgb_mean[3], const float rgb_std[3], int32_t interpolation, void* stream) {
     if (!bgr_u8_hwc || !out_chw_f32 || !rgb_mean || !rgb_std) return fail(MDPT_E_INVALID, "null argument");
+    if (interpolation != MDPT_INTERP_BILINEAR && interpolation != MDPT_INTERP_BICUBIC)
+        return fail(MDPT_E_UNSUPPORTED, "interpolation %d: antialiased resize exists for bilinear and bicubic only (as in torch)", interpolation);
     if (in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) return fail(MDPT_E_INVALID, "bad image size %dx%d -> %dx%d", in_h, in_w, out_h, out_w);
     const float inv_std[3] = {1.0f / rgb_std[0], 1.0f / rgb_std[1], 1.0f / rgb_std[2]};  // patch_embed.py:38-39,62
-    CHK(mdpt_launch_prepare_image((const unsigned char*)bgr_u8_hwc, (float*)out_chw_f32, in_h, in_w, out_h, out_w, rgb_mean, inv_std, (hipStream_t)stream));
+    CHK(mdpt_launch_prepare_image((const unsigned char*)bgr_u8_hwc, (float*)out_chw_f32, in_h, in_w, out_h, out_w, rgb_mean, inv_std, interpolation, (hipStream_t)stream));
     return 0;
 }
 

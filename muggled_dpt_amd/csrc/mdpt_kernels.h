@@ -116,7 +116,7 @@ int mdpt_launch_tokens_to_resid(const float* tokens, const float* pos, float* re
                                 hipStream_t stream);
 // uint8 HWC BGR -> normalised fp32 [3,oh,ow] RGB through PyTorch-compatible antialiased bilinear resize
 int mdpt_launch_prepare_image(const unsigned char* bgr, float* out, int ih, int iw, int oh, int ow, const float mean[3],
-                              const float inv_std[3], hipStream_t stream);
+                              const float inv_std[3], int interp, hipStream_t stream);  // interp: 0 bilinear, 1 bicubic (both antialiased)
 // BEiT relative position bias (reference v31_beit/components/relative_positional_encoder.py:117-309): bilinear-resize the
 // learned [(2Gh-1)(2Gw-1)+3, heads] table to the current grid and lay it out per head as an extended LUT so that the bias of
 // (query q, key k) is ext[tq[q] - tk[k]] including the three cls cases; also fills the per-token index terms tq / tk.

@@ -127,25 +127,24 @@ class PatchEmbed(_Stage):
         targ_hw = (largest_side, largest_side) if use_square_sizing else (img_h, img_w)
         scaled_hw = [max(1, round(side * scale / self._tiling_size)) * self._tiling_size for side in targ_hw]
         p = next(self.parameters())
-        if interpolation_mode == "bilinear" and p.device.type == "cuda" and image_bgr.dtype == np.uint8 and image_bgr.ndim == 3 \
-                and image_bgr.shape[2] == 3:
-            # native path: one HIP kernel (antialiased bilinear resize + BGR->RGB + normalisation), mdpt_prepare_image
-            lib = native.load()
-            src = torch.from_numpy(np.ascontiguousarray(image_bgr)).to(p.device, non_blocking=True)
-            out = torch.empty((1, 3, scaled_hw[0], scaled_hw[1]), device=p.device, dtype=torch.float32)
-            with torch.cuda.device(p.device):
-                stream = torch.cuda.current_stream(p.device).cuda_stream
-                mean3, std3 = (ctypes.c_float * 3)(*self.rgb_offset), (ctypes.c_float * 3)(*self.rgb_stdev)
-                native.check(lib, lib.mdpt_prepare_image(src.data_ptr(), img_h, img_w, out.data_ptr(), scaled_hw[0], scaled_hw[1],
-                                                         mean3, std3, stream))
-            return out if p.dtype == torch.float32 else out.to(p.dtype)
-        # other interpolation modes / non-uint8 inputs: the reference's own torch ops on the model device
-        rgb = np.ascontiguousarray(image_bgr[:, :, ::-1].transpose(2, 0, 1))
-        x = torch.from_numpy(rgb).to(device=p.device, dtype=p.dtype)
-        x = nn.functional.interpolate(x.unsqueeze(0), size=scaled_hw, align_corners=False, antialias=True, mode=interpolation_mode)
-        mean = torch.tensor(self.rgb_offset, device=p.device, dtype=p.dtype).view(1, 3, 1, 1)
-        inv_std = 1.0 / torch.tensor(self.rgb_stdev, device=p.device, dtype=p.dtype).view(1, 3, 1, 1)
-        return ((x / 255.0) - mean) * inv_std
+        # one HIP kernel (antialiased resize + BGR->RGB + normalisation), mdpt_prepare_image. No torch fallback: what the kernel does not
+        # cover raises, exactly where torch's own F.interpolate(antialias=True) would (it supports bilinear and bicubic only).
+        interp = {"bilinear": native.INTERP_BILINEAR, "bicubic": native.INTERP_BICUBIC}.get(interpolation_mode)
+        if interp is None:
+            raise ValueError(f"Anti-alias option is restricted to bilinear and bicubic modes (got interpolation_mode={interpolation_mode!r})")
+        if p.device.type != "cuda":
+            raise RuntimeError("prepare_image runs on the GPU only (no CPU fallback): move the model to a cuda device first")
+        if not (isinstance(image_bgr, np.ndarray) and image_bgr.dtype == np.uint8 and image_bgr.ndim == 3 and image_bgr.shape[2] == 3):
+            raise TypeError("prepare_image expects an OpenCV-style uint8 HxWx3 BGR image (cv2.imread output)")
+        lib = native.load()
+        src = torch.from_numpy(np.ascontiguousarray(image_bgr)).to(p.device, non_blocking=True)
+        out = torch.empty((1, 3, scaled_hw[0], scaled_hw[1]), device=p.device, dtype=torch.float32)
+        with torch.cuda.device(p.device):
+            stream = torch.cuda.current_stream(p.device).cuda_stream
+            mean3, std3 = (ctypes.c_float * 3)(*self.rgb_offset), (ctypes.c_float * 3)(*self.rgb_stdev)
+            native.check(lib, lib.mdpt_prepare_image(src.data_ptr(), img_h, img_w, out.data_ptr(), scaled_hw[0], scaled_hw[1],
+                                                     mean3, std3, interp, stream))
+        return out if p.dtype == torch.float32 else out.to(p.dtype)
 
     def verify_input(self, image_tensor_bchw: Tensor) -> bool:
         _, c, h, w = image_tensor_bchw.shape

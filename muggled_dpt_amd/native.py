@@ -29,6 +29,7 @@ FAMILY_BEIT = 2
 FAMILY_SWINV2 = 3
 E_GRID = -7
 POST_F32, POST_U8, POST_U24 = 0, 1, 2
+INTERP_BILINEAR, INTERP_BICUBIC = 0, 1
 
 
 def _hipcc() -> str:
@@ -44,6 +45,18 @@ def _stale() -> bool:
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel / host sources and headers libmdpt.so is built from. Measurements that are only
+    valid for one version of the kernels (profiles/*_hbm_traffic.json) are stamped with it and ignored when it differs."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in [os.path.join(CSRC, s) for s in SOURCES] + [x if os.path.isabs(x) else os.path.join(CSRC, x) for x in HEADERS]:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -129,7 +142,7 @@ SYMBOLS = {
     "mdpt_encoder_probe": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP4, _VP4, _VP, _SZ, _VP]),
     "mdpt_fusion_block": (ctypes.c_int, [_VP, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_head": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
-    "mdpt_prepare_image": (ctypes.c_int, [_VP, _I, _I, _VP, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _VP]),
+    "mdpt_prepare_image": (ctypes.c_int, [_VP, _I, _I, _VP, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _I, _VP]),
     "mdpt_post_minmax": (ctypes.c_int, [_VP, _SZ, _VP, _VP, _VP]),
     "mdpt_post_scale_prediction": (ctypes.c_int, [_VP, _I, _I, _I, _VP, _I, _I, _VP, _VP, _VP]),
     "mdpt_post_normalize": (ctypes.c_int, [_VP, _SZ, _VP, _VP, _I, _I, _VP]),

@@ -299,6 +299,24 @@ def gen_swinv2(report, skip_large, only_tiny256=False):
         print("[swin2_large_384] depth stats (min,max,mean,l2):", stats(depth))
 
 
+def gen_prepare_bicubic():
+    """prepare_image_bgr(..., interpolation_mode="bicubic") of the reference (patch_embed.py:108,136-142: antialiased bicubic, the only
+    other mode torch accepts with antialias=True) on down- and up-scaling cases; the oracle is checked against it on the way."""
+    osd, cfg, model, w = build("tiny", 0)  # patch 14: tiling 28, default side 518 (prepare_image does not touch the weights)
+    rng = np.random.default_rng(7)
+    prep = {}
+    for name, (h, wd), side, square in (("down", (150, 200), 84, False), ("sq", (90, 61), 56, True), ("up", (17, 23), 84, False)):
+        img = rng.integers(0, 256, (h, wd, 3), dtype=np.uint8)
+        out = model.prepare_image_bgr(img, side, square, "bicubic").detach()
+        mine = dpt_oracle.prepare_image(img, side, square, "bicubic")
+        assert out.shape == mine.shape and maxdiff(out, mine) <= 1e-5, (name, out.shape, mine.shape)
+        prep[f"{name}_img"] = img
+        prep[f"{name}_args"] = np.array([side, int(square)])
+        prep[f"{name}_out"] = out.numpy()
+        print(f"[prepare_image bicubic] {name}: {img.shape} -> {tuple(out.shape)}")
+    np.savez_compressed(os.path.join(GOLD, "prepare_image_bicubic.npz"), **prep)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-vitl", action="store_true")
@@ -306,12 +324,16 @@ def main():
     ap.add_argument("--only-swinv2", action="store_true", help="regenerate the SwinV2 fixtures only (report is merged)")
     ap.add_argument("--only-postprocess", action="store_true", help="regenerate the post-processing fixtures only")
     ap.add_argument("--only-swin-tiny256", action="store_true", help="generate the swin2_tiny_256 fixture only (report is merged)")
+    ap.add_argument("--only-prepare-bicubic", action="store_true", help="generate prepare_image_bicubic.npz only (interpolation_mode='bicubic')")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     report = {}
     if args.only_postprocess:
         gen_postprocess()
+        return
+    if args.only_prepare_bicubic:
+        gen_prepare_bicubic()
         return
     if args.only_beit or args.only_swinv2 or args.only_swin_tiny256:
         rp = os.path.join(GOLD, "oracle_vs_reference_report.json")

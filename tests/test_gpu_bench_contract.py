@@ -30,5 +30,5 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert roof["traffic"] is None or roof["traffic"] > 1e8
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["unit"] == "depth-maps/s" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
-    assert d["error_vs_cpu_fp32"]["rel_to_max"] < 3e-2
-    assert d["fp32_class_mode"]["error_vs_cpu_fp32"]["rel_to_max"] < 1e-3 and d["fp32_class_mode"]["value"] > 0
+    assert d["error_vs_cpu_fp32"]["rel_to_max"] < 2e-2
+    assert d["fp32_class_mode"]["error_vs_cpu_fp32"]["rel_to_max"] < 1e-4 and d["fp32_class_mode"]["value"] > 0

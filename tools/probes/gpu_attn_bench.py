@@ -2,7 +2,7 @@
 """Attention kernel at the ViT-L encoder shape (32 x 16 heads x 1297 tokens x 64) as it runs inside the model: whole forwards with the
 in-library HIP-event profile on, with and without the two-stream batch split; prints the forward time and the attention launches' average."""
 import ctypes, json, os, sys, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict, native
 from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict

@@ -2,7 +2,7 @@
 """Where does image 0 of a batch first differ (bitwise) from the same image run alone? (GPU diagnosis helper)"""
 import os, sys
 import torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict, native
 from tests.helpers import synthetic_model

@@ -2,7 +2,7 @@
 """Fusion-stage locator: compare internal decoder buffers of image 0 between (batch B, tile tb) and (batch 1, tile t1)."""
 import os, sys
 import torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
 from tests.helpers import synthetic_model

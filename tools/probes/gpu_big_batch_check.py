@@ -2,7 +2,7 @@
 """32-bit offset screen: ViT-L at batch 96 (504x504) and batch 24 at 1036x1036 must reproduce, image for image, what small batches give
 (every image is independent and all tile rules are bit-compatible), in both precision modes for the first case."""
 import os, sys, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
 from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict

@@ -2,7 +2,7 @@
 """Race screen for the LDS-DMA pipelines (8-phase GEMM, attention ring): N forwards of the same batch must be bit-identical, with
 and without the two-stream batch split, in both precision modes. A DMA that is read before it landed shows up as a rare mismatch."""
 import sys, os, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict, native
 from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict

@@ -3,7 +3,7 @@
 entry point and the fused forward against the CPU oracle, in both arithmetic modes, and writes
 gpurun_out/diag.json. Not a pytest file: it never stops at the first mismatch, so one GPU trip localises a bug.
 
-usage: python tests/gpu_diagnose.py [--skip-vitl] [--only tiny]
+usage: python tools/probes/gpu_diagnose.py [--skip-vitl] [--only tiny]
 """
 from __future__ import annotations
 
@@ -16,7 +16,7 @@ import time
 
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 
 from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict, native  # noqa: E402

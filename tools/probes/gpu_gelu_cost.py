@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What does the fused GELU cost in the fc1 epilogue? Same GEMM (M=41504, N=4096, K=1024, bf16 out, 8-phase tile) with act = none / relu / gelu."""
 import os, sys, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from muggled_dpt_amd import native
 lib = native.load()

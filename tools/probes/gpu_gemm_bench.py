@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GEMM kernel micro-benchmark on the encoder's real shapes (run on the MI355X box). Prints TFLOP/s per (shape, tile)
-and checks the result against torch.matmul. usage: python tests/gpu_gemm_bench.py [--iters 20]"""
+and checks the result against torch.matmul. usage: python tools/probes/gpu_gemm_bench.py [--iters 20]"""
 import argparse
 import json
 import os
@@ -8,7 +8,7 @@ import sys
 
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from muggled_dpt_amd import native  # noqa: E402
 

@@ -4,7 +4,7 @@ Same 256x256x64 kernel, K = 1024, N = 1024; M chosen so that 4 / 32 / 128 / 256 
 import os, sys
 import numpy as np
 import torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from muggled_dpt_amd import native
 

@@ -2,7 +2,7 @@
 """Which main-loop variant wins for which problem size? (feeds the AUTO rule in gemm.hip launch_tile)
 tile 1 = 128x128x64 lockstep, 5 = 256x256x64 8-phase, 6 = 64x64x64."""
 import os, sys, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from muggled_dpt_amd import native
 lib = native.load()

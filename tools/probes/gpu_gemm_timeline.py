@@ -3,7 +3,7 @@
 import os, sys
 import numpy as np
 import torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from muggled_dpt_amd import native
 

@@ -2,7 +2,7 @@
 """All main-loop variants on the ViT-L encoder GEMM shapes (half batch M = 20752 and full batch M = 41504): TFLOP/s per variant.
 tile 1 = 128x128x64 lockstep (2 WG/CU), 2 = 256x256x64 lockstep, 4 = 256x128x32 3-deep ring (2 WG/CU), 5 = 256x256x64 8-phase."""
 import os, sys, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from muggled_dpt_amd import native
 lib = native.load()

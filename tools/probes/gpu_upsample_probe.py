@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Achieved bandwidth of the two full-size upsample launches of a ViT-L B=32 forward (HBM-bound helper)."""
 import ctypes, os, sys, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from muggled_dpt_amd import native
 native.load()

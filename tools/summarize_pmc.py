@@ -39,7 +39,13 @@ def main():
         w_kib = write.get(k, (0.0, n))[0]
         rows[k] = {"launches": n, "fetch_mb_per_launch": round(2 * f_kib * 1024 / 1e6, 1), "write_mb_per_launch": round(w_kib * 1024 / 1e6, 1)}
     rows = dict(sorted(rows.items(), key=lambda kv: -(kv[1]["fetch_mb_per_launch"] + kv[1]["write_mb_per_launch"]) * kv[1]["launches"]))
-    json.dump(rows, open(out + ".json", "w"), indent=1)
+    try:  # stamp the kernel sources the passes were taken on: bench.py drops `roofline.traffic` when they have changed since
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from muggled_dpt_amd import native
+        meta = {"csrc_sha": native.source_hash(), "workload": os.environ.get("MDPT_PMC_WORKLOAD", "vitl/504/32/bf16")}
+    except Exception as e:  # noqa: BLE001
+        meta = {"csrc_sha": None, "error": str(e)}
+    json.dump({**rows, "_meta": meta}, open(out + ".json", "w"), indent=1)
     with open(out + ".md", "w") as fh:
         fh.write("| kernel | launches | FETCH_SIZE x2 (MB/launch) | WRITE_SIZE (MB/launch) |\n|---|---|---|---|\n")
         for k, r in rows.items():
