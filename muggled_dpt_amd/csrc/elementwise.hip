@@ -310,7 +310,8 @@ __global__ __launch_bounds__(256) void upsample_tiled_kernel(const float* __rest
 // one-time weight repack: fp32 PyTorch layouts -> bf16 hi(/lo) [Np][Kp], zero padded
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, bf16_t* dst_hi, bf16_t* dst_lo, int kind,
-                                                          int N, int K, int Np, int Kp, int ksz, int src_ld, int src_col0) {
+                                                          int N, int K, int Np, int Kp, int ksz, int src_ld, int src_col0,
+                                                          const float* __restrict__ row_scale) {
     const size_t total = (size_t)Np * Kp;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int kcol = (int)(idx % Kp);
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
         float v = 0.0f;
         if (kind == MDPT_PACK_LINEAR) {
             if (nrow < N && kcol < K) v = src[(size_t)nrow * src_ld + src_col0 + kcol];
+            if (row_scale && nrow < N) v *= row_scale[nrow];
         } else if (kind == MDPT_PACK_CONV3) {
             // src [N=Cout][K=Cin][3][3]; Kp = 9*Cinp; kcol = tap*Cinp + ci
             const int cinp = Kp / 9;
@@ -335,9 +337,9 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void pad_copy_kernel(const float* __restrict__ src, float* dst, int n, int np) {
+__global__ __launch_bounds__(256) void pad_copy_kernel(const float* __restrict__ src, float* dst, int n, int np, const float* __restrict__ scale) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < np) dst[i] = i < n ? src[i] : 0.0f;
+    if (i < np) dst[i] = i < n ? (scale ? src[i] * scale[i] : src[i]) : 0.0f;
 }
 
 __global__ __launch_bounds__(256) void memset_f32_kernel(float* dst, float value, size_t n) {
@@ -673,14 +675,14 @@ int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float*
 }
 
 int mdpt_launch_pack_weight(const float* src, bf16_t* dst_hi, bf16_t* dst_lo, int kind, int N, int K, int Np, int Kp, int ksz,
-                            hipStream_t stream, int src_ld, int src_col0) {
+                            hipStream_t stream, int src_ld, int src_col0, const float* row_scale) {
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)Np * Kp)), dim3(256), 0, stream, src, dst_hi, dst_lo, kind, N, K, Np, Kp, ksz,
-                       src_ld > 0 ? src_ld : K, src_col0);
+                       src_ld > 0 ? src_ld : K, src_col0, kind == MDPT_PACK_LINEAR ? row_scale : nullptr);
     LAUNCH_RET();
 }
 
-int mdpt_launch_pad_copy_f32(const float* src, float* dst, int n, int np, hipStream_t stream) {
-    hipLaunchKernelGGL(pad_copy_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, src, dst, n, np);
+int mdpt_launch_pad_copy_f32(const float* src, float* dst, int n, int np, hipStream_t stream, const float* scale) {
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, src, dst, n, np, scale);
     LAUNCH_RET();
 }
 

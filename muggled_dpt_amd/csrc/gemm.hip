@@ -309,7 +309,7 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const float*
                 const int mq = mbase + pr * RPP + erow;
                 const int mc = mq < p.M ? mq : p.M - 1;
                 res[pr][0] = res[pr][1] = bim[pr][0] = bim[pr][1] = zero4;
-                if (p.resid) {
+                if (p.resid && !p.acc_init) {
                     const float* rp = p.resid + (size_t)mc * p.ldr + nc;
                     res[pr][0] = *(const f32x4*)rp;
                     res[pr][1] = *(const f32x4*)(rp + 4);
@@ -340,7 +340,7 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const float*
                     for (int e = 0; e < 4; ++e) { v[0][e] = fmaxf(v[0][e], 0.0f); v[1][e] = fmaxf(v[1][e], 0.0f); }
                 }
                 if (p.gamma) { v[0] *= gam[0]; v[1] *= gam[1]; }
-                if (p.resid) { v[0] += res[pr][0]; v[1] += res[pr][1]; }
+                if (p.resid && !p.acc_init) { v[0] += res[pr][0]; v[1] += res[pr][1]; }
                 if (p.up_src) {
                     // + bilinear x2 (align_corners=True) of the previous fusion level (fusion_model.py:151,178)
                     const int hw = p.Ho * p.Wo;
@@ -483,6 +483,25 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    if (EKIND == MDPT_E_GENERIC && p.acc_init) {
+        // residual GEMMs (out = resid + A W^T + bias, in place): the accumulators START at the residual, the epilogue adds the bias and
+        // stores - the same order of operations in every tile variant (see gemm8_body's RI form, where this hides the residual read
+        // under the main loop). acc[i][j][r] = C[32 i + (r&3) + 8 (r>>2) + 4 half][32 j + (lane&31)]; out-of-range elements read 0.
+        const int mw = m0 + (wave / WN) * WTM, nw = n0 + (wave % WN) * WTN;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid), 0, (int)(unsigned)((size_t)p.M * p.ldr * 4 < 0xFFFFFFF0ull ? (size_t)p.M * p.ldr * 4 : 0xFFFFFFF0ull), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = nw + j * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const unsigned off = (n < p.N && m < p.M) ? ((unsigned)m * (unsigned)p.ldr + (unsigned)n) * 4u : 0xFFFFFFF0u;
+                    acc[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+                }
+            }
+    }
 
     // ---- main loop: NST-deep LDS ring. Iteration t: wait for THIS wave's DMA of slab t (counted vmcnt: with a
     //      3-deep ring the DMA of slab t+1 stays in flight across the barrier), barrier (everybody's part of slab t
@@ -588,8 +607,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
 //   DM_RESID : out_f32 = resid + gamma * (acc + bias), fp32      (attention proj, fc2: in-place residual update)
 //   DM_QK    : Q (pre-scaled) / K head-major bf16(/lo)            (QKV tiles without V columns)
 //   DM_F32   : out_f32 = acc + bias, fp32                          (1x1 projections, SwinV2 QKV / proj / fc2, SwiGLU inner linear)
+//   DM_RINIT : the DM_F32 epilogue behind a main loop whose accumulators were INITIALISED with the residual tile (attention proj,
+//              fc2 with the layer scale folded into the packed weights and bias): out = (resid + A W'^T) + bias'. The 256 KB residual
+//              read of a tile streams in under the first K tiles instead of sitting exposed in the epilogue.
 //   DM_VT    : V transposed, token-contiguous (epilogue_direct_vt: PLAIN operand order, a lane owns 4 consecutive tokens)
-enum { DM_NONE = 0, DM_BF16 = 1, DM_RESID = 2, DM_QK = 3, DM_VT = 4, DM_F32 = 5 };
+enum { DM_NONE = 0, DM_BF16 = 1, DM_RESID = 2, DM_QK = 3, DM_VT = 4, DM_F32 = 5, DM_RINIT = 6 };
 
 // Everything that selects code is a template parameter (MODE, X3 = hi+lo output planes, ACT) and every memory access is a raw
 // buffer op whose out-of-range lanes (tail rows: offset beyond num_records; tail columns: offset forced to ~0) are dropped by
@@ -991,9 +1013,10 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
     }
 };
 
-template <int AMODE, int EKIND, bool SW>
+template <int AMODE, int EKIND, bool SW, bool RI = false>
 __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, const int dmode, const int m0, const int n0,
                                            const unsigned long long t_start) {
+    static_assert(!RI || SW, "residual-initialised accumulators use the swapped operand order (4 consecutive columns per lane)");
     constexpr int A_BYTES = 256 * 128, BUF = 2 * A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1009,14 +1032,16 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
     const int b_off0 = A_BYTES + (wc * 32 + l15) * 128 + ((lh ^ key) << 4), b_off1 = A_BYTES + (wc * 32 + l15) * 128 + (((4 + lh) ^ key) << 4);
 
     f32x4 acc[2][2][4][2];
+    if constexpr (!RI) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
 
     bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
 #define PIN() __builtin_amdgcn_sched_barrier(0)
@@ -1047,6 +1072,14 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
     } while (0)
 #define WAIT_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory")
 #define WAIT_VM(N_) asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory")
+// RI form: quadrant (QM_, QN_)'s residual loads (inline asm, in-order return) have landed once at most N_ younger vector-memory operations
+// are outstanding; naming the eight accumulators as read-write operands keeps every use of them below this statement
+#define ACC_READY(QM_, QN_, N_)                                                                                                          \
+    asm volatile("s_waitcnt vmcnt(" #N_ ")"                                                                                              \
+                 : "+v"(acc[QM_][QN_][0][0]), "+v"(acc[QM_][QN_][0][1]), "+v"(acc[QM_][QN_][1][0]), "+v"(acc[QM_][QN_][1][1]),           \
+                   "+v"(acc[QM_][QN_][2][0]), "+v"(acc[QM_][QN_][2][1]), "+v"(acc[QM_][QN_][3][0]), "+v"(acc[QM_][QN_][3][1])            \
+                 :                                                                                                                       \
+                 : "memory")
 
     // ---- prologue: K tile 0 complete (even buffer), K tile 1 minus A1 (odd buffer); T >= 2 and even (checked by the launcher)
     const int T = (p.K / 64) * p.npass;
@@ -1056,55 +1089,108 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
     st.template issue_b<0>(p, bufE, wave);
     st.template issue_b<1>(p, bufE, wave);
     st.template issue_a<1>(p, bufE, wave);
-    st.template issue_b<0>(p, bufO, wave);
-    st.template issue_a<0>(p, bufO, wave);
-    st.template issue_b<1>(p, bufO, wave);
-    WAIT_VM(6);
+    if constexpr (RI) {
+        // Accumulators start at the residual tile (out = resid + A W^T + bias, in place): 32 x 16-byte loads per lane in the order the
+        // quadrants are first used (P1 (0,0), P2 (0,1), P3 (1,1), P4 (1,0)), issued between the DMAs of K tile 0 and K tile 1. vmcnt retires
+        // in order, so the first MFMA block waits for K tile 0 + quadrant (0,0) only; the other 24 loads land under the first phases (counted
+        // waits in front of each quadrant's first MFMA in the first iteration, ACC_READY). Lanes outside the tile read 0.
+        // The loads are inline asm: beside LDS-DMA hipcc waits vmcnt(0) for any register load it knows about (the whole prologue would
+        // drain before the first MFMA); an asm load is invisible to its wait insertion and is waited for by hand (ACC_READY below,
+        // which also names the destination registers so that nothing reads them earlier).
+        constexpr unsigned OOB = 0xFFFFFFF0u;
+        typedef __attribute__((ext_vector_type(4))) int i32x4;
+        const int rows_here = p.M - m0 < 256 ? p.M - m0 : 256;
+        const unsigned long long base = (unsigned long long)(p.resid + (size_t)m0 * p.ldr);
+        i32x4 rs;  // raw buffer descriptor of this tile's rows: base, stride 0, num_records = bytes, dst_sel/format word as tile_rsrc()
+        rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+        rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xFFFF);
+        rs[2] = __builtin_amdgcn_readfirstlane((int)(unsigned)((size_t)rows_here * p.ldr * 4));
+        rs[3] = 0x00020000;
+        const unsigned row_b = (unsigned)p.ldr * 4u;
+        auto load_quadrant = [&](int qm, int qn) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nc = n0 + qn * 128 + wc * 32 + j * 16 + 4 * lh;
+                const unsigned col = nc < p.N ? (unsigned)nc * 4u : OOB;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned row = (unsigned)(qm * 128 + grp * 64 + i * 16 + l15) * row_b;
+                    const unsigned off = col == OOB ? OOB : row + col;
+                    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(acc[qm][qn][i][j]) : "v"(off), "s"(rs) : "memory");
+                }
+            }
+        };
+        load_quadrant(0, 0);
+        st.template issue_b<0>(p, bufO, wave);
+        st.template issue_a<0>(p, bufO, wave);
+        st.template issue_b<1>(p, bufO, wave);
+        load_quadrant(0, 1);
+        load_quadrant(1, 1);
+        load_quadrant(1, 0);
+        WAIT_VM(38);  // K tile 0 has landed: 8 (quadrant (0,0)) + 6 (K tile 1) + 24 younger operations may still be in flight
+    } else {
+        st.template issue_b<0>(p, bufO, wave);
+        st.template issue_a<0>(p, bufO, wave);
+        st.template issue_b<1>(p, bufO, wave);
+        WAIT_VM(6);
+    }
     BAR();
     if (p.dbg_times) t_first = memtime_now();
     if (grp == 1) BAR();  // stagger: group 1 runs one barrier behind group 0
 
+#define GEMM8_ITER(MORE_, FIRST_)                                                                                           \
+    do {                                                                                                              \
+        /* P1 */                                                                                                      \
+        LOAD_B(fb0, 0, 0); PIN(); LOAD_A(0, 0); PIN();                                                                \
+        st.template issue_a<1>(p, bufO, wave);                                                                        \
+        PIN(); WAIT_LGKM(8); BAR(); WAIT_LGKM(0); PIN();                                                              \
+        if (FIRST_) { ACC_READY(0, 0, 32); PIN(); } /* younger: 6 (K tile 1) + 24 + 2 (this phase) */                  \
+        MFMA_Q(0, 0, fb0); BAR();                                                                                     \
+        /* P2 */                                                                                                      \
+        LOAD_B(fb1, 1, 0); PIN();                                                                                     \
+        if (MORE_) st.template issue_b<0>(p, bufE, wave);                                                             \
+        BAR(); WAIT_LGKM(0); PIN();                                                                                   \
+        if (FIRST_) { ACC_READY(0, 1, 20); PIN(); } /* younger: 16 + 4 */                                             \
+        MFMA_Q(0, 1, fb1); BAR();                                                                                     \
+        /* P3 */                                                                                                      \
+        LOAD_A(1, 0); PIN();                                                                                          \
+        if (MORE_) st.template issue_a<0>(p, bufE, wave);                                                             \
+        BAR(); WAIT_LGKM(0); PIN();                                                                                   \
+        if (FIRST_) { ACC_READY(1, 1, 14); PIN(); } /* younger: 8 + 6 */                                              \
+        MFMA_Q(1, 1, fb1); BAR();                                                                                     \
+        /* P4 */                                                                                                      \
+        if (MORE_) { st.template issue_b<1>(p, bufE, wave); PIN(); WAIT_VM(6); } else { WAIT_VM(0); }                 \
+        BAR();                                                                                                        \
+        if (FIRST_) { ACC_READY(1, 0, 6); PIN(); } /* the phase's own vmcnt(6) already covers the last 8 loads */     \
+        MFMA_Q(1, 0, fb0); BAR();                                                                                     \
+        /* P5 */                                                                                                      \
+        LOAD_B(fb0, 0, 1); PIN(); LOAD_A(0, 1); PIN();                                                                \
+        if (MORE_) st.template issue_a<1>(p, bufE, wave);                                                             \
+        PIN(); WAIT_LGKM(8); BAR(); WAIT_LGKM(0); PIN();                                                              \
+        MFMA_Q(0, 0, fb0); BAR();                                                                                     \
+        /* P6 */                                                                                                      \
+        LOAD_B(fb1, 1, 1); PIN();                                                                                     \
+        if (MORE_) st.template issue_b<0>(p, bufO, wave);                                                             \
+        BAR(); WAIT_LGKM(0); PIN();                                                                                   \
+        MFMA_Q(0, 1, fb1); BAR();                                                                                     \
+        /* P7 */                                                                                                      \
+        LOAD_A(1, 1); PIN();                                                                                          \
+        if (MORE_) st.template issue_a<0>(p, bufO, wave);                                                             \
+        BAR(); WAIT_LGKM(0); PIN();                                                                                   \
+        MFMA_Q(1, 1, fb1); BAR();                                                                                     \
+        /* P8 */                                                                                                      \
+        if (MORE_) { st.template issue_b<1>(p, bufO, wave); PIN(); WAIT_VM(6); }                                      \
+        BAR();                                                                                                        \
+        MFMA_Q(1, 0, fb0); BAR();                                                                                     \
+    } while (0)
+    // RI: the residual loads are waited for in the first iteration only (t == 0: T >= 4 is checked by the launcher, so that iteration's
+    // DMA issues all happen and the younger-operation counts of ACC_READY are exact); the accumulators stay in the loop-carried registers
     for (int t = 0; t < T; t += 2) {
         const bool more = t + 2 < T;  // wave-uniform: the last iteration issues nothing after P1 and drains at P4
-        // P1
-        LOAD_B(fb0, 0, 0); PIN(); LOAD_A(0, 0); PIN();
-        st.template issue_a<1>(p, bufO, wave);
-        PIN(); WAIT_LGKM(8); BAR(); WAIT_LGKM(0); PIN();
-        MFMA_Q(0, 0, fb0); BAR();
-        // P2
-        LOAD_B(fb1, 1, 0); PIN();
-        if (more) st.template issue_b<0>(p, bufE, wave);
-        BAR(); WAIT_LGKM(0); PIN();
-        MFMA_Q(0, 1, fb1); BAR();
-        // P3
-        LOAD_A(1, 0); PIN();
-        if (more) st.template issue_a<0>(p, bufE, wave);
-        BAR(); WAIT_LGKM(0); PIN();
-        MFMA_Q(1, 1, fb1); BAR();
-        // P4
-        if (more) { st.template issue_b<1>(p, bufE, wave); PIN(); WAIT_VM(6); } else { WAIT_VM(0); }
-        BAR();
-        MFMA_Q(1, 0, fb0); BAR();
-        // P5
-        LOAD_B(fb0, 0, 1); PIN(); LOAD_A(0, 1); PIN();
-        if (more) st.template issue_a<1>(p, bufE, wave);
-        PIN(); WAIT_LGKM(8); BAR(); WAIT_LGKM(0); PIN();
-        MFMA_Q(0, 0, fb0); BAR();
-        // P6
-        LOAD_B(fb1, 1, 1); PIN();
-        if (more) st.template issue_b<0>(p, bufO, wave);
-        BAR(); WAIT_LGKM(0); PIN();
-        MFMA_Q(0, 1, fb1); BAR();
-        // P7
-        LOAD_A(1, 1); PIN();
-        if (more) st.template issue_a<0>(p, bufO, wave);
-        BAR(); WAIT_LGKM(0); PIN();
-        MFMA_Q(1, 1, fb1); BAR();
-        // P8
-        if (more) { st.template issue_b<1>(p, bufO, wave); PIN(); WAIT_VM(6); }
-        BAR();
-        MFMA_Q(1, 0, fb0); BAR();
+        GEMM8_ITER(more, (RI && t == 0));
     }
+#undef GEMM8_ITER
+#undef ACC_READY
     if (grp == 0) BAR();  // re-join the two groups
 #undef LOAD_A
 #undef LOAD_B
@@ -1124,7 +1210,7 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
                 case 4: epilogue_direct<DM_BF16, true, MDPT_ACT_RELU>(p, acc, m0, n0, grp, wc, lane); break;
                 default: epilogue_direct<DM_BF16, true, MDPT_ACT_GELU>(p, acc, m0, n0, grp, wc, lane); break;
             }
-        } else if (dmode == DM_F32) {
+        } else if (dmode == DM_F32 || dmode == DM_RINIT) {  // DM_RINIT: the residual is already in the accumulators
             epilogue_direct<DM_F32, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
         } else {
             epilogue_direct<DM_RESID, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
@@ -1193,6 +1279,8 @@ __host__ __device__ inline int generic_direct_mode(const GemmParams& p) {
     if (plain && fits && p.out_hi && !p.out_f32 && !p.gamma && !p.resid && !(p.relu_bf16 && p.act != MDPT_ACT_NONE)) return DM_BF16;
     if (plain && fits && p.out_f32 && !p.out_hi && p.gamma && p.resid && p.resid == p.out_f32 && p.bias && p.act == MDPT_ACT_NONE && p.ldr == p.ldc)
         return DM_RESID;
+    if (plain && fits && p.acc_init && p.out_f32 && !p.out_hi && !p.gamma && p.resid == p.out_f32 && p.ldr == p.ldc && p.act == MDPT_ACT_NONE && !p.relu_bf16)
+        return DM_RINIT;
     if (plain && fits && p.out_f32 && !p.out_hi && !p.gamma && !p.resid && p.act == MDPT_ACT_NONE && !p.relu_bf16) return DM_F32;
     return DM_NONE;
 }
@@ -1212,7 +1300,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
             gemm8_body<AMODE, EKIND, false>(p, smem, DM_VT, m0, n0, t_start);
         else gemm8_body<AMODE, EKIND, false>(p, smem, DM_NONE, m0, n0, t_start);
     } else {
-        gemm8_body<AMODE, EKIND, DMODE != DM_NONE>(p, smem, DMODE, m0, n0, t_start);
+        gemm8_body<AMODE, EKIND, DMODE != DM_NONE, DMODE == DM_RINIT>(p, smem, DMODE, m0, n0, t_start);
     }
 }
 
@@ -1241,6 +1329,9 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
         if (dmode == DM_BF16) return launch_pp_mode<AMODE, EKIND, DM_BF16>(p, stream);
         if (dmode == DM_RESID) return launch_pp_mode<AMODE, EKIND, DM_RESID>(p, stream);
         if (dmode == DM_F32) return launch_pp_mode<AMODE, EKIND, DM_F32>(p, stream);
+        if constexpr (AMODE == MDPT_A_DENSE) {
+            if (dmode == DM_RINIT) return launch_pp_mode<AMODE, EKIND, DM_RINIT>(p, stream);
+        }
         return launch_pp_mode<AMODE, EKIND, DM_NONE>(p, stream);
     } else if constexpr (EKIND == MDPT_E_QKV) {
         return launch_pp_mode<AMODE, EKIND, DM_QK>(p, stream);
@@ -1287,6 +1378,13 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
         // narrow outputs with many rows (64-channel decoder convs of the small models): a 128-wide tile would spend half of its
         // MFMAs on padding columns. 128x64, four waves stacked in M: ViT-S B=32 +8.4 %
         if (!big && tiles128 > 330 && p.N <= 64) return launch_cfg<128, 64, 4, 1, 64, 2, 2, AMODE, EKIND>(p, stream);
+    }
+    if constexpr (EKIND == MDPT_E_GENERIC) {
+        // residual-initialised accumulators: the 8-phase kernel has them in its DM_RINIT form only (dense A, >= 4 K tiles, 32-bit tile
+        // offsets); anything else runs the lockstep 256x256 tile, whose prologue loads the residual the same way
+        if (tile == MDPT_TILE_PP256 && p.acc_init &&
+            !(AMODE == MDPT_A_DENSE && generic_direct_mode(p) == DM_RINIT && (p.K / 64) * p.npass >= 4))
+            tile = MDPT_TILE_256x256;
     }
     if (tile == MDPT_TILE_64x64) return launch_cfg<64, 64, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);
     if (tile == MDPT_TILE_PP256 && (((p.K / 64) * p.npass) & 1) == 0) return launch_pp<AMODE, EKIND>(p, stream);

@@ -63,6 +63,7 @@ struct WeightSpec {
 
 struct Mat {  // packed bf16 panel [Np][Kp]
     std::string src;
+    std::string row_scale;  // name of a per-output-feature fp32 parameter folded into the rows at pack time ("" = none)
     int kind, N, K, Np, Kp, ksz;
     size_t off_hi, off_lo;
     bf16_t* hi;
@@ -71,6 +72,7 @@ struct Mat {  // packed bf16 panel [Np][Kp]
 
 struct Vec {  // packed fp32 vector (zero padded)
     std::string src;
+    std::string scale;  // name of a parameter multiplied in element-wise at pack time ("" = none); src then carries an "@..." suffix
     int n, np;
     size_t off;
     float* ptr;
@@ -266,18 +268,24 @@ int build_inventory(mdpt_handle* h) {
             h->add_mat(p + ".mlp.inner_linear_doubled.weight", MDPT_PACK_LINEAR, 2 * sh, F, 2 * sh, F, 0);
             h->add_mat(p + ".mlp.outer_linear.weight", MDPT_PACK_LINEAR, F, sh, F, shp, 0);
             h->add_vec(p + ".mlp.inner_linear_doubled.bias", 2 * sh, 2 * sh);
-            h->add_vec(p + ".mlp.outer_linear.bias", F, F);
         } else {
             h->add_mat(p + ".mlp.layers.0.weight", MDPT_PACK_LINEAR, 4 * F, F, 4 * F, F, 0);
             h->add_mat(p + ".mlp.layers.2.weight", MDPT_PACK_LINEAR, F, 4 * F, F, 4 * F, 0);
             h->add_vec(p + ".mlp.layers.0.bias", 4 * F, 4 * F);
-            h->add_vec(p + ".mlp.layers.2.bias", F, F);
+        }
+        // LayerScale (x + gamma * f(x), transformer_block.py:58,63) is folded into the producing Linear at pack time: rows of W and the
+        // bias are multiplied by gamma, so the residual GEMMs compute out = (x + a W'^T) + b' with accumulators that START at x
+        {
+            const std::string fc2 = sh ? p + ".mlp.outer_linear" : p + ".mlp.layers.2";
+            h->mats[h->mat_index.at(p + ".attn.proj.weight")].row_scale = p + ".scale_attn";
+            h->mats[h->mat_index.at(fc2 + ".weight")].row_scale = p + ".scale_mlp";
+            h->add_vec(p + ".attn.proj.bias@ls", F, F);
+            h->vecs.back().scale = p + ".scale_attn";
+            h->add_vec(fc2 + ".bias@ls", F, F);
+            h->vecs.back().scale = p + ".scale_mlp";
         }
         if (beit) h->add_vec(p + ".attn.qkv.bias@qv", 0, 3 * F);  // assembled in finalize: [q_bias, 0, v_bias]
         else h->add_vec(p + ".attn.qkv.bias", 3 * F, 3 * F);
-        h->add_vec(p + ".attn.proj.bias", F, F);
-        h->add_vec(p + ".scale_attn", F, F);
-        h->add_vec(p + ".scale_mlp", F, F);
     }
 
     for (int i = 0; i < 4; ++i) {
@@ -563,8 +571,8 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
         DBG_STOP(2);
         {
             GemmParams g = base_params(c, h->M(n + ".attn.proj.weight"), att, rows, F);
-            g.bias = h->V(n + ".attn.proj.bias");
-            g.gamma = h->V(n + ".scale_attn");
+            g.bias = h->V(n + ".attn.proj.bias@ls");  // layer scale folded into W and the bias at pack time
+            g.acc_init = 1;
             g.resid = resid; g.out_f32 = resid; g.ldr = F; g.ldc = F;
             CHK(mdpt_launch_gemm(g, c.s));
         }
@@ -589,8 +597,8 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             const bool giant = h->gh_hidden != 0;
             GemmParams g = base_params(c, h->M(giant ? n + ".mlp.outer_linear.weight" : n + ".mlp.layers.2.weight"), hb, rows,
                                        giant ? h->gh_hidden_p : 4 * F);
-            g.bias = h->V(giant ? n + ".mlp.outer_linear.bias" : n + ".mlp.layers.2.bias");
-            g.gamma = h->V(n + ".scale_mlp");
+            g.bias = h->V(giant ? n + ".mlp.outer_linear.bias@ls" : n + ".mlp.layers.2.bias@ls");
+            g.acc_init = 1;
             g.resid = resid; g.out_f32 = resid; g.ldr = F; g.ldc = F;
             CHK(mdpt_launch_gemm(g, c.s));
         }
@@ -905,7 +913,8 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
             if (at != std::string::npos) { src_col0 = h->F; src_name = src_name.substr(0, at); }
         }
         const float* src = h->specs[h->spec_index.at(src_name)].ptr;
-        CHK(mdpt_launch_pack_weight(src, m.hi, m.lo, m.kind, m.N, m.K, m.Np, m.Kp, m.ksz, st, src_ld, src_col0));
+        const float* row_scale = m.row_scale.empty() ? nullptr : h->specs[h->spec_index.at(m.row_scale)].ptr;
+        CHK(mdpt_launch_pack_weight(src, m.hi, m.lo, m.kind, m.N, m.K, m.Np, m.Kp, m.ksz, st, src_ld, src_col0, row_scale));
     }
     for (Vec& v : h->vecs) {
         v.ptr = (float*)(base + v.off);
@@ -916,6 +925,11 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
             CHK(hipMemsetAsync(v.ptr, 0, (size_t)v.np * 4, st));
             CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(blk + ".attn.q_bias")].ptr, v.ptr, Fq, Fq, st));
             CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(blk + ".attn.v_bias")].ptr, v.ptr + 2 * Fq, Fq, Fq, st));
+            continue;
+        }
+        const size_t ls = v.src.find("@ls");
+        if (ls != std::string::npos) {  // bias * layer scale (see build_inventory)
+            CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(v.src.substr(0, ls))].ptr, v.ptr, v.n, v.np, st, h->specs[h->spec_index.at(v.scale)].ptr));
             continue;
         }
         CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(v.src)].ptr, v.ptr, v.n, v.np, st));
@@ -1360,6 +1374,10 @@ int mdpt_debug_gemm(const void* a_bf16, const void* w_bf16, void* out_f32, void*
     if ((tile >> 10) & 1) {  // bit 10: in-place residual epilogue (proj / fc2 form); bias and gamma are read from the out_bf16 buffer
         if (!out_f32 || !out_bf16) return fail(MDPT_E_INVALID, "residual mode needs both output buffers");
         g.bias = (const float*)out_bf16; g.gamma = (const float*)out_bf16 + N; g.resid = (const float*)out_f32; g.out_hi = nullptr;
+    }
+    if ((tile >> 11) & 1) {  // bit 11: residual-initialised accumulators (the encoder's proj / fc2 form): out = (out + A W^T) + bias, in place
+        if (!out_f32 || !out_bf16) return fail(MDPT_E_INVALID, "residual mode needs both output buffers");
+        g.bias = (const float*)out_bf16; g.resid = (const float*)out_f32; g.out_hi = nullptr; g.acc_init = 1;
     }
     for (int i = 0; i < iters; ++i) CHK(mdpt_launch_gemm(g, (hipStream_t)stream));
     return 0;

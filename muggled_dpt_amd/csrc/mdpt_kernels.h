@@ -36,6 +36,7 @@ struct GemmParams {
     int act;
     float* out_f32; bf16_t* out_hi; bf16_t* out_lo; int ldc;
     int relu_bf16;                            // apply ReLU to the bf16 planes only (fp32 copy stays raw)
+    int acc_init;                             // 1: accumulators start at resid[m,n] (resid == out_f32, gamma folded into W / bias): out = (resid + A W^T) + bias
     // E_QKV: scatter to head-major Q (pre-scaled), K and transposed V
     bf16_t* q_hi; bf16_t* q_lo; bf16_t* k_hi; bf16_t* k_lo; bf16_t* vt_hi; bf16_t* vt_lo;
     int F, heads, npad, npadv; float qscale;
@@ -98,10 +99,12 @@ int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float*
 enum { MDPT_PACK_LINEAR = 0,   // src [N][K]
        MDPT_PACK_CONV3 = 1,    // src [Cout][Cin][3][3] -> k = (ky*3+kx)*Cinp + ci
        MDPT_PACK_CONVT = 2 };  // src [Cin][Cout][k][k] -> row n = (ky*k+kx)*Coutp + co, col ci
+// row_scale != null (MDPT_PACK_LINEAR only): row n is multiplied by row_scale[n] in fp32 BEFORE the bf16 split (a per-output-feature
+// layer scale folded into the weights: diag(gamma) W)
 int mdpt_launch_pack_weight(const float* src, bf16_t* dst_hi, bf16_t* dst_lo, int kind, int N, int K, int Np, int Kp,
-                            int ksz, hipStream_t stream, int src_ld = 0, int src_col0 = 0);
+                            int ksz, hipStream_t stream, int src_ld = 0, int src_col0 = 0, const float* row_scale = nullptr);
 // fp32 vector copy with zero padding (biases); `rep` repeats are not needed: plain copy
-int mdpt_launch_pad_copy_f32(const float* src, float* dst, int n, int np, hipStream_t stream);
+int mdpt_launch_pad_copy_f32(const float* src, float* dst, int n, int np, hipStream_t stream, const float* scale = nullptr);  // dst = src (* scale)
 // layout conversions for the stage-level API / debug taps
 int mdpt_launch_nhwc_to_nchw(const float* in_f32, const bf16_t* in_hi, const bf16_t* in_lo, float* out, int B, int H, int W,
                              int C, int Cp, hipStream_t stream);

@@ -1,5 +1,5 @@
 """Randomised shapes through the bare GEMM entry point (mdpt_debug_gemm) for every main-loop variant and the epilogue forms it exposes:
-fp32 strip, bf16 direct, bf16 + erf-GELU, in-place residual. Ragged M exercises the bounds-check-drop stores of the direct epilogues
+fp32 strip, bf16 direct, bf16 + erf-GELU, in-place residual (read-modify-write epilogue and residual-initialised accumulators). Ragged M exercises the bounds-check-drop stores of the direct epilogues
 (tail tiles), N / K the tile rules. Reference: fp32 matmul of the same bf16-rounded operands. `pytest -m gpu`."""
 import numpy as np
 import pytest
@@ -22,8 +22,8 @@ def _run(lib, a, w, mode, tile):
     stream = torch.cuda.current_stream().cuda_stream
     out32 = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.float32)      # 3 guard rows behind the matrix
     out16 = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
-    flags = tile | (2 << 8 if mode == "gelu" else 0) | (1 << 10 if mode == "resid" else 0)
-    if mode == "resid":
+    flags = tile | (2 << 8 if mode == "gelu" else 0) | (1 << 10 if mode == "resid" else 0) | (1 << 11 if mode == "rinit" else 0)
+    if mode in ("resid", "rinit"):
         aux = torch.zeros(max(M * N, 4 * N), device="cuda", dtype=torch.bfloat16)  # carries bias (N floats) and gamma (N floats)
         bias = torch.linspace(-1, 1, N, device="cuda")
         gamma = torch.linspace(0.5, 1.5, N, device="cuda")
@@ -46,7 +46,7 @@ SHAPES = [(1, 256, 128), (17, 256, 256), (255, 512, 128), (256, 256, 1024), (257
 
 
 @pytest.mark.parametrize("tile", [5, 2, 1, 6, 4])
-@pytest.mark.parametrize("mode", ["f32", "bf16", "gelu", "resid"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "gelu", "resid", "rinit"])
 def test_gemm_variants_on_ragged_shapes(lib, tile, mode):
     rng = np.random.default_rng(tile * 10 + len(mode))
     for (M, N, K) in SHAPES:
@@ -60,9 +60,24 @@ def test_gemm_variants_on_ragged_shapes(lib, tile, mode):
         if mode == "resid":
             x0, bias, gamma = extra
             ref = x0 + gamma * (ref + bias)
+        if mode == "rinit":  # accumulators start at the residual, bias added by the epilogue (layer scale folded into W by the caller)
+            x0, bias, _ = extra
+            ref = x0 + ref + bias
         got = out[:M].float()
         scale = float(ref.abs().max())
-        tol = 2e-5 * scale if mode in ("f32", "resid") else 6e-3 * scale
+        tol = 2e-5 * scale if mode in ("f32", "resid", "rinit") else 6e-3 * scale
         err = float((got - ref).abs().max())
         assert err <= tol, f"tile {tile} mode {mode} M={M} N={N} K={K}: max err {err:.3e} > {tol:.3e}"
         assert torch.all(out[M:] == 7.0), f"tile {tile} mode {mode} M={M} N={N} K={K}: wrote past row M"
+
+
+def test_residual_initialised_accumulators_are_bitwise_identical_across_tile_variants(lib):
+    """out = (resid + A W^T) + bias with the accumulators STARTING at the residual: the 8-phase kernel (16-byte loads, swapped MFMA operands)
+    and the lockstep kernels (dword loads, plain order) must agree bit for bit - batch invariance of the encoder rests on it."""
+    rng = np.random.default_rng(3)
+    for (M, N, K) in [(1304, 1024, 1024), (777, 1024, 4096), (300, 768, 384), (4099, 512, 256)]:
+        a = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).cuda().to(torch.bfloat16)
+        w = torch.from_numpy(rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).cuda().to(torch.bfloat16)
+        outs = [_run(lib, a, w, "rinit", tile)[0][:M].clone() for tile in (5, 2, 1, 6, 4)]
+        for tile, o in zip((2, 1, 6, 4), outs[1:]):
+            assert torch.equal(o, outs[0]), f"M={M} N={N} K={K}: tile {tile} differs from the 8-phase kernel"

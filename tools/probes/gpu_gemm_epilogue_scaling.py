@@ -17,13 +17,13 @@ for M in (256, 16384, 41728):
     w = (torch.rand(N, K, device="cuda") * 2 - 1).to(torch.bfloat16)
     out = torch.empty(M, N, device="cuda", dtype=torch.float32)
     outb = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    for mode in ("f32", "bf16", "gelu", "resid"):
+    for mode in ("f32", "bf16", "gelu", "resid", "rinit"):
         nblk = ((M + 255) // 256) * (N // 256)
         dbg = torch.zeros(nblk * 6 + nblk * 16, dtype=torch.int64, device="cuda")
-        o32 = out.data_ptr() if mode in ("f32", "resid") else None
-        o16 = outb.data_ptr() if mode in ("bf16", "gelu", "resid") else None
-        tl = tile | (2 << 8 if mode == "gelu" else 0) | (1 << 10 if mode == "resid" else 0)
-        if mode == "resid":
+        o32 = out.data_ptr() if mode in ("f32", "resid", "rinit") else None
+        o16 = outb.data_ptr() if mode in ("bf16", "gelu", "resid", "rinit") else None
+        tl = tile | (2 << 8 if mode == "gelu" else 0) | (1 << 10 if mode == "resid" else 0) | (1 << 11 if mode == "rinit" else 0)
+        if mode in ("resid", "rinit"):
             outb.zero_(); out.zero_()
         native.check(lib, lib.mdpt_debug_gemm(a.data_ptr(), w.data_ptr(), o32, o16, M, N, K, tl, 2, stream, None))
         torch.cuda.synchronize()
