@@ -11,9 +11,15 @@
  * Conventions
  *   - return value: 0 = OK, otherwise a negative MDPT_E_* code or a positive hipError_t; mdpt_last_error() has text.
  *   - all `dev` pointers are device (HBM) pointers owned by the caller (PyTorch allocates them in our binding);
- *     the library allocates no device memory and never synchronises: every kernel goes on the caller's stream.
- *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
- *   - tensors at this boundary use the REFERENCE layouts (fp32): images/maps BCHW, tokens B x N x F, depth B x H x W.
+ *     the library allocates no device memory and never synchronises with the host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream). Every kernel is ordered on the caller's stream. ONE
+ *     exception, stated here because it is visible to tools: for batches >= 8 (mdpt_set_batch_split) mdpt_forward lazily creates
+ *     ONE internal non-blocking side stream + two events per handle and runs the second half batch there, forked from and joined
+ *     back into the caller's stream with events before it returns (also on the error path) - stream-ordering semantics for the
+ *     caller are unchanged, the call stays capturable into a hipGraph, results are bit-identical to the unsplit form.
+ *   - tensors at this boundary use the REFERENCE layouts: images/maps BCHW, tokens B x N x F, depth B x H x W. The hot entry points
+ *     (mdpt_bind_weight, mdpt_forward, mdpt_allgather) take a dtype tag per tensor (fp32, bf16 or fp16: whatever the caller's
+ *     model dtype is - no cast kernels at the boundary); the stage-level / debug entry points are fp32.
  *   - a handle is not thread-safe; distinct handles are independent.
  */
 #ifndef MDPT_H
@@ -26,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDPT_ABI_VERSION 2
+#define MDPT_ABI_VERSION 3
 
 /* arithmetic modes (all accumulate in fp32; residual stream, LayerNorm and softmax statistics are fp32) */
 #define MDPT_PREC_BF16 0   /* bf16 MFMA operands - the reference's GPU default dtype (demo_helpers/misc.py:73-77) */
@@ -91,9 +97,15 @@ int mdpt_num_weights(const mdpt_handle* h);
 const char* mdpt_weight_name(const mdpt_handle* h, int index);
 int mdpt_weight_shape(const mdpt_handle* h, int index, int32_t* ndim, int64_t shape[4]);
 
-/* replaces <sub-module>.load_state_dict(...) (make_depthanythingv2_dpt.py:55-59). `dev_f32` is a contiguous fp32
- * device tensor in the PyTorch layout of that parameter; it is only read during mdpt_finalize(). */
-int mdpt_bind_weight(mdpt_handle* h, const char* name, const void* dev_f32, int32_t ndim, const int64_t* shape);
+/* element types of the tensors handed to mdpt_bind_weight / mdpt_forward / mdpt_allgather */
+#define MDPT_DTYPE_F32 0
+#define MDPT_DTYPE_BF16 1
+#define MDPT_DTYPE_F16 2
+
+/* replaces <sub-module>.load_state_dict(...) (make_depthanythingv2_dpt.py:55-59). `dev_ptr` is a contiguous device tensor of
+ * element type `dtype` (MDPT_DTYPE_*: the parameter as the caller holds it, e.g. bf16 after model.to(torch.bfloat16)) in the
+ * PyTorch layout of that parameter; it is only read during mdpt_finalize(). */
+int mdpt_bind_weight(mdpt_handle* h, const char* name, const void* dev_ptr, int32_t dtype, int32_t ndim, const int64_t* shape);
 
 /* replaces model.to(device, dtype) (run_image.py:158): one-time repack of all bound weights into MFMA-friendly
  * bf16 (hi[/lo]) [N][K] panels inside the caller-provided `packed_dev` buffer (size from mdpt_packed_bytes).
@@ -104,10 +116,12 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream);
 /* Workspace (activations) needed for a batch of B images of H x W pixels. */
 int mdpt_workspace_bytes(const mdpt_handle* h, int32_t B, int32_t H, int32_t W, size_t* bytes);
 
-/* replaces DPTModel.forward (dpt_model.py:61-83): image [B,3,H,W] fp32 (RGB, normalised) -> depth [B,H,W] fp32.
+/* replaces DPTModel.forward (dpt_model.py:61-83): image [B,3,H,W] (RGB, normalised; element type image_dtype) -> depth [B,H,W]
+ * (element type depth_dtype: the reference returns the model dtype, dpt_model.py:105-107). The patchify kernel reads the image in its
+ * own dtype and the fused head epilogue writes the depth in the requested one: a bf16 model pays no cast kernels.
  * H, W multiples of patch_size_px with an even patch grid. */
-int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t B, int32_t H, int32_t W, void* depth_bhw, void* workspace,
-                 size_t workspace_bytes, void* stream);
+int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t image_dtype, int32_t B, int32_t H, int32_t W, void* depth_bhw,
+                 int32_t depth_dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Stage-level entry points == the five sub-module calls (simple_examples/internal_features.py:39-45). */
 /* PatchEmbed.forward (v2_depthanything/patch_embed.py:77-99): -> tokens [B, (H/P)*(W/P), F] */
@@ -125,9 +139,14 @@ int mdpt_fusion(mdpt_handle* h, const void* const maps_in[4], int32_t B, int32_t
 /* mdpt_encoder plus the explicit attention weights of selected blocks: what the reference's non-optimised attention exposes through its
  * nn.Softmax module (enable_optimizations=False, v2_depthanything/components/transformer_block.py:101,126-131; hooked by
  * experiments/attention_visualization.py:325-332). attn_out has num_blocks entries; every non-NULL entry receives that block's
- * softmax(q k^T / sqrt(d) [+ relative-position bias]) as fp32 [B, heads, N, N] (N = 1 + gh*gw). ViT / BEiT families. */
+ * softmax(q k^T / sqrt(d) [+ relative-position bias]) as fp32 [B, heads, N, N] (N = 1 + gh*gw) for the ViT / BEiT families.
+ * SwinV2 (whose window attention always goes through a hookable nn.Softmax, v31_swinv2/components/windowed_attention.py:60-61,119):
+ * blocks are numbered stage-major, an entry receives softmax(cosine attention * logit scale + position bias + shift mask) of every
+ * window as fp32 [B * windows, heads_of_the_stage, Nw, Nw] (windows in the reference's partition order, tokens in window order).
+ * mdpt_attn_probe_shape() gives the shape of a block's entry for a batch / grid. */
 int mdpt_encoder_probe(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, int32_t gw, void* const stage_out[4],
                        void* const* attn_out, void* workspace, size_t workspace_bytes, void* stream);
+int mdpt_attn_probe_shape(const mdpt_handle* h, int32_t B, int32_t gh, int32_t gw, int32_t block, int64_t shape[4]);
 /* FusionModel.blocks[index].forward (fusion_model.py:89-114 top-most block, :148-154 regular blocks; called one by one by
  * experiments/fusion_scaling.py:330-334): reassembly map [B,C,sh,sw] (+ the previous block's output [B,C,sh,sw]; NULL for index 3,
  * the top-most block) -> [B,C,2sh,2sw]. */
@@ -207,8 +226,9 @@ int mdpt_set_gemm_tile(mdpt_handle* h, int32_t tile);
 
 /* Data-parallel output collective (north star: "RCCL all-gather of the output depth maps"): thin wrapper over
  * ncclAllGather on a communicator created by the caller (torch.distributed's RCCL comm is used in the binding, so
- * this entry point is for non-torch hosts). `comm` is an ncclComm_t. Loaded lazily from librccl.so. */
-int mdpt_allgather_f32(void* comm, const void* send_dev, void* recv_dev, size_t count_per_rank, void* stream);
+ * this entry point is for non-torch hosts). `comm` is an ncclComm_t, `dtype` the element type of the maps (MDPT_DTYPE_*: the depth
+ * maps travel in the dtype mdpt_forward wrote them in). Loaded lazily from librccl.so. */
+int mdpt_allgather(void* comm, const void* send_dev, void* recv_dev, size_t count_per_rank, int32_t dtype, void* stream);
 
 #ifdef __cplusplus
 }

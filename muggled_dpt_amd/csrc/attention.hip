@@ -446,29 +446,38 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 // Attention-weight dump (diagnostic, not on the hot path): softmax(q k^T (+ relative-position bias)) of ONE block as an
 // explicit [B, H, N, N] fp32 tensor - what the reference exposes through its nn.Softmax module when enable_optimizations is
 // False (v2_depthanything/components/transformer_block.py:101,126-131; experiments/attention_visualization.py:325-332).
-// One workgroup per (batch*head, query row); operands are the Q (pre-scaled) / K planes the fused kernel consumes.
+// One workgroup per (batch*head, query row); operands are the Q (pre-scaled) / K planes the fused kernel consumes. The SwinV2
+// window attention has the same hookable nn.Softmax (v31_swinv2/components/windowed_attention.py:60-61,119): HD = 32 form below.
 // ------------------------------------------------------------------------------------------------------------
+template <int HD>
 __global__ __launch_bounds__(256) void attn_weights_kernel(const bf16_t* __restrict__ q_hi, const bf16_t* __restrict__ q_lo,
                                                            const bf16_t* __restrict__ k_hi, const bf16_t* __restrict__ k_lo,
                                                            const float* __restrict__ bias_lut, int bias_elen, const int* tq, const int* tk,
+                                                           const int* __restrict__ region, int region_ld, int win_nw,
                                                            float* __restrict__ out, int heads, int N, int npad) {
+    // HD = 32: SwinV2 window attention - the "batch" is (image, window), the operands are the L2-normalised, logit-scaled window
+    // tokens of swin_qkv_prep, the bias is the continuous-position-bias LUT and `region` the shifted-window region ids (score -100
+    // across regions, v31_swinv2/components/windowed_attention.py:100-119, :394-439)
     extern __shared__ float sc[];  // [N] scores, then 8 floats of reduction scratch
     const int row = blockIdx.x, bh = blockIdx.y, h = bh % heads, tid = threadIdx.x;
-    float q[64];
-    const bf16_t* qp = q_hi + ((size_t)bh * npad + row) * 64;
-    const bf16_t* qlp = q_lo ? q_lo + ((size_t)bh * npad + row) * 64 : nullptr;
+    float q[HD];
+    const bf16_t* qp = q_hi + ((size_t)bh * npad + row) * HD;
+    const bf16_t* qlp = q_lo ? q_lo + ((size_t)bh * npad + row) * HD : nullptr;
 #pragma unroll
-    for (int d = 0; d < 64; ++d) q[d] = (float)qp[d] + (qlp ? (float)qlp[d] : 0.0f);
+    for (int d = 0; d < HD; ++d) q[d] = (float)qp[d] + (qlp ? (float)qlp[d] : 0.0f);
     const float* lut = bias_lut ? bias_lut + (size_t)h * bias_elen : nullptr;
     const int tqr = lut ? tq[row] : 0;
+    const int* reg = region ? region + (size_t)((bh / heads) % win_nw) * region_ld : nullptr;
+    const int rq = reg ? reg[row] : 0;
     float lmax = -3.0e38f;
     for (int key = tid; key < N; key += 256) {
-        const bf16_t* kp = k_hi + ((size_t)bh * npad + key) * 64;
-        const bf16_t* klp = k_lo ? k_lo + ((size_t)bh * npad + key) * 64 : nullptr;
+        const bf16_t* kp = k_hi + ((size_t)bh * npad + key) * HD;
+        const bf16_t* klp = k_lo ? k_lo + ((size_t)bh * npad + key) * HD : nullptr;
         float s = 0.0f;
 #pragma unroll
-        for (int d = 0; d < 64; ++d) s += q[d] * ((float)kp[d] + (klp ? (float)klp[d] : 0.0f));
+        for (int d = 0; d < HD; ++d) s += q[d] * ((float)kp[d] + (klp ? (float)klp[d] : 0.0f));
         if (lut) s += lut[tqr - tk[key]];
+        if (reg && reg[key] != rq) s += -100.0f;
         sc[key] = s;
         lmax = fmaxf(lmax, s);
     }
@@ -580,10 +589,16 @@ int mdpt_launch_attention(const AttnParams& p, hipStream_t stream) {
 }
 
 int mdpt_launch_attn_weights(const AttnParams& p, float* out_bhnn, hipStream_t stream) {
-    if ((p.head_dim && p.head_dim != 64) || p.rowmap) return (int)hipErrorInvalidValue;
+    const bool swin = p.rowmap != nullptr;
+    const int hd = p.head_dim ? p.head_dim : 64;
+    if ((swin && (hd != 32 || p.win_nw <= 0)) || (!swin && hd != 64)) return (int)hipErrorInvalidValue;
     const size_t lds = (size_t)(p.N + 8) * 4;
     if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_weights_kernel, dim3(p.N, p.B * p.heads), dim3(256), lds, stream, p.q_hi, p.q_lo, p.k_hi, p.k_lo, p.bias_lut,
-                       p.bias_elen, p.tq, p.tk, out_bhnn, p.heads, p.N, p.npad);
+    if (swin)
+        hipLaunchKernelGGL(attn_weights_kernel<32>, dim3(p.N, p.B * p.heads), dim3(256), lds, stream, p.q_hi, p.q_lo, p.k_hi, p.k_lo, p.bias_lut,
+                           p.bias_elen, p.tq, p.tk, p.region, p.region_ld, p.win_nw, out_bhnn, p.heads, p.N, p.npad);
+    else
+        hipLaunchKernelGGL(attn_weights_kernel<64>, dim3(p.N, p.B * p.heads), dim3(256), lds, stream, p.q_hi, p.q_lo, p.k_hi, p.k_lo, p.bias_lut,
+                           p.bias_elen, p.tq, p.tk, (const int*)nullptr, 0, 1, out_bhnn, p.heads, p.N, p.npad);
     return (int)hipGetLastError();
 }

@@ -86,7 +86,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // patchify: NCHW fp32 -> rows [B*Np][Kp] with k = c*P*P + ky*P + kx (the conv weight's own flatten
 // order, patch_embed.py:56-62,92), zero padded to Kp. One thread = 4 consecutive k.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16_t* out_hi, bf16_t* out_lo, int B,
+// one element of a tensor that crosses the C ABI in the caller's dtype (MDPT_DT_*): images, raw weights
+__device__ __forceinline__ float ld_typed(const void* p, size_t i, int dt) {
+    if (dt == MDPT_DT_BF16) return (float)((const __bf16*)p)[i];
+    if (dt == MDPT_DT_F16) return (float)((const _Float16*)p)[i];
+    return ((const float*)p)[i];
+}
+
+__global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ img, int img_dt, bf16_t* out_hi, bf16_t* out_lo, int B,
                                                        int H, int W, int P, int Kp) {
     const int gw = W / P, gh = H / P;
     const int K = 3 * P * P;
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
             if (k < K) {
                 const int c = k / (P * P), rem = k - c * P * P;
                 const int ky = rem / P, kx = rem - ky * P;
-                val = img[(((size_t)b * 3 + c) * H + (py * P + ky)) * W + (px * P + kx)];
+                val = ld_typed(img, (((size_t)b * 3 + c) * H + (py * P + ky)) * W + (px * P + kx), img_dt);
             }
             v[e] = val;
         }
@@ -309,27 +316,27 @@ __global__ __launch_bounds__(256) void upsample_tiled_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------------
 // one-time weight repack: fp32 PyTorch layouts -> bf16 hi(/lo) [Np][Kp], zero padded
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, bf16_t* dst_hi, bf16_t* dst_lo, int kind,
+__global__ __launch_bounds__(256) void pack_weight_kernel(const void* __restrict__ src, int sdt, bf16_t* dst_hi, bf16_t* dst_lo, int kind,
                                                           int N, int K, int Np, int Kp, int ksz, int src_ld, int src_col0,
-                                                          const float* __restrict__ row_scale) {
+                                                          const void* __restrict__ row_scale, int rdt) {
     const size_t total = (size_t)Np * Kp;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int kcol = (int)(idx % Kp);
         const int nrow = (int)(idx / Kp);
         float v = 0.0f;
         if (kind == MDPT_PACK_LINEAR) {
-            if (nrow < N && kcol < K) v = src[(size_t)nrow * src_ld + src_col0 + kcol];
-            if (row_scale && nrow < N) v *= row_scale[nrow];
+            if (nrow < N && kcol < K) v = ld_typed(src, (size_t)nrow * src_ld + src_col0 + kcol, sdt);
+            if (row_scale && nrow < N) v *= ld_typed(row_scale, nrow, rdt);
         } else if (kind == MDPT_PACK_CONV3) {
             // src [N=Cout][K=Cin][3][3]; Kp = 9*Cinp; kcol = tap*Cinp + ci
             const int cinp = Kp / 9;
             const int tap = kcol / cinp, ci = kcol - tap * cinp;
-            if (nrow < N && ci < K) v = src[((size_t)nrow * K + ci) * 9 + tap];
+            if (nrow < N && ci < K) v = ld_typed(src, ((size_t)nrow * K + ci) * 9 + tap, sdt);
         } else {
             // ConvTranspose2d weight [Cin=K][Cout=N][ksz][ksz]; rows = (ky*ksz+kx)*Coutp + co with Np = ksz*ksz*Coutp
             const int coutp = Np / (ksz * ksz);
             const int kidx = nrow / coutp, co = nrow - kidx * coutp;
-            if (co < N && kcol < K) v = src[((size_t)kcol * N + co) * (ksz * ksz) + kidx];
+            if (co < N && kcol < K) v = ld_typed(src, ((size_t)kcol * N + co) * (ksz * ksz) + kidx, sdt);
         }
         const __bf16 h = (__bf16)v;
         dst_hi[idx] = h;
@@ -337,9 +344,9 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void pad_copy_kernel(const float* __restrict__ src, float* dst, int n, int np, const float* __restrict__ scale) {
+__global__ __launch_bounds__(256) void pad_copy_kernel(const void* __restrict__ src, int sdt, float* dst, int n, int np, const void* __restrict__ scale, int cdt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < np) dst[i] = i < n ? (scale ? src[i] * scale[i] : src[i]) : 0.0f;
+    if (i < np) dst[i] = i < n ? (scale ? ld_typed(src, i, sdt) * ld_typed(scale, i, cdt) : ld_typed(src, i, sdt)) : 0.0f;
 }
 
 __global__ __launch_bounds__(256) void memset_f32_kernel(float* dst, float value, size_t n) {
@@ -614,10 +621,10 @@ int mdpt_launch_swiglu(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t r
     LAUNCH_RET();
 }
 
-int mdpt_launch_patchify(const float* img, bf16_t* out_hi, bf16_t* out_lo, int B, int H, int W, int P, int Kp, hipStream_t stream) {
+int mdpt_launch_patchify(const void* img, int img_dtype, bf16_t* out_hi, bf16_t* out_lo, int B, int H, int W, int P, int Kp, hipStream_t stream) {
     const size_t total = (size_t)B * (H / P) * (W / P) * (Kp / 4);
     MdptProfScope prof("patchify_kernel", 0.0, stream);
-    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, stream, img, out_hi, out_lo, B, H, W, P, Kp);
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, stream, img, img_dtype, out_hi, out_lo, B, H, W, P, Kp);
     LAUNCH_RET();
 }
 
@@ -674,15 +681,15 @@ int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float*
     LAUNCH_RET();
 }
 
-int mdpt_launch_pack_weight(const float* src, bf16_t* dst_hi, bf16_t* dst_lo, int kind, int N, int K, int Np, int Kp, int ksz,
-                            hipStream_t stream, int src_ld, int src_col0, const float* row_scale) {
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)Np * Kp)), dim3(256), 0, stream, src, dst_hi, dst_lo, kind, N, K, Np, Kp, ksz,
-                       src_ld > 0 ? src_ld : K, src_col0, kind == MDPT_PACK_LINEAR ? row_scale : nullptr);
+int mdpt_launch_pack_weight(const void* src, int src_dtype, bf16_t* dst_hi, bf16_t* dst_lo, int kind, int N, int K, int Np, int Kp, int ksz,
+                            hipStream_t stream, int src_ld, int src_col0, const void* row_scale, int scale_dtype) {
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)Np * Kp)), dim3(256), 0, stream, src, src_dtype, dst_hi, dst_lo, kind, N, K, Np, Kp,
+                       ksz, src_ld > 0 ? src_ld : K, src_col0, kind == MDPT_PACK_LINEAR ? row_scale : nullptr, scale_dtype);
     LAUNCH_RET();
 }
 
-int mdpt_launch_pad_copy_f32(const float* src, float* dst, int n, int np, hipStream_t stream, const float* scale) {
-    hipLaunchKernelGGL(pad_copy_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, src, dst, n, np, scale);
+int mdpt_launch_pad_copy_f32(const void* src, int src_dtype, float* dst, int n, int np, hipStream_t stream, const void* scale, int scale_dtype) {
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, src, src_dtype, dst, n, np, scale, scale_dtype);
     LAUNCH_RET();
 }
 

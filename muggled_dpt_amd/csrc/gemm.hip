@@ -433,7 +433,11 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const float*
                 for (int o = 1; o < LPR; o <<= 1) sacc += __shfl_xor(sacc, o);
                 if ((lane % LPR) == 0) {
                     sacc += p.head_b[0];
-                    p.head_out[m] = p.head_sigmoid ? 1.0f / (1.0f + __expf(-sacc)) : fmaxf(sacc, 0.0f);
+                    const float dv = p.head_sigmoid ? 1.0f / (1.0f + __expf(-sacc)) : fmaxf(sacc, 0.0f);
+                    // depth leaves in the caller's dtype (the reference returns the model dtype, dpt_model.py:105-107)
+                    if (p.head_out_dtype == MDPT_DT_BF16) ((__bf16*)p.head_out)[m] = (__bf16)dv;
+                    else if (p.head_out_dtype == MDPT_DT_F16) ((_Float16*)p.head_out)[m] = (_Float16)dv;
+                    else ((float*)p.head_out)[m] = dv;
                 }
             }
         }

@@ -53,7 +53,8 @@ struct WeightSpec {
     std::string name;
     int ndim;
     int64_t shape[4];
-    const float* ptr;
+    const void* ptr;
+    int dtype;  // MDPT_DTYPE_* of the bound device tensor
     size_t numel() const {
         size_t n = 1;
         for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
@@ -152,6 +153,7 @@ struct mdpt_handle {
         for (int64_t d : shape) s.shape[i++] = d;
         for (; i < 4; ++i) s.shape[i] = 1;
         s.ptr = nullptr;
+        s.dtype = MDPT_DTYPE_F32;
         spec_index[name] = (int)specs.size();
         specs.push_back(s);
     }
@@ -497,11 +499,11 @@ int run_pos(const Ctx& c) {
                                 h->cfg.base_patch_grid_w, c.p.gh, c.p.gw, h->F, c.s);
 }
 
-int run_patch_embed_fused(const Ctx& c, const float* image) {
+int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype) {
     const mdpt_handle* h = c.h;
     const Plan& p = c.p;
     Planes im = c.pl(p.im2col);
-    CHK(mdpt_launch_patchify(image, im.hi, im.lo, p.B, p.H, p.W, h->P, h->Kpatch, c.s));
+    CHK(mdpt_launch_patchify(image, image_dtype, im.hi, im.lo, p.B, p.H, p.W, h->P, h->Kpatch, c.s));
     const bool beit = is_beit(h);
     if (!beit) CHK(run_pos(c));
     CHK(mdpt_launch_init_tokens(c.at<float>(p.resid), h->V("imgencoder.cls_token"), beit ? nullptr : h->V("imgencoder.posenc.cls_embedding"),
@@ -745,7 +747,7 @@ int run_fusion(const Ctx& c) {
 }
 
 // ---- stage: head
-int run_head(const Ctx& c, float* depth) {
+int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32) {
     const mdpt_handle* h = c.h;
     const Plan& p = c.p;
     const int fh = 8 * p.gh, fw = 8 * p.gw;
@@ -766,7 +768,7 @@ int run_head(const Ctx& c, float* depth) {
         g.head_w = h->V("head.proj_1ch.2.weight");
         g.head_b = h->V("head.proj_1ch.2.bias");
         g.head_sigmoid = h->cfg.is_metric;
-        g.head_out = depth;
+        g.head_out = depth; g.head_out_dtype = depth_dtype;
         CHK(mdpt_launch_gemm(g, c.s));
     }
     return 0;
@@ -868,8 +870,9 @@ int mdpt_weight_shape(const mdpt_handle* h, int index, int32_t* ndim, int64_t sh
     return 0;
 }
 
-int mdpt_bind_weight(mdpt_handle* h, const char* name, const void* dev_f32, int32_t ndim, const int64_t* shape) {
-    if (!h || !name || !dev_f32 || !shape) return fail(MDPT_E_INVALID, "null argument");
+int mdpt_bind_weight(mdpt_handle* h, const char* name, const void* dev_ptr, int32_t dtype, int32_t ndim, const int64_t* shape) {
+    if (!h || !name || !dev_ptr || !shape) return fail(MDPT_E_INVALID, "null argument");
+    if (dtype != MDPT_DTYPE_F32 && dtype != MDPT_DTYPE_BF16 && dtype != MDPT_DTYPE_F16) return fail(MDPT_E_INVALID, "bad dtype %d for \"%s\"", dtype, name);
     auto it = h->spec_index.find(name);
     if (it == h->spec_index.end()) return fail(MDPT_E_INVALID, "unexpected parameter \"%s\" (not part of this model config)", name);
     WeightSpec& s = h->specs[it->second];
@@ -881,7 +884,8 @@ int mdpt_bind_weight(mdpt_handle* h, const char* name, const void* dev_f32, int3
         for (int i = 0; i < s.ndim; ++i) want += (i ? "x" : "") + std::to_string(s.shape[i]);
         return fail(MDPT_E_SHAPE, "size mismatch for %s: got %s, model expects %s", name, got.c_str(), want.c_str());
     }
-    s.ptr = (const float*)dev_f32;
+    s.ptr = dev_ptr;
+    s.dtype = dtype;
     h->finalized = false;
     return 0;
 }
@@ -912,9 +916,10 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
             src_ld = 2 * h->F;
             if (at != std::string::npos) { src_col0 = h->F; src_name = src_name.substr(0, at); }
         }
-        const float* src = h->specs[h->spec_index.at(src_name)].ptr;
-        const float* row_scale = m.row_scale.empty() ? nullptr : h->specs[h->spec_index.at(m.row_scale)].ptr;
-        CHK(mdpt_launch_pack_weight(src, m.hi, m.lo, m.kind, m.N, m.K, m.Np, m.Kp, m.ksz, st, src_ld, src_col0, row_scale));
+        const WeightSpec& sp = h->specs[h->spec_index.at(src_name)];
+        const WeightSpec* rs = m.row_scale.empty() ? nullptr : &h->specs[h->spec_index.at(m.row_scale)];
+        CHK(mdpt_launch_pack_weight(sp.ptr, sp.dtype, m.hi, m.lo, m.kind, m.N, m.K, m.Np, m.Kp, m.ksz, st, src_ld, src_col0, rs ? rs->ptr : nullptr,
+                                    rs ? rs->dtype : 0));
     }
     for (Vec& v : h->vecs) {
         v.ptr = (float*)(base + v.off);
@@ -923,16 +928,21 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
             const std::string blk = v.src.substr(0, at);
             const int Fq = v.np / 3;
             CHK(hipMemsetAsync(v.ptr, 0, (size_t)v.np * 4, st));
-            CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(blk + ".attn.q_bias")].ptr, v.ptr, Fq, Fq, st));
-            CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(blk + ".attn.v_bias")].ptr, v.ptr + 2 * Fq, Fq, Fq, st));
+            const WeightSpec& qb = h->specs[h->spec_index.at(blk + ".attn.q_bias")];
+            const WeightSpec& vb = h->specs[h->spec_index.at(blk + ".attn.v_bias")];
+            CHK(mdpt_launch_pad_copy_f32(qb.ptr, qb.dtype, v.ptr, Fq, Fq, st));
+            CHK(mdpt_launch_pad_copy_f32(vb.ptr, vb.dtype, v.ptr + 2 * Fq, Fq, Fq, st));
             continue;
         }
         const size_t ls = v.src.find("@ls");
         if (ls != std::string::npos) {  // bias * layer scale (see build_inventory)
-            CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(v.src.substr(0, ls))].ptr, v.ptr, v.n, v.np, st, h->specs[h->spec_index.at(v.scale)].ptr));
+            const WeightSpec& bs = h->specs[h->spec_index.at(v.src.substr(0, ls))];
+            const WeightSpec& sc = h->specs[h->spec_index.at(v.scale)];
+            CHK(mdpt_launch_pad_copy_f32(bs.ptr, bs.dtype, v.ptr, v.n, v.np, st, sc.ptr, sc.dtype));
             continue;
         }
-        CHK(mdpt_launch_pad_copy_f32(h->specs[h->spec_index.at(v.src)].ptr, v.ptr, v.n, v.np, st));
+        const WeightSpec& vs = h->specs[h->spec_index.at(v.src)];
+        CHK(mdpt_launch_pad_copy_f32(vs.ptr, vs.dtype, v.ptr, v.n, v.np, st));
     }
     h->finalized = true;
     h->has_last = false;
@@ -971,11 +981,15 @@ int mdpt_set_gemm_tile(mdpt_handle* h, int32_t tile) {
     return 0;
 }
 
-static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, void* depth_bhw);
+static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, int image_dtype, void* depth_bhw, int depth_dtype);
 
-int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t B, int32_t H, int32_t W, void* depth_bhw, void* workspace,
-                 size_t workspace_bytes, void* stream) {
+static inline size_t dtype_bytes(int dt) { return dt == MDPT_DTYPE_F32 ? 4 : 2; }
+
+int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t image_dtype, int32_t B, int32_t H, int32_t W, void* depth_bhw,
+                 int32_t depth_dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (!h || !image_bchw || !depth_bhw) return fail(MDPT_E_INVALID, "null argument");
+    for (int dt : {image_dtype, depth_dtype})
+        if (dt != MDPT_DTYPE_F32 && dt != MDPT_DTYPE_BF16 && dt != MDPT_DTYPE_F16) return fail(MDPT_E_INVALID, "bad tensor dtype %d", dt);
     if (h->split_min > 0 && B >= h->split_min && B >= 2 && h->dbg_block < 0) {
         // two half batches, one on the caller's stream, one on the side stream; joined before returning to the caller's stream
         const int B0 = B / 2, B1 = B - B0;
@@ -996,38 +1010,44 @@ int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t B, int32_t H, i
         Ctx c0, c1;
         c0.h = h; c0.p = p0; c0.ws = (char*)workspace; c0.s = s0; c0.split = true;
         c1.h = h; c1.p = p1; c1.ws = (char*)workspace + off1; c1.s = h->side_stream; c1.split = true;
-        const size_t in_stride = (size_t)3 * H * W * 4, out_stride = (size_t)H * W * 4;
-        CHK(forward_one(h, c0, image_bchw, depth_bhw));
-        CHK(forward_one(h, c1, (const char*)image_bchw + in_stride * B0, (char*)depth_bhw + out_stride * B0));
-        CHK(hipEventRecord(h->ev_join, h->side_stream));
-        CHK(hipStreamWaitEvent(s0, h->ev_join, 0));
+        const size_t in_stride = (size_t)3 * H * W * dtype_bytes(image_dtype), out_stride = (size_t)H * W * dtype_bytes(depth_dtype);
+        // Whatever happens after the fork, the side stream is joined back into the caller's stream before returning: kernels already
+        // queued there keep using the second half of the workspace and the caller's tensors, which the caller may free or reuse on its
+        // own stream as soon as this call returns (also on the error path).
+        int rc = forward_one(h, c0, image_bchw, image_dtype, depth_bhw, depth_dtype);
+        if (rc == 0) rc = forward_one(h, c1, (const char*)image_bchw + in_stride * B0, image_dtype, (char*)depth_bhw + out_stride * B0, depth_dtype);
+        const hipError_t ej = hipEventRecord(h->ev_join, h->side_stream);
+        const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(s0, h->ev_join, 0) : ej;
+        if (ew != hipSuccess) hipStreamSynchronize(h->side_stream);  // last resort: never leave the side stream running un-joined
         h->has_last = false;  // taps live in two half-batch plans: mdpt_export_tap is for unsplit (small) batches
+        if (rc != 0) return rc;
+        CHK(ew);
         return 0;
     }
     Ctx c;
     CHK(make_ctx(h, B, H, W, workspace, workspace_bytes, stream, &c));
-    return forward_one(h, c, image_bchw, depth_bhw);
+    return forward_one(h, c, image_bchw, image_dtype, depth_bhw, depth_dtype);
 }
 
-static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, void* depth_bhw) {
+static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, int image_dtype, void* depth_bhw, int depth_dtype) {
     if (h->swin) {
-        CHK(run_patch_embed_swin(c, (const float*)image_bchw, nullptr));
+        CHK(run_patch_embed_swin(c, image_bchw, image_dtype, nullptr));
         h->last_plan = c.p;
         h->has_last = true;
         CHK(run_encoder_swin(c, nullptr));
         CHK(run_reassemble_swin(c));
         CHK(run_fusion(c));
-        CHK(run_head(c, (float*)depth_bhw));
+        CHK(run_head(c, depth_bhw, depth_dtype));
         return 0;
     }
-    CHK(run_patch_embed_fused(c, (const float*)image_bchw));
+    CHK(run_patch_embed_fused(c, image_bchw, image_dtype));
     h->last_plan = c.p;
     h->has_last = true;
     CHK(run_encoder(c, nullptr));
     if (h->dbg_block >= 0) return 0;  // test hook: encoder truncated, skip the decoder
     CHK(run_reassemble(c));
     CHK(run_fusion(c));
-    CHK(run_head(c, (float*)depth_bhw));
+    CHK(run_head(c, depth_bhw, depth_dtype));
     return 0;
 }
 
@@ -1041,7 +1061,7 @@ int mdpt_patch_embed(mdpt_handle* h, const void* image_bchw, int32_t B, int32_t 
     if (h->swin) {
         CHK(make_ctx(h, B, rup(H, 32), rup(W, 32), workspace, workspace_bytes, stream, &c));
         c.p.sw.g0h = H / h->P; c.p.sw.g0w = W / h->P;
-        CHK(run_patch_embed_swin(c, (const float*)image_bchw, (float*)tokens_bnf));
+        CHK(run_patch_embed_swin(c, image_bchw, MDPT_DTYPE_F32, (float*)tokens_bnf));
         h->has_last = false;
         return 0;
     }
@@ -1049,7 +1069,7 @@ int mdpt_patch_embed(mdpt_handle* h, const void* image_bchw, int32_t B, int32_t 
     CHK(make_ctx(h, B, He, We, workspace, workspace_bytes, stream, &c));
     const int Np = (H / h->P) * (W / h->P);
     Planes im = c.pl(c.p.im2col);
-    CHK(mdpt_launch_patchify((const float*)image_bchw, im.hi, im.lo, B, H, W, h->P, h->Kpatch, c.s));
+    CHK(mdpt_launch_patchify(image_bchw, MDPT_DTYPE_F32, im.hi, im.lo, B, H, W, h->P, h->Kpatch, c.s));
     GemmParams g = base_params(c, h->M("patch_embed.proj.weight"), im, B * Np, h->Kpatch);
     g.bias = h->V("patch_embed.proj.bias");
     g.out_f32 = (float*)tokens_bnf; g.ldc = h->F;
@@ -1100,11 +1120,22 @@ int mdpt_encoder(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, 
 int mdpt_encoder_probe(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, int32_t gw, void* const stage_out[4],
                        void* const* attn_out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!h || !tokens_bnf || !stage_out || !attn_out) return fail(MDPT_E_INVALID, "null argument");
-    if (h->swin) return fail(MDPT_E_UNSUPPORTED, "attention-weight dumps are implemented for the ViT / BEiT encoders (head dim 64) only");
     for (int i = 0; i < 4; ++i)
         if (!stage_out[i]) return fail(MDPT_E_INVALID, "null stage output %d", i);
     if (gh <= 0 || gw <= 0) return fail(MDPT_E_INVALID, "bad grid");
     Ctx c;
+    if (h->swin) {  // as mdpt_encoder, plus the window-attention weights of the listed blocks (stage-major block order)
+        CHK(make_ctx(h, B, gh * h->P, gw * h->P, workspace, workspace_bytes, stream, &c));
+        c.attn_dump = attn_out;
+        const size_t n = (size_t)B * gh * gw * h->F;
+        Planes xn = c.pl(c.p.sw.xn);
+        CHK(hipMemcpyAsync(c.at<float>(c.p.sw.resid[0]), tokens_bnf, n * 4, hipMemcpyDeviceToDevice, c.s));
+        CHK(swin_zero_pad_planes(c, B * gh * gw));
+        CHK(mdpt_launch_f32_to_planes((const float*)tokens_bnf, xn.hi, xn.lo, (size_t)B * gh * gw, h->F, rup(h->F, 64), c.s));
+        CHK(run_encoder_swin(c, stage_out));
+        h->has_last = false;
+        return 0;
+    }
     CHK(make_ctx(h, B, rup(gh, 2) * h->P, rup(gw, 2) * h->P, workspace, workspace_bytes, stream, &c));
     c.p.gh = gh; c.p.gw = gw; c.p.Np = gh * gw; c.p.N = c.p.Np + 1;
     if (rup(c.p.N, 8) > c.p.npad) return fail(MDPT_E_INVALID, "internal: plan too small");
@@ -1120,6 +1151,22 @@ int mdpt_encoder_probe(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_
     CHK(mdpt_launch_tokens_to_resid((const float*)tokens_bnf, c.at<float>(c.p.pos), c.at<float>(c.p.resid), B, c.p.Np, c.p.npad, h->F, c.s));
     CHK(run_encoder(c, stage_out));
     h->has_last = false;
+    return 0;
+}
+
+int mdpt_attn_probe_shape(const mdpt_handle* h, int32_t B, int32_t gh, int32_t gw, int32_t block, int64_t shape[4]) {
+    if (!h || !shape || B <= 0 || gh <= 0 || gw <= 0 || block < 0 || block >= h->nblocks) return fail(MDPT_E_INVALID, "bad argument");
+    if (!h->swin) {
+        const int64_t n = (int64_t)gh * gw + 1;
+        shape[0] = B; shape[1] = h->heads; shape[2] = n; shape[3] = n;
+        return 0;
+    }
+    int s = 0, l = block;
+    while (s < 4 && l >= h->sL[s]) { l -= h->sL[s]; ++s; }
+    if (s >= 4) return fail(MDPT_E_INVALID, "block %d out of range", block);
+    SwinStageGeom g;
+    CHK(swin_geom(h, gh, gw, s, &g));
+    shape[0] = (int64_t)B * g.nw; shape[1] = g.heads; shape[2] = g.wa; shape[3] = g.wa;
     return 0;
 }
 
@@ -1384,7 +1431,7 @@ int mdpt_debug_gemm(const void* a_bf16, const void* w_bf16, void* out_f32, void*
 }
 
 // ---- RCCL all-gather wrapper (resolved lazily so the library itself has no link-time dependency on RCCL)
-int mdpt_allgather_f32(void* comm, const void* send_dev, void* recv_dev, size_t count_per_rank, void* stream) {
+int mdpt_allgather(void* comm, const void* send_dev, void* recv_dev, size_t count_per_rank, int32_t dtype, void* stream) {
     typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, void*);
     static allgather_fn fn = nullptr;
     if (!fn) {
@@ -1394,8 +1441,10 @@ int mdpt_allgather_f32(void* comm, const void* send_dev, void* recv_dev, size_t 
         fn = (allgather_fn)dlsym(lib, "ncclAllGather");
         if (!fn) return fail(MDPT_E_STATE, "ncclAllGather not found in librccl.so");
     }
-    const int ncclFloat32 = 7;
-    const int rc = fn(send_dev, recv_dev, count_per_rank, ncclFloat32, comm, stream);
+    // ncclDataType_t: ncclFloat16 = 6, ncclFloat32 = 7, ncclBfloat16 = 9 (rccl.h)
+    if (dtype != MDPT_DTYPE_F32 && dtype != MDPT_DTYPE_BF16 && dtype != MDPT_DTYPE_F16) return fail(MDPT_E_INVALID, "bad dtype %d", dtype);
+    const int nccl_type = dtype == MDPT_DTYPE_F32 ? 7 : (dtype == MDPT_DTYPE_BF16 ? 9 : 6);
+    const int rc = fn(send_dev, recv_dev, count_per_rank, nccl_type, comm, stream);
     if (rc != 0) return fail(MDPT_E_STATE, "ncclAllGather failed with code %d", rc);
     return 0;
 }

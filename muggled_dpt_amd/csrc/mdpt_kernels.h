@@ -7,6 +7,9 @@
 
 typedef __bf16 bf16_t;
 
+// element types of tensors that cross the C ABI (= MDPT_DTYPE_* of include/mdpt.h)
+enum { MDPT_DT_F32 = 0, MDPT_DT_BF16 = 1, MDPT_DT_F16 = 2 };
+
 // ------------------------------------------------------------------------------------------------
 // GEMM / implicit-GEMM convolution family:  C[M,N] = A[M,K] * W[N,K]^T   (both operands K-contiguous)
 // A and W are bf16 "hi" planes plus optional "lo" planes (x = hi + lo, bf16x3 split precision).
@@ -45,7 +48,7 @@ struct GemmParams {
     // E_D2S: transposed conv k==s as GEMM: n = (ky*k + kx)*Cout + co ; out NHWC [B, Ho*k, Wo*k, Cout]
     int d2s_k, d2s_cout;
     // E_HEAD: N == 32: depth[m] = final( sum_n relu(acc+bias[n]) * head_w[n] + head_b )
-    const float* head_w; const float* head_b; int head_sigmoid; float* head_out;
+    const float* head_w; const float* head_b; int head_sigmoid; void* head_out; int head_out_dtype;  // MDPT_DT_*
     // test hook: per-workgroup phase timestamps (s_memtime): [start, first barrier passed, main loop done, epilogue done]
     int throughput_mode;  // 1: another stream runs the other half batch concurrently -> pick tiles by CU-time efficiency, not latency
     unsigned long long* dbg_times;
@@ -73,7 +76,8 @@ struct AttnParams {
     int tail_last;  // set by the launcher: dispatch nearly empty last q-tiles after all full ones
 };
 int mdpt_launch_attention(const AttnParams& p, hipStream_t stream);
-// diagnostic: explicit softmax(q k^T + bias) as fp32 [B, heads, N, N] from the same Q / K planes (head dim 64 families)
+// diagnostic: explicit softmax(q k^T + bias [+ shift mask]) as fp32 [B, heads, N, N] from the same Q / K planes (head dim 64 families;
+// SwinV2 windows: B = images * windows, head dim 32)
 int mdpt_launch_attn_weights(const AttnParams& p, float* out_bhnn, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
@@ -82,8 +86,8 @@ int mdpt_launch_attn_weights(const AttnParams& p, float* out_bhnn, hipStream_t s
 // LayerNorm over the last dim (eps 1e-6): fp32 rows -> bf16 hi (+lo) (+ optional fp32 copy)
 int mdpt_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* out_hi, bf16_t* out_lo,
                           float* out_f32, int rows, int F, hipStream_t stream);
-// NCHW fp32 image -> im2col rows [B*Np, Kp] bf16 hi (+lo), k = c*P*P + ky*P + kx, zero padded to Kp
-int mdpt_launch_patchify(const float* img, bf16_t* out_hi, bf16_t* out_lo, int B, int H, int W, int P, int Kp,
+// NCHW image (fp32 / bf16 / fp16: img_dtype) -> im2col rows [B*Np, Kp] bf16 hi (+lo), k = c*P*P + ky*P + kx, zero padded to Kp
+int mdpt_launch_patchify(const void* img, int img_dtype, bf16_t* out_hi, bf16_t* out_lo, int B, int H, int W, int P, int Kp,
                          hipStream_t stream);
 // bicubic (A=-0.75, align_corners=False) resize of the [Gh*Gw, F] position grid to [gh*gw, F]
 int mdpt_launch_posembed(const float* base, float* out, int Gh, int Gw, int gh, int gw, int F, hipStream_t stream);
@@ -95,16 +99,17 @@ int mdpt_launch_zero_vt_pad(bf16_t* vt_hi, bf16_t* vt_lo, int rows, int N, int n
 // bilinear align_corners=True resize of fp32 NHWC [B,Hi,Wi,C] -> [B,Ho,Wo,C] as bf16 hi (+lo) and/or fp32
 int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float* out_f32, int B, int Hi, int Wi, int Ho,
                          int Wo, int C, hipStream_t stream);
-// weight repack: fp32 source in PyTorch layout -> bf16 hi (+lo) [Np][Kp] rows, zero padded. Layout kinds:
+// weight repack: source (fp32 / bf16 / fp16: src_dtype) in PyTorch layout -> bf16 hi (+lo) [Np][Kp] rows, zero padded. Layout kinds:
 enum { MDPT_PACK_LINEAR = 0,   // src [N][K]
        MDPT_PACK_CONV3 = 1,    // src [Cout][Cin][3][3] -> k = (ky*3+kx)*Cinp + ci
        MDPT_PACK_CONVT = 2 };  // src [Cin][Cout][k][k] -> row n = (ky*k+kx)*Coutp + co, col ci
 // row_scale != null (MDPT_PACK_LINEAR only): row n is multiplied by row_scale[n] in fp32 BEFORE the bf16 split (a per-output-feature
 // layer scale folded into the weights: diag(gamma) W)
-int mdpt_launch_pack_weight(const float* src, bf16_t* dst_hi, bf16_t* dst_lo, int kind, int N, int K, int Np, int Kp,
-                            int ksz, hipStream_t stream, int src_ld = 0, int src_col0 = 0, const float* row_scale = nullptr);
+int mdpt_launch_pack_weight(const void* src, int src_dtype, bf16_t* dst_hi, bf16_t* dst_lo, int kind, int N, int K, int Np, int Kp,
+                            int ksz, hipStream_t stream, int src_ld = 0, int src_col0 = 0, const void* row_scale = nullptr, int scale_dtype = 0);
 // fp32 vector copy with zero padding (biases); `rep` repeats are not needed: plain copy
-int mdpt_launch_pad_copy_f32(const float* src, float* dst, int n, int np, hipStream_t stream, const float* scale = nullptr);  // dst = src (* scale)
+int mdpt_launch_pad_copy_f32(const void* src, int src_dtype, float* dst, int n, int np, hipStream_t stream, const void* scale = nullptr,
+                             int scale_dtype = 0);  // dst = float(src) (* float(scale))
 // layout conversions for the stage-level API / debug taps
 int mdpt_launch_nhwc_to_nchw(const float* in_f32, const bf16_t* in_hi, const bf16_t* in_lo, float* out, int B, int H, int W,
                              int C, int Cp, hipStream_t stream);

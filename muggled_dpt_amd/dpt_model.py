@@ -43,10 +43,15 @@ class _Node(nn.Module):
 
     # numeric children behave like the reference's nn.ModuleList / nn.Sequential (model.fusion.blocks[2], len(...), iteration)
     def __getitem__(self, idx):
+        if isinstance(idx, slice):  # blocks[:-4] etc. -> a list of the selected children, like slicing a ModuleList and iterating it
+            return [self[i] for i in range(*idx.indices(len(self)))]
         return getattr(self, str(int(idx) if int(idx) >= 0 else len(self) + int(idx)))
 
     def __len__(self):
         return sum(1 for name in self._modules if name.isdigit())
+
+    def __bool__(self):  # a container without numeric children (len 0) is still a module, not "empty"
+        return True
 
     def __iter__(self):
         return iter(getattr(self, str(i)) for i in range(len(self)))
@@ -112,7 +117,9 @@ class PatchEmbed(_Stage):
         b, _, h, w = x.shape
         gh, gw = h // self.patch_size_px, w // self.patch_size_px
         out = torch.empty((b, gh * gw, eng.F), device=x.device, dtype=torch.float32)
-        eng.call("mdpt_patch_embed", x, b, h, w, out, size_hw=(h, w), batch=b)
+        # PatchEmbed alone accepts odd patch grids (the reference only fails later, in fusion): the workspace is planned on the even-rounded size
+        tile = self._tiling_size if eng.swin else 2 * self.patch_size_px
+        eng.call("mdpt_patch_embed", x, b, h, w, out, size_hw=(-(-h // tile) * tile, -(-w // tile) * tile), batch=b)
         return eng.as_output(out), (gh, gw)
 
     def prepare_image(self, image_bgr: np.ndarray, max_side_length: int | None = None, use_square_sizing: bool = True,
@@ -166,14 +173,20 @@ class ImageEncoder(_Stage):
         assert x.shape[1] == gh * gw and x.shape[2] == eng.F, f"tokens {tuple(x.shape)} do not match grid {gh}x{gw}, F={eng.F}"
         probes = self.__dict__.get("_softmax_probes") or []
         hooked = [i for i, pr in enumerate(probes) if len(pr._forward_hooks) > 0]
-        if hooked:  # enable_optimizations=False + hooks on the softmax modules: same encoder pass, plus weight dumps
-            n = gh * gw + 1
-            heads = eng.F // 64
-            outs = [torch.empty((b, n, eng.F), device=x.device, dtype=torch.float32) for _ in range(4)]
-            dumps = {i: torch.empty((b, heads, n, n), device=x.device, dtype=torch.float32) for i in hooked}
+        if hooked:  # hooks on the softmax modules (enable_optimizations=False; SwinV2: always there): same encoder pass, plus weight dumps
+            if eng.swin:
+                outs = [torch.empty((b, (gh >> s) * (gw >> s), eng.stage_features[s]), device=x.device, dtype=torch.float32) for s in range(4)]
+                size_hw = (gh * eng.P, gw * eng.P)
+            else:
+                outs = [torch.empty((b, gh * gw + 1, eng.F), device=x.device, dtype=torch.float32) for _ in range(4)]
+                size_hw = ((gh + gh % 2) * eng.P, (gw + gw % 2) * eng.P)
+            dumps = {}
+            for i in hooked:  # [B, heads, N, N]; SwinV2: [B * windows, heads of the stage, Nw, Nw] (mdpt_attn_probe_shape)
+                shp = (ctypes.c_int64 * 4)()
+                native.check(eng.lib, eng.lib.mdpt_attn_probe_shape(eng.handle, b, gh, gw, i, shp))
+                dumps[i] = torch.empty(tuple(shp), device=x.device, dtype=torch.float32)
             arr = (ctypes.c_void_p * len(probes))(*[dumps[i].data_ptr() if i in dumps else None for i in range(len(probes))])
-            eng.call("mdpt_encoder_probe", x, b, gh, gw, eng.ptr_array(outs), arr,
-                     size_hw=((gh + gh % 2) * eng.P, (gw + gw % 2) * eng.P), batch=b)
+            eng.call_checked("mdpt_encoder_probe", x, b, gh, gw, eng.ptr_array(outs), arr, size_hw=size_hw, batch=b)
             for i in hooked:
                 probes[i](eng.as_output(dumps[i]))  # fires the registered forward hooks with the weights as module output
             return tuple(eng.as_output(o) for o in outs)
@@ -255,6 +268,10 @@ class MonocularDepthHead(_Stage):
         eng = self._engine()
         x = eng.as_input(imagelike_bchw, 4)
         b, _, fh, fw = x.shape
+        if fh % 8 or fw % 8:
+            # the fused map of a DPT forward is always 8x the patch grid; the kernels behind mdpt_head are planned on that grid (the
+            # reference's standalone head would take any size: say so instead of silently flooring)
+            raise RuntimeError(f"mdpt_head expects a fused feature map of 8x the patch grid, got {fh}x{fw} (not divisible by 8)")
         gh, gw = fh // 8, fw // 8
         out = torch.empty((b, gh * eng.Pdec, gw * eng.Pdec), device=x.device, dtype=torch.float32)
         eng.call_checked("mdpt_head", x, b, gh, gw, out, size_hw=(gh * eng.Pdec, gw * eng.Pdec), batch=b)
@@ -313,10 +330,13 @@ class _Engine:
                 name = self.lib.mdpt_weight_name(self.handle, i).decode()
                 if name not in params:
                     raise RuntimeError(f"Missing key(s) in state_dict: \"{name}\"")
-                t = params[name].detach().to(device=device, dtype=torch.float32).contiguous()
+                t = params[name].detach().to(device=device)
+                if t.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+                    t = t.to(torch.float32)
+                t = t.contiguous()  # bound in the parameter's own dtype (MDPT_DTYPE_*): the pack kernels read it as it is
                 keep.append(t)
                 shape = (ctypes.c_int64 * t.dim())(*t.shape)
-                native.check(self.lib, self.lib.mdpt_bind_weight(self.handle, name.encode(), t.data_ptr(), t.dim(), shape))
+                native.check(self.lib, self.lib.mdpt_bind_weight(self.handle, name.encode(), t.data_ptr(), native.dtype_code(t.dtype), t.dim(), shape))
             nbytes = ctypes.c_size_t()
             native.check(self.lib, self.lib.mdpt_packed_bytes(self.handle, ctypes.byref(nbytes)))
             self.packed = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=device)
@@ -334,13 +354,15 @@ class _Engine:
             pass
 
     # ---- tensor plumbing
-    def as_input(self, t: Tensor, ndim: int) -> Tensor:
+    def as_input(self, t: Tensor, ndim: int, keep_dtype: bool = False) -> Tensor:
         if not isinstance(t, torch.Tensor):
             raise TypeError("expected a torch.Tensor")
         if t.dim() != ndim:
             raise RuntimeError(f"expected a {ndim}-D tensor, got shape {tuple(t.shape)}")
         if t.device != self.device:
             raise RuntimeError(f"Expected all tensors to be on the same device, model is on {self.device} but input is on {t.device}")
+        if keep_dtype and t.dtype in (torch.float32, torch.bfloat16, torch.float16):  # mdpt_forward takes dtype-tagged tensors
+            return t.detach().contiguous()
         return t.detach().to(dtype=torch.float32).contiguous()
 
     def as_output(self, t: Tensor) -> Tensor:
@@ -352,12 +374,15 @@ class _Engine:
         return arr
 
     def workspace(self, batch: int, size_hw: tuple[int, int]) -> tuple[int, int]:
-        key = (batch, int(size_hw[0]), int(size_hw[1]))
+        # one scratch buffer per (shape, stream): work queued on two different streams never shares activations (the library orders
+        # everything on the stream it is given and keeps no other state per call)
+        key = (batch, int(size_hw[0]), int(size_hw[1]), torch.cuda.current_stream(self.device).cuda_stream)
         ws = self._workspaces.get(key)
         nbytes = ctypes.c_size_t()  # asked every call (host-side arithmetic only): settings such as the batch split change the need
         native.check(self.lib, self.lib.mdpt_workspace_bytes(self.handle, batch, key[1], key[2], ctypes.byref(nbytes)))
         if ws is None or ws.numel() < nbytes.value + 256:
-            if len(self._workspaces) >= 2:
+            if len(self._workspaces) >= 4:
+                torch.cuda.synchronize(self.device)  # buffers of other streams may still be in use
                 self._workspaces.clear()
             ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
             self._workspaces[key] = ws
@@ -429,6 +454,14 @@ class DPTModel(nn.Module):
                 node.attn.add_module("softmax", _SoftmaxProbe(dim=-1))
                 probes.append(node.attn.softmax)
             self.imgencoder.__dict__["_softmax_probes"] = probes
+        if family == "swinv2":  # the window attention always runs through a hookable nn.Softmax (windowed_attention.py:60-61,119)
+            probes = []
+            for s, nl in enumerate(self.config["layers_per_stage"]):
+                for l in range(int(nl)):
+                    node = self.imgencoder.stages[s].blocks[l]
+                    node.attn.add_module("softmax", _SoftmaxProbe(dim=-1))
+                    probes.append(node.attn.softmax)
+            self.imgencoder.__dict__["_softmax_probes"] = probes
         self.__dict__["_engine_obj"] = None
         self.__dict__["_gemm_tile"] = 0
         self.eval()  # inference only (dpt_model.py:57)
@@ -472,18 +505,20 @@ class DPTModel(nn.Module):
             tokens, hw = self.patch_embed(image_rgb_normalized_bchw)
             return self.head(self.fusion(*self.reassemble(*self.imgencoder(tokens, hw), hw)))
         eng = self._get_engine()
-        x = eng.as_input(image_rgb_normalized_bchw, 4)
+        x = eng.as_input(image_rgb_normalized_bchw, 4, keep_dtype=True)
         b, c, h, w = x.shape
         if c != 3:
             raise RuntimeError(f"expected 3 input channels, got {c}")
-        out = torch.empty((b, h, w), device=x.device, dtype=torch.float32)
+        # image in, depth out in their own dtypes (dtype-tagged pointers at the C ABI): no cast kernels around the call; the output
+        # dtype is the model's, like the reference's (dpt_model.py:105-107)
+        out = torch.empty((b, h, w), device=x.device, dtype=eng.dtype)
         try:
-            eng.call("mdpt_forward", x, b, h, w, out, size_hw=(h, w), batch=b)
+            eng.call("mdpt_forward", x, native.dtype_code(x.dtype), b, h, w, out, native.dtype_code(out.dtype), size_hw=(h, w), batch=b)
         except native.MdptError as e:
             if e.code == native.E_GRID:
                 raise RuntimeError(str(e)) from None  # the reference raises RuntimeError for odd grids too
             raise
-        return eng.as_output(out)
+        return out
 
     def inference(self, image_bgr: np.ndarray, max_side_length: int | None = None, use_square_sizing: bool = True) -> Tensor:
         """prepare_image + forward under inference_mode -> [1,H,W] (dpt_model.py:87-109)."""

@@ -20,7 +20,8 @@ LIB_PATH = os.path.join(CSRC, "libmdpt.so")
 SOURCES = ("gemm.hip", "attention.hip", "elementwise.hip", "swin.hip", "postprocess.hip", "mdpt_api.cpp", "mdpt_prof.cpp")
 HEADERS = ("mdpt_kernels.h", "mdpt_prof.h", "mdpt_swin.inc", os.path.join(REPO, "include", "mdpt.h"))
 
-ABI_VERSION = 2  # MDPT_ABI_VERSION in include/mdpt.h
+ABI_VERSION = 3  # MDPT_ABI_VERSION in include/mdpt.h
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 PREC_BF16 = 0
 PREC_BF16X3 = 1
 FAMILY_DAV2 = 0
@@ -130,16 +131,17 @@ SYMBOLS = {
     "mdpt_num_weights": (ctypes.c_int, [_VP]),
     "mdpt_weight_name": (ctypes.c_char_p, [_VP, ctypes.c_int]),
     "mdpt_weight_shape": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_int64)]),
-    "mdpt_bind_weight": (ctypes.c_int, [_VP, ctypes.c_char_p, _VP, _I, ctypes.POINTER(ctypes.c_int64)]),
+    "mdpt_bind_weight": (ctypes.c_int, [_VP, ctypes.c_char_p, _VP, _I, _I, ctypes.POINTER(ctypes.c_int64)]),
     "mdpt_packed_bytes": (ctypes.c_int, [_VP, ctypes.POINTER(_SZ)]),
     "mdpt_finalize": (ctypes.c_int, [_VP, _VP, _SZ, _VP]),
     "mdpt_workspace_bytes": (ctypes.c_int, [_VP, _I, _I, _I, ctypes.POINTER(_SZ)]),
-    "mdpt_forward": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
+    "mdpt_forward": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _I, _VP, _I, _VP, _SZ, _VP]),
     "mdpt_patch_embed": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_encoder": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP4, _VP, _SZ, _VP]),
     "mdpt_reassemble": (ctypes.c_int, [_VP, _VP4, _I, _I, _I, _VP4, _VP, _SZ, _VP]),
     "mdpt_fusion": (ctypes.c_int, [_VP, _VP4, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_encoder_probe": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP4, _VP4, _VP, _SZ, _VP]),
+    "mdpt_attn_probe_shape": (ctypes.c_int, [_VP, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int64)]),
     "mdpt_fusion_block": (ctypes.c_int, [_VP, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_head": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_prepare_image": (ctypes.c_int, [_VP, _I, _I, _VP, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _I, _VP]),
@@ -155,7 +157,7 @@ SYMBOLS = {
     "mdpt_profile_report": (ctypes.c_int, [ctypes.c_char_p, _SZ]),
     "mdpt_debug_set_stop": (ctypes.c_int, [_VP, _I, _I]),
     "mdpt_debug_read": (ctypes.c_int, [_VP, ctypes.c_char_p, _VP, _SZ, _VP, _SZ, _VP]),
-    "mdpt_allgather_f32": (ctypes.c_int, [_VP, _VP, _VP, _SZ, _VP]),
+    "mdpt_allgather": (ctypes.c_int, [_VP, _VP, _VP, _SZ, _I, _VP]),
 }
 
 _LIB = None
@@ -179,6 +181,15 @@ def load(auto_build: bool = True) -> ctypes.CDLL:
         raise RuntimeError("libmdpt ABI version mismatch")
     _LIB = lib
     return lib
+
+
+def dtype_code(torch_dtype) -> int:
+    """MDPT_DTYPE_* of a torch dtype (fp32 / bf16 / fp16 are the tensor types the C ABI takes)."""
+    import torch
+    try:
+        return {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16, torch.float16: DTYPE_F16}[torch_dtype]
+    except KeyError:
+        raise TypeError(f"libmdpt takes float32, bfloat16 or float16 tensors, not {torch_dtype}") from None
 
 
 class MdptError(RuntimeError):

@@ -334,7 +334,8 @@ def swin_cpb_bias(w: dict, pre: str, win_hw, pretrained_window, heads: int) -> t
     return bias.reshape(wh * ww, wh * ww, heads).permute(2, 0, 1).unsqueeze(0)
 
 
-def swin_window_attention(w: dict, pre: str, tokens: torch.Tensor, grid_hw, cfg: dict, stage: int, is_shift_block: bool) -> torch.Tensor:
+def swin_window_attention(w: dict, pre: str, tokens: torch.Tensor, grid_hw, cfg: dict, stage: int, is_shift_block: bool,
+                          capture: list | None = None) -> torch.Tensor:
     """Roll (shift blocks) -> windows -> cosine attention with logit scale, position bias and shift mask -> un-window -> roll
     back (windowed_attention.py:65-123, :171-260)."""
     b, n, c = tokens.shape
@@ -354,7 +355,10 @@ def swin_window_attention(w: dict, pre: str, tokens: torch.Tensor, grid_hw, cfg:
     att = att + swin_cpb_bias(w, f"{pre}.relpos_enc", win_hw, cfg["pretrained_window_sizes_per_stage"][stage], heads)
     if need_shift:
         att = att + swin_shift_mask(grid_hw, win_hw, shift_hw).repeat(b, 1, 1, 1)
-    out = (torch.softmax(att, dim=-1) @ v).transpose(1, 2).reshape(p, wa, c)
+    weights = torch.softmax(att, dim=-1)  # the reference's hookable self.softmax (windowed_attention.py:60-61,119): [B*nW, heads, Nw, Nw]
+    if capture is not None:
+        capture.append(weights)
+    out = (weights @ v).transpose(1, 2).reshape(p, wa, c)
     out = F.linear(out, w[f"{pre}.proj.weight"], w[f"{pre}.proj.bias"])
     img = swin_unpartition(out, win_hw, (b, gh, gw, c))
     if need_shift:
@@ -372,14 +376,14 @@ def swin_patch_merge(w: dict, pre: str, tokens: torch.Tensor, grid_hw):
     return F.layer_norm(x, (x.shape[-1],), w[f"{pre}.norm.weight"], w[f"{pre}.norm.bias"], 1e-5), out_hw
 
 
-def swin_image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw) -> list[torch.Tensor]:
+def swin_image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw, capture: list | None = None) -> list[torch.Tensor]:
     """4 stages of (plain, shifted) post-norm block pairs with a patch merge between stages; taps = stage outputs
     (image_encoder_model.py:77-98, :155-161, :213-225)."""
     tokens, hw, taps = patch_tokens, tuple(grid_hw), []
     for s in range(4):
         for l in range(cfg["layers_per_stage"][s]):
             pre = f"imgencoder.stages.{s}.blocks.{l}"
-            a = swin_window_attention(w, f"{pre}.attn", tokens, hw, cfg, s, is_shift_block=bool(l % 2))
+            a = swin_window_attention(w, f"{pre}.attn", tokens, hw, cfg, s, is_shift_block=bool(l % 2), capture=capture)
             tokens = tokens + F.layer_norm(a, (a.shape[-1],), w[f"{pre}.norm1.weight"], w[f"{pre}.norm1.bias"], 1e-5)
             m = mlp(w, f"{pre}.mlp", tokens)
             tokens = tokens + F.layer_norm(m, (m.shape[-1],), w[f"{pre}.norm2.weight"], w[f"{pre}.norm2.bias"], 1e-5)

@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
         HIPCK(hipMalloc(&d, it->second.data.size() * 4));
         HIPCK(hipMemcpy(d, it->second.data.data(), it->second.data.size() * 4, hipMemcpyHostToDevice));
         dev_weights.push_back(d);
-        MDCK(mdpt_bind_weight(h, name, d, (int32_t)it->second.shape.size(), it->second.shape.data()));
+        MDCK(mdpt_bind_weight(h, name, d, MDPT_DTYPE_F32, (int32_t)it->second.shape.size(), it->second.shape.data()));
     }
     size_t packed_bytes = 0;
     MDCK(mdpt_packed_bytes(h, &packed_bytes));
@@ -90,7 +90,7 @@ int main(int argc, char** argv) {
     HIPCK(hipMalloc(&d_depth, depth.size() * 4));
     HIPCK(hipMalloc(&ws, ws_bytes));
     HIPCK(hipMemcpyAsync(d_img, img.data(), img.size() * 4, hipMemcpyHostToDevice, stream));
-    MDCK(mdpt_forward(h, d_img, B, H, W, d_depth, ws, ws_bytes, stream));
+    MDCK(mdpt_forward(h, d_img, MDPT_DTYPE_F32, B, H, W, d_depth, MDPT_DTYPE_F32, ws, ws_bytes, stream));
     HIPCK(hipMemcpyAsync(depth.data(), d_depth, depth.size() * 4, hipMemcpyDeviceToHost, stream));
     HIPCK(hipStreamSynchronize(stream));
     FILE* fo = fopen(argv[3], "wb");

@@ -70,13 +70,13 @@ def test_bind_rejects_unknown_and_misshapen_weights_and_forward_needs_finalize(l
     h = ctypes.c_void_p()
     assert lib.mdpt_create(ctypes.byref(_cfg("tiny")), ctypes.byref(h)) == 0
     shape = (ctypes.c_int64 * 1)(64)
-    assert lib.mdpt_bind_weight(h, b"not.a.key", 4096, 1, shape) == -1
-    assert lib.mdpt_bind_weight(h, b"patch_embed.proj.bias", 4096, 1, (ctypes.c_int64 * 1)(63)) == -4
+    assert lib.mdpt_bind_weight(h, b"not.a.key", 4096, 0, 1, shape) == -1
+    assert lib.mdpt_bind_weight(h, b"patch_embed.proj.bias", 4096, 0, 1, (ctypes.c_int64 * 1)(63)) == -4
     assert b"size mismatch" in lib.mdpt_last_error()
-    assert lib.mdpt_bind_weight(h, b"patch_embed.proj.bias", 4096, 1, shape) == 0
+    assert lib.mdpt_bind_weight(h, b"patch_embed.proj.bias", 4096, 1, 1, shape) == 0  # a bf16 tensor
     # strict load: finalize refuses while parameters are missing (reference: strict load_state_dict RuntimeError)
     assert lib.mdpt_finalize(h, 4096 * 256, 1 << 40, None) == -3 and b"missing parameter" in lib.mdpt_last_error()
-    assert lib.mdpt_forward(h, 4096, 1, 56, 56, 4096, 4096 * 256, 1 << 40, None) == -2  # not finalized
+    assert lib.mdpt_forward(h, 4096, 0, 1, 56, 56, 4096, 0, 4096 * 256, 1 << 40, None) == -2  # not finalized
     lib.mdpt_destroy(h)
 
 

@@ -97,3 +97,48 @@ def test_single_block_hook_and_optimised_model_has_no_softmax_modules():
     tk, hw = model.patch_embed(x.cuda())
     model.imgencoder(tk, hw)
     assert len(got) == 2 and torch.equal(got[0], got[1])
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float32, ABS_TOL_X3), (torch.bfloat16, ABS_TOL_BF16)])
+def test_swinv2_window_softmax_hooks_receive_attention_weights(dtype, atol):
+    """SwinV2: every window-attention block owns a hookable nn.Softmax in the reference (v31_swinv2/components/windowed_attention.py:60-61,
+    :119 - no enable_optimizations switch), output [B * windows, heads_of_the_stage, Nw, Nw]. Here the hook fires with the dump of
+    mdpt_encoder_probe (cosine attention * logit scale + position-bias LUT + shift mask, softmax): shifted and unshifted blocks of all
+    four stages of swin2_tiny on a grid where stage 0/1 shift (16x24 patches), against the oracle's capture."""
+    import muggled_dpt_amd as mda
+    from muggled_dpt_amd import state_dict_conversion_swinv2 as conv
+    from muggled_dpt_amd.state_dict_conversion import flatten_components
+    from muggled_dpt_amd.synthetic import make_synthetic_swinv2_state_dict
+    orc = _oracle()
+    osd = make_synthetic_swinv2_state_dict("swin2_tiny", 3)
+    cfg, model = mda.make_swinv2_dpt_from_midas_v31_state_dict(osd)
+    w = flatten_components(conv.convert_state_dict_keys(cfg, osd))
+    model = model.to("cuda", dtype)
+    p = cfg["patch_size_px"]
+    x = seeded_input((2, 3, 16 * p, 24 * p), seed=13)
+    captured, handles = _hook_all_softmax(model)
+    nblk = sum(cfg["layers_per_stage"])
+    assert len(handles) == nblk
+    y = model(x.to("cuda", dtype))
+    assert len(captured) == nblk
+    tokens, grid = orc.patch_embed(w, x)
+    ref = []
+    orc.swin_image_encoder(w, cfg, tokens, grid, capture=ref)
+    assert len(ref) == nblk
+    for blk, (got, want) in enumerate(zip(captured, ref)):
+        assert got.dtype == dtype and tuple(got.shape) == tuple(want.shape), (blk, tuple(got.shape), tuple(want.shape))
+        g = got.float().cpu()
+        assert float((g - want).abs().max()) <= atol, f"block {blk}"
+        assert float((g.sum(-1) - 1).abs().max()) <= (1e-5 if dtype == torch.float32 else 2e-2)
+    assert rel_err(y.float().cpu(), orc.forward(w, cfg, x)) <= (1e-4 if dtype == torch.float32 else 3e-2)
+    for h in handles:
+        h.remove()
+    assert torch.equal(model(x.to("cuda", dtype)), y), "with or without listeners the prediction is the same"
+    # one listener on a shifted block of stage 1 only; stage-level call (simple_examples/internal_features.py usage)
+    got = []
+    blk_mod = model.imgencoder.stages[1].blocks[1].attn.softmax
+    blk_mod.register_forward_hook(lambda mod, args, out: got.append(out))
+    tk, hw = model.patch_embed(x.to("cuda", dtype))
+    model.imgencoder(tk, hw)
+    idx = cfg["layers_per_stage"][0] + 1
+    assert len(got) == 1 and float((got[0].float().cpu() - ref[idx]).abs().max()) <= atol

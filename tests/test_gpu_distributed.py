@@ -52,7 +52,7 @@ devs = (ctypes.c_int * 1)(0)
 assert rccl.ncclCommInitAll(ctypes.byref(comm), 1, devs) == 0
 x = torch.randn(3, 56, 84, device="cuda")
 out = torch.empty_like(x)
-native.check(lib, lib.mdpt_allgather_f32(comm, x.data_ptr(), out.data_ptr(), x.numel(), torch.cuda.current_stream().cuda_stream))
+native.check(lib, lib.mdpt_allgather(comm, x.data_ptr(), out.data_ptr(), x.numel(), native.dtype_code(x.dtype), torch.cuda.current_stream().cuda_stream))
 torch.cuda.synchronize()
 assert torch.equal(out, x)
 rccl.ncclCommDestroy(comm)
@@ -61,7 +61,7 @@ print("WRAPPER_OK")
 
 
 def test_c_abi_allgather_wrapper_on_a_one_rank_communicator():
-    """mdpt_allgather_f32 (the ncclAllGather wrapper for non-torch hosts): communicator created straight from librccl with ctypes
+    """mdpt_allgather (the dtype-tagged ncclAllGather wrapper for non-torch hosts): communicator created straight from librccl with ctypes
     (in a child process: RCCL prints a version banner at exit)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", WRAPPER_SCRIPT], capture_output=True, text=True, timeout=300, env=env)
