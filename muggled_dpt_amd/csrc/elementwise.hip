@@ -332,6 +332,12 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const void* __restrict
             const int cinp = Kp / 9;
             const int tap = kcol / cinp, ci = kcol - tap * cinp;
             if (nrow < N && ci < K) v = ld_typed(src, ((size_t)nrow * K + ci) * 9 + tap, sdt);
+        } else if (kind == MDPT_PACK_CONV3_KC32) {
+            // dst [Kp/8][32][8]: idx = (chunk*32 + n)*8 + e with k = chunk*8 + e = tap*Cinp + ci; src [N=32][K=Cin][3][3]
+            const int el = (int)(idx & 7), n = (int)((idx >> 3) & 31), chunk = (int)(idx >> 8);
+            const int cinp = Kp / 9, k = chunk * 8 + el;
+            const int tap = k / cinp, ci = k - tap * cinp;
+            if (n < N && ci < K) v = ld_typed(src, ((size_t)n * K + ci) * 9 + tap, sdt);
         } else {
             // ConvTranspose2d weight [Cin=K][Cout=N][ksz][ksz]; rows = (ky*ksz+kx)*Coutp + co with Np = ksz*ksz*Coutp
             const int coutp = Np / (ksz * ksz);

@@ -355,6 +355,8 @@ int build_inventory_decoder(mdpt_handle* h) {
     h->add_mat("head.spatial_upsampler.0.weight", MDPT_PACK_CONV3, h->C2, C, h->C2p, 9 * h->Cp, 3);
     h->add_vec("head.spatial_upsampler.0.bias", h->C2, h->C2p);
     h->add_mat("head.proj_1ch.0.weight", MDPT_PACK_CONV3, 32, h->C2, 32, 9 * h->C2p, 3);
+    if (!h->x3 && mdpt_head_tail_supported(h->C2p))  // LDS image of the same weights for the fused head tail (head.hip)
+        h->add_mat("head.proj_1ch.0.weight@kc32", MDPT_PACK_CONV3_KC32, 32, h->C2, 32, 9 * h->C2p, 3);
     h->add_vec("head.proj_1ch.0.bias", 32, 32);
     h->add_vec("head.proj_1ch.2.weight", 32, 32);
     h->add_vec("head.proj_1ch.2.bias", 1, 4);
@@ -751,6 +753,25 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32) {
     const mdpt_handle* h = c.h;
     const Plan& p = c.p;
     const int fh = 8 * p.gh, fw = 8 * p.gw;
+    if (!h->x3 && mdpt_head_tail_supported(h->C2p)) {
+        // bf16 mode: the first conv writes bf16 (the buffer of the fp32 map is reused), everything behind it is ONE kernel that keeps the
+        // upsampled map in LDS tiles: upsample + 3x3 conv + ReLU + 1x1 conv + ReLU | sigmoid (head.hip). The bf16x3 mode keeps the
+        // unfused form below (its hi + lo operand planes do not fit the LDS tile next to the weights).
+        bf16_t* h1b = c.at<bf16_t>(p.h1);
+        GemmParams g = base_params(c, h->M("head.spatial_upsampler.0.weight"), c.pl(p.fused), p.B * fh * fw, h->Cp);
+        as_conv(g, fh, fw, h->Cp, fh, fw, 1);
+        g.bias = h->V("head.spatial_upsampler.0.bias");
+        g.out_hi = h1b; g.ldc = h->C2p;
+        CHK(mdpt_launch_gemm(g, c.s));
+        HeadTailParams t;
+        memset(&t, 0, sizeof(t));
+        t.src = h1b; t.w_kc = h->M("head.proj_1ch.0.weight@kc32").hi;
+        t.bias = h->V("head.proj_1ch.0.bias"); t.head_w = h->V("head.proj_1ch.2.weight"); t.head_b = h->V("head.proj_1ch.2.bias");
+        t.out = depth; t.out_dtype = depth_dtype; t.sigmoid = h->cfg.is_metric;
+        t.B = p.B; t.Hi = fh; t.Wi = fw; t.Ho = p.H; t.Wo = p.W;
+        CHK(mdpt_launch_head_tail(t, h->C2p, c.s));
+        return 0;
+    }
     {
         GemmParams g = base_params(c, h->M("head.spatial_upsampler.0.weight"), c.pl(p.fused), p.B * fh * fw, h->Cp);
         as_conv(g, fh, fw, h->Cp, fh, fw, 1);
@@ -911,6 +932,8 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
         m.lo = m.off_lo == SIZE_MAX ? nullptr : (bf16_t*)(base + m.off_lo);
         std::string src_name = m.src;
         int src_ld = 0, src_col0 = 0;
+        const size_t kc = src_name.find("@kc32");
+        if (kc != std::string::npos) src_name = src_name.substr(0, kc);
         const size_t at = src_name.find("@cls");
         if (src_name.find(".readout_proj.1.weight") != std::string::npos) {  // [F, 2F] split into token / cls halves
             src_ld = 2 * h->F;

@@ -102,7 +102,9 @@ int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float*
 // weight repack: source (fp32 / bf16 / fp16: src_dtype) in PyTorch layout -> bf16 hi (+lo) [Np][Kp] rows, zero padded. Layout kinds:
 enum { MDPT_PACK_LINEAR = 0,   // src [N][K]
        MDPT_PACK_CONV3 = 1,    // src [Cout][Cin][3][3] -> k = (ky*3+kx)*Cinp + ci
-       MDPT_PACK_CONVT = 2 };  // src [Cin][Cout][k][k] -> row n = (ky*k+kx)*Coutp + co, col ci
+       MDPT_PACK_CONVT = 2,    // src [Cin][Cout][k][k] -> row n = (ky*k+kx)*Coutp + co, col ci
+       MDPT_PACK_CONV3_KC32 = 3 };  // src [32][Cin][3][3] -> [Kp/8][32][8] (k = (ky*3+kx)*Cinp + ci in 8-element chunks, Np = 32): the
+                                    // LDS image of head_tail_kernel, where a 32-lane fragment read is 512 consecutive bytes
 // row_scale != null (MDPT_PACK_LINEAR only): row n is multiplied by row_scale[n] in fp32 BEFORE the bf16 split (a per-output-feature
 // layer scale folded into the weights: diag(gamma) W)
 int mdpt_launch_pack_weight(const void* src, int src_dtype, bf16_t* dst_hi, bf16_t* dst_lo, int kind, int N, int K, int Np, int Kp,
@@ -141,6 +143,22 @@ int mdpt_launch_memset_f32(float* dst, float value, size_t n, hipStream_t stream
 int mdpt_launch_add_f32(float* dst, const float* src, size_t n, hipStream_t stream);  // dst += src
 // ViT-G SwiGLU gate: fp32 [rows, 2h] -> silu(first half) * second half as bf16 hi (+lo) [rows, hp] (pad columns zero)
 int mdpt_launch_swiglu(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t rows, int h, int hp, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// fused tail of the depth head (head.hip): x(P/8) bilinear upsample -> 3x3 conv (cin -> 32) + ReLU -> 1x1 (32 -> 1) + ReLU | sigmoid
+// ------------------------------------------------------------------------------------------------
+struct HeadTailParams {
+    const bf16_t* src;    // [B, Hi, Wi, cin] bf16 NHWC: output of the head's first conv (pad channels zero)
+    const bf16_t* w_kc;   // MDPT_PACK_CONV3_KC32 image of the 3x3 conv weights
+    const float* bias;    // [32]
+    const float* head_w;  // [32] 1x1 conv weights
+    const float* head_b;  // [1]
+    void* out; int out_dtype;  // depth [B, Ho, Wo], MDPT_DT_*
+    int sigmoid;
+    int B, Hi, Wi, Ho, Wo;
+};
+bool mdpt_head_tail_supported(int cin);
+int mdpt_launch_head_tail(const HeadTailParams& p, int cin, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // SwinV2 helpers (swin.hip)

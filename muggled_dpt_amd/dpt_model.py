@@ -469,19 +469,35 @@ class DPTModel(nn.Module):
     # ---- engine lifetime
     def _invalidate(self):
         self.__dict__["_engine_obj"] = None
+        self.__dict__["_plist"] = None
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
         self._invalidate()
         return out
 
+    def _param_versions(self) -> tuple:
+        plist = self.__dict__.get("_plist")
+        if plist is None:
+            plist = self.__dict__["_plist"] = list(self.parameters())
+        return tuple(p._version for p in plist)
+
     def _get_engine(self) -> _Engine:
+        """The engine holds a PACKED SNAPSHOT of the weights (bf16 hi[/lo] panels, layer scales folded in). It is rebuilt when the model
+        moves / changes dtype (_apply), when a state dict is loaded, and when any parameter was modified in place since the snapshot
+        (tensor version counters: p.data.copy_(), nn.init.*, p.mul_() under no_grad ... - the reference always reads the live tensors)."""
         p = next(self.parameters())
         eng = self.__dict__["_engine_obj"]
-        if eng is None or eng.device != p.device or eng.dtype != p.dtype:
+        versions = self._param_versions()
+        if eng is None or eng.device != p.device or eng.dtype != p.dtype or eng.param_versions != versions:
             eng = _Engine(self, p.device, p.dtype)
+            eng.param_versions = versions
             self.__dict__["_engine_obj"] = eng
         return eng
+
+    def refresh_weights(self) -> None:
+        """Force a re-pack of the weights on the next call (for edits the version counters cannot see, e.g. writes through raw pointers)."""
+        self._invalidate()
 
     def set_gemm_tile(self, tile: int) -> None:
         """Benchmark knob: 0 auto, 1 = 128x128, 2 = 256x256 GEMM tiles."""

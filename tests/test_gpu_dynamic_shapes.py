@@ -90,3 +90,22 @@ def test_bf16_and_fp16_tensors_cross_the_c_abi_without_casts():
                                                    (ws.data_ptr() + 255) & ~255, n.value, torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         assert torch.equal(out, y), "the image dtype tag only changes how the pixels are read"
+
+
+def test_in_place_parameter_edits_are_picked_up():
+    """The engine packs a snapshot of the weights; an in-place edit of a parameter after the first forward (p.data.copy_, nn.init, mul_
+    under no_grad) must be visible in the next forward, as in the reference, which reads the live tensors."""
+    from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+    from oracle import dpt_oracle
+    osd, cfg, w = synthetic_model("tiny", 0)
+    _, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
+    model = model.to("cuda", torch.float32)
+    x = seeded_input((1, 3, 56, 56), 3)
+    y0 = model(x.cuda())
+    with torch.no_grad():
+        model.head.proj_1ch[2].bias.add_(0.25)
+    y1 = model(x.cuda())
+    w2 = dict(w)
+    w2["head.proj_1ch.2.bias"] = w["head.proj_1ch.2.bias"] + 0.25
+    assert not torch.equal(y0, y1) and rel_err(y1.cpu(), dpt_oracle.forward(w2, cfg, x)) <= REL_TOL_X3
+    assert model._get_engine() is model._get_engine(), "no edit, no re-pack"
