@@ -9,21 +9,23 @@
 // 2.08 GB written by the upsample kernel and read back 9x from L2 by the im2col-free conv: profiles/r01_hbm_traffic.md). Here it only
 // ever exists as a 16x16-pixel tile (+1 halo) in LDS:
 //
-//   persistent workgroup (8 waves), weights of the 3x3 conv resident in LDS for its whole life ([K/8][32][8] bf16 image: a fragment
-//   read is 32 lanes x 16 consecutive bytes = conflict-free), per output tile:
-//     1. halo tile: the 18x18 upsampled pixels the tile's 3x3 taps touch are interpolated from the low-resolution map (four 16-byte
-//        L1/L2-resident loads + 3 lerps per 8 channels, same arithmetic as upsample_kernel) and written to LDS as bf16; pixels
-//        outside the image are the conv's zero padding. 16-byte channel chunks are XOR-swizzled with the pixel's column so that the
-//        32 pixels of an MFMA fragment hit distinct banks for every tap.
-//     2. implicit GEMM straight out of LDS: wave w owns tile rows 2w, 2w+1 (32 pixels); for each of the 9 taps the B fragment is the
-//        halo read shifted by (ky, kx) - no im2col, no re-fetch from L2. 32x32x16 bf16 MFMA with the WEIGHTS as the A operand, so
-//        the accumulator holds C[n][pixel]: a lane owns one pixel and 16 of the 32 conv outputs.
-//     3. epilogue in registers: + bias, ReLU, dot with the 1x1 conv weights (16 per lane + one exchange with lane^32), + bias,
-//        ReLU | sigmoid, store in the caller's dtype.
-// LDS: 9*CIN*64 B of weights + 324*CIN*2 B of halo = 153 KiB at CIN = 128 (one workgroup per CU), 76.5 KiB at CIN = 64 (two).
-// The MFMA phase is LDS-bandwidth bound by construction (N = 32: every fragment byte read feeds one MFMA; 2 x 1 KiB reads per
-// 32-cycle MFMA x 8 waves = 256 B/clk, the LDS peak), the staging phase VALU bound; both are far cheaper than the 4.2 GB of
-// HBM/L2 traffic they replace.
+//   persistent workgroup of 8 waves = two groups of 4. The 3x3 conv weights live in REGISTERS for the workgroup's whole life: group g
+//   keeps the MFMA fragments of the k-steps ks = g, g+2, ... of all nine taps (9 * CIN/32 fragments = 144 VGPRs at CIN = 128), i.e.
+//   the contraction is split in two halves whose partial sums meet in the epilogue. Per output tile:
+//     1. source patch: the <= 12x12 low-resolution pixels the tile's 18x18 halo interpolates from go global -> LDS by LDS-DMA, issued
+//        one tile AHEAD (right after the previous tile's halo was built) so the transfer hides under the previous MFMA phase;
+//     2. halo tile: the 18x18 upsampled pixels the tile's 3x3 taps touch are interpolated out of the LDS patch (four 16-byte LDS reads
+//        + 3 lerps per 8 channels in packed fp32 math, offsets and weights from per-tile row / column tables) and written to LDS as
+//        bf16; pixels outside the image are the conv's zero padding. 16-byte channel chunks are XOR-swizzled with the pixel's column so that the 32 pixels of an MFMA
+//        fragment hit distinct banks for every tap;
+//     3. implicit GEMM straight out of LDS: wave q of a group owns tile rows 4q .. 4q+3 (two blocks of 32 pixels); for each tap the
+//        pixel fragment is the halo read shifted by (ky, kx) - no im2col, no re-fetch from L2 - and feeds one 32x32x16 bf16 MFMA per
+//        block against the register-resident weight fragment (weights = A operand: the accumulator holds C[n][pixel], a lane owns one
+//        pixel and 16 of the 32 conv outputs). One LDS read per MFMA: 128 B/clk at the MFMA peak, half the LDS bandwidth;
+//     4. the two groups exchange one block each through LDS (fixed order: group 0's partial + group 1's), then per pixel in registers:
+//        + bias, ReLU, dot with the 1x1 conv weights (16 per lane + one exchange with lane^32), + bias, ReLU | sigmoid, store in the
+//        caller's dtype.
+// LDS at CIN = 128: halo 81 KiB + patch 36 KiB + exchange 32 KiB = 149 KiB (one workgroup per CU).
 
 #include "mdpt_kernels.h"
 #include "mdpt_prof.h"
@@ -36,117 +38,211 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 namespace {
 
 constexpr int TS = 16, HS = TS + 2;  // output tile side, halo side
+constexpr int PS = 12;               // max side of the source patch (launcher checks 17 * scale + 2 <= PS)
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    // 64 lanes x 16 B -> lds_wave_base + lane*16 (LDS-DMA: the destination is wave-uniform base + lane*16, no register round trip)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+struct TileGeom {
+    int b, oy0, ox0, py0, px0, ph, pw;
+};
 
 template <int CIN>
 __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams p) {
-#pragma clang fp contract(off)  // same rounding as upsample_kernel (and independent of how the compiler would fuse per instantiation)
     constexpr int NCH = CIN / 8;               // 16-byte channel chunks per pixel
-    constexpr int PIXB = CIN * 2;              // bytes per halo pixel
-    constexpr int W_BYTES = 9 * CIN * 32 * 2;  // [9*NCH][32][8] bf16
+    constexpr int PIXB = CIN * 2;              // bytes per pixel (bf16)
     constexpr int KSTEPS = CIN / 16;           // MFMA k-steps per tap
+    constexpr int KG = KSTEPS / 2;             // ... of which each wave group takes every second one
+    constexpr int PPI = 64 / NCH;              // pixels per 1 KiB DMA instruction
+    constexpr int HALO_BYTES = HS * HS * PIXB, PATCH_BYTES = PS * PS * PIXB, XCH_BYTES = 8 * 16 * 64 * 4;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const sW = smem;
-    char* const sH = smem + W_BYTES;
+    char* const sH = smem;
+    char* const sP = smem + HALO_BYTES;
+    float* const sX = (float*)(smem + HALO_BYTES + PATCH_BYTES);  // [8 waves][16 regs][64 lanes] fp32: block exchange between the groups
+    // interpolation tables of the tile, y rows then x columns: byte offsets of the two source rows / columns (-1: outside the image), weight
+    int* const sT0 = (int*)(smem + HALO_BYTES + PATCH_BYTES + XCH_BYTES);
+    int* const sT1 = sT0 + 2 * HS;
+    float* const sTL = (float*)(sT1 + 2 * HS);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, q = wave & 3;
     const int l31 = lane & 31, half = lane >> 5;
 
-    // ---- weights -> LDS once per workgroup (linear copy of the pre-arranged image)
-    for (int i = tid; i < W_BYTES / 16; i += 512) *(u32x4*)(sW + (size_t)i * 16) = *(const u32x4*)((const char*)p.w_kc + (size_t)i * 16);
-
-    // ---- per-lane epilogue constants: conv output n(r) = (r&3) + 8*(r>>2) + 4*half
-    float bias_r[16], hw_r[16];
+    // ---- this wave's weight fragments -> registers, once: W[n = l31][k = tap*CIN + (2*kg + grp)*16 + half*8 .. +8]
+    //      (w_kc image: chunk (k/8), row n, 8 elements: 16 consecutive bytes per lane, 512 per fragment and half)
+    bf16x8 wreg[9][KG];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int n = (r & 3) + 8 * (r >> 2) + 4 * half;
-        bias_r[r] = p.bias[n];
-        hw_r[r] = p.head_w[n];
-    }
-    const float head_b = p.head_b[0];
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            const int chunk = tap * NCH + (2 * kg + grp) * 2 + half;
+            wreg[tap][kg] = *(const bf16x8*)((const char*)p.w_kc + ((size_t)chunk * 32 + l31) * 16);
+        }
 
     const float sy = p.Ho > 1 ? (float)(p.Hi - 1) / (float)(p.Ho - 1) : 0.0f;
     const float sx = p.Wo > 1 ? (float)(p.Wi - 1) / (float)(p.Wo - 1) : 0.0f;
     const int tiles_x = (p.Wo + TS - 1) / TS, tiles_y = (p.Ho + TS - 1) / TS;
     const int ntiles = p.B * tiles_y * tiles_x;
+    const float head_b = p.head_b[0];
 
-    // fragment geometry of this lane: pixel (py, px) of the tile, channel chunk parity = half
-    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;
+    // tile -> image, origin and the source patch its halo interpolates from (halo rows / columns outside the image are zero padding)
+    auto geom = [&](int tile) {
+        TileGeom g;
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
+        g.b = tile / (tiles_x * tiles_y);
+        g.oy0 = ty * TS; g.ox0 = tx * TS;
+        const int oy_first = g.oy0 == 0 ? 0 : g.oy0 - 1, ox_first = g.ox0 == 0 ? 0 : g.ox0 - 1;
+        const int oy_last = min(g.oy0 + TS, p.Ho - 1), ox_last = min(g.ox0 + TS, p.Wo - 1);
+        g.py0 = (int)(sy * (float)oy_first); g.px0 = (int)(sx * (float)ox_first);
+        g.ph = min((int)(sy * (float)oy_last) + 1, p.Hi - 1) - g.py0 + 1;
+        g.pw = min((int)(sx * (float)ox_last) + 1, p.Wi - 1) - g.px0 + 1;  // <= PS (launcher's scale check)
+        return g;
+    };
+    // source patch global -> LDS by LDS-DMA, dense [ph*pw][CIN] image (pixel pitch pw): 1 KiB = PPI pixels per wave instruction
+    auto issue_patch = [&](const TileGeom& g) {
+        const bf16_t* src = p.src + (size_t)g.b * p.Hi * p.Wi * CIN;
+        const int npix = g.ph * g.pw, c = lane % NCH;
+        for (int j = wave; j * PPI < npix; j += 8) {
+            int pp = j * PPI + lane / NCH;
+            pp = pp < npix ? pp : npix - 1;  // tail lanes re-fetch the last pixel into the slack behind the image
+            const int yy = pp / g.pw, xx = pp - yy * g.pw;
+            glds16(src + ((size_t)(g.py0 + yy) * p.Wi + (g.px0 + xx)) * CIN + c * 8, sP + (size_t)j * 1024);
+        }
+    };
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-        const int oy0 = ty * TS, ox0 = tx * TS;
-        __syncthreads();  // previous tile's MFMA phase is done with the halo (first pass: the weight copy is published below)
+    int tile = blockIdx.x;
+    TileGeom g = geom(tile < ntiles ? tile : 0);
+    if (tile < ntiles) issue_patch(g);
 
-        // ---- 1. halo tile
-        const bf16_t* src = p.src + (size_t)b * p.Hi * p.Wi * CIN;
-        for (int item = tid; item < HS * HS * NCH; item += 512) {
-            const int c = item % NCH, hp = item / NCH;
-            const int hy = hp / HS, hx = hp - hy * HS;
-            const int oy = oy0 + hy - 1, ox = ox0 + hx - 1;
-            bf16x8 out;
-            if ((unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo) {
-                const float fy = sy * (float)oy, fx = sx * (float)ox;
-                const int y0 = (int)fy, x0 = (int)fx;
-                const int y1 = y0 + (y0 < p.Hi - 1), x1 = x0 + (x0 < p.Wi - 1);
-                const float ly = fy - (float)y0, lx = fx - (float)x0;
-                const bf16x8 v00 = *(const bf16x8*)(src + ((size_t)y0 * p.Wi + x0) * CIN + c * 8);
-                const bf16x8 v01 = *(const bf16x8*)(src + ((size_t)y0 * p.Wi + x1) * CIN + c * 8);
-                const bf16x8 v10 = *(const bf16x8*)(src + ((size_t)y1 * p.Wi + x0) * CIN + c * 8);
-                const bf16x8 v11 = *(const bf16x8*)(src + ((size_t)y1 * p.Wi + x1) * CIN + c * 8);
+    for (; tile < ntiles; tile += gridDim.x) {
+        // ---- interpolation tables of this tile (align_corners=True): per halo row {byte offset of source row y0, of y1, ly, inside};
+        //      per halo column the same in x. Written before, read after the barrier that also publishes the patch.
+        if (tid < 2 * HS) {
+            const bool isx = tid >= HS;
+            const int hidx = isx ? tid - HS : tid;
+            const int o = (isx ? g.ox0 : g.oy0) + hidx - 1, lim_o = isx ? p.Wo : p.Ho, lim_i = isx ? p.Wi : p.Hi;
+            const float f = (isx ? sx : sy) * (float)o;
+            const int i0 = (int)f, i1 = i0 + (i0 < lim_i - 1);
+            const int pitch = isx ? PIXB : g.pw * PIXB, org = isx ? g.px0 : g.py0;
+            const bool ok = (unsigned)o < (unsigned)lim_o;
+            sT0[tid] = ok ? (i0 - org) * pitch : -1;
+            sT1[tid] = ok ? (i1 - org) * pitch : -1;
+            sTL[tid] = f - (float)i0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the patch has landed
+        __syncthreads();
+
+        // ---- halo tile out of the patch: t = v0 + l (v1 - v0) along x for the two source rows, then along y. bf16 -> fp32 is a shift
+        //      for the even element of a packed pair; the odd one is used IN PLACE (its low 16 bits are the neighbour's bits: a relative
+        //      perturbation below 2^-16, two hundred times finer than the bf16 rounding of the result)
+        {
+            const int c = tid % NCH;
+            for (int hp = tid / NCH; hp < HS * HS; hp += 512 / NCH) {
+                const int hy = hp / HS, hx = hp - hy * HS;
+                const int oy_0 = sT0[hy], oy_1 = sT1[hy], ox_0 = sT0[HS + hx], ox_1 = sT1[HS + hx];
+                u32x4 outw = {0u, 0u, 0u, 0u};
+                if ((oy_0 | ox_0) >= 0) {
+                    const float ly = sTL[hy], lx = sTL[HS + hx];
+                    const char* base = sP + c * 16;
+                    const u32x4 v00 = *(const u32x4*)(base + oy_0 + ox_0);
+                    const u32x4 v01 = *(const u32x4*)(base + oy_0 + ox_1);
+                    const u32x4 v10 = *(const u32x4*)(base + oy_1 + ox_0);
+                    const u32x4 v11 = *(const u32x4*)(base + oy_1 + ox_1);
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    out[e] = (__bf16)((1.0f - ly) * ((1.0f - lx) * (float)v00[e] + lx * (float)v01[e]) +
-                                      ly * ((1.0f - lx) * (float)v10[e] + lx * (float)v11[e]));
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) out[e] = (__bf16)0.0f;
+                    for (int w = 0; w < 4; ++w) {
+                        // (scalar copies first: __builtin_bit_cast applied directly to a vector ELEMENT expression reads element 0)
+                        const unsigned d00 = v00[w], d01 = v01[w], d10 = v10[w], d11 = v11[w];
+                        const f32x2 a00 = {__builtin_bit_cast(float, d00 << 16), __builtin_bit_cast(float, d00)};
+                        const f32x2 a01 = {__builtin_bit_cast(float, d01 << 16), __builtin_bit_cast(float, d01)};
+                        const f32x2 a10 = {__builtin_bit_cast(float, d10 << 16), __builtin_bit_cast(float, d10)};
+                        const f32x2 a11 = {__builtin_bit_cast(float, d11 << 16), __builtin_bit_cast(float, d11)};
+                        const f32x2 t0 = a00 + lx * (a01 - a00);
+                        const f32x2 t1 = a10 + lx * (a11 - a10);
+                        const f32x2 o2 = t0 + ly * (t1 - t0);
+                        outw[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(o2, bf16x2));
+                    }
+                }
+                const int key = (NCH == 16 ? hx : (hx >> 1)) & (NCH - 1);
+                *(u32x4*)(sH + (size_t)hp * PIXB + ((c ^ key) << 4)) = outw;
             }
-            const int key = (NCH == 16 ? hx : (hx >> 1)) & (NCH - 1);
-            *(bf16x8*)(sH + (size_t)hp * PIXB + ((c ^ key) << 4)) = out;
         }
         __syncthreads();
 
-        // ---- 2. implicit GEMM out of LDS: C[n][pixel] += W[n][tap, ci] * halo[pixel + tap][ci]
-        f32x16 acc;
+        // ---- the next tile's patch streams in under this tile's MFMA phase (the patch region is free from here on)
+        const int next = tile + gridDim.x;
+        const TileGeom gn = geom(next < ntiles ? next : tile);
+        if (next < ntiles) issue_patch(gn);
+
+        // ---- implicit GEMM out of LDS: C[n][pixel] += W[n][tap, ci] * halo[pixel + tap][ci] over this group's k-steps
+        //      block blk of this wave = tile rows 4q + 2 blk, 4q + 2 blk + 1; lane pixel (row + (l31 >> 4), l31 & 15)
+        f32x16 acc[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[blk][r] = 0.0f;
+        const int px = l31 & 15, prow = 4 * q + (l31 >> 4);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
             const int hx = px + kx;
             const int key = (NCH == 16 ? hx : (hx >> 1)) & (NCH - 1);
-            const char* hrow = sH + (size_t)((py + ky) * HS + hx) * PIXB;
-            const char* wrow = sW + ((size_t)tap * NCH * 32 + l31) * 16;
+            const char* h0 = sH + (size_t)((prow + ky) * HS + hx) * PIXB;
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const int c = ks * 2 + half;
-                const bf16x8 wf = *(const bf16x8*)(wrow + (size_t)c * 32 * 16);
-                const bf16x8 xf = *(const bf16x8*)(hrow + ((c ^ key) << 4));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc, 0, 0, 0);
+            for (int kg = 0; kg < KG; ++kg) {
+                const int c = (2 * kg + grp) * 2 + half;
+                const bf16x8 x0 = *(const bf16x8*)(h0 + ((c ^ key) << 4));
+                const bf16x8 x1 = *(const bf16x8*)(h0 + 2 * HS * PIXB + ((c ^ key) << 4));
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[tap][kg], x0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[tap][kg], x1, acc[1], 0, 0, 0);
             }
         }
 
-        // ---- 3. relu(conv + bias) . w + b -> relu | sigmoid   (head_model.py:80-85)
+        // ---- the groups swap one block each (group 0 finishes block 0, group 1 block 1), summing group 0's partial + group 1's
+        {
+            float* mine = sX + (size_t)wave * 16 * 64 + lane;
+            const f32x16& give = acc[grp ^ 1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r * 64] = give[r];
+        }
+        __syncthreads();
+        f32x16 tot;
+        {
+            const float* theirs = sX + (size_t)(wave ^ 4) * 16 * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[r] = grp == 0 ? acc[0][r] + theirs[r * 64] : theirs[r * 64] + acc[1][r];
+        }
+        //      relu(conv + bias) . w + b -> relu | sigmoid   (head_model.py:80-85); conv output n(r) = (r&3) + 8*(r>>2) + 4*half
         float s = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s += fmaxf(acc[r] + bias_r[r], 0.0f) * hw_r[r];
+        for (int r = 0; r < 16; ++r) {
+            const int n = (r & 3) + 8 * (r >> 2) + 4 * half;
+            s += fmaxf(tot[r] + p.bias[n], 0.0f) * p.head_w[n];
+        }
         s += __shfl_xor(s, 32);
         s += head_b;
         const float dv = p.sigmoid ? 1.0f / (1.0f + __expf(-s)) : fmaxf(s, 0.0f);
-        const int oy = oy0 + py, ox = ox0 + px;
+        const int oy = g.oy0 + prow + 2 * grp, ox = g.ox0 + px;
         if (half == 0 && oy < p.Ho && ox < p.Wo) {
-            const size_t o = ((size_t)b * p.Ho + oy) * p.Wo + ox;
+            const size_t o = ((size_t)g.b * p.Ho + oy) * p.Wo + ox;
             if (p.out_dtype == MDPT_DT_BF16) ((__bf16*)p.out)[o] = (__bf16)dv;
             else if (p.out_dtype == MDPT_DT_F16) ((_Float16*)p.out)[o] = (_Float16)dv;
             else ((float*)p.out)[o] = dv;
         }
+        g = gn;
+        // barriers: the table / patch of the next tile are written after this tile's staging ended (barrier 2) and published by its
+        // barrier 1, which also orders this tile's exchange reads before the next exchange writes
     }
 }
 
 template <int CIN>
 int launch_cin(const HeadTailParams& p, hipStream_t stream) {
-    constexpr unsigned LDS = 9 * CIN * 32 * 2 + HS * HS * CIN * 2;
+    constexpr unsigned LDS = HS * HS * CIN * 2 + PS * PS * CIN * 2 + 8 * 16 * 64 * 4 + 2 * HS * 16;  // + tables: 3 arrays of 2*HS words (rounded up)
     auto kern = head_tail_kernel<CIN>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -155,8 +251,7 @@ int launch_cin(const HeadTailParams& p, hipStream_t stream) {
         attr_done = true;
     }
     const int ntiles = p.B * ((p.Ho + TS - 1) / TS) * ((p.Wo + TS - 1) / TS);
-    const int per_cu = LDS <= 80 * 1024 ? 2 : 1;
-    const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;  // persistent: the weights are staged once per workgroup
+    const int grid = ntiles < 256 ? ntiles : 256;  // persistent: the weights are loaded into registers once per workgroup
     static char prof_name[48] = "";
     if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "head_tail_kernel<%d>", CIN);
     MdptProfScope prof(prof_name, 2.0 * p.B * p.Ho * p.Wo * 32.0 * 9.0 * CIN, stream);
@@ -168,8 +263,14 @@ int launch_cin(const HeadTailParams& p, hipStream_t stream) {
 
 bool mdpt_head_tail_supported(int cin) { return cin == 64 || cin == 128; }
 
+// the 18 halo pixels of a tile side must interpolate from at most PS source pixels: floor(17 * scale) + 2 <= PS with
+// scale = (in - 1) / (out - 1) (x1.75 for patch 14: 11, x2 for patch 16: 10)
+bool mdpt_head_tail_scale_ok(int Hi, int Wi, int Ho, int Wo) {
+    return Ho > 1 && Wo > 1 && (long)17 * (Hi - 1) < (long)(PS - 1) * (Ho - 1) && (long)17 * (Wi - 1) < (long)(PS - 1) * (Wo - 1);
+}
+
 int mdpt_launch_head_tail(const HeadTailParams& p, int cin, hipStream_t stream) {
-    if (p.B <= 0 || p.Hi <= 0 || p.Wi <= 0 || p.Ho <= 0 || p.Wo <= 0) return (int)hipErrorInvalidValue;
+    if (p.B <= 0 || p.Hi <= 0 || p.Wi <= 0 || p.Ho <= 0 || p.Wo <= 0 || !mdpt_head_tail_scale_ok(p.Hi, p.Wi, p.Ho, p.Wo)) return (int)hipErrorInvalidValue;
     if (cin == 128) return launch_cin<128>(p, stream);
     if (cin == 64) return launch_cin<64>(p, stream);
     return (int)hipErrorInvalidValue;

@@ -753,7 +753,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32) {
     const mdpt_handle* h = c.h;
     const Plan& p = c.p;
     const int fh = 8 * p.gh, fw = 8 * p.gw;
-    if (!h->x3 && mdpt_head_tail_supported(h->C2p)) {
+    if (!h->x3 && mdpt_head_tail_supported(h->C2p) && mdpt_head_tail_scale_ok(fh, fw, p.H, p.W)) {
         // bf16 mode: the first conv writes bf16 (the buffer of the fp32 map is reused), everything behind it is ONE kernel that keeps the
         // upsampled map in LDS tiles: upsample + 3x3 conv + ReLU + 1x1 conv + ReLU | sigmoid (head.hip). The bf16x3 mode keeps the
         // unfused form below (its hi + lo operand planes do not fit the LDS tile next to the weights).

@@ -158,6 +158,7 @@ struct HeadTailParams {
     int B, Hi, Wi, Ho, Wo;
 };
 bool mdpt_head_tail_supported(int cin);
+bool mdpt_head_tail_scale_ok(int Hi, int Wi, int Ho, int Wo);
 int mdpt_launch_head_tail(const HeadTailParams& p, int cin, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------

@@ -366,7 +366,7 @@ def test_float16_model_dtype_runs_on_the_bf16_path():
     x = seeded_input((2, 3, 56, 84), 23)
     y = model(x.to("cuda", torch.float16))
     assert y.dtype == torch.float16 and tuple(y.shape) == (2, 56, 84)
-    assert rel_err(y.float().cpu(), _oracle().forward(w, cfg, x)) <= REL_TOL_BF16
+    assert rel_err(y.float().cpu(), _oracle().forward(w, cfg, x)) <= REL_TOL_BF16_TOY
     tok, hw = model.patch_embed(x.to("cuda", torch.float16))
     assert tok.dtype == torch.float16 and tuple(hw) == (4, 6)
 
@@ -381,8 +381,8 @@ def test_latency_mode_split_kv_attention_matches_the_oracle():
         y_default = model(x.to("cuda", torch.bfloat16))
         model.set_latency_mode(True)
         y_fast = model(x.to("cuda", torch.bfloat16))
-        assert rel_err(y_fast.float().cpu(), ref) <= REL_TOL_BF16
-        assert rel_err(y_fast.float().cpu(), y_default.float().cpu()) <= REL_TOL_BF16
+        assert rel_err(y_fast.float().cpu(), ref) <= (REL_TOL_BF16_TOY if name == "tiny" else REL_TOL_BF16)
+        assert rel_err(y_fast.float().cpu(), y_default.float().cpu()) <= (REL_TOL_BF16_TOY if name == "tiny" else REL_TOL_BF16)
         model.set_latency_mode(False)
         assert torch.equal(model(x.to("cuda", torch.bfloat16)), y_default)  # and back: the default form is reproduced exactly
 
