@@ -16,8 +16,7 @@
 //        one tile AHEAD (right after the previous tile's halo was built) so the transfer hides under the previous MFMA phase;
 //     2. halo tile: the 18x18 upsampled pixels the tile's 3x3 taps touch are interpolated out of the LDS patch (four 16-byte LDS reads
 //        + 3 lerps per 8 channels in packed fp32 math, offsets and weights from per-tile row / column tables) and written to LDS as
-//        bf16; pixels outside the image are the conv's zero padding. 16-byte channel chunks are XOR-swizzled with the pixel's column so that the 32 pixels of an MFMA
-//        fragment hit distinct banks for every tap;
+//        bf16; pixels outside the image are the conv's zero padding. padded pixel / row pitches make every MFMA fragment read conflict-free at immediate offsets;
 //     3. implicit GEMM straight out of LDS: wave q of a group owns tile rows 4q .. 4q+3 (two blocks of 32 pixels); for each tap the
 //        pixel fragment is the halo read shifted by (ky, kx) - no im2col, no re-fetch from L2 - and feeds one 32x32x16 bf16 MFMA per
 //        block against the register-resident weight fragment (weights = A operand: the accumulator holds C[n][pixel], a lane owns one
@@ -25,14 +24,16 @@
 //     4. the two groups exchange one block each through LDS (fixed order: group 0's partial + group 1's), then per pixel in registers:
 //        + bias, ReLU, dot with the 1x1 conv weights (16 per lane + one exchange with lane^32), + bias, ReLU | sigmoid, store in the
 //        caller's dtype.
-// LDS at CIN = 128: halo 81 KiB + patch 36 KiB + exchange 32 KiB = 149 KiB (one workgroup per CU).
+// LDS at CIN = 128: halo 90 KiB + patch 36 KiB + exchange 32 KiB = 158.6 KiB (one workgroup per CU).
 
 #include "mdpt_kernels.h"
 #include "mdpt_prof.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 namespace {
@@ -57,7 +58,12 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
     constexpr int KSTEPS = CIN / 16;           // MFMA k-steps per tap
     constexpr int KG = KSTEPS / 2;             // ... of which each wave group takes every second one
     constexpr int PPI = 64 / NCH;              // pixels per 1 KiB DMA instruction
-    constexpr int HALO_BYTES = HS * HS * PIXB, PATCH_BYTES = PS * PS * PIXB, XCH_BYTES = 8 * 16 * 64 * 4;
+    // halo image: pixel pitch PIXB + 16 (an odd number of 16-byte slots: the 16 pixels of a tile row land on 16 different slots of the
+    // 256-byte bank row for every channel chunk) and a row pitch that is a multiple of 256 bytes (tile rows r and r+1, which share the
+    // 16-lane service groups of a ds_read_b128, see the same slot pattern): conflict-free fragment reads at plain immediate offsets
+    constexpr int PIXP = PIXB + 16, ROWB = ((HS * PIXP + 255) / 256) * 256;
+    static_assert((PIXP / 16) % 2 == 1 && ROWB % 256 == 0, "halo pitches");
+    constexpr int HALO_BYTES = HS * ROWB, PATCH_BYTES = PS * PS * PIXB, XCH_BYTES = 8 * 16 * 64 * 4;
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -68,6 +74,7 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
     int* const sT0 = (int*)(smem + HALO_BYTES + PATCH_BYTES + XCH_BYTES);
     int* const sT1 = sT0 + 2 * HS;
     float* const sTL = (float*)(sT1 + 2 * HS);
+    float* const sC = (float*)(smem + HALO_BYTES + PATCH_BYTES + XCH_BYTES + 2 * HS * 16);  // [32] conv bias, [32] 1x1 conv weights
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -90,6 +97,7 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
     const int tiles_x = (p.Wo + TS - 1) / TS, tiles_y = (p.Ho + TS - 1) / TS;
     const int ntiles = p.B * tiles_y * tiles_x;
     const float head_b = p.head_b[0];
+    if (tid < 64) sC[tid] = tid < 32 ? p.bias[tid] : p.head_w[tid - 32];  // published by the first tile's first barrier
 
     // tile -> image, origin and the source patch its halo interpolates from (halo rows / columns outside the image are zero padding)
     auto geom = [&](int tile) {
@@ -107,9 +115,11 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
     // source patch global -> LDS by LDS-DMA, dense [ph*pw][CIN] image (pixel pitch pw): 1 KiB = PPI pixels per wave instruction
     auto issue_patch = [&](const TileGeom& g) {
         const bf16_t* src = p.src + (size_t)g.b * p.Hi * p.Wi * CIN;
-        const int npix = g.ph * g.pw, c = lane % NCH;
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));  // opaque: keeps hipcc from hoisting the lane's address part to kernel entry (it gets spilled there)
+        const int npix = g.ph * g.pw, c = lane_o % NCH;
         for (int j = wave; j * PPI < npix; j += 8) {
-            int pp = j * PPI + lane / NCH;
+            int pp = j * PPI + lane_o / NCH;
             pp = pp < npix ? pp : npix - 1;  // tail lanes re-fetch the last pixel into the slack behind the image
             const int yy = pp / g.pw, xx = pp - yy * g.pw;
             glds16(src + ((size_t)(g.py0 + yy) * p.Wi + (g.px0 + xx)) * CIN + c * 8, sP + (size_t)j * 1024);
@@ -120,7 +130,16 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
     TileGeom g = geom(tile < ntiles ? tile : 0);
     if (tile < ntiles) issue_patch(g);
 
-    for (; tile < ntiles; tile += gridDim.x) {
+    int tile_no = 0;
+    auto stamp = [&](int slot) {
+        if (p.dbg_times && tile_no == 1 && tid == 0) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            p.dbg_times[(size_t)blockIdx.x * 8 + slot] = t;
+        }
+    };
+    for (; tile < ntiles; tile += gridDim.x, ++tile_no) {
+        stamp(0);
         // ---- interpolation tables of this tile (align_corners=True): per halo row {byte offset of source row y0, of y1, ly, inside};
         //      per halo column the same in x. Written before, read after the barrier that also publishes the patch.
         if (tid < 2 * HS) {
@@ -137,42 +156,98 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the patch has landed
         __syncthreads();
+        stamp(1);
 
-        // ---- halo tile out of the patch: t = v0 + l (v1 - v0) along x for the two source rows, then along y. bf16 -> fp32 is a shift
-        //      for the even element of a packed pair; the odd one is used IN PLACE (its low 16 bits are the neighbour's bits: a relative
-        //      perturbation below 2^-16, two hundred times finer than the bf16 rounding of the result)
-        {
-            const int c = tid % NCH;
-            for (int hp = tid / NCH; hp < HS * HS; hp += 512 / NCH) {
-                const int hy = hp / HS, hx = hp - hy * HS;
-                const int oy_0 = sT0[hy], oy_1 = sT1[hy], ox_0 = sT0[HS + hx], ox_1 = sT1[HS + hx];
+        // ---- halo tile out of the patch. A thread owns a column strip: halo column hx, channel chunk c, nine consecutive halo rows. It
+        //      keeps the two source rows y0, y1 of the current halo row ALREADY interpolated along x (t = v0 + lx (v1 - v0), fp32) in
+        //      registers: going down the strip the source row advances every ~1.75 halo rows, so most steps only do the vertical
+        //      lerp (the branches depend on the row only: wave-uniform). bf16 -> fp32 is a shift for the even element of a packed pair;
+        //      the odd one is used IN PLACE (its low 16 bits are the neighbour's bits: a relative perturbation below 2^-16, two
+        //      hundred times finer than the bf16 rounding of the result)
+        auto to_f2 = [](unsigned d) { return f32x2{__builtin_bit_cast(float, d << 16), __builtin_bit_cast(float, d)}; };
+        if (tid < 2 * TS * NCH) {
+            // strips: halo columns 0..15, chunk c, rows 9 part .. 9 part + 8
+            const int part = tid / (TS * NCH), rem = tid - part * (TS * NCH);
+            const int hx = rem / NCH, c = rem - hx * NCH;
+            const int ox_0 = sT0[HS + hx], ox_1 = sT1[HS + hx];
+            const float lx = sTL[HS + hx];
+            const char* const pbase = sP + c * 16;
+            char* const hcol = sH + hx * PIXP + c * 16;
+            auto hlerp = [&](int row_off, f32x2 (&t)[4]) {
+                const u32x4 v0 = *(const u32x4*)(pbase + row_off + ox_0);
+                const u32x4 v1 = *(const u32x4*)(pbase + row_off + ox_1);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned d0 = v0[w], d1 = v1[w];  // (scalar copies: __builtin_bit_cast on a vector ELEMENT expression reads element 0)
+                    const f32x2 a0 = to_f2(d0), a1 = to_f2(d1);
+                    t[w] = a0 + lx * (a1 - a0);
+                }
+            };
+            f32x2 t0[4], t1[4];
+            int c0 = -2, c1 = -2;  // patch row offsets currently held in t0 / t1
+            int oy_0 = sT0[9 * part], oy_1 = sT1[9 * part];
+            for (int hy = 9 * part; hy < 9 * part + 9; ++hy) {
+                // next row's table entries are fetched before this row's work (LDS latency under the arithmetic)
+                const int hn = hy + 1 < HS ? hy + 1 : hy;
+                const int ny_0 = sT0[hn], ny_1 = sT1[hn];
+                const float ly = sTL[hy];
                 u32x4 outw = {0u, 0u, 0u, 0u};
                 if ((oy_0 | ox_0) >= 0) {
-                    const float ly = sTL[hy], lx = sTL[HS + hx];
-                    const char* base = sP + c * 16;
-                    const u32x4 v00 = *(const u32x4*)(base + oy_0 + ox_0);
-                    const u32x4 v01 = *(const u32x4*)(base + oy_0 + ox_1);
-                    const u32x4 v10 = *(const u32x4*)(base + oy_1 + ox_0);
-                    const u32x4 v11 = *(const u32x4*)(base + oy_1 + ox_1);
+                    if (oy_0 != c0) {
+                        if (oy_0 == c1) {
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) t0[w] = t1[w];
+                        } else {
+                            hlerp(oy_0, t0);
+                        }
+                        c0 = oy_0;
+                    }
+                    if (oy_1 != c1) {
+                        if (oy_1 == c0) {
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) t1[w] = t0[w];
+                        } else {
+                            hlerp(oy_1, t1);
+                        }
+                        c1 = oy_1;
+                    }
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
-                        // (scalar copies first: __builtin_bit_cast applied directly to a vector ELEMENT expression reads element 0)
-                        const unsigned d00 = v00[w], d01 = v01[w], d10 = v10[w], d11 = v11[w];
-                        const f32x2 a00 = {__builtin_bit_cast(float, d00 << 16), __builtin_bit_cast(float, d00)};
-                        const f32x2 a01 = {__builtin_bit_cast(float, d01 << 16), __builtin_bit_cast(float, d01)};
-                        const f32x2 a10 = {__builtin_bit_cast(float, d10 << 16), __builtin_bit_cast(float, d10)};
-                        const f32x2 a11 = {__builtin_bit_cast(float, d11 << 16), __builtin_bit_cast(float, d11)};
-                        const f32x2 t0 = a00 + lx * (a01 - a00);
-                        const f32x2 t1 = a10 + lx * (a11 - a10);
-                        const f32x2 o2 = t0 + ly * (t1 - t0);
+                        const f32x2 o2 = t0[w] + ly * (t1[w] - t0[w]);
                         outw[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(o2, bf16x2));
                     }
                 }
-                const int key = (NCH == 16 ? hx : (hx >> 1)) & (NCH - 1);
-                *(u32x4*)(sH + (size_t)hp * PIXB + ((c ^ key) << 4)) = outw;
+                *(u32x4*)(hcol + hy * ROWB) = outw;
+                oy_0 = ny_0; oy_1 = ny_1;
             }
         }
+        // the two right-most halo columns (16, 17), one (row, chunk) item at a time over all threads: full bilinear from four reads
+        for (int item = tid; item < 2 * HS * NCH; item += 512) {
+            const int c = item % NCH, rest = item / NCH;
+            const int hy = rest % HS, hx = TS + rest / HS;
+            const int oy_0 = sT0[hy], oy_1 = sT1[hy], ox_0 = sT0[HS + hx], ox_1 = sT1[HS + hx];
+            u32x4 outw = {0u, 0u, 0u, 0u};
+            if ((oy_0 | ox_0) >= 0) {
+                const float ly = sTL[hy], lx = sTL[HS + hx];
+                const char* base = sP + c * 16;
+                const u32x4 v00 = *(const u32x4*)(base + oy_0 + ox_0);
+                const u32x4 v01 = *(const u32x4*)(base + oy_0 + ox_1);
+                const u32x4 v10 = *(const u32x4*)(base + oy_1 + ox_0);
+                const u32x4 v11 = *(const u32x4*)(base + oy_1 + ox_1);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned d00 = v00[w], d01 = v01[w], d10 = v10[w], d11 = v11[w];
+                    const f32x2 a00 = to_f2(d00), a01 = to_f2(d01), a10 = to_f2(d10), a11 = to_f2(d11);
+                    const f32x2 u0 = a00 + lx * (a01 - a00);
+                    const f32x2 u1 = a10 + lx * (a11 - a10);
+                    const f32x2 o2 = u0 + ly * (u1 - u0);
+                    outw[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(o2, bf16x2));
+                }
+            }
+            *(u32x4*)(sH + hy * ROWB + hx * PIXP + c * 16) = outw;
+        }
         __syncthreads();
+        stamp(2);
 
         // ---- the next tile's patch streams in under this tile's MFMA phase (the patch region is free from here on)
         const int next = tile + gridDim.x;
@@ -187,42 +262,62 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[blk][r] = 0.0f;
         const int px = l31 & 15, prow = 4 * q + (l31 >> 4);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        // fragment reads run a PAIR of k-steps ahead of the MFMAs (register double buffer, issue order pinned: hipcc's own waits are
+        // always lgkmcnt(0), so each one is placed four MFMAs behind the newest reads)
+        const char* const hbase = sH + prow * ROWB + px * PIXP + ((2 * grp + half) << 4);
+        auto frag = [&](int step, int blk) -> bf16x8 {
+            const int tap = step / KG, kg = step - tap * KG;
             const int ky = tap / 3, kx = tap - 3 * ky;
-            const int hx = px + kx;
-            const int key = (NCH == 16 ? hx : (hx >> 1)) & (NCH - 1);
-            const char* h0 = sH + (size_t)((prow + ky) * HS + hx) * PIXB;
+            return *(const bf16x8*)(hbase + (ky + 2 * blk) * ROWB + kx * PIXP + kg * 64);
+        };
+        constexpr int NSTEP = 9 * KG;
+        static_assert(NSTEP % 2 == 0, "k-steps are consumed in pairs");
+        bf16x8 xf[2][2][2];  // [buffer][step of the pair][block]
 #pragma unroll
-            for (int kg = 0; kg < KG; ++kg) {
-                const int c = (2 * kg + grp) * 2 + half;
-                const bf16x8 x0 = *(const bf16x8*)(h0 + ((c ^ key) << 4));
-                const bf16x8 x1 = *(const bf16x8*)(h0 + 2 * HS * PIXB + ((c ^ key) << 4));
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[tap][kg], x0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[tap][kg], x1, acc[1], 0, 0, 0);
+        for (int u = 0; u < 2; ++u) { xf[0][u][0] = frag(u, 0); xf[0][u][1] = frag(u, 1); }
+#pragma unroll
+        for (int pair = 0; pair < NSTEP / 2; ++pair) {
+            const int cur = pair & 1;
+            // first MFMA of the pair (its lgkmcnt(0) retires the reads issued during the previous pair), THEN the next pair's reads
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(2 * pair) / KG][(2 * pair) % KG], xf[cur][0][0], acc[0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pair + 1 < NSTEP / 2) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { xf[cur ^ 1][u][0] = frag(2 * pair + 2 + u, 0); xf[cur ^ 1][u][1] = frag(2 * pair + 2 + u, 1); }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(2 * pair) / KG][(2 * pair) % KG], xf[cur][0][1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(2 * pair + 1) / KG][(2 * pair + 1) % KG], xf[cur][1][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(2 * pair + 1) / KG][(2 * pair + 1) % KG], xf[cur][1][1], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
-        // ---- the groups swap one block each (group 0 finishes block 0, group 1 block 1), summing group 0's partial + group 1's
+        stamp(3);
+        // ---- the groups swap one block each (group 0 finishes block 0, group 1 block 1), summing group 0's partial + group 1's.
+        //      Exchange image [wave][r / 4][lane][4 floats]: 16-byte accesses at a 16-byte lane stride (conflict-free)
         {
-            float* mine = sX + (size_t)wave * 16 * 64 + lane;
+            f32x4* mine = (f32x4*)sX + (size_t)wave * 4 * 64 + lane;
             const f32x16& give = acc[grp ^ 1];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mine[r * 64] = give[r];
+            for (int r4 = 0; r4 < 4; ++r4) mine[r4 * 64] = f32x4{give[4 * r4], give[4 * r4 + 1], give[4 * r4 + 2], give[4 * r4 + 3]};
         }
         __syncthreads();
-        f32x16 tot;
-        {
-            const float* theirs = sX + (size_t)(wave ^ 4) * 16 * 64 + lane;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tot[r] = grp == 0 ? acc[0][r] + theirs[r * 64] : theirs[r * 64] + acc[1][r];
-        }
-        //      relu(conv + bias) . w + b -> relu | sigmoid   (head_model.py:80-85); conv output n(r) = (r&3) + 8*(r>>2) + 4*half
+        stamp(4);
+        //      relu(conv + bias) . w + b -> relu | sigmoid   (head_model.py:80-85); conv outputs of register group r4: n = 8 r4 + 4 half + 0..3
         float s = 0.0f;
+        {
+            const f32x4* theirs = (const f32x4*)sX + (size_t)(wave ^ 4) * 4 * 64 + lane;
+            const f32x4* cb = (const f32x4*)sC;  // [8] bias, [8] 1x1 conv weights, as groups of 4 consecutive outputs
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = (r & 3) + 8 * (r >> 2) + 4 * half;
-            s += fmaxf(tot[r] + p.bias[n], 0.0f) * p.head_w[n];
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 th = theirs[r4 * 64], b4 = cb[2 * r4 + half], w4 = cb[8 + 2 * r4 + half];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float mine_v = grp == 0 ? acc[0][4 * r4 + e] : acc[1][4 * r4 + e];
+                    const float tot = grp == 0 ? mine_v + th[e] : th[e] + mine_v;
+                    s += fmaxf(tot + b4[e], 0.0f) * w4[e];
+                }
+            }
         }
         s += __shfl_xor(s, 32);
         s += head_b;
@@ -234,6 +329,7 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
             else if (p.out_dtype == MDPT_DT_F16) ((_Float16*)p.out)[o] = (_Float16)dv;
             else ((float*)p.out)[o] = dv;
         }
+        stamp(5);
         g = gn;
         // barriers: the table / patch of the next tile are written after this tile's staging ended (barrier 2) and published by its
         // barrier 1, which also orders this tile's exchange reads before the next exchange writes
@@ -242,7 +338,7 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
 
 template <int CIN>
 int launch_cin(const HeadTailParams& p, hipStream_t stream) {
-    constexpr unsigned LDS = HS * HS * CIN * 2 + PS * PS * CIN * 2 + 8 * 16 * 64 * 4 + 2 * HS * 16;  // + tables: 3 arrays of 2*HS words (rounded up)
+    constexpr unsigned LDS = HS * (((HS * (CIN * 2 + 16) + 255) / 256) * 256) + PS * PS * CIN * 2 + 8 * 16 * 64 * 4 + 2 * HS * 16 + 256;  // halo, patch, exchange, tables, epilogue constants
     auto kern = head_tail_kernel<CIN>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -255,6 +351,25 @@ int launch_cin(const HeadTailParams& p, hipStream_t stream) {
     static char prof_name[48] = "";
     if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "head_tail_kernel<%d>", CIN);
     MdptProfScope prof(prof_name, 2.0 * p.B * p.Ho * p.Wo * 32.0 * 9.0 * CIN, stream);
+    static const bool dbg_on = getenv("MDPT_HEAD_DBG") != nullptr;
+    if (dbg_on) {  // debug hook only (allocates and synchronises): phase stamps of every workgroup's second tile
+        static unsigned long long* dbuf = nullptr;
+        if (!dbuf) hipMalloc((void**)&dbuf, 256 * 8 * sizeof(unsigned long long));
+        hipMemsetAsync(dbuf, 0, 256 * 8 * sizeof(unsigned long long), stream);
+        HeadTailParams q = p;
+        q.dbg_times = dbuf;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, q);
+        hipStreamSynchronize(stream);
+        static unsigned long long host[256 * 8];
+        hipMemcpy(host, dbuf, sizeof(host), hipMemcpyDeviceToHost);
+        double d[5] = {0, 0, 0, 0, 0};
+        int n = 0;
+        for (int w = 0; w < grid; ++w)
+            if (host[w * 8 + 5] > host[w * 8]) { for (int k = 0; k < 5; ++k) d[k] += (double)(host[w * 8 + k + 1] - host[w * 8 + k]); ++n; }
+        if (n) fprintf(stderr, "head_tail<%d> phases (cycles, mean of %d workgroups' 2nd tile): tables+patch wait %.0f | halo %.0f | mfma %.0f | exchange wait %.0f | epilogue %.0f\n",
+                       CIN, n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, p);
     return (int)hipGetLastError();
 }

@@ -156,6 +156,7 @@ struct HeadTailParams {
     void* out; int out_dtype;  // depth [B, Ho, Wo], MDPT_DT_*
     int sigmoid;
     int B, Hi, Wi, Ho, Wo;
+    unsigned long long* dbg_times;  // test hook (MDPT_HEAD_DBG=1): per-workgroup s_memtime stamps of the phases of its 2nd tile
 };
 bool mdpt_head_tail_supported(int cin);
 bool mdpt_head_tail_scale_ok(int Hi, int Wi, int Ho, int Wo);

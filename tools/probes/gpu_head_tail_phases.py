@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Per-phase s_memtime stamps of head_tail_kernel (MDPT_HEAD_DBG=1 debug hook) on the headline shape: ViT-L head, batch 32, 288^2 -> 504^2."""
+import os, sys, time
+os.environ["MDPT_HEAD_DBG"] = "1"
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict
+osd = make_synthetic_original_state_dict("vitl", 0)
+_, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
+model = model.to("cuda", torch.bfloat16)
+fused = torch.randn(int(sys.argv[1]) if len(sys.argv) > 1 else 16, 256, 288, 288, device="cuda", dtype=torch.bfloat16)
+for _ in range(3):
+    y = model.head(fused)
+torch.cuda.synchronize()
