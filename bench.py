@@ -194,7 +194,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="do not record per-launch HIP events in the timed region")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event passes behind the timed region (no roofline object)")
     ap.add_argument("--no-split", action="store_true", help="disable the two-stream half-batch split inside mdpt_forward")
     args = ap.parse_args()
     midas = args.model in SYNTH_NAME
@@ -237,31 +237,26 @@ def main():
             y = dp.forward_shard(x)
         torch.cuda.synchronize()
         barrier()
-        if not args.no_profile:
-            lib.mdpt_profile_enable(1)
-        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             y = dp.forward_shard(x)
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
+    # Per-kernel measurements are taken AFTER the timed region, in extra passes of the same steps on rank 0 (local forward only, no
+    # collective): HIP events around every launch cost host time per launch, which would otherwise be charged to `value` (visibly so for
+    # the many-small-kernel models). Pass 1: as timed (two-stream half-batch split: kernels of the two halves overlap, so a launch's
+    # begin->end duration includes sharing). Pass 2: split off (every kernel alone on the GPU) - the per-kernel roofline.
     prof = prof_alone = None
-    if not args.no_profile:
-        buf = ctypes.create_string_buffer(1 << 16)
-        if lib.mdpt_profile_report(buf, len(buf)) == 0:
-            prof = json.loads(buf.value.decode())
-        lib.mdpt_profile_enable(0)
-        if not args.no_split and rank == 0:
-            # The timed region above ran mdpt_forward's default two-stream half-batch split: its kernels overlap pairwise, so a
-            # launch's begin->end duration includes the time it shared the GPU with the other half's kernel. For the per-kernel
-            # roofline, time the same steps once more with the split off (every kernel alone on the GPU, same stream events).
-            handle = model._get_engine().handle
-            native.check(lib, lib.mdpt_set_batch_split(handle, 0))
-            with torch.inference_mode():  # local forward only (no collective: the other ranks are not in this pass)
+    if not args.no_profile and rank == 0:
+        handle = model._get_engine().handle
+        with torch.inference_mode():
+            prof = profile_pass(lib, lambda: model(x), args.steps)
+            if not args.no_split:
+                native.check(lib, lib.mdpt_set_batch_split(handle, 0))
                 model(x)
                 prof_alone = profile_pass(lib, lambda: model(x), args.steps)
-            native.check(lib, lib.mdpt_set_batch_split(handle, 8))
+                native.check(lib, lib.mdpt_set_batch_split(handle, 8))
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -288,12 +283,13 @@ def main():
             line["path_frac_of_mfma_peak"] = round(value * gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
         if prof and prof["kernels"]:
             if prof_alone and prof_alone["kernels"]:
-                line["roofline"] = roofline(args, prof_alone, "HIP events, second pass of the same steps with the batch split off (kernel alone on the GPU; "
-                                                              "`bench.py --no-split` + rocprofv3 reproduce it)")
-                line["roofline_in_timed_region"] = roofline(args, prof, "HIP events in the timed region: two half-batch kernels overlap, durations include sharing")
+                line["roofline"] = roofline(args, prof_alone, "HIP events, extra pass of the same steps after the timed region with the batch split off (kernel alone on the "
+                                                              "GPU; `bench.py --no-split` + rocprofv3 reproduce it)")
+                line["roofline_in_timed_region"] = roofline(args, prof, "HIP events, extra pass of the same steps as timed (batch split on): two half-batch kernels overlap, "
+                                                                        "durations include sharing")
                 shares = prof_alone
             else:
-                line["roofline"] = roofline(args, prof, "HIP events in the timed region")
+                line["roofline"] = roofline(args, prof, "HIP events, extra pass of the same steps after the timed region")
                 shares = prof
             tot = sum(k["total_ms"] for k in shares["kernels"])
             line["kernel_time_share"] = {k["name"]: round(k["total_ms"] / tot, 4) for k in shares["kernels"][:12]}

@@ -4,6 +4,7 @@
 
 #include "mdpt_kernels.h"
 #include "mdpt_prof.h"
+#include "ln_row.h"
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -42,44 +43,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + (size_t)row * F;
-    f32x4 v[NV];
-    float s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < F) {
-            v[i] = *(const f32x4*)(xr + c);
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        }
-    }
-    const float mean = wave_sum(s) / (float)F;
-    float ss = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < F) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = v[i][e] - mean;
-                ss += d * d;
-            }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(ss) / (float)F + 1e-6f);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < F) {
-            const f32x4 g = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
-            f32x4 y;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + bt[e];
-            const size_t o = (size_t)row * F + c;
-            if (out_hi) split_store4(out_hi, out_lo, o, y);
-            if (out_f32) *(f32x4*)(out_f32 + o) = y;
-        }
-    }
+    ln_row<NV>(x + (size_t)row * F, gamma, beta, out_hi, out_lo, out_f32, (size_t)row * F, F, lane);  // ln_row.h: shared with gemm.hip
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,70 @@
+// LayerNorm of ONE row by ONE wave (eps 1e-6; reference LayerNormEPS6, components/misc_helpers.py:190-210): the row sits in registers
+// (NV float4 per lane, F <= 256 NV), two-pass mean / centred variance in fp32, output as bf16 hi (+lo) planes and / or fp32.
+// One routine for every kernel that normalises rows (today the standalone kernel in elementwise.hip; round 2 also tried it behind the
+// residual GEMM - the last-arriving workgroup of a 256-row block normalising those rows out of L2 - which was bit-identical and 2.2x
+// slower per GEMM launch). Whoever calls it must produce the SAME BITS, so every multiply-add is an explicit fma /
+// separate operation and contraction is off inside this function, whatever the translation unit's setting is.
+#pragma once
+#include "mdpt_kernels.h"
+
+typedef __attribute__((ext_vector_type(4))) float ln_f32x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 ln_bf16x4;
+
+__device__ __forceinline__ float ln_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int NV>
+__device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       bf16_t* out_hi, bf16_t* out_lo, float* out_f32, size_t out_off, int F, int lane) {
+#pragma clang fp contract(off)
+    ln_f32x4 v[NV];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < F) {
+            v[i] = *(const ln_f32x4*)(xr + c);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = ln_wave_sum(s) / (float)F;
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < F) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                ss = __builtin_fmaf(d, d, ss);
+            }
+        }
+    }
+    const float rstd = rsqrtf(ln_wave_sum(ss) / (float)F + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < F) {
+            const ln_f32x4 g = *(const ln_f32x4*)(gamma + c), bt = *(const ln_f32x4*)(beta + c);
+            ln_f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((v[i][e] - mean) * rstd, g[e], bt[e]);
+            if (out_hi) {
+                ln_bf16x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (__bf16)y[e];
+                *(ln_bf16x4*)(out_hi + out_off + c) = h;
+                if (out_lo) {
+                    ln_bf16x4 l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) l[e] = (__bf16)(y[e] - (float)h[e]);
+                    *(ln_bf16x4*)(out_lo + out_off + c) = l;
+                }
+            }
+            if (out_f32) *(ln_f32x4*)(out_f32 + out_off + c) = y;
+        }
+    }
+}

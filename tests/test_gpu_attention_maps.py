@@ -135,7 +135,8 @@ def test_swinv2_window_softmax_hooks_receive_attention_weights(dtype, atol):
     assert rel_err(y.float().cpu(), orc.forward(w, cfg, x)) <= (1e-4 if dtype == torch.float32 else 3e-2)
     for h in handles:
         h.remove()
-    assert torch.equal(model(x.to("cuda", dtype)), y), "with or without listeners the prediction is the same"
+    y2 = model(x.to("cuda", dtype))  # no hooks left -> fused single-call path (bf16: the stage-by-stage path rounds the stage outputs to the model dtype)
+    assert torch.equal(y2, y) if dtype == torch.float32 else rel_err(y2.float().cpu(), y.float().cpu()) <= 3e-2
     # one listener on a shifted block of stage 1 only; stage-level call (simple_examples/internal_features.py usage)
     got = []
     blk_mod = model.imgencoder.stages[1].blocks[1].attn.softmax

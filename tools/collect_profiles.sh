@@ -1,27 +1,38 @@
 #!/bin/bash
 # Runs ON the MI355X box (through gpurun): the rocprofv3 passes whose summaries are committed under profiles/.
-#   1. kernel trace + stats of the default bench command (two-stream batch split) and of `--no-split`
-#   2. PMC passes (separate runs, --kernel-trace only): FETCH_SIZE, WRITE_SIZE -> HBM traffic per launch; SQ wave-state counters
+#   1. kernel trace + stats of the default bench command (two-stream batch split), of `--no-split`, and of the bf16x3 (fp32-class) mode
+#   2. PMC passes (separate runs, --kernel-trace only): FETCH_SIZE, WRITE_SIZE -> HBM traffic per launch; SQ wave-state counters;
+#      GRBM_GUI_ACTIVE -> effective clock per kernel
+#   3. the driver-runnable secondary configurations (1036x1036, BEiT-L, SwinV2-L) as plain bench lines
 # Output: gpurun_out/profiles_<tag>/ ; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/split" -- python "$R/bench.py" --steps 10 --warmup 3 > "$OUT/bench_under_rocprof.json" 2> "$OUT/split.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/nosplit" -- python "$R/bench.py" --no-split --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_nosplit_under_rocprof.json" 2> "$OUT/nosplit.log"
-for C in FETCH_SIZE WRITE_SIZE; do
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/x3" -- python "$R/bench.py" --precision bf16x3 --no-split --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_x3_nosplit_under_rocprof.json" 2> "$OUT/x3.log"
+for C in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -- python "$R/bench.py" --no-split --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> "$OUT/pmc_$C.log"
 done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS \
   --kernel-trace --output-format csv -d "$OUT/pmc_SQ" -- python "$R/bench.py" --no-split --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> "$OUT/pmc_SQ.log"
 python "$R/tools/summarize_sq.py" "$OUT/pmc_SQ" "$OUT/sq_counters.md" > "$OUT/sq_counters.log" 2>&1
-for d in split nosplit; do
+python "$R/tools/summarize_clock.py" "$OUT/pmc_GRBM_GUI_ACTIVE" "$OUT/effective_clock.md" > "$OUT/effective_clock.log" 2>&1
+for d in split nosplit x3; do
   f=$(find "$OUT/$d" -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${d}_kernel_stats.csv"
 done
 python "$R/tools/summarize_pmc.py" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/hbm_traffic" > "$OUT/hbm_traffic.log" 2>&1
 # the raw per-dispatch traces are large; keep the summaries only
-rm -rf "$OUT/split" "$OUT/nosplit" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ"
+rm -rf "$OUT/split" "$OUT/nosplit" "$OUT/x3" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ" "$OUT/pmc_GRBM_GUI_ACTIVE"
+cd "$R"
+python bench.py --steps 20 --warmup 3 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+python bench.py --precision bf16x3 --steps 20 --warmup 3 > "$OUT/bench_x3.json" 2> "$OUT/bench_x3.err"
+python bench.py --size 1036 --steps 10 --warmup 2 > "$OUT/bench_1036.json" 2> "$OUT/bench_1036.err"
+python bench.py --model beitl --steps 10 --warmup 2 > "$OUT/bench_beitl.json" 2> "$OUT/bench_beitl.err"
+python bench.py --model swinl --steps 10 --warmup 2 > "$OUT/bench_swinl.json" 2> "$OUT/bench_swinl.err"
+[ -x tools/probes/_bin/exp_throughput ] && tools/probes/_bin/exp_throughput > "$OUT/exp_throughput.txt" 2>&1
 ls -la "$OUT"
