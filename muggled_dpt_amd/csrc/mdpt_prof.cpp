@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -17,6 +18,7 @@ std::vector<Slot> g_slots;
 std::map<std::string, int> g_slot_index;
 std::vector<hipEvent_t> g_pool;
 size_t g_pool_next = 0;
+std::mutex g_mu;
 
 hipEvent_t take_event() {
     if (g_pool_next == g_pool.size()) {
@@ -30,7 +32,9 @@ hipEvent_t take_event() {
 
 bool mdpt_prof_on() { return g_on; }
 
-void mdpt_prof_begin(const char* name, double flops, hipStream_t stream) {
+int mdpt_prof_begin(const char* name, double flops, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_on) return -1;
     auto it = g_slot_index.find(name);
     int slot;
     if (it == g_slot_index.end()) {
@@ -44,13 +48,16 @@ void mdpt_prof_begin(const char* name, double flops, hipStream_t stream) {
     r.slot = slot; r.flops = flops; r.a = take_event(); r.b = take_event();
     hipEventRecord(r.a, stream);
     g_recs.push_back(r);
+    return (int)g_recs.size() - 1;
 }
 
-void mdpt_prof_end(hipStream_t stream) {
-    if (!g_recs.empty()) hipEventRecord(g_recs.back().b, stream);
+void mdpt_prof_end(int record, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (record >= 0 && record < (int)g_recs.size()) hipEventRecord(g_recs[record].b, stream);
 }
 
 extern "C" int mdpt_profile_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_mu);
     g_on = on != 0;
     g_recs.clear();
     g_pool_next = 0;
@@ -60,6 +67,7 @@ extern "C" int mdpt_profile_enable(int on) {
 // JSON: {"kernels":[{"name":..,"launches":n,"total_ms":t,"avg_us":a,"gflop":g,"tflops":x}, ...]} sorted by total time
 extern "C" int mdpt_profile_report(char* buf, size_t cap) {
     if (!buf || cap < 64) return -1;
+    std::lock_guard<std::mutex> lock(g_mu);
     struct Acc { int n = 0; double ms = 0, flops = 0; };
     std::vector<Acc> acc(g_slots.size());
     for (const Rec& r : g_recs) {

@@ -3,17 +3,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-void mdpt_prof_begin(const char* name, double flops, hipStream_t stream);
-void mdpt_prof_end(hipStream_t stream);
+int mdpt_prof_begin(const char* name, double flops, hipStream_t stream);  // returns the record index of this scope (-1: profiling off)
+void mdpt_prof_end(int record, hipStream_t stream);
 bool mdpt_prof_on();
 
+// Each scope closes ITS OWN record (nested scopes and launches from several host threads - the two half-batch streams of one forward are
+// driven by one thread, but two handles may run on two threads - cannot close each other's); the record table is guarded by a mutex.
 struct MdptProfScope {
     hipStream_t s;
-    bool on;
-    MdptProfScope(const char* name, double flops, hipStream_t stream) : s(stream), on(mdpt_prof_on()) {
-        if (on) mdpt_prof_begin(name, flops, s);
-    }
+    int rec;
+    MdptProfScope(const char* name, double flops, hipStream_t stream) : s(stream), rec(mdpt_prof_on() ? mdpt_prof_begin(name, flops, stream) : -1) {}
     ~MdptProfScope() {
-        if (on) mdpt_prof_end(s);
+        if (rec >= 0) mdpt_prof_end(rec, s);
     }
 };

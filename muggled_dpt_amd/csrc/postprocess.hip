@@ -22,31 +22,39 @@ __global__ void minmax_init_kernel(unsigned* mm) {
     mm[1] = 0u;           // running max
 }
 
-__device__ __forceinline__ void block_minmax(float lo, float hi, unsigned* mm) {
+// torch's .min() / .max() PROPAGATE NaN (normalize_01 of a map with a NaN gives an all-NaN map) while fminf / fmaxf drop it: a thread
+// that saw a NaN says so, and the block then pins the running min to ordered 0 and the running max to ordered ~0, both of which
+// ord2f() maps back to NaN bit patterns.
+__device__ __forceinline__ void block_minmax(float lo, float hi, bool saw_nan, unsigned* mm) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         lo = fminf(lo, __shfl_xor(lo, o));
         hi = fmaxf(hi, __shfl_xor(hi, o));
     }
+    const bool wave_nan = __any(saw_nan);
     __shared__ float slo[4], shi[4];
+    __shared__ int snan[4];
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { slo[wave] = lo; shi[wave] = hi; }
+    if ((threadIdx.x & 63) == 0) { slo[wave] = lo; shi[wave] = hi; snan[wave] = wave_nan; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) { lo = fminf(lo, slo[w]); hi = fmaxf(hi, shi[w]); }
-        atomicMin(mm + 0, f2ord(lo));
-        atomicMax(mm + 1, f2ord(hi));
+        bool any_nan = wave_nan;
+        for (int w = 1; w < 4; ++w) { lo = fminf(lo, slo[w]); hi = fmaxf(hi, shi[w]); any_nan |= snan[w] != 0; }
+        atomicMin(mm + 0, any_nan ? 0u : f2ord(lo));
+        atomicMax(mm + 1, any_nan ? 0xffffffffu : f2ord(hi));
     }
 }
 
 __global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ in, size_t n, unsigned* mm) {
     float lo = INFINITY, hi = -INFINITY;
+    bool saw_nan = false;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = in[i];
+        saw_nan |= v != v;
         lo = fminf(lo, v);
         hi = fmaxf(hi, v);
     }
-    block_minmax(lo, hi, mm);
+    block_minmax(lo, hi, saw_nan, mm);
 }
 
 __global__ void minmax_finish_kernel(const unsigned* mm, float* out) {
@@ -61,6 +69,7 @@ __global__ __launch_bounds__(256) void scale_bilinear_kernel(const float* __rest
     const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
     const size_t total = (size_t)B * oh * ow;
     float lo = INFINITY, hi = -INFINITY;
+    bool saw_nan = false;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int ox = (int)(idx % ow), oy = (int)((idx / ow) % oh);
         const size_t b = idx / ((size_t)ow * oh);
@@ -72,10 +81,11 @@ __global__ __launch_bounds__(256) void scale_bilinear_kernel(const float* __rest
         const float v = (1.0f - ly) * ((1.0f - lx) * p[(size_t)y0 * iw + x0] + lx * p[(size_t)y0 * iw + x1]) +
                         ly * ((1.0f - lx) * p[(size_t)y1 * iw + x0] + lx * p[(size_t)y1 * iw + x1]);
         out[idx] = v;
+        saw_nan |= v != v;
         lo = fminf(lo, v);
         hi = fmaxf(hi, v);
     }
-    if (mm) block_minmax(lo, hi, mm);
+    if (mm) block_minmax(lo, hi, saw_nan, mm);
 }
 
 // mode 0: fp32 (x - min) / (max - min); mode 1: u8 = trunc(255 * norm) (Tensor.byte()); mode 2: BGRA u8 = 24-bit
@@ -87,10 +97,15 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict_
     const float lo = minmax ? minmax[0] : 0.0f, hi = minmax ? minmax[1] : 1.0f;
     const float range = hi - lo;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float v = minmax ? (in[i] - lo) / range : in[i];
+        float v = minmax ? (in[i] - lo) / range : in[i];
         if (MODE == 0) {
-            ((float*)out)[i] = v;
-        } else if (MODE == 1) {
+            ((float*)out)[i] = v;  // NaN (NaN input, or max == min) propagates like the reference's fp32 result
+            continue;
+        }
+        // integer outputs: a NaN (max == min: 0 / 0; NaN anywhere in the map) becomes 0 - converting NaN to an integer is undefined in
+        // C and implementation-defined in torch's .byte(); values are clamped to the representable range before the conversion
+        v = v == v ? fminf(fmaxf(v, 0.0f), 1.0f) : 0.0f;
+        if (MODE == 1) {
             ((unsigned char*)out)[i] = (unsigned char)(int)(255.0f * v);
         } else {
             const int q = (int)rintf(16777215.0f * v);

@@ -91,3 +91,18 @@ def test_hip_postprocess_on_random_shapes_vs_oracle():
         assert torch.equal(postprocess.normalize_01(x.cuda()).cpu(), dpt_oracle.normalize_01(x))
         assert torch.equal(postprocess.convert_to_uint8(x.cuda()).cpu(), dpt_oracle.convert_to_uint8(x))
         assert torch.equal(postprocess.pack_depth_u24(x[:1].cuda()).cpu(), dpt_oracle.pack_depth_u24(x[:1]))
+
+
+def test_nan_and_constant_maps_behave_like_torch_min_max():
+    """torch's .min() / .max() propagate NaN (fminf / fmaxf would drop it), and a constant map has max == min: the fp32 normalisation
+    yields NaN like the reference's (x - min) / (max - min); the integer conversions write 0 instead of converting a NaN."""
+    from muggled_dpt_amd.postprocess import convert_to_uint8, normalize_01
+    x = torch.rand(2, 40, 56, device="cuda")
+    x[1, 3, 5] = float("nan")
+    y = normalize_01(x)
+    assert bool(torch.isnan(y).all()), "a NaN anywhere makes min and max NaN (torch semantics)"
+    u = convert_to_uint8(x)  # NaN min / max -> every normalised value is NaN -> written as 0, never converted
+    assert u.dtype == torch.uint8 and int(u.max()) == 0
+    c = torch.full((1, 8, 8), 0.25, device="cuda")
+    assert bool(torch.isnan(normalize_01(c)).all())
+    assert int(convert_to_uint8(torch.zeros(1, 8, 8, device="cuda")).max()) == 0
