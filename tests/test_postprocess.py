@@ -93,6 +93,7 @@ def test_hip_postprocess_on_random_shapes_vs_oracle():
         assert torch.equal(postprocess.pack_depth_u24(x[:1].cuda()).cpu(), dpt_oracle.pack_depth_u24(x[:1]))
 
 
+@pytest.mark.gpu
 def test_nan_and_constant_maps_behave_like_torch_min_max():
     """torch's .min() / .max() propagate NaN (fminf / fmaxf would drop it), and a constant map has max == min: the fp32 normalisation
     yields NaN like the reference's (x - min) / (max - min); the integer conversions write 0 instead of converting a NaN."""
