@@ -3,6 +3,7 @@
 #   1. kernel trace + stats of the default bench command (two-stream batch split), of `--no-split`, and of the bf16x3 (fp32-class) mode
 #   2. PMC passes (separate runs, --kernel-trace only): FETCH_SIZE, WRITE_SIZE -> HBM traffic per launch; SQ wave-state counters;
 #      GRBM_GUI_ACTIVE -> effective clock per kernel
+#      plus one forward as a launch-by-launch timeline (tools/forward_timeline.py)
 #   3. the driver-runnable secondary configurations (1036x1036, BEiT-L, SwinV2-L) as plain bench lines
 # Output: gpurun_out/profiles_<tag>/ ; copy what is to be judged into profiles/.
 set -u
@@ -14,6 +15,8 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/split" -- python "$R/bench.py" --steps 10 --warmup 3 > "$OUT/bench_under_rocprof.json" 2> "$OUT/split.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/nosplit" -- python "$R/bench.py" --no-split --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_nosplit_under_rocprof.json" 2> "$OUT/nosplit.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/x3" -- python "$R/bench.py" --precision bf16x3 --no-split --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_x3_nosplit_under_rocprof.json" 2> "$OUT/x3.log"
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/timeline" -- python "$R/bench.py" --no-split --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> "$OUT/timeline.log"
+python "$R/tools/forward_timeline.py" "$OUT/timeline" "$OUT/forward_timeline.md" > /dev/null 2>> "$OUT/timeline.log"
 for C in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -- python "$R/bench.py" --no-split --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> "$OUT/pmc_$C.log"
 done
@@ -27,7 +30,7 @@ for d in split nosplit x3; do
 done
 python "$R/tools/summarize_pmc.py" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/hbm_traffic" > "$OUT/hbm_traffic.log" 2>&1
 # the raw per-dispatch traces are large; keep the summaries only
-rm -rf "$OUT/split" "$OUT/nosplit" "$OUT/x3" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ" "$OUT/pmc_GRBM_GUI_ACTIVE"
+rm -rf "$OUT/split" "$OUT/nosplit" "$OUT/x3" "$OUT/timeline" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ" "$OUT/pmc_GRBM_GUI_ACTIVE"
 cd "$R"
 python bench.py --steps 20 --warmup 3 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 python bench.py --precision bf16x3 --steps 20 --warmup 3 > "$OUT/bench_x3.json" 2> "$OUT/bench_x3.err"
