@@ -31,10 +31,11 @@ def _kernel_stats(src, tmp_path):
     return stats
 
 
-@pytest.mark.parametrize("src,pattern", [("gemm.hip", "gemm8_kernel"), ("attention.hip", "attn_kernel")])
-def test_hot_kernels_do_not_spill(tmp_path, src, pattern):
+@pytest.mark.parametrize("src,pattern,at_least", [("gemm.hip", "gemm8_kernel", 6), ("attention.hip", "attn_kernel", 6),
+                                                  ("head.hip", "head_tail_kernel", 2)])
+def test_hot_kernels_do_not_spill(tmp_path, src, pattern, at_least):
     stats = {k: v for k, v in _kernel_stats(src, tmp_path).items() if pattern in k}
-    assert len(stats) >= 6, sorted(stats)
+    assert len(stats) >= at_least, sorted(stats)
     for name, s in stats.items():
         assert s["ScratchSize"] == 0, f"{name} spills {s['ScratchSize']} bytes of scratch per lane ({s['NumVgprs']} VGPRs)"
         assert s["NumVgprs"] <= 256
