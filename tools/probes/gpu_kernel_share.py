@@ -11,6 +11,8 @@ _, model = make_depthanythingv2_dpt_from_original_state_dict(make_synthetic_orig
 model = model.to("cuda", torch.bfloat16)
 x = torch.randn(32, 3, 504, 504, generator=torch.Generator().manual_seed(1)).to("cuda", torch.bfloat16)
 native.check(lib, lib.mdpt_set_batch_split(model._get_engine().handle, 0))
+if os.environ.get("TILE"):
+    model.set_gemm_tile(int(os.environ["TILE"]))  # force one tile variant for every GEMM (MDPT_TILE_*)
 with torch.inference_mode():
     for _ in range(2): model(x)
     torch.cuda.synchronize()
