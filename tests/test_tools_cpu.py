@@ -1,5 +1,5 @@
-"""Host-side tooling that produces the committed profile summaries: tools/summarize_pmc.py on a synthetic rocprofv3 counter CSV."""
-import csv
+"""The profile post-processing tools (tools/*.py) are part of the measurement chain behind profiles/: keep them runnable. CPU only, tiny
+synthetic inputs in the formats rocprofv3 / the test session write."""
 import json
 import os
 import subprocess
@@ -8,31 +8,39 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _write_pass(folder, counter, rows):
-    os.makedirs(os.path.join(folder, "node"), exist_ok=True)
-    with open(os.path.join(folder, "node", "1_counter_collection.csv"), "w", newline="") as fh:
-        w = csv.DictWriter(fh, fieldnames=["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
-        w.writeheader()
-        for disp, kernel, value in rows:
-            w.writerow({"Dispatch_Id": disp, "Kernel_Name": kernel, "Counter_Name": counter, "Counter_Value": value})
+def test_forward_timeline_collapses_runs_and_starts_at_the_last_patchify(tmp_path):
+    d = tmp_path / "trace" / "host"
+    d.mkdir(parents=True)
+    head = '"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name","Correlation_Id","Start_Timestamp","End_Timestamp","Workgroup_Size_X","Workgroup_Size_Y","Workgroup_Size_Z","Grid_Size_X","Grid_Size_Y","Grid_Size_Z"\n'
+    rows = []
+    t = 1000
 
+    def k(name, dur, wg, grid):
+        nonlocal t
+        rows.append(f'"KERNEL_DISPATCH",1,1,1,1,{len(rows)},1,"{name}",0,{t},{t + dur},{wg},1,1,{grid},1,1\n')
+        t += dur + 10
 
-def test_summarize_pmc_units_and_gfx950_fetch_correction(tmp_path):
-    k1 = "void (anonymous namespace)::layernorm_kernel<4>(float const*, float const*, int)"
-    k2 = "void (anonymous namespace)::gemm8_kernel<0, 0, 2>(GemmParams)"
-    # two dispatches of k1 with several per-XCD rows each (rocprofv3 emits one row per counter instance), one of k2
-    _write_pass(tmp_path / "f", "FETCH_SIZE", [(1, k1, 40000), (1, k1, 43000), (2, k1, 83000), (3, k2, 250000)])
-    _write_pass(tmp_path / "w", "WRITE_SIZE", [(1, k1, 83000), (2, k1, 84000), (3, k2, 167000)])
-    out = str(tmp_path / "traffic")
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "summarize_pmc.py"), str(tmp_path / "f"), str(tmp_path / "w"), out],
-                       capture_output=True, text=True)
+    for _ in range(2):  # two forwards: only the second one is reported
+        k("(anonymous namespace)::patchify_kernel(void const*, int)", 500, 256, 256 * 16)
+        k("void (anonymous namespace)::gemm8_kernel<0, 0, 6>(GemmParams)", 2000, 512, 512 * 652)
+        k("void (anonymous namespace)::gemm8_kernel<0, 0, 6>(GemmParams)", 3000, 512, 512 * 652)
+        k("void (anonymous namespace)::layernorm_kernel<4>(float const*)", 400, 256, 256 * 100)
+    (d / "1_kernel_trace.csv").write_text(head + "".join(rows))
+    out = tmp_path / "tl.md"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "forward_timeline.py"), str(tmp_path / "trace"), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    rows = json.load(open(out + ".json"))
-    ln = rows["layernorm_kernel<4>"]
-    assert ln["launches"] == 2
-    assert ln["fetch_mb_per_launch"] == round(2 * 83000 * 1024 / 1e6, 1)  # KiB -> bytes, doubled on gfx950
-    assert ln["write_mb_per_launch"] == round(83500 * 1024 / 1e6, 1)
-    g = rows["gemm8_kernel<0, 0, 2>"]
-    assert g["launches"] == 1 and g["fetch_mb_per_launch"] == 512.0 and g["write_mb_per_launch"] == 171.0
-    assert list(rows)[0] == "gemm8_kernel<0, 0, 2>" or list(rows)[0] == "layernorm_kernel<4>"  # sorted by total traffic
-    assert "| `layernorm_kernel<4>` | 2 |" in open(out + ".md").read()
+    text = out.read_text()
+    assert "One forward, 4 launches" in text
+    assert "| 1 | `gemm8_kernel<0, 0, 6>` | 2 | 652 | 512 | 2.5 | 5.0 |" in text  # two launches of one kernel at one grid: one row
+    assert text.count("patchify_kernel") == 1
+
+
+def test_summarize_parity_groups_by_file_worst_first(tmp_path):
+    rec = {"tests/test_a.py::test_x[dtype1-0.02]": 1.3e-2, "tests/test_a.py::test_x[dtype0-0.0001]": 2.5e-5, "tests/test_b.py::test_y": 4e-3}
+    src, out = tmp_path / "r.json", tmp_path / "r.md"
+    src.write_text(json.dumps(rec))
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "summarize_parity.py"), str(src), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = out.read_text()
+    assert text.index("test_x[dtype1-0.02]") < text.index("test_x[dtype0-0.0001]") < text.index("### tests/test_b.py")
+    assert "| `test_y` | 0.004 |" in text
