@@ -1,0 +1,467 @@
+// Halo-staged 3x3 convolution (stride 1, pad 1, Cout = 256) for gfx950 (MI355X): the 256-channel residual-conv-unit and projection convs
+// of the DPT decoder. Reference call sites: FusionBlock / ResidualConv2D  v2_depthanything/fusion_model.py:148-154,178-182,210-220
+// (relu -> conv3x3 -> relu -> conv3x3 + skip, and `x = RCU(reassembled) + upsampled previous level`), the reassembly model's final 3x3
+// projection  reassembly_model.py:135,302-309.
+//
+// The implicit-GEMM form in gemm.hip (A-row generator MDPT_A_CONV3) re-fetches every input pixel from L2 once per tap: nine 32 KB A tiles
+// per 64-channel block and output tile (measured 1.25 GB fetched per launch against ~0.2 GB of unique operands). Here an output tile is a
+// 16x16 pixel SQUARE of one image (M = 256) times all 256 output channels, and the 18x18-pixel input patch the nine taps of a 64-channel
+// block touch is staged in LDS ONCE (41 KB, LDS-DMA, one channel block ahead, spread over the K tiles of the current block). The nine
+// taps are nine K tiles whose A fragments are shifted ds_read_b128 of that halo patch:
+//
+//     K order: k = (cb * 9 + ky * 3 + kx) * 64 + c   (cb = 64-channel block; weights are packed in this order, MDPT_PACK_CONV3)
+//     halo image of block cb: pixel (y', x') of the 18x18 patch at  y' * 2304 + x' * 128 + ((chunk ^ (x' & 7)) << 4)
+//         - 2304 = 9 * 256: a row shift (ky) does not move the bank pattern; the x-dependent XOR makes the 16 pixels x 16 bytes of every
+//           ds_read_b128 service group land on 16 different 16-byte slots of the 256-byte bank row for kx = 0, 1, 2 (checked exhaustively)
+//         - the lane part of the address depends on kx only: three lane constants, (cb, ky) enter through one scalar add
+//     pixels outside the image read the zero page (= the conv's zero padding); partial tiles compute and drop the rows outside
+//
+// Main loop = the 8-phase schedule of gemm8_kernel (two wave groups one barrier apart, 16 MFMA 16x16x32 per phase, B half-tiles re-staged
+// one / two phases after their last read, counted vmcnt): the B (weight) side is identical; the A side has no per-K-tile DMA at all - one
+// halo DMA instruction per wave and K tile (dummy 16-byte-per-lane reads of the zero page into a scratch KiB once the 41 real ones are
+// issued, so that the vmcnt arithmetic is the same in every K tile).
+// Epilogues are the direct register -> global forms (swapped MFMA operands: a lane owns 4 consecutive channels of one pixel):
+//     out = ((conv + bias) [+ x2 bilinear of the coarser level]) [+ skip]  ->  fp32 map and / or bf16 map (optionally ReLU'd)
+// `skip` (fp32) initialises the accumulators (loaded under the first K tiles like gemm8's DM_RINIT form); the coarser level's 10x10 source
+// patch of the bilinear add is staged in the (then free) LDS once per tile.
+// Summation order per output element = K order above, fp32 accumulation in the MFMA pipe, then (skip + sum) + bias (+ up): the generic
+// kernels of gemm.hip walk K in the same order and apply the same epilogue expressions, so a tile-rule change between batch sizes does not
+// change a bit (tests/test_gpu_conv3h.py).
+
+#include "mdpt_kernels.h"
+#include "mdpt_prof.h"
+#include <stdio.h>
+#include <stdlib.h>
+
+#pragma clang fp contract(off)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+namespace {
+
+constexpr int HROW = 18 * 128;                 // bytes per halo row: 18 pixels x 64 channels bf16
+constexpr int HALO_INSTR = 41;                 // ceil(18 * 18 * 128 / 1024) LDS-DMA instructions per halo patch
+constexpr int HALO_BYTES = HALO_INSTR * 1024;
+constexpr int BTILE = 256 * 128;               // one K tile of weights: 256 rows x 64 k, bf16
+constexpr int OFF_H = 2 * BTILE, OFF_SCR = OFF_H + 2 * HALO_BYTES;
+constexpr int LDS_BYTES = OFF_SCR + 1024;
+constexpr int UPW = 10;                        // side of the coarse patch of the bilinear add (16 fine pixels span <= 9.x coarse ones)
+static_assert(UPW * UPW * 1024 <= LDS_BYTES, "coarse patch must fit the ring");
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ unsigned long long memtime_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)(bytes < 0xFFFFFFF0ull ? bytes : 0xFFFFFFF0ull), 0x00020000);
+}
+
+template <bool SKIP, bool F32OUT, bool RELU, bool UP>
+__global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    unsigned long long t_start = 0, t_first = 0, t_loop = 0;
+    if (p.dbg_times) t_start = memtime_now();
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, lh = lane >> 4;
+
+    // ---- tile -> (image, tile row, tile column); the dispatcher places block b on XCD b % 8: every XCD gets a contiguous run of tiles
+    //      (neighbouring tiles share halo rows / columns in that XCD's L2)
+    const int tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 15) >> 4;
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+        tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    }
+    const int img = tile / (tiles_x * tiles_y), trem = tile - img * (tiles_x * tiles_y);
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int Y0 = ty * 16, X0 = tx * 16;
+    const bf16_t* const in_img = p.in + (size_t)img * p.H * p.W * p.Cin;
+    const int ncb = p.Cin >> 6;
+
+    // ---- B (weights) stager: rows r = 8 * (wave + 8 i) + lane / 8, 16-byte slot lane % 8 holds k-chunk slot ^ ((r >> 1) & 7)
+    const bf16_t* b_ptr[4];
+    {
+        const int lrow = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (wave + 8 * i) * 8 + lrow;
+            b_ptr[i] = p.w + (size_t)r * (p.Cin * 9) + ((slot ^ ((r >> 1) & 7)) << 3);
+        }
+    }
+    const int b_step = (p.dbg_flags & 2) ? 0 : 64;  // (timing experiments only: flag 2 re-reads the same weight tile)
+    auto issue_b = [&](int half, char* buf) {  // half-tile `half` (128 weight rows) of the next K tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((i >> 1) == half) {
+                glds16(b_ptr[i], buf + (wave + 8 * i) * 1024);
+                b_ptr[i] += b_step;
+            }
+    };
+    // ---- A (halo) stager: DMA instruction c of a patch covers halo bytes [1024 c, 1024 c + 1024): 8 pixels x 8 slots. Branch-free: lanes
+    //      outside the image (zero padding), the slack behind pixel 323 and whole "dummy" instructions (c >= 41, or no next channel block)
+    //      read the zero page; a dummy goes to the scratch KiB. One instruction per wave and K tile keeps the vmcnt arithmetic constant.
+    const unsigned long long zero_addr = (unsigned long long)p.zero_page, img_addr = (unsigned long long)in_img;
+    auto issue_halo = [&](int t9, int cbn, int hbn, bool exists) {
+        const int c = wave + 8 * t9;
+        const bool real = c < HALO_INSTR && exists;                      // wave-uniform
+        const int q = c * 8 + (lane >> 3), slot = lane & 7;
+        const int yy = (q * 3641) >> 16, xx = q - yy * 18;              // q / 18, q % 18 for q < 400
+        const int Y = Y0 + yy - 1, X = X0 + xx - 1;
+        const bool ok = real && q < 324 && (unsigned)Y < (unsigned)p.H && (unsigned)X < (unsigned)p.W;
+        const unsigned off = ((unsigned)(Y * p.W + X) * (unsigned)p.Cin + (unsigned)(cbn * 64 + ((slot ^ (xx & 7)) << 3))) * 2u;
+        const unsigned long long src = ok ? img_addr + off : zero_addr;
+        const int dst = real ? OFF_H + hbn * HALO_BYTES + c * 1024 : OFF_SCR;
+        glds16((const void*)src, smem + dst);
+    };
+
+    // fragment read offsets. B as in gemm8 (row l15 of a 16-row block, k-chunk lh / 4 + lh, key (row >> 1) & 7);
+    // A: pixel x' = l15 + kx of the halo row, k-chunk lh (kk = 0) / 4 + lh (kk = 1: address ^ 64), key x' & 7
+    const int bkey = (l15 >> 1) & 7;
+    const int b_off0 = (wc * 32 + l15) * 128 + ((lh ^ bkey) << 4), b_off1 = (wc * 32 + l15) * 128 + (((4 + lh) ^ bkey) << 4);
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+#define BAR() do { PIN(); __builtin_amdgcn_s_barrier(); PIN(); } while (0)
+#define LOAD_A(QM_, VA_)                                                                                              \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+            fa[i][0] = *(const bf16x8*)(smem + (VA_) + ((QM_) * 8 + i) * HROW);                                        \
+            fa[i][1] = *(const bf16x8*)(smem + ((VA_) ^ 64) + ((QM_) * 8 + i) * HROW);                                 \
+        }                                                                                                             \
+    } while (0)
+#define LOAD_B(DST_, QN_, BUF_)                                                                                       \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                               \
+            DST_[j][0] = *(const bf16x8*)(smem + (BUF_) * BTILE + (QN_) * 16384 + j * 2048 + b_off0);                  \
+            DST_[j][1] = *(const bf16x8*)(smem + (BUF_) * BTILE + (QN_) * 16384 + j * 2048 + b_off1);                  \
+        }                                                                                                             \
+    } while (0)
+#define MFMA_Q(QM_, QN_, FB_)                                                                                         \
+    do {                                                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                                \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                              \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+                    acc[QM_][QN_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB_[j][kk], fa[i][kk], acc[QM_][QN_][i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                \
+    } while (0)
+#define WAIT_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory")
+#define WAIT_VM(N_) asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory")
+
+    // ---- prologue: the whole halo patch of channel block 0 (6 instructions per wave: the 41 real ones + dummies), K tile 0 -> even B
+    //      buffer, K tile 1 -> odd B buffer
+    const int T = 9 * ncb;  // K tiles; even (the launcher checks Cin % 128 == 0)
+    char* const bufE = smem;
+    char* const bufO = smem + BTILE;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) issue_halo(j, 0, 0, true);
+    issue_b(0, bufE);
+    issue_b(1, bufE);
+    issue_b(0, bufO);
+    issue_b(1, bufO);
+    WAIT_VM(4);
+    BAR();
+    if (p.dbg_times) t_first = memtime_now();
+    if (grp == 1) BAR();  // stagger: group 1 runs one barrier behind group 0
+
+    // tap state of the K tile being computed: channel block cb (its patch is in halo buffer hb), tap t9 = 3 ky + kx
+    int cb = 0, hb = 0, t9 = 0, ky = 0, kx = 0;
+    auto a_base = [&]() -> int {  // lane address of this K tile's A fragments (row block 0, kk = 0) inside smem
+        const int xh = l15 + ((p.dbg_flags & 4) ? 0 : kx);  // halo column of this lane's pixel for this tap (flag 4: timing experiment)
+        return (xh << 7) + (((lh ^ xh) & 7) << 4) + (OFF_H + hb * HALO_BYTES + (grp * 4 + ky) * HROW);
+    };
+    auto next_tap = [&]() {
+        ++t9;
+        if (++kx == 3) { kx = 0; ++ky; }
+        if (t9 == 9) { t9 = 0; ky = 0; ++cb; hb ^= 1; }
+    };
+    // SKIP: the fp32 skip tile (256 KB, read once, no reuse) is added in the EPILOGUE ((conv + bias) + skip, the order of the generic
+    // epilogue); one more DMA instruction per wave and K tile pulls pixel `8 slot + wave` of it towards the CU during the last 32 K tiles
+    // that still issue (its 1 KiB lands in the scratch KiB and is ignored: an L2 / MALL prefetch), so the epilogue's loads do not start
+    // from HBM with nothing to hide behind.
+    const unsigned long long skip_addr = SKIP ? (unsigned long long)(p.skip + (size_t)img * p.H * p.W * 256) : 0ull;
+    auto issue_prefetch = [&](int slot) {
+        const int pp = slot * 8 + wave;  // tile pixel (row pp >> 4, column pp & 15); slot outside [0, 32): dummy
+        const int Y = Y0 + (pp >> 4), X = X0 + (pp & 15);
+        const bool ok = (unsigned)slot < 32u && Y < p.H && X < p.W;
+        const unsigned off = (unsigned)(Y * p.W + X) * 1024u + (unsigned)(lane << 4);
+        const unsigned long long src = ok ? skip_addr + off : zero_addr;
+        glds16((const void*)src, smem + OFF_SCR);
+    };
+
+    // One iteration = two K tiles (even / odd B buffer), four phases each:
+    //   P1: read B0, A rows 0-7                   -> MFMA(0,0)      P2: read B1 | B0 of tile t+2 (| skip prefetch) -> MFMA(0,1)
+    //   P3: read A rows 8-15 | halo DMA            -> MFMA(1,1)      P4: B1 of tile t+2, vmcnt(5 | 6)              -> MFMA(1,0)
+    // vmcnt at P4: B1, B0 of tile t+2, this K tile's halo instruction (and prefetch) may stay in flight; everything older (tile t+1's
+    // weights, the halo instructions of earlier K tiles) has landed - one phase and >= one workgroup barrier before its first read.
+#define CONV_KTILE(BUFI_, BUFP_, MORE_, KT_)                                                                            \
+    do {                                                                                                              \
+        const int va = a_base();                                                                                      \
+        LOAD_B(fb0, 0, BUFI_); PIN(); LOAD_A(0, va); PIN();                                                           \
+        WAIT_LGKM(8); BAR(); WAIT_LGKM(0); PIN();                                                                     \
+        MFMA_Q(0, 0, fb0); BAR();                                                                                     \
+        LOAD_B(fb1, 1, BUFI_); PIN();                                                                                 \
+        if (MORE_) { issue_b(0, BUFP_); if constexpr (SKIP) issue_prefetch((KT_) - (T - 34)); }                        \
+        BAR(); WAIT_LGKM(0); PIN();                                                                                   \
+        MFMA_Q(0, 1, fb1); BAR();                                                                                     \
+        LOAD_A(1, va); PIN();                                                                                         \
+        if (MORE_ && !(p.dbg_flags & 1)) issue_halo(t9, cb + 1, hb ^ 1, cb + 1 < ncb);                                \
+        BAR(); WAIT_LGKM(0); PIN();                                                                                   \
+        MFMA_Q(1, 1, fb1); BAR();                                                                                     \
+        if (MORE_) { issue_b(1, BUFP_); PIN(); if (p.dbg_flags & 1) WAIT_VM(4); else if constexpr (SKIP) WAIT_VM(6); else WAIT_VM(5); } else { WAIT_VM(0); } \
+        BAR();                                                                                                        \
+        MFMA_Q(1, 0, fb0); BAR();                                                                                     \
+        next_tap();                                                                                                   \
+    } while (0)
+    for (int t = 0; t < T; t += 2) {
+        const bool more = t + 2 < T;  // wave-uniform: the last iteration issues nothing and drains
+        CONV_KTILE(0, bufE, more, t);
+        CONV_KTILE(1, bufO, more, t + 1);
+    }
+#undef CONV_KTILE
+    if (grp == 0) BAR();  // re-join the two groups
+#undef LOAD_A
+#undef LOAD_B
+#undef MFMA_Q
+    if (p.dbg_times) t_loop = memtime_now();
+
+    // ---- epilogue. Lane (l15, lh) of wave (grp, wc) holds, for tile row y = 8 qm + 4 grp + i, pixel x = l15, the four consecutive channels
+    //      n = 128 qn + 32 wc + 16 j + 4 lh .. +3 in acc[qm][qn][i][j].
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const size_t plane_px = (size_t)p.H * p.W;
+    const __amdgpu_buffer_rsrc_t rs_f = plane_rsrc(F32OUT ? p.out_f32 + (size_t)img * plane_px * 256 : nullptr, F32OUT ? plane_px * 1024 : 0);
+    const __amdgpu_buffer_rsrc_t rs_b = plane_rsrc(p.out_bf + (size_t)img * plane_px * 256, plane_px * 512);
+    const bool xok = X0 + l15 < p.W;
+
+    // bilinear x2 (align_corners=True) add of the coarser fusion level (fusion_model.py:151,178): stage the <= 10x10 coarse pixels this
+    // tile touches (fp32, 1 KiB per pixel, 16-byte chunk c of coarse column cx at slot c ^ (cx & 15)) in the ring, then four reads per value
+    int up_x0 = 0, up_x1 = 0, up_py0 = 0, up_pw = 0;
+    float up_lx = 0.0f, up_sy = 0.0f;
+    if constexpr (UP) {
+        up_sy = (float)(p.Hu - 1) / (float)(p.H - 1);
+        const float sxs = (float)(p.Wu - 1) / (float)(p.W - 1);
+        const int ylast = min(Y0 + 15, p.H - 1), xlast = min(X0 + 15, p.W - 1);
+        up_py0 = (int)(up_sy * (float)Y0);
+        const int px0 = (int)(sxs * (float)X0);
+        const int ph = min((int)(up_sy * (float)ylast) + 1, p.Hu - 1) - up_py0 + 1;
+        up_pw = min((int)(sxs * (float)xlast) + 1, p.Wu - 1) - px0 + 1;  // <= UPW (launcher checks the scale)
+        const int xq = min(X0 + l15, p.W - 1);
+        const float sx = sxs * (float)xq;
+        const int x0 = (int)sx, x1 = x0 + (x0 < p.Wu - 1);
+        up_lx = sx - (float)x0;
+        up_x0 = x0 - px0; up_x1 = x1 - px0;
+        __syncthreads();  // every wave is done reading the ring
+        const float* src = p.up_src + (size_t)img * p.Hu * p.Wu * 256;
+        const int npix = ph * up_pw;
+        for (int pp = wave; pp < npix; pp += 8) {
+            const int cy = pp / up_pw, cx = pp - cy * up_pw;
+            glds16(src + ((size_t)(up_py0 + cy) * p.Wu + (px0 + cx)) * 256 + ((lane ^ (cx & 15)) << 2), smem + pp * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // per-channel constants of both column halves are loaded before the first store (a wait placed after a store would also wait for that
+    // store's acknowledgement)
+    f32x4 bias_q[2][2];
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            bias_q[qn][j] = p.bias ? *(const f32x4*)(p.bias + qn * 128 + wc * 32 + j * 16 + 4 * lh) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const __amdgpu_buffer_rsrc_t rs_s = plane_rsrc(SKIP ? p.skip + (size_t)img * plane_px * 256 : nullptr, SKIP ? plane_px * 1024 : 0);
+    // groups g = 2 qm + qn of 8 accumulators (4 tile rows x 2 column blocks); byte offset of (group, i, j) in an fp32 plane
+    auto f32_off = [&](int g, int i, int j) -> unsigned {
+        const int Y = Y0 + (g >> 1) * 8 + grp * 4 + i;
+        return (xok && Y < p.H) ? (unsigned)(Y * p.W + X0 + l15) * 1024u + (unsigned)((g & 1) * 128 + wc * 32 + j * 16 + 4 * lh) * 4u : OOB;
+    };
+    auto load_skip = [&](int g, u32x4 (&dst)[4][2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dst[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_s, f32_off(g, i, j), 0, 0);
+    };
+    // result of group g, in place, in two steps: base(g) = (conv + bias) [+ x2 bilinear of the coarser level] (LDS only - run for all four
+    // groups before the first skip load is issued, so the skip values never compete with the interpolation's registers), then add_skip(g)
+    auto base = [&](int g) {
+        const int qm = g >> 1, qn = g & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[qm][qn][i][j] += bias_q[qn][j];
+        if constexpr (UP) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int yq = min(Y0 + qm * 8 + grp * 4 + i, p.H - 1);
+                const float sy = up_sy * (float)yq;
+                const int y0 = (int)sy, y1 = y0 + (y0 < p.Hu - 1);
+                const float ly = sy - (float)y0, lx = up_lx;
+                const int r0 = (y0 - up_py0) * up_pw, r1 = (y1 - up_py0) * up_pw;
+                const int o00 = (r0 + up_x0) * 1024, o01 = (r0 + up_x1) * 1024, o10 = (r1 + up_x0) * 1024, o11 = (r1 + up_x1) * 1024;
+                const int k0 = up_x0 & 15, k1 = up_x1 & 15;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int ch = qn * 32 + wc * 8 + j * 4 + lh;  // 16-byte chunk of this lane's four channels
+                    const f32x4 v00 = *(const f32x4*)(smem + o00 + ((ch ^ k0) << 4)), v01 = *(const f32x4*)(smem + o01 + ((ch ^ k1) << 4));
+                    const f32x4 v10 = *(const f32x4*)(smem + o10 + ((ch ^ k0) << 4)), v11 = *(const f32x4*)(smem + o11 + ((ch ^ k1) << 4));
+                    acc[qm][qn][i][j] += (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+                }
+                // one row's eight LDS reads at a time: the empty asm pins the two results HERE (without it the arithmetic of all 128 reads
+                // sinks below the last read and every value read is spilled)
+                asm volatile("" : "+v"(acc[qm][qn][i][0]), "+v"(acc[qm][qn][i][1]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto add_skip = [&](int g, const u32x4 (&sk)[4][2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[g >> 1][g & 1][i][j] += __builtin_bit_cast(f32x4, sk[i][j]);
+    };
+    auto store = [&](int g) {
+        const int qm = g >> 1, qn = g & 1;
+        const unsigned colb = (unsigned)(qn * 128 + wc * 32 + (lh & 1) * 16 + (lh >> 1) * 8) * 2u;  // first of the 8 channels this lane stores as bf16
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int Y = Y0 + qm * 8 + grp * 4 + i;
+            const bool ok = xok && Y < p.H;
+            const unsigned pix = (unsigned)(Y * p.W + X0 + l15);
+            f32x4 v[2] = {acc[qm][qn][i][0], acc[qm][qn][i][1]};
+            if constexpr (F32OUT) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rs_f, f32_off(g, i, j), 0, 0);
+            }
+            if constexpr (RELU) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[j][e] = fmaxf(v[j][e], 0.0f);
+            }
+            unsigned hw_[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2) {
+                    const f32x2 pp = {v[j][2 * w2], v[j][2 * w2 + 1]};
+                    hw_[j][w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(pp, bf16x2));
+                }
+            unsigned ph[4];
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2) {
+                auto r = __builtin_amdgcn_permlane16_swap(hw_[0][w2], hw_[1][w2], false, false);
+                ph[w2] = r[0];
+                ph[w2 + 2] = r[1];
+            }
+            // (the bf16 map is always present: no branch around the stores, hipcc would wait for every store's acknowledgement)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{ph[0], ph[1], ph[2], ph[3]}, rs_b, ok ? pix * 512u + colb : OOB, 0, 0);
+        }
+    };
+    if constexpr (SKIP) {
+        // vmcnt retires in order: a wait for loads issued after a store also waits for that store's acknowledgement. So group g+1's loads
+        // are issued BEFORE group g's stores (one group = 8 x 16 bytes per lane in flight; the results are kept in the accumulators)
+        u32x4 sk[4][2];
+        load_skip(0, sk);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) base(g);
+        __builtin_amdgcn_sched_barrier(0);
+        add_skip(0, sk);
+        load_skip(1, sk);
+        store(0);
+        add_skip(1, sk);
+        load_skip(2, sk);
+        store(1);
+        add_skip(2, sk);
+        load_skip(3, sk);
+        store(2);
+        add_skip(3, sk);
+        store(3);
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { base(g); store(g); }
+    }
+    if (p.dbg_times && tid == 0) {
+        const unsigned long long t_issued = memtime_now();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = p.dbg_times + (size_t)blockIdx.x * 6;
+        d[0] = t_start; d[1] = t_first; d[2] = t_loop; d[3] = memtime_now();
+        d[4] = t_issued;
+        d[5] = __builtin_amdgcn_s_getreg(20 << 0 | 0 << 6 | 3 << 11);  // HW_REG_XCC_ID
+    }
+}
+#undef PIN
+#undef BAR
+#undef WAIT_LGKM
+#undef WAIT_VM
+
+template <bool SKIP, bool F32OUT, bool RELU, bool UP>
+int launch_variant(const Conv3hParams& p, hipStream_t stream) {
+    auto kern = conv3h_kernel<SKIP, F32OUT, RELU, UP>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles = p.B * ((p.H + 15) / 16) * ((p.W + 15) / 16);
+    static char prof_name[64] = "";
+    if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "conv3h_kernel<%d, %d, %d, %d>", (int)SKIP, (int)F32OUT, (int)RELU, (int)UP);
+    MdptProfScope prof(prof_name, 2.0 * p.B * p.H * p.W * 256.0 * 9.0 * p.Cin, stream);
+    static const int dbg_flags = getenv("MDPT_CONV3H_DBG") ? atoi(getenv("MDPT_CONV3H_DBG")) : 0;  // timing experiments (wrong results)
+    Conv3hParams q = p;
+    q.dbg_flags = dbg_flags;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS_BYTES, stream, q);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// the combinations the decoder uses (anything else runs the implicit-GEMM path of gemm.hip)
+bool mdpt_conv3h_supported(const Conv3hParams& p) {
+    if (p.B <= 0 || p.H < 2 || p.W < 2 || p.Cin <= 0 || (p.Cin & 127) || !p.in || !p.w || !p.out_bf || !p.zero_page) return false;
+    if ((size_t)p.H * p.W * 1024 >= 0xFFFFFFF0ull) return false;  // 32-bit byte offsets inside one image plane
+    const bool skip = p.skip != nullptr, f32 = p.out_f32 != nullptr, relu = p.relu_bf != 0, up = p.up_src != nullptr;
+    if (up) {
+        // the 16 fine rows / columns of a tile must interpolate from <= UPW coarse ones: floor(15 * scale) + 3 <= UPW
+        if (p.Hu < 1 || p.Wu < 1 || (long)15 * (p.Hu - 1) >= (long)(UPW - 2) * (p.H - 1) || (long)15 * (p.Wu - 1) >= (long)(UPW - 2) * (p.W - 1)) return false;
+        return skip && f32 && relu;
+    }
+    if (!skip && !f32 && relu) return true;
+    if (skip && !f32 && !relu) return true;
+    if (!skip && f32 && relu) return true;
+    return false;
+}
+
+int mdpt_launch_conv3h(const Conv3hParams& p, hipStream_t stream) {
+    if (!mdpt_conv3h_supported(p)) return (int)hipErrorInvalidValue;
+    const bool skip = p.skip != nullptr, f32 = p.out_f32 != nullptr, up = p.up_src != nullptr;
+    if (up) return launch_variant<true, true, true, true>(p, stream);
+    if (!skip && !f32) return launch_variant<false, false, true, false>(p, stream);
+    if (skip && !f32) return launch_variant<true, false, false, false>(p, stream);
+    return launch_variant<false, true, true, false>(p, stream);
+}

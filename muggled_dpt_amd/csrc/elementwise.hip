@@ -292,9 +292,10 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const void* __restrict
             if (nrow < N && kcol < K) v = ld_typed(src, (size_t)nrow * src_ld + src_col0 + kcol, sdt);
             if (row_scale && nrow < N) v *= ld_typed(row_scale, nrow, rdt);
         } else if (kind == MDPT_PACK_CONV3) {
-            // src [N=Cout][K=Cin][3][3]; Kp = 9*Cinp; kcol = tap*Cinp + ci
-            const int cinp = Kp / 9;
-            const int tap = kcol / cinp, ci = kcol - tap * cinp;
+            // src [N=Cout][K=Cin][3][3]; Kp = 9*Cinp (Cinp % 64 == 0); kcol = (cb * 9 + tap) * 64 + c with ci = cb * 64 + c: the nine taps of
+            // a 64-channel block are consecutive K tiles (the halo-staged conv kernel stages a block's input patch once for all of them)
+            const int blk = kcol / 576, rem = kcol - blk * 576;
+            const int tap = rem >> 6, ci = blk * 64 + (rem & 63);
             if (nrow < N && ci < K) v = ld_typed(src, ((size_t)nrow * K + ci) * 9 + tap, sdt);
         } else if (kind == MDPT_PACK_CONV3_KC32) {
             // dst [Kp/8][32][8]: idx = (chunk*32 + n)*8 + e with k = chunk*8 + e = tap*Cinp + ci; src [N=32][K=Cin][3][3]

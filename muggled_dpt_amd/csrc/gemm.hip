@@ -149,7 +149,7 @@ struct Stager {
     const bf16_t* b_ptr[CB];
     ptrdiff_t a_hi_minus_lo, w_lo_minus_hi;
     const bf16_t* conv_plane;
-    int st_pass, st_k0, st_tap, st_ci;
+    int st_pass, st_k0, st_tap, st_ci, st_sub;  // conv K order: 64-channel block (st_ci) outer, tap, then the BK-wide part of the block (st_sub)
 
     __device__ __forceinline__ void init(const GemmParams& p, int m0, int n0, int wave, int lane) {
         const int lrow = lane / CPR, slot = lane % CPR;
@@ -189,7 +189,7 @@ struct Stager {
         a_hi_minus_lo = p.npass == 3 ? p.A_hi - p.A_lo : 0;
         w_lo_minus_hi = p.npass == 3 ? p.W_lo - p.W_hi : 0;
         conv_plane = A0;
-        st_pass = st_k0 = st_tap = st_ci = 0;
+        st_pass = st_k0 = st_tap = st_ci = st_sub = 0;
     }
 
     // issue this wave's NLOAD LDS-DMA instructions for the next slab into the ring slot at `slab_base`, then advance
@@ -203,7 +203,7 @@ struct Stager {
                 const int ky = (st_tap * 11) >> 5, kx = st_tap - 3 * ky;
                 const int iy = a_y[i] + ky, ix = a_x[i] + kx;
                 const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-                src = ok ? conv_plane + ((size_t)(a_pix[i] + iy * p.Wi + ix) * p.Cin + st_ci + a_ko[i]) : p.zero_page + a_ko[i];
+                src = ok ? conv_plane + ((size_t)(a_pix[i] + iy * p.Wi + ix) * p.Cin + st_ci + st_sub + a_ko[i]) : p.zero_page + a_ko[i];
             } else {
                 src = a_ptr[i];
                 a_ptr[i] += BK;
@@ -216,12 +216,15 @@ struct Stager {
             b_ptr[i] += BK;
         }
         st_k0 += BK;
-        if (AMODE == MDPT_A_CONV3) {
-            st_ci += BK;
-            if (st_ci == p.Cin) { st_ci = 0; ++st_tap; }
+        if (AMODE == MDPT_A_CONV3) {  // k = (cb * 9 + tap) * 64 + c: the nine taps of a 64-channel block are consecutive K tiles
+            st_sub += BK;
+            if (st_sub == 64) {
+                st_sub = 0;
+                if (++st_tap == 9) { st_tap = 0; st_ci += 64; }
+            }
         }
         if (st_k0 == p.K) {  // next pass: rewind K and switch operand planes
-            st_k0 = 0; st_tap = 0; st_ci = 0;
+            st_k0 = 0; st_tap = 0; st_ci = 0; st_sub = 0;
             const ptrdiff_t da = (st_pass == 0 ? a_hi_minus_lo : 0) - p.K;
             const ptrdiff_t dw = (st_pass == 0 ? w_lo_minus_hi : -w_lo_minus_hi) - p.K;
             if (st_pass == 0) conv_plane = p.A_hi;
@@ -360,7 +363,6 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const float*
                     for (int e = 0; e < 4; ++e) { v[0][e] = fmaxf(v[0][e], 0.0f); v[1][e] = fmaxf(v[1][e], 0.0f); }
                 }
                 if (p.gamma) { v[0] *= gam[0]; v[1] *= gam[1]; }
-                if (p.resid && !p.acc_init) { v[0] += res[pr][0]; v[1] += res[pr][1]; }
                 if (p.up_src) {
                     // + bilinear x2 (align_corners=True) of the previous fusion level (fusion_model.py:151,178)
                     const int hw = p.Ho * p.Wo;
@@ -381,6 +383,8 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const float*
                         v[q] += (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
                     }
                 }
+                // order: ((acc + bias) [* gamma] [+ up]) + resid - the halo-staged conv kernel (conv3h.hip) applies the same one
+                if (p.resid && !p.acc_init) { v[0] += res[pr][0]; v[1] += res[pr][1]; }
                 const size_t o = (size_t)m * p.ldc + n;
                 if (p.out_f32) { *(f32x4*)(p.out_f32 + o) = v[0]; *(f32x4*)(p.out_f32 + o + 4) = v[1]; }
                 if (p.out_hi) {
@@ -511,8 +515,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
         // residual GEMMs (out = resid + A W^T + bias, in place): the accumulators START at the residual, the epilogue adds the bias and
         // stores - the same order of operations in every tile variant (see gemm8_body's RI form, where this hides the residual read
         // under the main loop). acc[i][j][r] = C[32 i + (r&3) + 8 (r>>2) + 4 half][32 j + (lane&31)]; out-of-range elements read 0.
+        // descriptor over THIS tile's rows (base = row m0, byte offsets inside the tile: < BM * ldr * 4, so no 32-bit wrap however large M is)
         const int mw = m0 + (wave / WN) * WTM, nw = n0 + (wave % WN) * WTN;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid), 0, (int)(unsigned)((size_t)p.M * p.ldr * 4 < 0xFFFFFFF0ull ? (size_t)p.M * p.ldr * 4 : 0xFFFFFFF0ull), 0x00020000);
+        const size_t tile_bytes = (size_t)(p.M - m0 < BM ? p.M - m0 : BM) * p.ldr * 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid + (size_t)m0 * p.ldr), 0, (int)(unsigned)(tile_bytes < 0xFFFFFFF0ull ? tile_bytes : 0xFFFFFFF0ull), 0x00020000);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const unsigned off = (n < p.N && m < p.M) ? ((unsigned)m * (unsigned)p.ldr + (unsigned)n) * 4u : 0xFFFFFFF0u;
+                    const unsigned off = (n < p.N && m < p.M) ? ((unsigned)(m - m0) * (unsigned)p.ldr + (unsigned)n) * 4u : 0xFFFFFFF0u;
                     acc[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
                 }
             }
@@ -1005,9 +1011,8 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
         }
         if (H == 1) {  // both halves of this K tile are on their way: advance K (and the bf16x3 operand planes at roll-over)
             a_k0 += 64;
-            if (AMODE == MDPT_A_CONV3) {
-                a_ci += 64;
-                if (a_ci == p.Cin) { a_ci = 0; ++a_tap; }
+            if (AMODE == MDPT_A_CONV3) {  // tap-inner K order (see Stager)
+                if (++a_tap == 9) { a_tap = 0; a_ci += 64; }
             }
             if (a_k0 == p.K) {
                 a_k0 = 0; a_tap = 0; a_ci = 0;

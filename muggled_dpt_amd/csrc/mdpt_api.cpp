@@ -625,6 +625,9 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
     return 0;
 }
 
+int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int sw, const float* bias, const float* skip, const float* up_src,
+                    int Hu, int Wu, float* out_f32, Planes out, int relu_bf16);
+
 // ---- stage: reassemble
 int run_reassemble(const Ctx& c) {
     const mdpt_handle* h = c.h;
@@ -684,28 +687,51 @@ int run_reassemble(const Ctx& c) {
             src = d; sh = gh / 2; sw = gw / 2;
         }
         {   // 3x3 projection to the fusion width (no bias): fp32 copy (skip path) + ReLU'd bf16 (next conv input)
-            Planes rb = c.pl(p.r_bf[i]);
-            GemmParams g = base_params(c, h->M(n + ".fuse_proj.weight"), src, p.B * sh * sw, hp);
-            as_conv(g, sh, sw, hp, sh, sw, 1);
-            g.out_f32 = c.at<float>(p.r_f32[i]);
-            g.out_hi = rb.hi; g.out_lo = rb.lo; g.relu_bf16 = 1; g.ldc = h->Cp;
-            CHK(mdpt_launch_gemm(g, c.s));
+            CHK(conv3_to_fusion(c, h->M(n + ".fuse_proj.weight"), src, hp, sh, sw, nullptr, nullptr, nullptr, 0, 0, c.at<float>(p.r_f32[i]),
+                                c.pl(p.r_bf[i]), 1));
         }
     }
     return 0;
+}
+
+// Halo-staged conv kernel (conv3h.hip) for a 3x3 stride-1 conv to the 256-wide fusion width, used for big launches; small ones run the
+// implicit-GEMM kernels of gemm.hip. Both walk K in the same order and apply the same epilogue expressions (((conv + bias) + up) + skip),
+// so one image's bits do not depend on the batch it is part of. Partial 16x16 tiles may waste at most 10 % of the MFMA work (72x72: 25
+// tiles for 20.25 -> implicit GEMM).
+bool conv3h_shape_ok(const mdpt_handle* h, int H, int W, int Cin) {
+    if (h->x3 || h->Cp != 256 || (Cin & 127) || H < 2 || W < 2) return false;
+    const long tile_px = (long)((H + 15) / 16) * ((W + 15) / 16) * 256, px = (long)H * W;
+    return tile_px * 10 <= px * 11;
+}
+
+// one 3x3 stride-1 conv Cin -> Cp: out = [skip +] conv(in) [+ bias] [+ up2(up_src)] -> fp32 map and / or bf16 planes (ReLU'd if relu_bf16)
+int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int sw, const float* bias, const float* skip, const float* up_src,
+                    int Hu, int Wu, float* out_f32, Planes out, int relu_bf16) {
+    const mdpt_handle* h = c.h;
+    const bool eligible = conv3h_shape_ok(h, sh, sw, Cin);
+    if (eligible && h->gemm_tile == MDPT_TILE_AUTO) {
+        Conv3hParams q;
+        memset(&q, 0, sizeof(q));
+        q.in = in.hi; q.w = w.hi; q.bias = bias; q.skip = skip; q.up_src = up_src; q.Hu = Hu; q.Wu = Wu;
+        q.out_f32 = out_f32; q.out_bf = out.hi; q.relu_bf = relu_bf16;
+        q.B = c.p.B; q.H = sh; q.W = sw; q.Cin = Cin; q.zero_page = h->zero_page;
+        const long tiles256 = ((long)c.p.B * sh * sw + 255) / 256;
+        if (tiles256 >= (c.split ? 24 : 140) && mdpt_conv3h_supported(q)) return mdpt_launch_conv3h(q, c.s);
+    }
+    GemmParams g = base_params(c, w, in, c.p.B * sh * sw, Cin);
+    as_conv(g, sh, sw, Cin, sh, sw, 1);
+    g.bias = bias;
+    g.resid = skip; g.ldr = h->Cp;
+    g.up_src = up_src; g.Hu = Hu; g.Wu = Wu;
+    g.out_f32 = out_f32; g.out_hi = out.hi; g.out_lo = out.lo; g.relu_bf16 = relu_bf16; g.ldc = h->Cp;
+    return mdpt_launch_gemm(g, c.s);
 }
 
 // one 3x3 conv C->C of a residual conv unit at level `lv` (spatial sh x sw)
 int rcu_conv(const Ctx& c, const std::string& wname, Planes in, int sh, int sw, const float* skip, const float* up_src, int Hu, int Wu,
              float* out_f32, Planes out, int relu_bf16) {
     const mdpt_handle* h = c.h;
-    GemmParams g = base_params(c, h->M(wname + ".weight"), in, c.p.B * sh * sw, h->Cp);
-    as_conv(g, sh, sw, h->Cp, sh, sw, 1);
-    g.bias = h->V(wname + ".bias");
-    g.resid = skip; g.ldr = h->Cp;
-    g.up_src = up_src; g.Hu = Hu; g.Wu = Wu;
-    g.out_f32 = out_f32; g.out_hi = out.hi; g.out_lo = out.lo; g.relu_bf16 = relu_bf16; g.ldc = h->Cp;
-    return mdpt_launch_gemm(g, c.s);
+    return conv3_to_fusion(c, h->M(wname + ".weight"), in, h->Cp, sh, sw, h->V(wname + ".bias"), skip, up_src, Hu, Wu, out_f32, out, relu_bf16);
 }
 
 // ---- stage: fusion. Level index i: 3 = coarsest (gh/2), 0 = finest (4gh). Output: flo[0] (fp32, 4gh x 4gw, before the
@@ -1449,6 +1475,43 @@ int mdpt_debug_gemm(const void* a_bf16, const void* w_bf16, void* out_f32, void*
         if (!out_f32 || !out_bf16) return fail(MDPT_E_INVALID, "residual mode needs both output buffers");
         g.bias = (const float*)out_bf16; g.resid = (const float*)out_f32; g.out_hi = nullptr; g.acc_init = 1;
     }
+    for (int i = 0; i < iters; ++i) CHK(mdpt_launch_gemm(g, (hipStream_t)stream));
+    return 0;
+}
+
+// ---- test/bench hook: one 3x3 stride-1 conv Cin -> 256 on caller-provided operands (bf16 NHWC input, MDPT_PACK_CONV3 weights [256][9 Cin]):
+//      path 0 = the implicit-GEMM kernels of gemm.hip (tile = MDPT_TILE_*), path 1 = the halo-staged kernel of conv3h.hip.
+//      out = [skip +] conv + [bias] [+ up2(up)] -> out_f32 (optional) and out_bf16 (ReLU'd if relu_bf16); both paths use the same arithmetic
+int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void* bias_f32, const void* skip_f32, const void* up_f32, int32_t Hu,
+                     int32_t Wu, void* out_f32, void* out_bf16, int32_t relu_bf16, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t path,
+                     int32_t tile, int32_t iters, void* stream, void* dbg_times) {
+    if (!in_bf16 || !w_packed_bf16 || !out_bf16) return fail(MDPT_E_INVALID, "null argument");
+    static bf16_t* zero_page = nullptr;  // test hook only: allocated once, never freed
+    if (!zero_page) {
+        if (hipMalloc((void**)&zero_page, 256) != hipSuccess || hipMemset(zero_page, 0, 256) != hipSuccess) return fail(MDPT_E_STATE, "zero page allocation failed");
+    }
+    if (path == 1) {
+        Conv3hParams q;
+        memset(&q, 0, sizeof(q));
+        q.in = (const bf16_t*)in_bf16; q.w = (const bf16_t*)w_packed_bf16; q.bias = (const float*)bias_f32; q.skip = (const float*)skip_f32;
+        q.up_src = (const float*)up_f32; q.Hu = Hu; q.Wu = Wu; q.out_f32 = (float*)out_f32; q.out_bf = (bf16_t*)out_bf16; q.relu_bf = relu_bf16;
+        q.B = B; q.H = H; q.W = W; q.Cin = Cin; q.zero_page = zero_page;
+        q.dbg_times = (unsigned long long*)dbg_times;
+        if (!mdpt_conv3h_supported(q)) return fail(MDPT_E_UNSUPPORTED, "conv3h does not cover this combination");
+        for (int i = 0; i < iters; ++i) CHK(mdpt_launch_conv3h(q, (hipStream_t)stream));
+        return 0;
+    }
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.A_hi = (const bf16_t*)in_bf16; g.W_hi = (const bf16_t*)w_packed_bf16;
+    g.M = B * H * W; g.N = 256; g.K = 9 * Cin; g.lda = Cin; g.npass = 1;
+    g.zero_page = zero_page;
+    g.amode = MDPT_A_CONV3; g.ekind = MDPT_E_GENERIC; g.tile = tile;
+    g.Hi = H; g.Wi = W; g.Cin = Cin; g.Ho = H; g.Wo = W; g.cstride = 1;
+    g.bias = (const float*)bias_f32; g.resid = (const float*)skip_f32; g.ldr = 256;
+    g.up_src = (const float*)up_f32; g.Hu = Hu; g.Wu = Wu;
+    g.out_f32 = (float*)out_f32; g.out_hi = (bf16_t*)out_bf16; g.relu_bf16 = relu_bf16; g.ldc = 256;
+    g.dbg_times = (unsigned long long*)dbg_times;
     for (int i = 0; i < iters; ++i) CHK(mdpt_launch_gemm(g, (hipStream_t)stream));
     return 0;
 }

@@ -57,6 +57,28 @@ struct GemmParams {
 int mdpt_launch_gemm(const GemmParams& p, hipStream_t stream);   // returns hipError_t as int
 
 // ------------------------------------------------------------------------------------------------
+// halo-staged 3x3 convolution, stride 1, pad 1, Cout = 256 (conv3h.hip): the 256-channel convs of the DPT decoder at large batch.
+//   out = ((conv3x3(in) [+ bias]) [+ x2 bilinear (align_corners) of up_src]) [+ skip]  ->  out_f32 (optional) and out_bf (ReLU'd if relu_bf)
+// Same K order (MDPT_PACK_CONV3 weights) and epilogue arithmetic as the MDPT_A_CONV3 path of mdpt_launch_gemm (generic epilogue, resid = skip).
+// ------------------------------------------------------------------------------------------------
+struct Conv3hParams {
+    const bf16_t* in;          // NHWC [B, H, W, Cin] bf16, Cin % 128 == 0
+    const bf16_t* w;           // [256][9 * Cin] bf16, MDPT_PACK_CONV3 order
+    const float* bias;         // [256] or null
+    const float* skip;         // fp32 NHWC [B, H, W, 256] or null
+    const float* up_src; int Hu, Wu;  // fp32 NHWC [B, Hu, Wu, 256] or null
+    float* out_f32;            // fp32 NHWC [B, H, W, 256] or null
+    bf16_t* out_bf;            // bf16 NHWC [B, H, W, 256]
+    int relu_bf;
+    int B, H, W, Cin;
+    const bf16_t* zero_page;   // >= 256 B of zeros
+    unsigned long long* dbg_times;  // test hook: per-workgroup s_memtime stamps [start, first barrier, loop done, stores acknowledged, stores issued, XCC id]
+    int dbg_flags;                  // set by the launcher from MDPT_CONV3H_DBG (timing experiments that skip parts of the loop; results are wrong)
+};
+bool mdpt_conv3h_supported(const Conv3hParams& p);
+int mdpt_launch_conv3h(const Conv3hParams& p, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
 // fused multi-head attention (head dim 64), Q/K head-major [B,H,npad,64], Vt [B,H,64,npadv]
 // ------------------------------------------------------------------------------------------------
 struct AttnParams {
@@ -101,7 +123,7 @@ int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float*
                          int Wo, int C, hipStream_t stream);
 // weight repack: source (fp32 / bf16 / fp16: src_dtype) in PyTorch layout -> bf16 hi (+lo) [Np][Kp] rows, zero padded. Layout kinds:
 enum { MDPT_PACK_LINEAR = 0,   // src [N][K]
-       MDPT_PACK_CONV3 = 1,    // src [Cout][Cin][3][3] -> k = (ky*3+kx)*Cinp + ci
+       MDPT_PACK_CONV3 = 1,    // src [Cout][Cin][3][3] -> k = (cb*9 + ky*3+kx)*64 + c, ci = cb*64 + c (64-channel block outer, tap inner)
        MDPT_PACK_CONVT = 2,    // src [Cin][Cout][k][k] -> row n = (ky*k+kx)*Coutp + co, col ci
        MDPT_PACK_CONV3_KC32 = 3 };  // src [32][Cin][3][3] -> [Kp/8][32][8] (k = (ky*3+kx)*Cinp + ci in 8-element chunks, Np = 32): the
                                     // LDS image of head_tail_kernel, where a 32-lane fragment read is 512 consecutive bytes

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -12,7 +13,8 @@
 namespace {
 struct Rec { int slot; double flops; hipEvent_t a, b; };
 struct Slot { std::string name; };
-bool g_on = false;
+std::atomic<bool> g_on{false};
+int g_gen = 0;  // bumped by every mdpt_profile_enable(): a scope opened before a reset must not close a record of the new table
 std::vector<Rec> g_recs;
 std::vector<Slot> g_slots;
 std::map<std::string, int> g_slot_index;
@@ -30,11 +32,11 @@ hipEvent_t take_event() {
 }
 }  // namespace
 
-bool mdpt_prof_on() { return g_on; }
+bool mdpt_prof_on() { return g_on.load(std::memory_order_relaxed); }
 
 int mdpt_prof_begin(const char* name, double flops, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_mu);
-    if (!g_on) return -1;
+    if (!g_on.load(std::memory_order_relaxed)) return -1;
     auto it = g_slot_index.find(name);
     int slot;
     if (it == g_slot_index.end()) {
@@ -48,17 +50,20 @@ int mdpt_prof_begin(const char* name, double flops, hipStream_t stream) {
     r.slot = slot; r.flops = flops; r.a = take_event(); r.b = take_event();
     hipEventRecord(r.a, stream);
     g_recs.push_back(r);
-    return (int)g_recs.size() - 1;
+    return ((g_gen & 0x7F) << 24) | ((int)g_recs.size() - 1);  // (generation, index): see mdpt_prof_end
 }
 
 void mdpt_prof_end(int record, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_mu);
-    if (record >= 0 && record < (int)g_recs.size()) hipEventRecord(g_recs[record].b, stream);
+    if (record < 0 || ((record >> 24) & 0x7F) != (g_gen & 0x7F)) return;  // profiling was reset while this scope was open
+    const int idx = record & 0xFFFFFF;
+    if (idx < (int)g_recs.size()) hipEventRecord(g_recs[idx].b, stream);
 }
 
 extern "C" int mdpt_profile_enable(int on) {
     std::lock_guard<std::mutex> lock(g_mu);
-    g_on = on != 0;
+    g_on.store(on != 0, std::memory_order_relaxed);
+    ++g_gen;
     g_recs.clear();
     g_pool_next = 0;
     return 0;

@@ -3,7 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-int mdpt_prof_begin(const char* name, double flops, hipStream_t stream);  // returns the record index of this scope (-1: profiling off)
+int mdpt_prof_begin(const char* name, double flops, hipStream_t stream);  // returns this scope's record handle = (profiling generation, index); -1: profiling off
 void mdpt_prof_end(int record, hipStream_t stream);
 bool mdpt_prof_on();
 

@@ -469,7 +469,6 @@ class DPTModel(nn.Module):
     # ---- engine lifetime
     def _invalidate(self):
         self.__dict__["_engine_obj"] = None
-        self.__dict__["_plist"] = None
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -477,10 +476,13 @@ class DPTModel(nn.Module):
         return out
 
     def _param_versions(self) -> tuple:
-        plist = self.__dict__.get("_plist")
-        if plist is None:
-            plist = self.__dict__["_plist"] = list(self.parameters())
-        return tuple(p._version for p in plist)
+        """(identity, version) of every parameter. Inference tensors (a model built / loaded / moved under torch.inference_mode()) have
+        no version counter - reading it raises - and cannot be modified in place either, so identity + storage address stand in for it.
+        The parameter list itself is re-collected on every call: a Parameter replaced by attribute assignment must force a re-pack."""
+        out = []
+        for p in self.parameters():
+            out.append((id(p), p.data_ptr()) if p.is_inference() else (id(p), p._version))
+        return tuple(out)
 
     def _get_engine(self) -> _Engine:
         """The engine holds a PACKED SNAPSHOT of the weights (bf16 hi[/lo] panels, layer scales folded in). It is rebuilt when the model

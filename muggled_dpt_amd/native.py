@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(CSRC, "libmdpt.so")
-SOURCES = ("gemm.hip", "attention.hip", "elementwise.hip", "swin.hip", "postprocess.hip", "head.hip", "mdpt_api.cpp", "mdpt_prof.cpp")
+SOURCES = ("gemm.hip", "conv3h.hip", "attention.hip", "elementwise.hip", "swin.hip", "postprocess.hip", "head.hip", "mdpt_api.cpp", "mdpt_prof.cpp")
 HEADERS = ("mdpt_kernels.h", "mdpt_prof.h", "mdpt_swin.inc", "ln_row.h", os.path.join(REPO, "include", "mdpt.h"))
 
 ABI_VERSION = 3  # MDPT_ABI_VERSION in include/mdpt.h
@@ -153,6 +153,7 @@ SYMBOLS = {
     "mdpt_set_batch_split": (ctypes.c_int, [_VP, _I]),
     "mdpt_set_latency_mode": (ctypes.c_int, [_VP, _I]),
     "mdpt_debug_gemm": (ctypes.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _VP]),
+    "mdpt_debug_conv3": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP]),
     "mdpt_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "mdpt_profile_report": (ctypes.c_int, [ctypes.c_char_p, _SZ]),
     "mdpt_debug_set_stop": (ctypes.c_int, [_VP, _I, _I]),

@@ -151,3 +151,31 @@ def test_enable_optimizations_false_adds_hookable_softmax_modules_only():
     orc.image_encoder(w, cfg, tokens, grid, capture=cap)
     assert len(cap) == cfg["num_blocks"] and tuple(cap[0].shape) == (1, cfg["num_heads"], 17, 17)
     assert float((cap[-1].sum(-1) - 1).abs().max()) < 1e-5
+
+
+def test_parameter_snapshot_key_works_for_inference_tensors_and_sees_replaced_parameters():
+    """reading p._version of an inference tensor raises, so a model built under torch.inference_mode() failed on
+    every call; and a Parameter replaced by attribute assignment kept the old packed snapshot alive."""
+    import torch
+    import muggled_dpt_amd as mda
+    from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict
+    osd = make_synthetic_original_state_dict("tiny", 0)
+    with torch.inference_mode():
+        _, model = mda.make_depthanythingv2_dpt_from_original_state_dict(osd)
+        model = model.to(torch.bfloat16)
+    assert any(p.is_inference() for p in model.parameters())
+    key0 = model._param_versions()  # must not raise
+    assert key0 == model._param_versions()
+    _, m2 = mda.make_depthanythingv2_dpt_from_original_state_dict(osd)
+    k_before = m2._param_versions()
+    with torch.no_grad():
+        next(m2.parameters()).mul_(1.0)  # in-place edit: version counter moves
+    assert m2._param_versions() != k_before
+    k_before = m2._param_versions()
+    name, old = next(iter(m2.named_parameters()))
+    mod = m2
+    *path, leaf = name.split(".")
+    for part in path:
+        mod = getattr(mod, part)
+    setattr(mod, leaf, torch.nn.Parameter(old.detach().clone()))  # replaced Parameter object: identity moves
+    assert m2._param_versions() != k_before

@@ -1,0 +1,90 @@
+"""Halo-staged 3x3 conv kernel (csrc/conv3h.hip) vs a CPU fp32 conv on the same bf16-rounded operands, and bit-for-bit vs the
+implicit-GEMM kernels of gemm.hip in every tile variant (a tile-rule change between batch sizes must not change a bit).
+Reference ops: nn.Conv2d(C, C, 3, padding=1) of ResidualConv2D / the fusion blocks, + skip, + x2 bilinear (align_corners=True) of the
+previous level (v2_depthanything/fusion_model.py:148-154,178-182,210-220)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _pack(w):  # [256][Cin][3][3] fp32 -> [256][9 Cin], k = (cb * 9 + ky * 3 + kx) * 64 + c  (MDPT_PACK_CONV3)
+    n, cin = w.shape[:2]
+    return w.view(n, cin // 64, 64, 3, 3).permute(0, 1, 3, 4, 2).reshape(n, 9 * cin).contiguous()
+
+
+def _run(lib, native, path, tile, x, wp, bias, skip, up, want_f32, relu, dbg=None):
+    B, H, W, Cin = x.shape
+    out_bf = torch.full((B, H, W, 256), float("nan"), device="cuda", dtype=torch.bfloat16)
+    out_f32 = torch.full((B, H, W, 256), float("nan"), device="cuda", dtype=torch.float32) if want_f32 else None
+    stream = torch.cuda.current_stream().cuda_stream
+    native.check(lib, lib.mdpt_debug_conv3(x.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                           skip.data_ptr() if skip is not None else None, up.data_ptr() if up is not None else None,
+                                           up.shape[1] if up is not None else 0, up.shape[2] if up is not None else 0,
+                                           out_f32.data_ptr() if want_f32 else None, out_bf.data_ptr(), int(relu), B, H, W, Cin, path, tile, 1, stream,
+                                           dbg.data_ptr() if dbg is not None else None))
+    torch.cuda.synchronize()
+    return out_f32, out_bf
+
+
+# (skip, fp32 out, relu on bf16, upsample add): the four combinations the decoder uses
+VARIANTS = [(False, False, True, False), (True, False, False, False), (False, True, True, False), (True, True, True, True)]
+SHAPES = [(2, 32, 32, 128), (1, 48, 40, 256), (3, 16, 16, 128), (1, 18, 34, 128)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_conv3h_vs_cpu_conv_and_bitwise_vs_implicit_gemm(shape, variant):
+    from muggled_dpt_amd import native
+    lib = native.load()
+    B, H, W, Cin = shape
+    has_skip, want_f32, relu, has_up = variant
+    if has_up and (H % 2 or W % 2):
+        pytest.skip("the x2 prior needs even sizes")
+    g = torch.Generator().manual_seed(1000 * H + W + Cin + 7 * int(has_skip) + 13 * int(has_up))
+    x = (torch.randn(B, H, W, Cin, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(256, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).to(torch.bfloat16)
+    bias = torch.randn(256, generator=g)
+    skip = torch.randn(B, H, W, 256, generator=g) if has_skip else None
+    up = torch.randn(B, H // 2, W // 2, 256, generator=g) if has_up else None
+    # CPU reference in fp64 on the same bf16 operands
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), padding=1)
+    if has_skip:
+        ref = ref + skip.double().permute(0, 3, 1, 2)
+    if has_up:
+        ref = ref + F.interpolate(up.double().permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=True)
+    ref = ref.permute(0, 2, 3, 1)
+    ref_bf = ref.clamp_min(0) if relu else ref
+
+    xd, wp, bd = x.cuda(), _pack(w.float()).to(torch.bfloat16).cuda(), bias.cuda()
+    sd = skip.cuda() if has_skip else None
+    ud = up.cuda() if has_up else None
+    o32, obf = _run(lib, native, 1, 0, xd, wp, bd, sd, ud, want_f32, relu)
+    scale = float(ref.abs().max())
+    if want_f32:
+        err = float((o32.double().cpu() - ref).abs().max()) / scale
+        assert err < 2e-5, f"fp32 output: rel err {err:.3e}"
+    err_bf = float((obf.double().cpu() - ref_bf).abs().max()) / scale
+    assert err_bf < 6e-3, f"bf16 output: rel err {err_bf:.3e}"  # bf16 rounding of the result (2^-9 of the largest value)
+    # bit-for-bit vs the implicit-GEMM kernels: 64x64 and 128x128 lockstep tiles, the lockstep 256x256 tile, the automatic rule
+    for tile in (6, 1, 2, 0):
+        r32, rbf = _run(lib, native, 0, tile, xd, wp, bd, sd, ud, want_f32, relu)
+        assert torch.equal(rbf.view(torch.int16), obf.view(torch.int16)), f"bf16 output differs from implicit GEMM tile {tile}"
+        if want_f32:
+            assert torch.equal(r32.view(torch.int32), o32.view(torch.int32)), f"fp32 output differs from implicit GEMM tile {tile}"
+
+
+def test_conv3h_is_deterministic_and_batch_independent():
+    from muggled_dpt_amd import native
+    lib = native.load()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 32, 48, 128, generator=g).to(torch.bfloat16).cuda()
+    wp = _pack(torch.randn(256, 128, 3, 3, generator=g) / 30.0).to(torch.bfloat16).cuda()
+    bias = torch.randn(256, generator=g).cuda()
+    skip = torch.randn(6, 32, 48, 256, generator=g).cuda()
+    _, full = _run(lib, native, 1, 0, x, wp, bias, skip, None, False, False)
+    _, again = _run(lib, native, 1, 0, x, wp, bias, skip, None, False, False)
+    assert torch.equal(full.view(torch.int16), again.view(torch.int16))
+    _, one = _run(lib, native, 1, 0, x[4:5].contiguous(), wp, bias, skip[4:5].contiguous(), None, False, False)
+    assert torch.equal(full[4:5].view(torch.int16), one.view(torch.int16))

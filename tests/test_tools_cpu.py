@@ -44,3 +44,19 @@ def test_summarize_parity_groups_by_file_worst_first(tmp_path):
     text = out.read_text()
     assert text.index("test_x[dtype1-0.02]") < text.index("test_x[dtype0-0.0001]") < text.index("### tests/test_b.py")
     assert "| `test_y` | 0.004 |" in text
+
+
+def test_every_probe_and_tool_script_compiles_and_resolves_its_repo_imports():
+    """two probes still imported a module from its old location. Byte-compile every script under tools/ and check that
+    every `from tests...` / `from tools...` / `from muggled_dpt_amd...` import names a module that exists in the repo."""
+    import ast, glob, importlib.util, os, py_compile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scripts = sorted(glob.glob(os.path.join(repo, "tools", "*.py")) + glob.glob(os.path.join(repo, "tools", "probes", "*.py")))
+    assert scripts
+    for path in scripts:
+        py_compile.compile(path, doraise=True)
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom) and node.module and node.module.split(".")[0] in ("tests", "tools", "muggled_dpt_amd", "oracle"):
+                rel = os.path.join(repo, *node.module.split("."))
+                assert os.path.exists(rel + ".py") or os.path.isdir(rel), f"{os.path.relpath(path, repo)} imports missing module {node.module}"

@@ -6,7 +6,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, REPO)
 from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict, native
 from tests.helpers import synthetic_model
-from tests.gpu_diagnose import dbg_read, set_stop
+from tools.probes.gpu_diagnose import dbg_read, set_stop
 
 name, B, S = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 dtype = torch.bfloat16 if len(sys.argv) < 5 or sys.argv[4] == "bf16" else torch.float32

@@ -6,7 +6,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, REPO)
 from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
 from tests.helpers import synthetic_model
-from tests.gpu_diagnose import dbg_read
+from tools.probes.gpu_diagnose import dbg_read
 
 name, B, S = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 osd, cfg, w = synthetic_model(name, 0)
