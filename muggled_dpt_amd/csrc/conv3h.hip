@@ -92,46 +92,60 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     const bf16_t* const in_img = p.in + (size_t)img * p.H * p.W * p.Cin;
     const int ncb = p.Cin >> 6;
 
-    // ---- B (weights) stager: rows r = 8 * (wave + 8 i) + lane / 8, 16-byte slot lane % 8 holds k-chunk slot ^ ((r >> 1) & 7)
-    const bf16_t* b_ptr[4];
-    {
-        const int lrow = lane >> 3, slot = lane & 7;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (wave + 8 * i) * 8 + lrow;
-            b_ptr[i] = p.w + (size_t)r * (p.Cin * 9) + ((slot ^ ((r >> 1) & 7)) << 3);
-        }
-    }
-    const int b_step = (p.dbg_flags & 2) ? 0 : 64;  // (timing experiments only: flag 2 re-reads the same weight tile)
-    auto issue_b = [&](int half, char* buf) {  // half-tile `half` (128 weight rows) of the next K tile
+    // ---- operand staging: LDS-DMA through BUFFER descriptors (buffer_load_dwordx4 ... offen lds). The per-lane byte offsets are
+    //      constants of the tile, the position along K is a scalar offset, and a lane whose offset fails the descriptor's bounds check
+    //      gets ZEROS written to LDS (tools/probes/buffer_lds_oob.hip): conv zero padding, the slack behind halo pixel 323 and dummy
+    //      instructions need no zero page, no 64-bit pointer arithmetic and no selects inside the loop.
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int Kw = p.Cin * 9;
+    const __amdgpu_buffer_rsrc_t rs_w = plane_rsrc(p.w, (size_t)256 * Kw * 2);
+    const __amdgpu_buffer_rsrc_t rs_in = plane_rsrc(in_img, (size_t)p.H * p.W * p.Cin * 2);
+    // B (weights): DMA instruction i of a wave stages rows r = 8 * (wave + 8 i) + lane / 8 = r0 + 64 i; 16-byte slot lane % 8 holds k-chunk
+    // slot ^ ((r >> 1) & 7) (the key is the same for all four i). One lane constant; (K tile kt, i) enter through the scalar offset.
+    const unsigned b_voff = (unsigned)((wave * 8 + (lane >> 3)) * Kw + (((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)) << 3)) * 2u;
+    auto issue_b = [&](int half, int buf, int kt) {  // half-tile `half` (128 weight rows) of K tile kt -> B buffer `buf`
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if ((i >> 1) == half) {
-                glds16(b_ptr[i], buf + (wave + 8 * i) * 1024);
-                b_ptr[i] += b_step;
-            }
+            if ((i >> 1) == half)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(smem + buf * BTILE + (wave + 8 * i) * 1024), 16, b_voff, kt * 128 + i * 128 * Kw, 0, 0);
     };
-    // ---- A (halo) stager: DMA instruction c of a patch covers halo bytes [1024 c, 1024 c + 1024): 8 pixels x 8 slots. Branch-free: lanes
-    //      outside the image (zero padding), the slack behind pixel 323 and whole "dummy" instructions (c >= 41, or no next channel block)
-    //      read the zero page; a dummy goes to the scratch KiB. One instruction per wave and K tile keeps the vmcnt arithmetic constant.
-    const unsigned long long zero_addr = (unsigned long long)p.zero_page, img_addr = (unsigned long long)in_img;
-    auto issue_halo = [&](int t9, int cbn, int hbn, bool exists) {
-        const int c = wave + 8 * t9;
-        const bool real = c < HALO_INSTR && exists;                      // wave-uniform
+    // A (halo): DMA instruction c = wave + 8 j of a patch covers halo bytes [1024 c, 1024 c + 1024) = 8 pixels x 8 slots; channel block
+    // cb at soffset 128 cb. Instructions 41..47 (j = 5 of waves 1-7) do not exist: all lanes out of range, destination = the scratch KiB.
+    unsigned h_voff[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int c = wave + 8 * j;
         const int q = c * 8 + (lane >> 3), slot = lane & 7;
-        const int yy = (q * 3641) >> 16, xx = q - yy * 18;              // q / 18, q % 18 for q < 400
+        const int yy = (q * 3641) >> 16, xx = q - yy * 18;  // q / 18, q % 18 for q < 400
         const int Y = Y0 + yy - 1, X = X0 + xx - 1;
-        const bool ok = real && q < 324 && (unsigned)Y < (unsigned)p.H && (unsigned)X < (unsigned)p.W;
-        const unsigned off = ((unsigned)(Y * p.W + X) * (unsigned)p.Cin + (unsigned)(cbn * 64 + ((slot ^ (xx & 7)) << 3))) * 2u;
-        const unsigned long long src = ok ? img_addr + off : zero_addr;
-        const int dst = real ? OFF_H + hbn * HALO_BYTES + c * 1024 : OFF_SCR;
-        glds16((const void*)src, smem + dst);
+        const bool ok = c < HALO_INSTR && q < 324 && (unsigned)Y < (unsigned)p.H && (unsigned)X < (unsigned)p.W;
+        h_voff[j] = ok ? ((unsigned)(Y * p.W + X) * (unsigned)p.Cin + (unsigned)((slot ^ (xx & 7)) << 3)) * 2u : OOB;
+    }
+    auto issue_halo = [&](int j, int cbn, int hbn, bool dummy) {  // dummy (wave-uniform): no next channel block - zeros into the scratch KiB
+        const int c = wave + 8 * j;
+        const bool real = c < HALO_INSTR && !dummy;
+        const unsigned voff = dummy ? OOB : h_voff[j];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(smem + (real ? OFF_H + hbn * HALO_BYTES + c * 1024 : OFF_SCR)), 16, voff, cbn * 128, 0, 0);
+    };
+    // SKIP: the fp32 skip tile (256 KB, read once, no reuse) is added in the EPILOGUE (((conv + bias) + up) + skip, the order of the generic
+    // epilogue); one more DMA instruction per wave and K tile pulls pixel `8 slot + wave` of it towards the CU (its 1 KiB lands in the
+    // scratch KiB and is ignored: an L2 / MALL prefetch), so the epilogue's loads do not start from HBM with nothing to hide behind.
+    const __amdgpu_buffer_rsrc_t rs_skip = plane_rsrc(SKIP ? p.skip + (size_t)img * p.H * p.W * 256 : nullptr, SKIP ? (size_t)p.H * p.W * 1024 : 0);
+    const unsigned pf_voff = (unsigned)lane << 4;
+    auto issue_prefetch = [&](int slot) {
+        const int pp = slot * 8 + wave;  // tile pixel (row pp >> 4, column pp & 15); slot outside [0, 32): nothing to fetch
+        const int Y = Y0 + (pp >> 4), X = X0 + (pp & 15);
+        const bool ok = (unsigned)slot < 32u && Y < p.H && X < p.W;  // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_skip, (lds_ptr_t)(smem + OFF_SCR), 16, ok ? pf_voff : OOB, ok ? (Y * p.W + X) * 1024 : 0, 0, 0);
     };
 
     // fragment read offsets. B as in gemm8 (row l15 of a 16-row block, k-chunk lh / 4 + lh, key (row >> 1) & 7);
-    // A: pixel x' = l15 + kx of the halo row, k-chunk lh (kk = 0) / 4 + lh (kk = 1: address ^ 64), key x' & 7
+    // A: pixel x' = l15 + kx of halo row (4 grp + ky + 8 qm + i), k-chunk lh (kk = 0) / 4 + lh (kk = 1: address ^ 64), key x' & 7
     const int bkey = (l15 >> 1) & 7;
     const int b_off0 = (wc * 32 + l15) * 128 + ((lh ^ bkey) << 4), b_off1 = (wc * 32 + l15) * 128 + (((4 + lh) ^ bkey) << 4);
+    int a_lane[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) a_lane[kx] = ((l15 + kx) << 7) + (((lh ^ (l15 + kx)) & 7) << 4) + grp * 4 * HROW + OFF_H;
 
     f32x4 acc[2][2][4][2];
 #pragma unroll
@@ -146,11 +160,11 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
 #define PIN() __builtin_amdgcn_sched_barrier(0)
 #define BAR() do { PIN(); __builtin_amdgcn_s_barrier(); PIN(); } while (0)
-#define LOAD_A(QM_, VA_)                                                                                              \
+#define LOAD_A(QM_, VA_, ROW0_)                                                                                       \
     do {                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
-            fa[i][0] = *(const bf16x8*)(smem + (VA_) + ((QM_) * 8 + i) * HROW);                                        \
-            fa[i][1] = *(const bf16x8*)(smem + ((VA_) ^ 64) + ((QM_) * 8 + i) * HROW);                                 \
+            fa[i][0] = *(const bf16x8*)(smem + (VA_) + ((ROW0_) + (QM_) * 8 + i) * HROW);                              \
+            fa[i][1] = *(const bf16x8*)(smem + ((VA_) ^ 64) + ((ROW0_) + (QM_) * 8 + i) * HROW);                       \
         }                                                                                                             \
     } while (0)
 #define LOAD_B(DST_, QN_, BUF_)                                                                                       \
@@ -170,79 +184,59 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
         __builtin_amdgcn_s_setprio(0);                                                                                \
     } while (0)
 #define WAIT_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory")
-#define WAIT_VM(N_) asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory")
+#define WAIT_VM_IMM(N_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory")
 
-    // ---- prologue: the whole halo patch of channel block 0 (6 instructions per wave: the 41 real ones + dummies), K tile 0 -> even B
-    //      buffer, K tile 1 -> odd B buffer
-    const int T = 9 * ncb;  // K tiles; even (the launcher checks Cin % 128 == 0)
-    char* const bufE = smem;
-    char* const bufO = smem + BTILE;
+    // ---- prologue: the whole halo patch of channel block 0 (6 instructions per wave), K tile 0 -> even B buffer, K tile 1 -> odd B buffer
+    const int T = 9 * ncb;  // K tiles; ncb is even (the launcher checks Cin % 128 == 0)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) issue_halo(j, 0, 0, true);
-    issue_b(0, bufE);
-    issue_b(1, bufE);
-    issue_b(0, bufO);
-    issue_b(1, bufO);
-    WAIT_VM(4);
+    for (int j = 0; j < 6; ++j) issue_halo(j, 0, 0, false);
+    issue_b(0, 0, 0);
+    issue_b(1, 0, 0);
+    issue_b(0, 1, 1);
+    issue_b(1, 1, 1);
+    WAIT_VM_IMM(4);
     BAR();
     if (p.dbg_times) t_first = memtime_now();
     if (grp == 1) BAR();  // stagger: group 1 runs one barrier behind group 0
 
-    // tap state of the K tile being computed: channel block cb (its patch is in halo buffer hb), tap t9 = 3 ky + kx
-    int cb = 0, hb = 0, t9 = 0, ky = 0, kx = 0;
-    auto a_base = [&]() -> int {  // lane address of this K tile's A fragments (row block 0, kk = 0) inside smem
-        const int xh = l15 + ((p.dbg_flags & 4) ? 0 : kx);  // halo column of this lane's pixel for this tap (flag 4: timing experiment)
-        return (xh << 7) + (((lh ^ xh) & 7) << 4) + (OFF_H + hb * HALO_BYTES + (grp * 4 + ky) * HROW);
-    };
-    auto next_tap = [&]() {
-        ++t9;
-        if (++kx == 3) { kx = 0; ++ky; }
-        if (t9 == 9) { t9 = 0; ky = 0; ++cb; hb ^= 1; }
-    };
-    // SKIP: the fp32 skip tile (256 KB, read once, no reuse) is added in the EPILOGUE ((conv + bias) + skip, the order of the generic
-    // epilogue); one more DMA instruction per wave and K tile pulls pixel `8 slot + wave` of it towards the CU during the last 32 K tiles
-    // that still issue (its 1 KiB lands in the scratch KiB and is ignored: an L2 / MALL prefetch), so the epilogue's loads do not start
-    // from HBM with nothing to hide behind.
-    const unsigned long long skip_addr = SKIP ? (unsigned long long)(p.skip + (size_t)img * p.H * p.W * 256) : 0ull;
-    auto issue_prefetch = [&](int slot) {
-        const int pp = slot * 8 + wave;  // tile pixel (row pp >> 4, column pp & 15); slot outside [0, 32): dummy
-        const int Y = Y0 + (pp >> 4), X = X0 + (pp & 15);
-        const bool ok = (unsigned)slot < 32u && Y < p.H && X < p.W;
-        const unsigned off = (unsigned)(Y * p.W + X) * 1024u + (unsigned)(lane << 4);
-        const unsigned long long src = ok ? skip_addr + off : zero_addr;
-        glds16((const void*)src, smem + OFF_SCR);
-    };
-
-    // One iteration = two K tiles (even / odd B buffer), four phases each:
-    //   P1: read B0, A rows 0-7                   -> MFMA(0,0)      P2: read B1 | B0 of tile t+2 (| skip prefetch) -> MFMA(0,1)
-    //   P3: read A rows 8-15 | halo DMA            -> MFMA(1,1)      P4: B1 of tile t+2, vmcnt(5 | 6)              -> MFMA(1,0)
-    // vmcnt at P4: B1, B0 of tile t+2, this K tile's halo instruction (and prefetch) may stay in flight; everything older (tile t+1's
-    // weights, the halo instructions of earlier K tiles) has landed - one phase and >= one workgroup barrier before its first read.
-#define CONV_KTILE(BUFI_, BUFP_, MORE_, KT_)                                                                            \
+    // Main loop: one iteration = a PAIR of channel blocks = 18 K tiles, fully unrolled - tap (ky, kx), halo buffer, B buffer, which halo
+    // instruction to issue and how many operations may stay in flight are all compile-time constants of the K tile's position U in the pair:
+    //     cb = cbp + U / 9 (its patch is in halo buffer U / 9), tap t9 = U % 9 = 3 ky + kx, B buffer U & 1.
+    // Four phases per K tile (the 8-phase schedule of gemm8_kernel):
+    //   P1: read B0, A rows 0-7                        -> MFMA(0,0)      P2: read B1 | B0 of tile kt+2 (| skip prefetch) -> MFMA(0,1)
+    //   P3: read A rows 8-15 | halo DMA (t9 < 6)        -> MFMA(1,1)      P4: B1 of tile kt+2, counted vmcnt                -> MFMA(1,0)
+    // vmcnt at P4: the operations issued during this K tile may stay in flight (B0 + B1 of tile kt+2 = 4, + 1 halo instruction, + 1 skip
+    // prefetch); everything older (tile kt+1's weights, the halo instructions of earlier K tiles) has landed - one phase and >= one
+    // workgroup barrier before its first read. The halo patch of block cb+1 (t9 = 0..5 of block cb) has three more K tiles to land.
+#define CONV_KT(U_)                                                                                                   \
     do {                                                                                                              \
-        const int va = a_base();                                                                                      \
-        LOAD_B(fb0, 0, BUFI_); PIN(); LOAD_A(0, va); PIN();                                                           \
+        constexpr int cbl = (U_) / 9, t9 = (U_) % 9, ky = t9 / 3, kx = t9 % 3, bi = (U_) & 1;                          \
+        constexpr bool halo_slot = t9 < 6;                                                                            \
+        constexpr int inflight = 4 + (halo_slot ? 1 : 0) + (SKIP ? 1 : 0);                                            \
+        const int kt = cbp * 9 + (U_);                                                                                \
+        const bool more = (U_) < 16 || !last;      /* K tile kt + 2 exists */                                         \
+        const int va = a_lane[kx] + cbl * HALO_BYTES;                                                                 \
+        LOAD_B(fb0, 0, bi); PIN(); LOAD_A(0, va, ky); PIN();                                                          \
         WAIT_LGKM(8); BAR(); WAIT_LGKM(0); PIN();                                                                     \
         MFMA_Q(0, 0, fb0); BAR();                                                                                     \
-        LOAD_B(fb1, 1, BUFI_); PIN();                                                                                 \
-        if (MORE_) { issue_b(0, BUFP_); if constexpr (SKIP) issue_prefetch((KT_) - (T - 34)); }                        \
+        LOAD_B(fb1, 1, bi); PIN();                                                                                    \
+        if (more) { issue_b(0, bi, kt + 2); if constexpr (SKIP) issue_prefetch(kt - 2); }                             \
         BAR(); WAIT_LGKM(0); PIN();                                                                                   \
         MFMA_Q(0, 1, fb1); BAR();                                                                                     \
-        LOAD_A(1, va); PIN();                                                                                         \
-        if (MORE_ && !(p.dbg_flags & 1)) issue_halo(t9, cb + 1, hb ^ 1, cb + 1 < ncb);                                \
+        LOAD_A(1, va, ky); PIN();                                                                                     \
+        if constexpr (halo_slot) { if (more) issue_halo(t9, cbp + cbl + 1, cbl ^ 1, cbl == 1 && last); }              \
         BAR(); WAIT_LGKM(0); PIN();                                                                                   \
         MFMA_Q(1, 1, fb1); BAR();                                                                                     \
-        if (MORE_) { issue_b(1, BUFP_); PIN(); if (p.dbg_flags & 1) WAIT_VM(4); else if constexpr (SKIP) WAIT_VM(6); else WAIT_VM(5); } else { WAIT_VM(0); } \
+        if (more) { issue_b(1, bi, kt + 2); PIN(); WAIT_VM_IMM(inflight); } else { WAIT_VM_IMM(0); }                  \
         BAR();                                                                                                        \
         MFMA_Q(1, 0, fb0); BAR();                                                                                     \
-        next_tap();                                                                                                   \
     } while (0)
-    for (int t = 0; t < T; t += 2) {
-        const bool more = t + 2 < T;  // wave-uniform: the last iteration issues nothing and drains
-        CONV_KTILE(0, bufE, more, t);
-        CONV_KTILE(1, bufO, more, t + 1);
+    for (int cbp = 0; cbp < ncb; cbp += 2) {
+        const bool last = cbp + 2 >= ncb;  // wave-uniform: the last two K tiles issue nothing and drain
+        CONV_KT(0); CONV_KT(1); CONV_KT(2); CONV_KT(3); CONV_KT(4); CONV_KT(5); CONV_KT(6); CONV_KT(7); CONV_KT(8);
+        CONV_KT(9); CONV_KT(10); CONV_KT(11); CONV_KT(12); CONV_KT(13); CONV_KT(14); CONV_KT(15); CONV_KT(16); CONV_KT(17);
     }
-#undef CONV_KTILE
+#undef CONV_KT
     if (grp == 0) BAR();  // re-join the two groups
 #undef LOAD_A
 #undef LOAD_B
@@ -417,7 +411,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 #undef PIN
 #undef BAR
 #undef WAIT_LGKM
-#undef WAIT_VM
+#undef WAIT_VM_IMM
 
 template <bool SKIP, bool F32OUT, bool RELU, bool UP>
 int launch_variant(const Conv3hParams& p, hipStream_t stream) {

@@ -951,6 +951,18 @@ __device__ __forceinline__ void epilogue_direct_vt(const GemmParams& p, f32x4 (&
 template <int AMODE>
 struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i covers rows 8c..8c+7; half h = chunks i in {2h, 2h+1}
     static constexpr int A_BYTES = 256 * 128;
+    static constexpr bool BUFFERED = AMODE != MDPT_A_CONV3;
+    // Dense / token rows (BUFFERED): LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds) whose base is THIS tile's
+    // first row: the per-lane byte offsets are constants of the tile (row, swizzled k-chunk), the position along K and the 64-row step
+    // between a wave's DMA instructions are SCALAR offsets - no 64-bit pointer arithmetic in the loop (16 VALU operations per K tile in
+    // the pointer form: measured 2500 -> 2200 cycles per K tile on the conv kernel that was written this way first) - and rows past
+    // M / N fail the descriptor's bounds check and are staged as zeros (tools/probes/buffer_lds_oob.hip) instead of being clamped.
+    // 3x3 taps (im2col-free conv): per-lane source pointers, recomputed per tap (global_load_lds).
+    __amdgpu_buffer_rsrc_t rs_a, rs_w;
+    unsigned a_voff[4], b_voff;
+    int a_soff, b_soff, a_row_step, b_row_step;
+    const bf16_t* a_base_hi; const bf16_t* a_base_lo; const bf16_t* w_base_hi; const bf16_t* w_base_lo;
+    size_t a_bytes, w_bytes;
     const bf16_t* a_ptr[4];
     int a_pix[4], a_y[4], a_x[4], a_ko[4];
     const bf16_t* b_ptr[4];
@@ -958,24 +970,55 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
     const bf16_t* conv_plane;
     int a_pass, a_k0, a_tap, a_ci, b_pass, b_k0;
 
+    static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, size_t bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)(bytes < 0xFFFFFFF0ull ? bytes : 0xFFFFFFF0ull), 0x00020000);
+    }
+
     __device__ __forceinline__ void init(const GemmParams& p, int m0, int n0, int wave, int lane) {
         const int lrow = lane >> 3, slot = lane & 7;
         const bf16_t* A0 = p.npass == 3 ? p.A_lo : p.A_hi;
+        a_pass = a_k0 = a_tap = a_ci = b_pass = b_k0 = 0;
+        if constexpr (BUFFERED) {
+            constexpr unsigned OOB = 0xFFFFFFF0u;
+            const int rows_here = p.M - m0 < 256 ? p.M - m0 : 256, cols_here = p.N - n0 < 256 ? p.N - n0 : 256;
+            // source row of logical row m (token rows skip the cls row of every image)
+            auto src_row = [&](int m) -> size_t {
+                if (AMODE == MDPT_A_TOKENS) { const int b = m / p.tok_np, t = m - b * p.tok_np; return (size_t)b * p.tok_stride + 1 + t; }
+                return (size_t)m;
+            };
+            const size_t row0 = src_row(m0), row_last = src_row(m0 + rows_here - 1);
+            a_base_hi = p.A_hi + row0 * p.lda; a_base_lo = p.npass == 3 ? p.A_lo + row0 * p.lda : a_base_hi;
+            a_bytes = (row_last - row0 + 1) * p.lda * 2;
+            w_base_hi = p.W_hi + (size_t)n0 * p.K; w_base_lo = p.npass == 3 ? p.W_lo + (size_t)n0 * p.K : w_base_hi;
+            w_bytes = (size_t)cols_here * p.K * 2;
+            rs_a = rsrc(p.npass == 3 ? a_base_lo : a_base_hi, a_bytes);  // pass 0 of bf16x3: A_lo * W_hi
+            rs_w = rsrc(w_base_hi, w_bytes);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (wave + 8 * i) * 8 + lrow;
+                const int koff = (slot ^ ((r >> 1) & 7)) * 8;
+                a_voff[i] = r < rows_here ? (unsigned)(((src_row(m0 + r) - row0) * p.lda + koff) * 2) : OOB;
+            }
+            {
+                const int r = wave * 8 + lrow;  // rows of DMA instruction i: r + 64 i, same swizzle key
+                b_voff = (unsigned)(((size_t)r * p.K + ((slot ^ ((r >> 1) & 7)) * 8)) * 2);
+            }
+            a_soff = b_soff = 0;
+            b_row_step = 64 * p.K * 2;
+            a_row_step = 0;
+            a_hi_minus_lo = w_lo_minus_hi = 0;
+            conv_plane = nullptr;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = (wave + 8 * i) * 8 + lrow;
             const int koff = (slot ^ ((r >> 1) & 7)) * 8;
             int m = m0 + r;
             m = m < p.M ? m : p.M - 1;
-            a_pix[i] = a_y[i] = a_x[i] = 0;
             a_ko[i] = koff;
             a_ptr[i] = nullptr;
-            if (AMODE == MDPT_A_DENSE) {
-                a_ptr[i] = A0 + (size_t)m * p.lda + koff;
-            } else if (AMODE == MDPT_A_TOKENS) {
-                const int b = m / p.tok_np, t = m - b * p.tok_np;
-                a_ptr[i] = A0 + ((size_t)b * p.tok_stride + 1 + t) * p.lda + koff;
-            } else {
+            {
                 const int hw = p.Ho * p.Wo;
                 const int b = m / hw, rem = m - b * hw;
                 const int y = rem / p.Wo, x = rem - y * p.Wo;
@@ -990,37 +1033,39 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
         a_hi_minus_lo = p.npass == 3 ? p.A_hi - p.A_lo : 0;
         w_lo_minus_hi = p.npass == 3 ? p.W_lo - p.W_hi : 0;
         conv_plane = A0;
-        a_pass = a_k0 = a_tap = a_ci = b_pass = b_k0 = 0;
     }
 
     template <int H>
     __device__ __forceinline__ void issue_a(const GemmParams& p, char* buf, int wave) {
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        if constexpr (BUFFERED) {
+#pragma unroll
+            for (int i = 2 * H; i < 2 * H + 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(buf + (wave + 8 * i) * 1024), 16, a_voff[i], a_soff, 0, 0);
+            if (H == 1) {  // both halves of this K tile are on their way: advance K (and the bf16x3 operand planes at roll-over)
+                a_soff += 128;
+                if (a_soff == p.K * 2) {
+                    a_soff = 0;
+                    if (a_pass == 0) rs_a = rsrc(a_base_hi, a_bytes);  // passes 1, 2 read A_hi
+                    ++a_pass;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 2 * H; i < 2 * H + 2; ++i) {
-            const bf16_t* src;
-            if (AMODE == MDPT_A_CONV3) {
-                const int ky = (a_tap * 11) >> 5, kx = a_tap - 3 * ky;
-                const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-                const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-                src = ok ? conv_plane + ((size_t)(a_pix[i] + iy * p.Wi + ix) * p.Cin + a_ci + a_ko[i]) : p.zero_page + a_ko[i];
-            } else {
-                src = a_ptr[i];
-                a_ptr[i] += 64;
-            }
+            const int ky = (a_tap * 11) >> 5, kx = a_tap - 3 * ky;
+            const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const bf16_t* src = ok ? conv_plane + ((size_t)(a_pix[i] + iy * p.Wi + ix) * p.Cin + a_ci + a_ko[i]) : p.zero_page + a_ko[i];
             glds16(src, buf + (wave + 8 * i) * 1024);
         }
         if (H == 1) {  // both halves of this K tile are on their way: advance K (and the bf16x3 operand planes at roll-over)
             a_k0 += 64;
-            if (AMODE == MDPT_A_CONV3) {  // tap-inner K order (see Stager)
-                if (++a_tap == 9) { a_tap = 0; a_ci += 64; }
-            }
+            if (++a_tap == 9) { a_tap = 0; a_ci += 64; }  // tap-inner K order (see Stager)
             if (a_k0 == p.K) {
                 a_k0 = 0; a_tap = 0; a_ci = 0;
-                const ptrdiff_t da = (a_pass == 0 ? a_hi_minus_lo : 0) - p.K;
                 if (a_pass == 0) conv_plane = p.A_hi;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (AMODE != MDPT_A_CONV3) a_ptr[i] += da;
                 ++a_pass;
             }
         }
@@ -1028,6 +1073,21 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
 
     template <int H>
     __device__ __forceinline__ void issue_b(const GemmParams& p, char* buf, int wave) {
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        if constexpr (BUFFERED) {
+#pragma unroll
+            for (int i = 2 * H; i < 2 * H + 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(buf + A_BYTES + (wave + 8 * i) * 1024), 16, b_voff, b_soff + i * b_row_step, 0, 0);
+            if (H == 1) {
+                b_soff += 128;
+                if (b_soff == p.K * 2) {  // bf16x3 passes: W_hi, W_lo, W_hi
+                    b_soff = 0;
+                    rs_w = rsrc(b_pass == 0 ? w_base_lo : w_base_hi, w_bytes);
+                    ++b_pass;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 2 * H; i < 2 * H + 2; ++i) {
             glds16(b_ptr[i], buf + A_BYTES + (wave + 8 * i) * 1024);

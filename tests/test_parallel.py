@@ -60,3 +60,25 @@ def test_two_rank_gloo_allgather_matches_single_process(global_batch):
         ret = mgr.dict()
         mp.spawn(_worker, args=(world, _free_port(), global_batch, ret), nprocs=world, join=True)
         assert dict(ret) == {0: True, 1: True}
+
+
+def test_bench_control_flow_at_world_size_2_on_gloo():
+    """bench.py's N-rank control flow (barrier, timed region, max-over-ranks all_reduce right behind it, rank-0-only JSON line with
+    cpu_baseline null, no rank left parked in a collective) under torch.distributed.run with a stand-in model on CPU / gloo - the
+    driver runs the real thing ONCE on 8 GPUs with no retry."""
+    import json, os, socket, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--fake-model"],
+                       capture_output=True, text=True, timeout=600, cwd=repo, env={**os.environ, "OMP_NUM_THREADS": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["cpu_baseline"] is None and d["roofline"] is None and "secondary" not in d
+    assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2" and d["gathered_shape"] == [4, 16, 16]
+    assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-3
