@@ -65,8 +65,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* base, s
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)(bytes < 0xFFFFFFF0ull ? bytes : 0xFFFFFFF0ull), 0x00020000);
 }
 
-template <bool SKIP, bool F32OUT, bool RELU, bool UP>
+template <int NQN, bool SKIP, bool F32OUT, bool RELU, bool UP>
 __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
+    constexpr int COUT = 128 * NQN;  // output channels: 256 (two 128-column halves per wave) or 128
+    static_assert(NQN == 2 || (!SKIP && !F32OUT && !UP), "the 128-channel form has the plain bf16 epilogue only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr unsigned OOB = 0xFFFFFFF0u;
     unsigned long long t_start = 0, t_first = 0, t_loop = 0;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     //      instructions need no zero page, no 64-bit pointer arithmetic and no selects inside the loop.
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const int Kw = p.Cin * 9;
-    const __amdgpu_buffer_rsrc_t rs_w = plane_rsrc(p.w, (size_t)256 * Kw * 2);
+    const __amdgpu_buffer_rsrc_t rs_w = plane_rsrc(p.w, (size_t)COUT * Kw * 2);
     const __amdgpu_buffer_rsrc_t rs_in = plane_rsrc(in_img, (size_t)p.H * p.W * p.Cin * 2);
     // B (weights): DMA instruction i of a wave stages rows r = 8 * (wave + 8 i) + lane / 8 = r0 + 64 i; 16-byte slot lane % 8 holds k-chunk
     // slot ^ ((r >> 1) & 7) (the key is the same for all four i). One lane constant; (K tile kt, i) enter through the scalar offset.
@@ -108,6 +110,11 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
         for (int i = 0; i < 4; ++i)
             if ((i >> 1) == half)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(smem + buf * BTILE + (wave + 8 * i) * 1024), 16, b_voff, kt * 128 + i * 128 * Kw, 0, 0);
+    };
+    auto issue_b128 = [&](int buf4, int kt) {  // COUT = 128: the whole 16 KB K tile kt -> slot buf4 of a FOUR-deep ring (two instructions per wave)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(smem + buf4 * (BTILE / 2) + (wave + 8 * i) * 1024), 16, b_voff, kt * 128 + i * 128 * Kw, 0, 0);
     };
     // A (halo): DMA instruction c = wave + 8 j of a patch covers halo bytes [1024 c, 1024 c + 1024) = 8 pixels x 8 slots; channel block
     // cb at soffset 128 cb. Instructions 41..47 (j = 5 of waves 1-7) do not exist: all lanes out of range, destination = the scratch KiB.
@@ -147,11 +154,11 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) a_lane[kx] = ((l15 + kx) << 7) + (((lh ^ (l15 + kx)) & 7) << 4) + grp * 4 * HROW + OFF_H;
 
-    f32x4 acc[2][2][4][2];
+    f32x4 acc[2][NQN][4][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NQN; ++b)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -174,6 +181,13 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
             DST_[j][1] = *(const bf16x8*)(smem + (BUF_) * BTILE + (QN_) * 16384 + j * 2048 + b_off1);                  \
         }                                                                                                             \
     } while (0)
+#define LOAD_B_AT(DST_, BYTES_) /* COUT = 128: ring slot at a run-time byte offset */                                 \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                               \
+            DST_[j][0] = *(const bf16x8*)(smem + (BYTES_) + j * 2048 + b_off0);                                        \
+            DST_[j][1] = *(const bf16x8*)(smem + (BYTES_) + j * 2048 + b_off1);                                        \
+        }                                                                                                             \
+    } while (0)
 #define MFMA_Q(QM_, QN_, FB_)                                                                                         \
     do {                                                                                                              \
         __builtin_amdgcn_s_setprio(1);                                                                                \
@@ -186,8 +200,47 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 #define WAIT_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory")
 #define WAIT_VM_IMM(N_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory")
 
-    // ---- prologue: the whole halo patch of channel block 0 (6 instructions per wave), K tile 0 -> even B buffer, K tile 1 -> odd B buffer
     const int T = 9 * ncb;  // K tiles; ncb is even (the launcher checks Cin % 128 == 0)
+    if constexpr (NQN == 1) {
+        // ---- COUT = 128 (head conv 1, head_model.py:74-76): a K tile of weights is 16 KB, a wave owns two 64 x 32 quadrants (qm = 0, 1), so a
+        //      K tile has TWO phases of 16 MFMAs and the weights live in a four-deep ring (K tile kt in slot kt & 3, staged three K tiles ahead):
+        //   P1: read B, A rows 0-7 | halo DMA (t9 < 6) -> MFMA(0)      P2: read A rows 8-15 | B of tile kt+3, counted vmcnt -> MFMA(1)
+        // vmcnt at P2: what this K tile and the previous one issued may stay in flight (2 weight + 0/1 halo instructions each); everything
+        // older - tile kt+1's weights above all - has landed one phase and >= one workgroup barrier before P1 of tile kt+1 reads it.
+#pragma unroll
+        for (int j = 0; j < 6; ++j) issue_halo(j, 0, 0, false);
+        issue_b128(0, 0);
+        issue_b128(1, 1);
+        issue_b128(2, 2);
+        WAIT_VM_IMM(4);
+        BAR();
+        if (p.dbg_times) t_first = memtime_now();
+        if (grp == 1) BAR();
+#define CONV_KT128(U_)                                                                                                \
+        do {                                                                                                          \
+            constexpr int cbl = (U_) / 9, t9 = (U_) % 9, ky = t9 / 3, kx = t9 % 3;                                     \
+            constexpr int h_now = t9 < 6 ? 1 : 0, h_prev = ((U_) % 9 == 0) ? 0 : (((U_) - 1) % 9 < 6 ? 1 : 0);         \
+            const int kt = cbp * 9 + (U_);                                                                            \
+            const bool more = (U_) < 15 || !last;      /* K tile kt + 3 exists */                                     \
+            const int va = a_lane[kx] + cbl * HALO_BYTES;                                                             \
+            const int bslot = (kt & 3) * (BTILE / 2);                                                                 \
+            LOAD_B_AT(fb0, bslot); PIN(); LOAD_A(0, va, ky); PIN();                                                   \
+            if constexpr (h_now) { if (more) issue_halo(t9, cbp + cbl + 1, cbl ^ 1, cbl == 1 && last); }              \
+            BAR(); WAIT_LGKM(0); PIN();                                                                               \
+            MFMA_Q(0, 0, fb0); BAR();                                                                                 \
+            LOAD_A(1, va, ky); PIN();                                                                                 \
+            if (more) { issue_b128((kt + 3) & 3, kt + 3); PIN(); WAIT_VM_IMM(4 + h_now + h_prev); } else { WAIT_VM_IMM(0); } \
+            BAR(); WAIT_LGKM(0); PIN();                                                                               \
+            MFMA_Q(1, 0, fb0); BAR();                                                                                 \
+        } while (0)
+        for (int cbp = 0; cbp < ncb; cbp += 2) {
+            const bool last = cbp + 2 >= ncb;
+            CONV_KT128(0); CONV_KT128(1); CONV_KT128(2); CONV_KT128(3); CONV_KT128(4); CONV_KT128(5); CONV_KT128(6); CONV_KT128(7); CONV_KT128(8);
+            CONV_KT128(9); CONV_KT128(10); CONV_KT128(11); CONV_KT128(12); CONV_KT128(13); CONV_KT128(14); CONV_KT128(15); CONV_KT128(16); CONV_KT128(17);
+        }
+#undef CONV_KT128
+    } else {
+    // ---- prologue: the whole halo patch of channel block 0 (6 instructions per wave), K tile 0 -> even B buffer, K tile 1 -> odd B buffer
 #pragma unroll
     for (int j = 0; j < 6; ++j) issue_halo(j, 0, 0, false);
     issue_b(0, 0, 0);
@@ -237,9 +290,11 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
         CONV_KT(9); CONV_KT(10); CONV_KT(11); CONV_KT(12); CONV_KT(13); CONV_KT(14); CONV_KT(15); CONV_KT(16); CONV_KT(17);
     }
 #undef CONV_KT
+    }
     if (grp == 0) BAR();  // re-join the two groups
 #undef LOAD_A
 #undef LOAD_B
+#undef LOAD_B_AT
 #undef MFMA_Q
     if (p.dbg_times) t_loop = memtime_now();
 
@@ -248,8 +303,8 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     const size_t plane_px = (size_t)p.H * p.W;
-    const __amdgpu_buffer_rsrc_t rs_f = plane_rsrc(F32OUT ? p.out_f32 + (size_t)img * plane_px * 256 : nullptr, F32OUT ? plane_px * 1024 : 0);
-    const __amdgpu_buffer_rsrc_t rs_b = plane_rsrc(p.out_bf + (size_t)img * plane_px * 256, plane_px * 512);
+    const __amdgpu_buffer_rsrc_t rs_f = plane_rsrc(F32OUT ? p.out_f32 + (size_t)img * plane_px * COUT : nullptr, F32OUT ? plane_px * COUT * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rs_b = plane_rsrc(p.out_bf + (size_t)img * plane_px * COUT, plane_px * COUT * 2);
     const bool xok = X0 + l15 < p.W;
 
     // bilinear x2 (align_corners=True) add of the coarser fusion level (fusion_model.py:151,178): stage the <= 10x10 coarse pixels this
@@ -282,9 +337,9 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 
     // per-channel constants of both column halves are loaded before the first store (a wait placed after a store would also wait for that
     // store's acknowledgement)
-    f32x4 bias_q[2][2];
+    f32x4 bias_q[NQN][2];
 #pragma unroll
-    for (int qn = 0; qn < 2; ++qn)
+    for (int qn = 0; qn < NQN; ++qn)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             bias_q[qn][j] = p.bias ? *(const f32x4*)(p.bias + qn * 128 + wc * 32 + j * 16 + 4 * lh) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -292,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     // groups g = 2 qm + qn of 8 accumulators (4 tile rows x 2 column blocks); byte offset of (group, i, j) in an fp32 plane
     auto f32_off = [&](int g, int i, int j) -> unsigned {
         const int Y = Y0 + (g >> 1) * 8 + grp * 4 + i;
-        return (xok && Y < p.H) ? (unsigned)(Y * p.W + X0 + l15) * 1024u + (unsigned)((g & 1) * 128 + wc * 32 + j * 16 + 4 * lh) * 4u : OOB;
+        return (xok && Y < p.H) ? (unsigned)(Y * p.W + X0 + l15) * (unsigned)(COUT * 4) + (unsigned)((g & 1) * 128 + wc * 32 + j * 16 + 4 * lh) * 4u : OOB;
     };
     auto load_skip = [&](int g, u32x4 (&dst)[4][2]) {
 #pragma unroll
@@ -373,7 +428,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
                 ph[w2 + 2] = r[1];
             }
             // (the bf16 map is always present: no branch around the stores, hipcc would wait for every store's acknowledgement)
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{ph[0], ph[1], ph[2], ph[3]}, rs_b, ok ? pix * 512u + colb : OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{ph[0], ph[1], ph[2], ph[3]}, rs_b, ok ? pix * (unsigned)(COUT * 2) + colb : OOB, 0, 0);
         }
     };
     if constexpr (SKIP) {
@@ -397,7 +452,8 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
         store(3);
     } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { base(g); store(g); }
+        for (int g = 0; g < 4; ++g)
+            if (NQN == 2 || (g & 1) == 0) { base(g); store(g); }
     }
     if (p.dbg_times && tid == 0) {
         const unsigned long long t_issued = memtime_now();
@@ -413,9 +469,9 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 #undef WAIT_LGKM
 #undef WAIT_VM_IMM
 
-template <bool SKIP, bool F32OUT, bool RELU, bool UP>
+template <int NQN, bool SKIP, bool F32OUT, bool RELU, bool UP>
 int launch_variant(const Conv3hParams& p, hipStream_t stream) {
-    auto kern = conv3h_kernel<SKIP, F32OUT, RELU, UP>;
+    auto kern = conv3h_kernel<NQN, SKIP, F32OUT, RELU, UP>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -424,8 +480,8 @@ int launch_variant(const Conv3hParams& p, hipStream_t stream) {
     }
     const int tiles = p.B * ((p.H + 15) / 16) * ((p.W + 15) / 16);
     static char prof_name[64] = "";
-    if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "conv3h_kernel<%d, %d, %d, %d>", (int)SKIP, (int)F32OUT, (int)RELU, (int)UP);
-    MdptProfScope prof(prof_name, 2.0 * p.B * p.H * p.W * 256.0 * 9.0 * p.Cin, stream);
+    if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "conv3h_kernel<%d, %d, %d, %d, %d>", 128 * NQN, (int)SKIP, (int)F32OUT, (int)RELU, (int)UP);
+    MdptProfScope prof(prof_name, 2.0 * p.B * p.H * p.W * (128.0 * NQN) * 9.0 * p.Cin, stream);
     static const int dbg_flags = getenv("MDPT_CONV3H_DBG") ? atoi(getenv("MDPT_CONV3H_DBG")) : 0;  // timing experiments (wrong results)
     Conv3hParams q = p;
     q.dbg_flags = dbg_flags;
@@ -437,9 +493,11 @@ int launch_variant(const Conv3hParams& p, hipStream_t stream) {
 
 // the combinations the decoder uses (anything else runs the implicit-GEMM path of gemm.hip)
 bool mdpt_conv3h_supported(const Conv3hParams& p) {
-    if (p.B <= 0 || p.H < 2 || p.W < 2 || p.Cin <= 0 || (p.Cin & 127) || !p.in || !p.w || !p.out_bf || !p.zero_page) return false;
-    if ((size_t)p.H * p.W * 1024 >= 0xFFFFFFF0ull) return false;  // 32-bit byte offsets inside one image plane
+    if (p.B <= 0 || p.H < 2 || p.W < 2 || p.Cin <= 0 || (p.Cin & 127) || !p.in || !p.w || !p.out_bf) return false;
+    if (p.Cout != 256 && p.Cout != 128) return false;
+    if ((size_t)p.H * p.W * p.Cout * 4 >= 0xFFFFFFF0ull || (size_t)p.H * p.W * p.Cin * 2 >= 0xFFFFFFF0ull) return false;  // 32-bit byte offsets inside one image plane
     const bool skip = p.skip != nullptr, f32 = p.out_f32 != nullptr, relu = p.relu_bf != 0, up = p.up_src != nullptr;
+    if (p.Cout == 128) return !skip && !f32 && !relu && !up;
     if (up) {
         // the 16 fine rows / columns of a tile must interpolate from <= UPW coarse ones: floor(15 * scale) + 3 <= UPW
         if (p.Hu < 1 || p.Wu < 1 || (long)15 * (p.Hu - 1) >= (long)(UPW - 2) * (p.H - 1) || (long)15 * (p.Wu - 1) >= (long)(UPW - 2) * (p.W - 1)) return false;
@@ -454,8 +512,9 @@ bool mdpt_conv3h_supported(const Conv3hParams& p) {
 int mdpt_launch_conv3h(const Conv3hParams& p, hipStream_t stream) {
     if (!mdpt_conv3h_supported(p)) return (int)hipErrorInvalidValue;
     const bool skip = p.skip != nullptr, f32 = p.out_f32 != nullptr, up = p.up_src != nullptr;
-    if (up) return launch_variant<true, true, true, true>(p, stream);
-    if (!skip && !f32) return launch_variant<false, false, true, false>(p, stream);
-    if (skip && !f32) return launch_variant<true, false, false, false>(p, stream);
-    return launch_variant<false, true, true, false>(p, stream);
+    if (p.Cout == 128) return launch_variant<1, false, false, false, false>(p, stream);
+    if (up) return launch_variant<2, true, true, true, true>(p, stream);
+    if (!skip && !f32) return launch_variant<2, false, false, true, false>(p, stream);
+    if (skip && !f32) return launch_variant<2, true, false, false, false>(p, stream);
+    return launch_variant<2, false, true, true, false>(p, stream);
 }

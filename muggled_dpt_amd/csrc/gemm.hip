@@ -951,7 +951,14 @@ __device__ __forceinline__ void epilogue_direct_vt(const GemmParams& p, f32x4 (&
 template <int AMODE>
 struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i covers rows 8c..8c+7; half h = chunks i in {2h, 2h+1}
     static constexpr int A_BYTES = 256 * 128;
+    // Measured on one box, interleaved (profiles/r03_gemm8_staging_ab.txt): the buffered form is NOT faster for the dense GEMMs (QKV 240.7
+    // vs 237.8 us, fc1 366.8 vs 364.0, residual GEMMs 231.5 vs 230.5) - their loop is bound by the 64 DMA instructions per K tile, not by
+    // the 16 VALU operations of the pointer form - so the pointer form stays the default and -DMDPT_GEMM8_BUF_STAGING builds the other one.
+#ifdef MDPT_GEMM8_BUF_STAGING
     static constexpr bool BUFFERED = AMODE != MDPT_A_CONV3;
+#else
+    static constexpr bool BUFFERED = false;
+#endif
     // Dense / token rows (BUFFERED): LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds) whose base is THIS tile's
     // first row: the per-lane byte offsets are constants of the tile (row, swizzled k-chunk), the position along K and the 64-row step
     // between a wave's DMA instructions are SCALAR offsets - no 64-bit pointer arithmetic in the loop (16 VALU operations per K tile in
@@ -1018,7 +1025,13 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
             m = m < p.M ? m : p.M - 1;
             a_ko[i] = koff;
             a_ptr[i] = nullptr;
-            {
+            a_pix[i] = a_y[i] = a_x[i] = 0;
+            if (AMODE == MDPT_A_DENSE) {
+                a_ptr[i] = A0 + (size_t)m * p.lda + koff;
+            } else if (AMODE == MDPT_A_TOKENS) {
+                const int b = m / p.tok_np, t = m - b * p.tok_np;
+                a_ptr[i] = A0 + ((size_t)b * p.tok_stride + 1 + t) * p.lda + koff;
+            } else {
                 const int hw = p.Ho * p.Wo;
                 const int b = m / hw, rem = m - b * hw;
                 const int y = rem / p.Wo, x = rem - y * p.Wo;
@@ -1054,18 +1067,30 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
         }
 #pragma unroll
         for (int i = 2 * H; i < 2 * H + 2; ++i) {
-            const int ky = (a_tap * 11) >> 5, kx = a_tap - 3 * ky;
-            const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            const bf16_t* src = ok ? conv_plane + ((size_t)(a_pix[i] + iy * p.Wi + ix) * p.Cin + a_ci + a_ko[i]) : p.zero_page + a_ko[i];
+            const bf16_t* src;
+            if (AMODE == MDPT_A_CONV3) {
+                const int ky = (a_tap * 11) >> 5, kx = a_tap - 3 * ky;
+                const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+                const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                src = ok ? conv_plane + ((size_t)(a_pix[i] + iy * p.Wi + ix) * p.Cin + a_ci + a_ko[i]) : p.zero_page + a_ko[i];
+            } else {
+                src = a_ptr[i];
+                a_ptr[i] += 64;
+            }
             glds16(src, buf + (wave + 8 * i) * 1024);
         }
         if (H == 1) {  // both halves of this K tile are on their way: advance K (and the bf16x3 operand planes at roll-over)
             a_k0 += 64;
-            if (++a_tap == 9) { a_tap = 0; a_ci += 64; }  // tap-inner K order (see Stager)
+            if (AMODE == MDPT_A_CONV3) {
+                if (++a_tap == 9) { a_tap = 0; a_ci += 64; }  // tap-inner K order (see Stager)
+            }
             if (a_k0 == p.K) {
                 a_k0 = 0; a_tap = 0; a_ci = 0;
+                const ptrdiff_t da = (a_pass == 0 ? a_hi_minus_lo : 0) - p.K;
                 if (a_pass == 0) conv_plane = p.A_hi;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (AMODE != MDPT_A_CONV3) a_ptr[i] += da;
                 ++a_pass;
             }
         }

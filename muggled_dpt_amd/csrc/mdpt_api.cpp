@@ -696,12 +696,12 @@ int run_reassemble(const Ctx& c) {
 
 // Halo-staged conv kernel (conv3h.hip) for a 3x3 stride-1 conv to the 256-wide fusion width, used for big launches; small ones run the
 // implicit-GEMM kernels of gemm.hip. Both walk K in the same order and apply the same epilogue expressions (((conv + bias) + up) + skip),
-// so one image's bits do not depend on the batch it is part of. Partial 16x16 tiles may waste at most 10 % of the MFMA work (72x72: 25
-// tiles for 20.25 -> implicit GEMM).
+// so one image's bits do not depend on the batch it is part of. Partial 16x16 tiles may waste at most 25 % of the MFMA work (72x72: 25
+// tiles for 20.25 image-tiles' worth of pixels - the halo-staged loop is ~30 % faster per K tile; 36x36: 9 for 5.06 -> implicit GEMM).
 bool conv3h_shape_ok(const mdpt_handle* h, int H, int W, int Cin) {
     if (h->x3 || h->Cp != 256 || (Cin & 127) || H < 2 || W < 2) return false;
     const long tile_px = (long)((H + 15) / 16) * ((W + 15) / 16) * 256, px = (long)H * W;
-    return tile_px * 10 <= px * 11;
+    return tile_px * 4 <= px * 5;
 }
 
 // one 3x3 stride-1 conv Cin -> Cp: out = [skip +] conv(in) [+ bias] [+ up2(up_src)] -> fp32 map and / or bf16 planes (ReLU'd if relu_bf16)
@@ -714,7 +714,7 @@ int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int 
         memset(&q, 0, sizeof(q));
         q.in = in.hi; q.w = w.hi; q.bias = bias; q.skip = skip; q.up_src = up_src; q.Hu = Hu; q.Wu = Wu;
         q.out_f32 = out_f32; q.out_bf = out.hi; q.relu_bf = relu_bf16;
-        q.B = c.p.B; q.H = sh; q.W = sw; q.Cin = Cin; q.zero_page = h->zero_page;
+        q.B = c.p.B; q.H = sh; q.W = sw; q.Cin = Cin; q.Cout = 256; q.zero_page = h->zero_page;
         const long tiles256 = ((long)c.p.B * sh * sw + 255) / 256;
         if (tiles256 >= (c.split ? 24 : 140) && mdpt_conv3h_supported(q)) return mdpt_launch_conv3h(q, c.s);
     }
@@ -784,11 +784,25 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32) {
         // upsampled map in LDS tiles: upsample + 3x3 conv + ReLU + 1x1 conv + ReLU | sigmoid (head.hip). The bf16x3 mode keeps the
         // unfused form below (its hi + lo operand planes do not fit the LDS tile next to the weights).
         bf16_t* h1b = c.at<bf16_t>(p.h1);
-        GemmParams g = base_params(c, h->M("head.spatial_upsampler.0.weight"), c.pl(p.fused), p.B * fh * fw, h->Cp);
-        as_conv(g, fh, fw, h->Cp, fh, fw, 1);
-        g.bias = h->V("head.spatial_upsampler.0.bias");
-        g.out_hi = h1b; g.ldc = h->C2p;
-        CHK(mdpt_launch_gemm(g, c.s));
+        bool done = false;
+        if (h->C2p == 128 && conv3h_shape_ok(h, fh, fw, h->Cp) && h->gemm_tile == MDPT_TILE_AUTO) {  // halo-staged form, 128 output channels
+            Conv3hParams q;
+            memset(&q, 0, sizeof(q));
+            q.in = c.pl(p.fused).hi; q.w = h->M("head.spatial_upsampler.0.weight").hi; q.bias = h->V("head.spatial_upsampler.0.bias");
+            q.out_bf = h1b; q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
+            const long tiles256 = ((long)p.B * fh * fw + 255) / 256;
+            if (tiles256 >= (c.split ? 24 : 140) && mdpt_conv3h_supported(q)) {
+                CHK(mdpt_launch_conv3h(q, c.s));
+                done = true;
+            }
+        }
+        if (!done) {
+            GemmParams g = base_params(c, h->M("head.spatial_upsampler.0.weight"), c.pl(p.fused), p.B * fh * fw, h->Cp);
+            as_conv(g, fh, fw, h->Cp, fh, fw, 1);
+            g.bias = h->V("head.spatial_upsampler.0.bias");
+            g.out_hi = h1b; g.ldc = h->C2p;
+            CHK(mdpt_launch_gemm(g, c.s));
+        }
         HeadTailParams t;
         memset(&t, 0, sizeof(t));
         t.src = h1b; t.w_kc = h->M("head.proj_1ch.0.weight@kc32").hi;
@@ -1479,12 +1493,13 @@ int mdpt_debug_gemm(const void* a_bf16, const void* w_bf16, void* out_f32, void*
     return 0;
 }
 
-// ---- test/bench hook: one 3x3 stride-1 conv Cin -> 256 on caller-provided operands (bf16 NHWC input, MDPT_PACK_CONV3 weights [256][9 Cin]):
+// ---- test/bench hook: one 3x3 stride-1 conv Cin -> Cout (256 | 128) on caller-provided operands (bf16 NHWC input, MDPT_PACK_CONV3 weights [Cout][9 Cin]):
 //      path 0 = the implicit-GEMM kernels of gemm.hip (tile = MDPT_TILE_*), path 1 = the halo-staged kernel of conv3h.hip.
 //      out = [skip +] conv + [bias] [+ up2(up)] -> out_f32 (optional) and out_bf16 (ReLU'd if relu_bf16); both paths use the same arithmetic
 int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void* bias_f32, const void* skip_f32, const void* up_f32, int32_t Hu,
-                     int32_t Wu, void* out_f32, void* out_bf16, int32_t relu_bf16, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t path,
-                     int32_t tile, int32_t iters, void* stream, void* dbg_times) {
+                     int32_t Wu, void* out_f32, void* out_bf16, int32_t relu_bf16, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                     int32_t path, int32_t tile, int32_t iters, void* stream, void* dbg_times) {
+    if (Cout != 256 && Cout != 128) return fail(MDPT_E_INVALID, "Cout must be 256 or 128");
     if (!in_bf16 || !w_packed_bf16 || !out_bf16) return fail(MDPT_E_INVALID, "null argument");
     static bf16_t* zero_page = nullptr;  // test hook only: allocated once, never freed
     if (!zero_page) {
@@ -1495,7 +1510,7 @@ int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void*
         memset(&q, 0, sizeof(q));
         q.in = (const bf16_t*)in_bf16; q.w = (const bf16_t*)w_packed_bf16; q.bias = (const float*)bias_f32; q.skip = (const float*)skip_f32;
         q.up_src = (const float*)up_f32; q.Hu = Hu; q.Wu = Wu; q.out_f32 = (float*)out_f32; q.out_bf = (bf16_t*)out_bf16; q.relu_bf = relu_bf16;
-        q.B = B; q.H = H; q.W = W; q.Cin = Cin; q.zero_page = zero_page;
+        q.B = B; q.H = H; q.W = W; q.Cin = Cin; q.Cout = Cout; q.zero_page = zero_page;
         q.dbg_times = (unsigned long long*)dbg_times;
         if (!mdpt_conv3h_supported(q)) return fail(MDPT_E_UNSUPPORTED, "conv3h does not cover this combination");
         for (int i = 0; i < iters; ++i) CHK(mdpt_launch_conv3h(q, (hipStream_t)stream));
@@ -1504,13 +1519,13 @@ int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void*
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.A_hi = (const bf16_t*)in_bf16; g.W_hi = (const bf16_t*)w_packed_bf16;
-    g.M = B * H * W; g.N = 256; g.K = 9 * Cin; g.lda = Cin; g.npass = 1;
+    g.M = B * H * W; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.npass = 1;
     g.zero_page = zero_page;
     g.amode = MDPT_A_CONV3; g.ekind = MDPT_E_GENERIC; g.tile = tile;
     g.Hi = H; g.Wi = W; g.Cin = Cin; g.Ho = H; g.Wo = W; g.cstride = 1;
-    g.bias = (const float*)bias_f32; g.resid = (const float*)skip_f32; g.ldr = 256;
+    g.bias = (const float*)bias_f32; g.resid = (const float*)skip_f32; g.ldr = Cout;
     g.up_src = (const float*)up_f32; g.Hu = Hu; g.Wu = Wu;
-    g.out_f32 = (float*)out_f32; g.out_hi = (bf16_t*)out_bf16; g.relu_bf16 = relu_bf16; g.ldc = 256;
+    g.out_f32 = (float*)out_f32; g.out_hi = (bf16_t*)out_bf16; g.relu_bf16 = relu_bf16; g.ldc = Cout;
     g.dbg_times = (unsigned long long*)dbg_times;
     for (int i = 0; i < iters; ++i) CHK(mdpt_launch_gemm(g, (hipStream_t)stream));
     return 0;

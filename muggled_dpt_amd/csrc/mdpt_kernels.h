@@ -63,15 +63,16 @@ int mdpt_launch_gemm(const GemmParams& p, hipStream_t stream);   // returns hipE
 // ------------------------------------------------------------------------------------------------
 struct Conv3hParams {
     const bf16_t* in;          // NHWC [B, H, W, Cin] bf16, Cin % 128 == 0
-    const bf16_t* w;           // [256][9 * Cin] bf16, MDPT_PACK_CONV3 order
-    const float* bias;         // [256] or null
+    const bf16_t* w;           // [Cout][9 * Cin] bf16, MDPT_PACK_CONV3 order
+    const float* bias;         // [Cout] or null
     const float* skip;         // fp32 NHWC [B, H, W, 256] or null
     const float* up_src; int Hu, Wu;  // fp32 NHWC [B, Hu, Wu, 256] or null
     float* out_f32;            // fp32 NHWC [B, H, W, 256] or null
     bf16_t* out_bf;            // bf16 NHWC [B, H, W, 256]
     int relu_bf;
     int B, H, W, Cin;
-    const bf16_t* zero_page;   // >= 256 B of zeros
+    int Cout;                  // 256 (every epilogue form) or 128 (bias-only bf16 output: the head's first conv)
+    const bf16_t* zero_page;   // unused (out-of-image pixels are staged as zeros by the buffer bounds check)
     unsigned long long* dbg_times;  // test hook: per-workgroup s_memtime stamps [start, first barrier, loop done, stores acknowledged, stores issued, XCC id]
     int dbg_flags;                  // set by the launcher from MDPT_CONV3H_DBG (timing experiments that skip parts of the loop; results are wrong)
 };

@@ -16,13 +16,14 @@ def _pack(w):  # [256][Cin][3][3] fp32 -> [256][9 Cin], k = (cb * 9 + ky * 3 + k
 
 def _run(lib, native, path, tile, x, wp, bias, skip, up, want_f32, relu, dbg=None):
     B, H, W, Cin = x.shape
-    out_bf = torch.full((B, H, W, 256), float("nan"), device="cuda", dtype=torch.bfloat16)
-    out_f32 = torch.full((B, H, W, 256), float("nan"), device="cuda", dtype=torch.float32) if want_f32 else None
+    cout = wp.shape[0]
+    out_bf = torch.full((B, H, W, cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    out_f32 = torch.full((B, H, W, cout), float("nan"), device="cuda", dtype=torch.float32) if want_f32 else None
     stream = torch.cuda.current_stream().cuda_stream
     native.check(lib, lib.mdpt_debug_conv3(x.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
                                            skip.data_ptr() if skip is not None else None, up.data_ptr() if up is not None else None,
                                            up.shape[1] if up is not None else 0, up.shape[2] if up is not None else 0,
-                                           out_f32.data_ptr() if want_f32 else None, out_bf.data_ptr(), int(relu), B, H, W, Cin, path, tile, 1, stream,
+                                           out_f32.data_ptr() if want_f32 else None, out_bf.data_ptr(), int(relu), B, H, W, Cin, cout, path, tile, 1, stream,
                                            dbg.data_ptr() if dbg is not None else None))
     torch.cuda.synchronize()
     return out_f32, out_bf
@@ -88,3 +89,24 @@ def test_conv3h_is_deterministic_and_batch_independent():
     assert torch.equal(full.view(torch.int16), again.view(torch.int16))
     _, one = _run(lib, native, 1, 0, x[4:5].contiguous(), wp, bias, skip[4:5].contiguous(), None, False, False)
     assert torch.equal(full[4:5].view(torch.int16), one.view(torch.int16))
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 256), (1, 48, 40, 128), (1, 18, 34, 128)])
+def test_conv3h_128_output_channels_head_conv1_form(shape):
+    """The head's first conv (256 -> 128 channels, bias, no activation: head_model.py:74-76) in the halo-staged kernel's 128-channel
+    form (two MFMA phases per K tile, four-deep weight ring) vs a CPU fp64 conv and bit-for-bit vs the implicit-GEMM kernels."""
+    from muggled_dpt_amd import native
+    lib = native.load()
+    B, H, W, Cin = shape
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16)
+    w = (torch.randn(128, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).to(torch.bfloat16)
+    bias = torch.randn(128, generator=g)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    xd, wp, bd = x.cuda(), _pack(w.float()).to(torch.bfloat16).cuda(), bias.cuda()
+    _, obf = _run(lib, native, 1, 0, xd, wp, bd, None, None, False, False)
+    err = float((obf.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 6e-3, f"rel err {err:.3e}"
+    for tile in (6, 1, 0):
+        _, rbf = _run(lib, native, 0, tile, xd, wp, bd, None, None, False, False)
+        assert torch.equal(rbf.view(torch.int16), obf.view(torch.int16)), f"differs from implicit GEMM tile {tile}"

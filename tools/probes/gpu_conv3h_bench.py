@@ -14,22 +14,22 @@ lib = native.load()
 stream = torch.cuda.current_stream().cuda_stream
 VARIANTS = {"bf16+relu": (False, False, True, False), "skip->bf16": (True, False, False, False), "f32+bf16relu": (False, True, True, False),
             "skip+up->f32+bf16": (True, True, True, True)}
-shapes = [(32, 144, 144, 256)] + ([(32, 288, 288, 256)] if "--big" in sys.argv else [])
-for (B, H, W, Cin) in shapes:
+shapes = [(32, 144, 144, 256, 256)] + ([(32, 288, 288, 256, 128)] if "--head" in sys.argv else [])
+for (B, H, W, Cin, Cout) in shapes:
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).cuda()
-    wp = _pack(torch.randn(256, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).to(torch.bfloat16).cuda()
-    bias = torch.randn(256, generator=g).cuda()
-    skip = torch.randn(B, H, W, 256, generator=g).cuda()
-    up = torch.randn(B, H // 2, W // 2, 256, generator=g).cuda()
-    obf = torch.empty(B, H, W, 256, device="cuda", dtype=torch.bfloat16)
-    o32 = torch.empty(B, H, W, 256, device="cuda", dtype=torch.float32)
-    flops = 2.0 * B * H * W * 256 * 9 * Cin
-    for name, (has_skip, want_f32, relu, has_up) in VARIANTS.items():
+    wp = _pack(torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).to(torch.bfloat16).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    skip = torch.randn(B, H, W, Cout, generator=g).cuda() if Cout == 256 else None
+    up = torch.randn(B, H // 2, W // 2, Cout, generator=g).cuda() if Cout == 256 else None
+    obf = torch.empty(B, H, W, Cout, device="cuda", dtype=torch.bfloat16)
+    o32 = torch.empty(B, H, W, Cout, device="cuda", dtype=torch.float32) if Cout == 256 else None
+    flops = 2.0 * B * H * W * Cout * 9 * Cin
+    for name, (has_skip, want_f32, relu, has_up) in (VARIANTS.items() if Cout == 256 else [("bias->bf16 (head conv1)", (False, False, False, False))]):
         def launch(path, iters, dbg=None):
             native.check(lib, lib.mdpt_debug_conv3(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), skip.data_ptr() if has_skip else None,
                                                    up.data_ptr() if has_up else None, H // 2 if has_up else 0, W // 2 if has_up else 0,
-                                                   o32.data_ptr() if want_f32 else None, obf.data_ptr(), int(relu), B, H, W, Cin, path, 0, iters, stream,
+                                                   o32.data_ptr() if want_f32 else None, obf.data_ptr(), int(relu), B, H, W, Cin, Cout, path, 0, iters, stream,
                                                    dbg.data_ptr() if dbg is not None else None))
         res = {0: [], 1: []}
         for path in (0, 1):
