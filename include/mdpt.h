@@ -214,13 +214,19 @@ int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_
  * fp32 and/or bf16 output), tile as in mdpt_set_gemm_tile. */
 int mdpt_debug_gemm(const void* a_bf16, const void* w_bf16, void* out_f32, void* out_bf16, int32_t M, int32_t N, int32_t K,
                     int32_t tile, int32_t iters, void* stream, void* dbg_times_or_null);
+/* test/bench hook: the fused attention kernel (replaces F.scaled_dot_product_attention, v2_depthanything/components/transformer_block.py:164)
+ * on caller-provided head-major bf16 operands: Q (pre-scaled by 1/sqrt(64)), K [B, heads, npad, 64]; Vt [B, heads, 64, npadv] with zero pad
+ * columns; out [B * npad, heads * 64]. */
+int mdpt_debug_attention(const void* q_bf16, const void* k_bf16, const void* vt_bf16, void* out_bf16, int32_t B, int32_t heads, int32_t N,
+                         int32_t npad, int32_t npadv, int32_t iters, void* stream);
 /* test/bench hook: one 3x3 stride-1 conv Cin -> Cout (256 = the decoder's fusion width, every epilogue form; 128 = the head's first conv,
  * bias only) on caller-provided operands, through the implicit-GEMM
  * kernels (path 0, tile = MDPT_TILE_*) or the halo-staged kernel (path 1). Replaces one nn.Conv2d(…, 3, padding=1) of the reference's
  * ResidualConv2D / fusion blocks (v2_depthanything/fusion_model.py:178-182,210-220) incl. its skip add and the x2-upsampled prior. */
 int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void* bias_f32, const void* skip_f32, const void* up_f32, int32_t Hu,
                      int32_t Wu, void* out_f32, void* out_bf16, int32_t relu_bf16, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
-                     int32_t path, int32_t tile, int32_t iters, void* stream, void* dbg_times);
+                     int32_t path, int32_t tile, int32_t iters, void* stream, void* dbg_times, const void* in_lo_bf16_or_null,
+                     const void* w_lo_bf16_or_null, void* out_lo_bf16_or_null);  /* lo planes: the bf16x3 (fp32-class) mode */
 
 /* Per-launch HIP-event profiler (bench.py's roofline leg): events are recorded on the launch stream around every
  * kernel launch while enabled. mdpt_profile_report() waits for the recorded events and writes a JSON summary

@@ -37,6 +37,12 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
+// Deferred running maximum of the online softmax: the reference point m of a query row only moves when a tile's maximum exceeds it by
+// more than kDeferMax (score units; e^5.5 = 2^7.9), so after the first tile or two NO lane of a wave changes m any more and the wave
+// skips the 64-wide rescale of O^T for the rest of the key loop (before: the exact running maximum of at least one of a wave's 64
+// queries moves in almost every tile, so the skip never fired). p = exp(s - m) <= e^5.5 is harmless in fp32 / bf16 and the final
+// O / l is the same number mathematically; a lane's decision depends on its own query only (batch-invariant bits).
+constexpr float kDeferMax = 5.5f;
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                 const unsigned s0 = sw[0], s1 = sw[1];
                 mloc = fmaxf(__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1));
             }
-            const float m_new = fmaxf(m_run[qb], mloc);
+            const float m_new = mloc > m_run[qb] + kDeferMax ? mloc : m_run[qb];
             const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kLog2e);
             const float mb = m_new * kLog2e;
             m_run[qb] = m_new;
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                 }
             const float psum = psum2[0] + psum2[1];
             l_run[qb] = l_run[qb] * alpha + psum;
-            if (__any(alpha != 1.0f)) {  // after the first tiles the running max rarely moves: skip 32 multiplies
+            if (__any(alpha != 1.0f)) {  // the reference point moved for some query of this wave (first tiles, outlier keys): rescale O^T
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
 #pragma unroll

@@ -65,10 +65,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* base, s
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)(bytes < 0xFFFFFFF0ull ? bytes : 0xFFFFFFF0ull), 0x00020000);
 }
 
-template <int NQN, bool SKIP, bool F32OUT, bool RELU, bool UP>
+// X3: bf16x3 split precision (x = hi + lo planes for the input and the weights, hi / lo output planes): the K loop runs three times,
+// A_lo * W_hi, A_hi * W_lo, A_hi * W_hi, into the same fp32 accumulators - the pass order of the implicit-GEMM kernels. A pass is just
+// ncb more channel blocks whose halo patches / weight tiles come from the other operand planes ("virtual" channel block vcb = pass * ncb + cb).
+// BFOUT: bf16 output planes (false: fp32 map only - the bf16x3 head keeps the fp32 map for its bilinear upsample).
+template <int NQN, bool X3, bool SKIP, bool F32OUT, bool RELU, bool UP, bool BFOUT>
 __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     constexpr int COUT = 128 * NQN;  // output channels: 256 (two 128-column halves per wave) or 128
-    static_assert(NQN == 2 || (!SKIP && !F32OUT && !UP), "the 128-channel form has the plain bf16 epilogue only");
+    static_assert(NQN == 2 || (!SKIP && !UP && !RELU), "the 128-channel form has the bias-only epilogues");
+    static_assert(BFOUT || F32OUT, "no output");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr unsigned OOB = 0xFFFFFFF0u;
     unsigned long long t_start = 0, t_first = 0, t_loop = 0;
@@ -100,21 +105,33 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     //      instructions need no zero page, no 64-bit pointer arithmetic and no selects inside the loop.
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const int Kw = p.Cin * 9;
-    const __amdgpu_buffer_rsrc_t rs_w = plane_rsrc(p.w, (size_t)COUT * Kw * 2);
-    const __amdgpu_buffer_rsrc_t rs_in = plane_rsrc(in_img, (size_t)p.H * p.W * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rs_w_hi = plane_rsrc(p.w, (size_t)COUT * Kw * 2);
+    const __amdgpu_buffer_rsrc_t rs_w_lo = plane_rsrc(X3 ? p.w_lo : p.w, (size_t)COUT * Kw * 2);
+    const __amdgpu_buffer_rsrc_t rs_in_hi = plane_rsrc(in_img, (size_t)p.H * p.W * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rs_in_lo = plane_rsrc(X3 ? p.in_lo + (size_t)img * p.H * p.W * p.Cin : in_img, (size_t)p.H * p.W * p.Cin * 2);
+    const int nvcb = X3 ? 3 * ncb : ncb;  // channel blocks of all passes
+    const int T = 9 * ncb;                // K tiles per pass; ncb is even (the launcher checks Cin % 128 == 0)
+    // K tile kt of the whole loop -> (operand plane of the weights, byte offset of its K tile inside the plane)
+    auto w_pass = [&](int kt) -> int { return X3 ? (kt >= 2 * T ? 2 : (kt >= T ? 1 : 0)) : 0; };
     // B (weights): DMA instruction i of a wave stages rows r = 8 * (wave + 8 i) + lane / 8 = r0 + 64 i; 16-byte slot lane % 8 holds k-chunk
     // slot ^ ((r >> 1) & 7) (the key is the same for all four i). One lane constant; (K tile kt, i) enter through the scalar offset.
     const unsigned b_voff = (unsigned)((wave * 8 + (lane >> 3)) * Kw + (((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)) << 3)) * 2u;
     auto issue_b = [&](int half, int buf, int kt) {  // half-tile `half` (128 weight rows) of K tile kt -> B buffer `buf`
+        const int ps = w_pass(kt);
+        const __amdgpu_buffer_rsrc_t rs = ps == 1 ? rs_w_lo : rs_w_hi;
+        const int soff = (kt - ps * T) * 128;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if ((i >> 1) == half)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(smem + buf * BTILE + (wave + 8 * i) * 1024), 16, b_voff, kt * 128 + i * 128 * Kw, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf * BTILE + (wave + 8 * i) * 1024), 16, b_voff, soff + i * 128 * Kw, 0, 0);
     };
     auto issue_b128 = [&](int buf4, int kt) {  // COUT = 128: the whole 16 KB K tile kt -> slot buf4 of a FOUR-deep ring (two instructions per wave)
+        const int ps = w_pass(kt);
+        const __amdgpu_buffer_rsrc_t rs = ps == 1 ? rs_w_lo : rs_w_hi;
+        const int soff = (kt - ps * T) * 128;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(smem + buf4 * (BTILE / 2) + (wave + 8 * i) * 1024), 16, b_voff, kt * 128 + i * 128 * Kw, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf4 * (BTILE / 2) + (wave + 8 * i) * 1024), 16, b_voff, soff + i * 128 * Kw, 0, 0);
     };
     // A (halo): DMA instruction c = wave + 8 j of a patch covers halo bytes [1024 c, 1024 c + 1024) = 8 pixels x 8 slots; channel block
     // cb at soffset 128 cb. Instructions 41..47 (j = 5 of waves 1-7) do not exist: all lanes out of range, destination = the scratch KiB.
@@ -128,11 +145,14 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
         const bool ok = c < HALO_INSTR && q < 324 && (unsigned)Y < (unsigned)p.H && (unsigned)X < (unsigned)p.W;
         h_voff[j] = ok ? ((unsigned)(Y * p.W + X) * (unsigned)p.Cin + (unsigned)((slot ^ (xx & 7)) << 3)) * 2u : OOB;
     }
-    auto issue_halo = [&](int j, int cbn, int hbn, bool dummy) {  // dummy (wave-uniform): no next channel block - zeros into the scratch KiB
+    auto issue_halo = [&](int j, int vcbn, int hbn, bool dummy) {  // dummy (wave-uniform): no next channel block - zeros into the scratch KiB
         const int c = wave + 8 * j;
         const bool real = c < HALO_INSTR && !dummy;
         const unsigned voff = dummy ? OOB : h_voff[j];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(smem + (real ? OFF_H + hbn * HALO_BYTES + c * 1024 : OFF_SCR)), 16, voff, cbn * 128, 0, 0);
+        const bool lo_plane = X3 && vcbn < ncb;  // pass 0 reads the lo plane of the input
+        const int cbn = X3 ? (vcbn >= 2 * ncb ? vcbn - 2 * ncb : (vcbn >= ncb ? vcbn - ncb : vcbn)) : vcbn;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(lo_plane ? rs_in_lo : rs_in_hi, (lds_ptr_t)(smem + (real ? OFF_H + hbn * HALO_BYTES + c * 1024 : OFF_SCR)), 16, voff,
+                                                 cbn * 128, 0, 0);
     };
     // SKIP: the fp32 skip tile (256 KB, read once, no reuse) is added in the EPILOGUE (((conv + bias) + up) + skip, the order of the generic
     // epilogue); one more DMA instruction per wave and K tile pulls pixel `8 slot + wave` of it towards the CU (its 1 KiB lands in the
@@ -200,7 +220,6 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 #define WAIT_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory")
 #define WAIT_VM_IMM(N_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory")
 
-    const int T = 9 * ncb;  // K tiles; ncb is even (the launcher checks Cin % 128 == 0)
     if constexpr (NQN == 1) {
         // ---- COUT = 128 (head conv 1, head_model.py:74-76): a K tile of weights is 16 KB, a wave owns two 64 x 32 quadrants (qm = 0, 1), so a
         //      K tile has TWO phases of 16 MFMAs and the weights live in a four-deep ring (K tile kt in slot kt & 3, staged three K tiles ahead):
@@ -233,8 +252,8 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
             BAR(); WAIT_LGKM(0); PIN();                                                                               \
             MFMA_Q(1, 0, fb0); BAR();                                                                                 \
         } while (0)
-        for (int cbp = 0; cbp < ncb; cbp += 2) {
-            const bool last = cbp + 2 >= ncb;
+        for (int cbp = 0; cbp < nvcb; cbp += 2) {
+            const bool last = cbp + 2 >= nvcb;
             CONV_KT128(0); CONV_KT128(1); CONV_KT128(2); CONV_KT128(3); CONV_KT128(4); CONV_KT128(5); CONV_KT128(6); CONV_KT128(7); CONV_KT128(8);
             CONV_KT128(9); CONV_KT128(10); CONV_KT128(11); CONV_KT128(12); CONV_KT128(13); CONV_KT128(14); CONV_KT128(15); CONV_KT128(16); CONV_KT128(17);
         }
@@ -273,7 +292,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
         WAIT_LGKM(8); BAR(); WAIT_LGKM(0); PIN();                                                                     \
         MFMA_Q(0, 0, fb0); BAR();                                                                                     \
         LOAD_B(fb1, 1, bi); PIN();                                                                                    \
-        if (more) { issue_b(0, bi, kt + 2); if constexpr (SKIP) issue_prefetch(kt - 2); }                             \
+        if (more) { issue_b(0, bi, kt + 2); if constexpr (SKIP) issue_prefetch(kt - (9 * nvcb - 34)); }                             \
         BAR(); WAIT_LGKM(0); PIN();                                                                                   \
         MFMA_Q(0, 1, fb1); BAR();                                                                                     \
         LOAD_A(1, va, ky); PIN();                                                                                     \
@@ -284,8 +303,8 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
         BAR();                                                                                                        \
         MFMA_Q(1, 0, fb0); BAR();                                                                                     \
     } while (0)
-    for (int cbp = 0; cbp < ncb; cbp += 2) {
-        const bool last = cbp + 2 >= ncb;  // wave-uniform: the last two K tiles issue nothing and drain
+    for (int cbp = 0; cbp < nvcb; cbp += 2) {
+        const bool last = cbp + 2 >= nvcb;  // wave-uniform: the last two K tiles issue nothing and drain
         CONV_KT(0); CONV_KT(1); CONV_KT(2); CONV_KT(3); CONV_KT(4); CONV_KT(5); CONV_KT(6); CONV_KT(7); CONV_KT(8);
         CONV_KT(9); CONV_KT(10); CONV_KT(11); CONV_KT(12); CONV_KT(13); CONV_KT(14); CONV_KT(15); CONV_KT(16); CONV_KT(17);
     }
@@ -304,7 +323,8 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     const size_t plane_px = (size_t)p.H * p.W;
     const __amdgpu_buffer_rsrc_t rs_f = plane_rsrc(F32OUT ? p.out_f32 + (size_t)img * plane_px * COUT : nullptr, F32OUT ? plane_px * COUT * 4 : 0);
-    const __amdgpu_buffer_rsrc_t rs_b = plane_rsrc(p.out_bf + (size_t)img * plane_px * COUT, plane_px * COUT * 2);
+    const __amdgpu_buffer_rsrc_t rs_b = plane_rsrc(BFOUT ? p.out_bf + (size_t)img * plane_px * COUT : nullptr, BFOUT ? plane_px * COUT * 2 : 0);
+    const __amdgpu_buffer_rsrc_t rs_bl = plane_rsrc(BFOUT && X3 ? p.out_bf_lo + (size_t)img * plane_px * COUT : nullptr, BFOUT && X3 ? plane_px * COUT * 2 : 0);
     const bool xok = X0 + l15 < p.W;
 
     // bilinear x2 (align_corners=True) add of the coarser fusion level (fusion_model.py:151,178): stage the <= 10x10 coarse pixels this
@@ -412,23 +432,37 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[j][e] = fmaxf(v[j][e], 0.0f);
             }
-            unsigned hw_[2][2];
+            if constexpr (BFOUT) {
+                unsigned hw_[2][2], lw_[2][2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int w2 = 0; w2 < 2; ++w2) {
+                        const f32x2 pp = {v[j][2 * w2], v[j][2 * w2 + 1]};
+                        const bf16x2 hh = __builtin_convertvector(pp, bf16x2);
+                        hw_[j][w2] = __builtin_bit_cast(unsigned, hh);
+                        if constexpr (X3) {
+                            const f32x2 rr = pp - __builtin_convertvector(hh, f32x2);
+                            lw_[j][w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                        }
+                    }
+                unsigned ph[4], pl[4];
 #pragma unroll
                 for (int w2 = 0; w2 < 2; ++w2) {
-                    const f32x2 pp = {v[j][2 * w2], v[j][2 * w2 + 1]};
-                    hw_[j][w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(pp, bf16x2));
+                    auto r = __builtin_amdgcn_permlane16_swap(hw_[0][w2], hw_[1][w2], false, false);
+                    ph[w2] = r[0];
+                    ph[w2 + 2] = r[1];
+                    if constexpr (X3) {
+                        auto rl = __builtin_amdgcn_permlane16_swap(lw_[0][w2], lw_[1][w2], false, false);
+                        pl[w2] = rl[0];
+                        pl[w2 + 2] = rl[1];
+                    }
                 }
-            unsigned ph[4];
-#pragma unroll
-            for (int w2 = 0; w2 < 2; ++w2) {
-                auto r = __builtin_amdgcn_permlane16_swap(hw_[0][w2], hw_[1][w2], false, false);
-                ph[w2] = r[0];
-                ph[w2 + 2] = r[1];
+                // (no branch around the stores: hipcc would wait for every store's acknowledgement)
+                const unsigned boff = ok ? pix * (unsigned)(COUT * 2) + colb : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{ph[0], ph[1], ph[2], ph[3]}, rs_b, boff, 0, 0);
+                if constexpr (X3) __builtin_amdgcn_raw_buffer_store_b128(u32x4{pl[0], pl[1], pl[2], pl[3]}, rs_bl, boff, 0, 0);
             }
-            // (the bf16 map is always present: no branch around the stores, hipcc would wait for every store's acknowledgement)
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{ph[0], ph[1], ph[2], ph[3]}, rs_b, ok ? pix * (unsigned)(COUT * 2) + colb : OOB, 0, 0);
         }
     };
     if constexpr (SKIP) {
@@ -469,9 +503,9 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 #undef WAIT_LGKM
 #undef WAIT_VM_IMM
 
-template <int NQN, bool SKIP, bool F32OUT, bool RELU, bool UP>
+template <int NQN, bool X3, bool SKIP, bool F32OUT, bool RELU, bool UP, bool BFOUT = true>
 int launch_variant(const Conv3hParams& p, hipStream_t stream) {
-    auto kern = conv3h_kernel<NQN, SKIP, F32OUT, RELU, UP>;
+    auto kern = conv3h_kernel<NQN, X3, SKIP, F32OUT, RELU, UP, BFOUT>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -479,9 +513,10 @@ int launch_variant(const Conv3hParams& p, hipStream_t stream) {
         attr_done = true;
     }
     const int tiles = p.B * ((p.H + 15) / 16) * ((p.W + 15) / 16);
-    static char prof_name[64] = "";
-    if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "conv3h_kernel<%d, %d, %d, %d, %d>", 128 * NQN, (int)SKIP, (int)F32OUT, (int)RELU, (int)UP);
-    MdptProfScope prof(prof_name, 2.0 * p.B * p.H * p.W * (128.0 * NQN) * 9.0 * p.Cin, stream);
+    static char prof_name[80] = "";
+    if (!prof_name[0])
+        snprintf(prof_name, sizeof(prof_name), "conv3h_kernel<%d, %s, %d, %d, %d, %d>", 128 * NQN, X3 ? "x3" : "bf16", (int)SKIP, (int)F32OUT, (int)RELU, (int)UP);
+    MdptProfScope prof(prof_name, 2.0 * p.B * p.H * p.W * (128.0 * NQN) * 9.0 * p.Cin, stream);  // algorithmic flops (one pass, whatever the mode)
     static const int dbg_flags = getenv("MDPT_CONV3H_DBG") ? atoi(getenv("MDPT_CONV3H_DBG")) : 0;  // timing experiments (wrong results)
     Conv3hParams q = p;
     q.dbg_flags = dbg_flags;
@@ -489,15 +524,33 @@ int launch_variant(const Conv3hParams& p, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// the epilogue combinations the decoder uses
+template <bool X3>
+int launch_mode(const Conv3hParams& p, hipStream_t stream) {
+    const bool skip = p.skip != nullptr, f32 = p.out_f32 != nullptr, up = p.up_src != nullptr;
+    if (p.Cout == 128) {
+        if (p.out_bf) return launch_variant<1, X3, false, false, false, false>(p, stream);
+        return launch_variant<1, X3, false, true, false, false, false>(p, stream);
+    }
+    if (up) return launch_variant<2, X3, true, true, true, true>(p, stream);
+    if (!skip && !f32) return launch_variant<2, X3, false, false, true, false>(p, stream);
+    if (skip && !f32) return launch_variant<2, X3, true, false, false, false>(p, stream);
+    return launch_variant<2, X3, false, true, true, false>(p, stream);
+}
+
 }  // namespace
 
 // the combinations the decoder uses (anything else runs the implicit-GEMM path of gemm.hip)
 bool mdpt_conv3h_supported(const Conv3hParams& p) {
-    if (p.B <= 0 || p.H < 2 || p.W < 2 || p.Cin <= 0 || (p.Cin & 127) || !p.in || !p.w || !p.out_bf) return false;
+    if (p.B <= 0 || p.H < 2 || p.W < 2 || p.Cin <= 0 || (p.Cin & 127) || !p.in || !p.w) return false;
     if (p.Cout != 256 && p.Cout != 128) return false;
     if ((size_t)p.H * p.W * p.Cout * 4 >= 0xFFFFFFF0ull || (size_t)p.H * p.W * p.Cin * 2 >= 0xFFFFFFF0ull) return false;  // 32-bit byte offsets inside one image plane
+    const bool x3 = p.in_lo != nullptr;
+    if (x3 && (!p.w_lo || (p.out_bf && !p.out_bf_lo))) return false;
+    if (!x3 && (p.w_lo || p.out_bf_lo)) return false;
     const bool skip = p.skip != nullptr, f32 = p.out_f32 != nullptr, relu = p.relu_bf != 0, up = p.up_src != nullptr;
-    if (p.Cout == 128) return !skip && !f32 && !relu && !up;
+    if (p.Cout == 128) return !skip && !relu && !up && ((p.out_bf != nullptr) != f32);  // bias -> bf16 planes, or bias -> fp32 map
+    if (!p.out_bf) return false;
     if (up) {
         // the 16 fine rows / columns of a tile must interpolate from <= UPW coarse ones: floor(15 * scale) + 3 <= UPW
         if (p.Hu < 1 || p.Wu < 1 || (long)15 * (p.Hu - 1) >= (long)(UPW - 2) * (p.H - 1) || (long)15 * (p.Wu - 1) >= (long)(UPW - 2) * (p.W - 1)) return false;
@@ -511,10 +564,5 @@ bool mdpt_conv3h_supported(const Conv3hParams& p) {
 
 int mdpt_launch_conv3h(const Conv3hParams& p, hipStream_t stream) {
     if (!mdpt_conv3h_supported(p)) return (int)hipErrorInvalidValue;
-    const bool skip = p.skip != nullptr, f32 = p.out_f32 != nullptr, up = p.up_src != nullptr;
-    if (p.Cout == 128) return launch_variant<1, false, false, false, false>(p, stream);
-    if (up) return launch_variant<2, true, true, true, true>(p, stream);
-    if (!skip && !f32) return launch_variant<2, false, false, true, false>(p, stream);
-    if (skip && !f32) return launch_variant<2, true, false, false, false>(p, stream);
-    return launch_variant<2, false, true, true, false>(p, stream);
+    return p.in_lo ? launch_mode<true>(p, stream) : launch_mode<false>(p, stream);
 }

@@ -699,7 +699,7 @@ int run_reassemble(const Ctx& c) {
 // so one image's bits do not depend on the batch it is part of. Partial 16x16 tiles may waste at most 25 % of the MFMA work (72x72: 25
 // tiles for 20.25 image-tiles' worth of pixels - the halo-staged loop is ~30 % faster per K tile; 36x36: 9 for 5.06 -> implicit GEMM).
 bool conv3h_shape_ok(const mdpt_handle* h, int H, int W, int Cin) {
-    if (h->x3 || h->Cp != 256 || (Cin & 127) || H < 2 || W < 2) return false;
+    if (h->Cp != 256 || (Cin & 127) || H < 2 || W < 2) return false;
     const long tile_px = (long)((H + 15) / 16) * ((W + 15) / 16) * 256, px = (long)H * W;
     return tile_px * 4 <= px * 5;
 }
@@ -712,8 +712,8 @@ int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int 
     if (eligible && h->gemm_tile == MDPT_TILE_AUTO) {
         Conv3hParams q;
         memset(&q, 0, sizeof(q));
-        q.in = in.hi; q.w = w.hi; q.bias = bias; q.skip = skip; q.up_src = up_src; q.Hu = Hu; q.Wu = Wu;
-        q.out_f32 = out_f32; q.out_bf = out.hi; q.relu_bf = relu_bf16;
+        q.in = in.hi; q.in_lo = in.lo; q.w = w.hi; q.w_lo = w.lo; q.bias = bias; q.skip = skip; q.up_src = up_src; q.Hu = Hu; q.Wu = Wu;
+        q.out_f32 = out_f32; q.out_bf = out.hi; q.out_bf_lo = out.lo; q.relu_bf = relu_bf16;
         q.B = c.p.B; q.H = sh; q.W = sw; q.Cin = Cin; q.Cout = 256; q.zero_page = h->zero_page;
         const long tiles256 = ((long)c.p.B * sh * sw + 255) / 256;
         if (tiles256 >= (c.split ? 24 : 140) && mdpt_conv3h_supported(q)) return mdpt_launch_conv3h(q, c.s);
@@ -813,11 +813,27 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32) {
         return 0;
     }
     {
-        GemmParams g = base_params(c, h->M("head.spatial_upsampler.0.weight"), c.pl(p.fused), p.B * fh * fw, h->Cp);
-        as_conv(g, fh, fw, h->Cp, fh, fw, 1);
-        g.bias = h->V("head.spatial_upsampler.0.bias");
-        g.out_f32 = c.at<float>(p.h1); g.ldc = h->C2p;
-        CHK(mdpt_launch_gemm(g, c.s));
+        bool done = false;
+        if (h->C2p == 128 && conv3h_shape_ok(h, fh, fw, h->Cp) && h->gemm_tile == MDPT_TILE_AUTO) {  // halo-staged form, fp32 map out
+            const Mat& w1 = h->M("head.spatial_upsampler.0.weight");
+            Planes fu = c.pl(p.fused);
+            Conv3hParams q;
+            memset(&q, 0, sizeof(q));
+            q.in = fu.hi; q.in_lo = fu.lo; q.w = w1.hi; q.w_lo = w1.lo; q.bias = h->V("head.spatial_upsampler.0.bias");
+            q.out_f32 = c.at<float>(p.h1); q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
+            const long tiles256 = ((long)p.B * fh * fw + 255) / 256;
+            if (tiles256 >= (c.split ? 24 : 140) && mdpt_conv3h_supported(q)) {
+                CHK(mdpt_launch_conv3h(q, c.s));
+                done = true;
+            }
+        }
+        if (!done) {
+            GemmParams g = base_params(c, h->M("head.spatial_upsampler.0.weight"), c.pl(p.fused), p.B * fh * fw, h->Cp);
+            as_conv(g, fh, fw, h->Cp, fh, fw, 1);
+            g.bias = h->V("head.spatial_upsampler.0.bias");
+            g.out_f32 = c.at<float>(p.h1); g.ldc = h->C2p;
+            CHK(mdpt_launch_gemm(g, c.s));
+        }
     }
     Planes hu = c.pl(p.h1u);
     CHK(mdpt_launch_upsample(c.at<float>(p.h1), hu.hi, hu.lo, nullptr, p.B, fh, fw, p.H, p.W, h->C2p, c.s));
@@ -1498,9 +1514,11 @@ int mdpt_debug_gemm(const void* a_bf16, const void* w_bf16, void* out_f32, void*
 //      out = [skip +] conv + [bias] [+ up2(up)] -> out_f32 (optional) and out_bf16 (ReLU'd if relu_bf16); both paths use the same arithmetic
 int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void* bias_f32, const void* skip_f32, const void* up_f32, int32_t Hu,
                      int32_t Wu, void* out_f32, void* out_bf16, int32_t relu_bf16, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
-                     int32_t path, int32_t tile, int32_t iters, void* stream, void* dbg_times) {
+                     int32_t path, int32_t tile, int32_t iters, void* stream, void* dbg_times, const void* in_lo_bf16, const void* w_lo_bf16,
+                     void* out_lo_bf16) {
     if (Cout != 256 && Cout != 128) return fail(MDPT_E_INVALID, "Cout must be 256 or 128");
-    if (!in_bf16 || !w_packed_bf16 || !out_bf16) return fail(MDPT_E_INVALID, "null argument");
+    if ((in_lo_bf16 != nullptr) != (w_lo_bf16 != nullptr)) return fail(MDPT_E_INVALID, "bf16x3 needs the lo planes of input and weights");
+    if (!in_bf16 || !w_packed_bf16 || (!out_bf16 && !out_f32)) return fail(MDPT_E_INVALID, "null argument");
     static bf16_t* zero_page = nullptr;  // test hook only: allocated once, never freed
     if (!zero_page) {
         if (hipMalloc((void**)&zero_page, 256) != hipSuccess || hipMemset(zero_page, 0, 256) != hipSuccess) return fail(MDPT_E_STATE, "zero page allocation failed");
@@ -1509,6 +1527,7 @@ int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void*
         Conv3hParams q;
         memset(&q, 0, sizeof(q));
         q.in = (const bf16_t*)in_bf16; q.w = (const bf16_t*)w_packed_bf16; q.bias = (const float*)bias_f32; q.skip = (const float*)skip_f32;
+        q.in_lo = (const bf16_t*)in_lo_bf16; q.w_lo = (const bf16_t*)w_lo_bf16; q.out_bf_lo = (bf16_t*)out_lo_bf16;
         q.up_src = (const float*)up_f32; q.Hu = Hu; q.Wu = Wu; q.out_f32 = (float*)out_f32; q.out_bf = (bf16_t*)out_bf16; q.relu_bf = relu_bf16;
         q.B = B; q.H = H; q.W = W; q.Cin = Cin; q.Cout = Cout; q.zero_page = zero_page;
         q.dbg_times = (unsigned long long*)dbg_times;
@@ -1518,16 +1537,29 @@ int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void*
     }
     GemmParams g;
     memset(&g, 0, sizeof(g));
-    g.A_hi = (const bf16_t*)in_bf16; g.W_hi = (const bf16_t*)w_packed_bf16;
-    g.M = B * H * W; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.npass = 1;
+    g.A_hi = (const bf16_t*)in_bf16; g.W_hi = (const bf16_t*)w_packed_bf16; g.A_lo = (const bf16_t*)in_lo_bf16; g.W_lo = (const bf16_t*)w_lo_bf16;
+    g.M = B * H * W; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.npass = in_lo_bf16 ? 3 : 1;
     g.zero_page = zero_page;
     g.amode = MDPT_A_CONV3; g.ekind = MDPT_E_GENERIC; g.tile = tile;
     g.Hi = H; g.Wi = W; g.Cin = Cin; g.Ho = H; g.Wo = W; g.cstride = 1;
     g.bias = (const float*)bias_f32; g.resid = (const float*)skip_f32; g.ldr = Cout;
     g.up_src = (const float*)up_f32; g.Hu = Hu; g.Wu = Wu;
-    g.out_f32 = (float*)out_f32; g.out_hi = (bf16_t*)out_bf16; g.relu_bf16 = relu_bf16; g.ldc = Cout;
+    g.out_f32 = (float*)out_f32; g.out_hi = (bf16_t*)out_bf16; g.out_lo = (bf16_t*)out_lo_bf16; g.relu_bf16 = relu_bf16; g.ldc = Cout;
     g.dbg_times = (unsigned long long*)dbg_times;
     for (int i = 0; i < iters; ++i) CHK(mdpt_launch_gemm(g, (hipStream_t)stream));
+    return 0;
+}
+
+// ---- test hook: the fused attention kernel on caller-provided head-major operands (bf16 mode, head dim 64, no bias):
+//      Q, K [B, heads, npad, 64] (Q pre-scaled by 1/8), Vt [B, heads, 64, npadv] (pad columns zero) -> out [B * npad, heads * 64]
+int mdpt_debug_attention(const void* q_bf16, const void* k_bf16, const void* vt_bf16, void* out_bf16, int32_t B, int32_t heads, int32_t N,
+                         int32_t npad, int32_t npadv, int32_t iters, void* stream) {
+    if (!q_bf16 || !k_bf16 || !vt_bf16 || !out_bf16) return fail(MDPT_E_INVALID, "null argument");
+    AttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.q_hi = (const bf16_t*)q_bf16; a.k_hi = (const bf16_t*)k_bf16; a.vt_hi = (const bf16_t*)vt_bf16; a.out_hi = (bf16_t*)out_bf16;
+    a.B = B; a.heads = heads; a.N = N; a.npad = npad; a.npadv = npadv; a.F = heads * 64;
+    for (int i = 0; i < iters; ++i) CHK(mdpt_launch_attention(a, (hipStream_t)stream));
     return 0;
 }
 

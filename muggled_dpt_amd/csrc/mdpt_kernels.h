@@ -62,13 +62,16 @@ int mdpt_launch_gemm(const GemmParams& p, hipStream_t stream);   // returns hipE
 // Same K order (MDPT_PACK_CONV3 weights) and epilogue arithmetic as the MDPT_A_CONV3 path of mdpt_launch_gemm (generic epilogue, resid = skip).
 // ------------------------------------------------------------------------------------------------
 struct Conv3hParams {
-    const bf16_t* in;          // NHWC [B, H, W, Cin] bf16, Cin % 128 == 0
-    const bf16_t* w;           // [Cout][9 * Cin] bf16, MDPT_PACK_CONV3 order
+    const bf16_t* in;          // NHWC [B, H, W, Cin] bf16 (hi plane), Cin % 128 == 0
+    const bf16_t* in_lo;       // lo plane of the input: non-null selects the bf16x3 mode (then w_lo and, with out_bf, out_bf_lo are required)
+    const bf16_t* w;           // [Cout][9 * Cin] bf16, MDPT_PACK_CONV3 order (hi plane)
+    const bf16_t* w_lo;
     const float* bias;         // [Cout] or null
     const float* skip;         // fp32 NHWC [B, H, W, 256] or null
     const float* up_src; int Hu, Wu;  // fp32 NHWC [B, Hu, Wu, 256] or null
     float* out_f32;            // fp32 NHWC [B, H, W, 256] or null
-    bf16_t* out_bf;            // bf16 NHWC [B, H, W, 256]
+    bf16_t* out_bf;            // bf16 NHWC [B, H, W, Cout] (hi plane); Cout = 128 may write the fp32 map alone instead
+    bf16_t* out_bf_lo;
     int relu_bf;
     int B, H, W, Cin;
     int Cout;                  // 256 (every epilogue form) or 128 (bias-only bf16 output: the head's first conv)

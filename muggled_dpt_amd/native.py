@@ -153,7 +153,8 @@ SYMBOLS = {
     "mdpt_set_batch_split": (ctypes.c_int, [_VP, _I]),
     "mdpt_set_latency_mode": (ctypes.c_int, [_VP, _I]),
     "mdpt_debug_gemm": (ctypes.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _VP]),
-    "mdpt_debug_conv3": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP]),
+    "mdpt_debug_attention": (ctypes.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
+    "mdpt_debug_conv3": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "mdpt_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "mdpt_profile_report": (ctypes.c_int, [ctypes.c_char_p, _SZ]),
     "mdpt_debug_set_stop": (ctypes.c_int, [_VP, _I, _I]),

@@ -14,18 +14,22 @@ def _pack(w):  # [256][Cin][3][3] fp32 -> [256][9 Cin], k = (cb * 9 + ky * 3 + k
     return w.view(n, cin // 64, 64, 3, 3).permute(0, 1, 3, 4, 2).reshape(n, 9 * cin).contiguous()
 
 
-def _run(lib, native, path, tile, x, wp, bias, skip, up, want_f32, relu, dbg=None):
+def _run(lib, native, path, tile, x, wp, bias, skip, up, want_f32, relu, dbg=None, x_lo=None, wp_lo=None, want_bf=True):
     B, H, W, Cin = x.shape
     cout = wp.shape[0]
-    out_bf = torch.full((B, H, W, cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    out_bf = torch.full((B, H, W, cout), float("nan"), device="cuda", dtype=torch.bfloat16) if want_bf else None
+    out_lo = torch.full((B, H, W, cout), float("nan"), device="cuda", dtype=torch.bfloat16) if (want_bf and x_lo is not None) else None
     out_f32 = torch.full((B, H, W, cout), float("nan"), device="cuda", dtype=torch.float32) if want_f32 else None
     stream = torch.cuda.current_stream().cuda_stream
     native.check(lib, lib.mdpt_debug_conv3(x.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
                                            skip.data_ptr() if skip is not None else None, up.data_ptr() if up is not None else None,
                                            up.shape[1] if up is not None else 0, up.shape[2] if up is not None else 0,
-                                           out_f32.data_ptr() if want_f32 else None, out_bf.data_ptr(), int(relu), B, H, W, Cin, cout, path, tile, 1, stream,
-                                           dbg.data_ptr() if dbg is not None else None))
+                                           out_f32.data_ptr() if want_f32 else None, out_bf.data_ptr() if want_bf else None, int(relu), B, H, W, Cin, cout, path, tile, 1, stream,
+                                           dbg.data_ptr() if dbg is not None else None, x_lo.data_ptr() if x_lo is not None else None,
+                                           wp_lo.data_ptr() if wp_lo is not None else None, out_lo.data_ptr() if out_lo is not None else None))
     torch.cuda.synchronize()
+    if x_lo is not None:
+        return out_f32, (out_bf, out_lo)
     return out_f32, out_bf
 
 
@@ -110,3 +114,67 @@ def test_conv3h_128_output_channels_head_conv1_form(shape):
     for tile in (6, 1, 0):
         _, rbf = _run(lib, native, 0, tile, xd, wp, bd, None, None, False, False)
         assert torch.equal(rbf.view(torch.int16), obf.view(torch.int16)), f"differs from implicit GEMM tile {tile}"
+
+
+def _split(t):  # fp32 -> (hi, lo) bf16 planes, t ~= hi + lo
+    hi = t.to(torch.bfloat16)
+    return hi, (t - hi.float()).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_conv3h_bf16x3_mode_fp32_class_accuracy_and_bitwise_vs_implicit_gemm(variant):
+    """bf16x3 (hi + lo operand planes, three MFMA passes): the halo-staged kernel against an fp64 conv on the fp32 operands (fp32-class
+    error) and bit-for-bit against the implicit-GEMM kernels (same pass order A_lo W_hi, A_hi W_lo, A_hi W_hi)."""
+    from muggled_dpt_amd import native
+    lib = native.load()
+    B, H, W, Cin = 2, 32, 48, 128
+    has_skip, want_f32, relu, has_up = variant
+    g = torch.Generator().manual_seed(77 + 3 * int(has_skip) + 5 * int(has_up))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(256, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    bias = torch.randn(256, generator=g)
+    skip = torch.randn(B, H, W, 256, generator=g) if has_skip else None
+    up = torch.randn(B, H // 2, W // 2, 256, generator=g) if has_up else None
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), padding=1)
+    if has_up:
+        ref = ref + F.interpolate(up.double().permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=True)
+    if has_skip:
+        ref = ref + skip.double().permute(0, 3, 1, 2)
+    ref = ref.permute(0, 2, 3, 1)
+    xh, xl = _split(x)
+    wh, wl = _split(_pack(w))
+    args = dict(x_lo=xl.cuda(), wp_lo=wl.cuda())
+    sd = skip.cuda() if has_skip else None
+    ud = up.cuda() if has_up else None
+    o32, (ohi, olo) = _run(lib, native, 1, 0, xh.cuda(), wh.cuda(), bias.cuda(), sd, ud, want_f32, relu, **args)
+    got = ohi.double().cpu() + olo.double().cpu()
+    want = ref.clamp_min(0) if relu else ref
+    err = float((got - want).abs().max()) / float(ref.abs().max())
+    assert err < 3e-5, f"hi + lo planes: rel err {err:.3e}"
+    if want_f32:
+        e32 = float((o32.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+        assert e32 < 1e-5, f"fp32 map: rel err {e32:.3e}"
+    for tile in (6, 1, 0):
+        r32, (rhi, rlo) = _run(lib, native, 0, tile, xh.cuda(), wh.cuda(), bias.cuda(), sd, ud, want_f32, relu, **args)
+        assert torch.equal(rhi.view(torch.int16), ohi.view(torch.int16)) and torch.equal(rlo.view(torch.int16), olo.view(torch.int16)), f"tile {tile}"
+        if want_f32:
+            assert torch.equal(r32.view(torch.int32), o32.view(torch.int32)), f"fp32 map differs, tile {tile}"
+
+
+def test_conv3h_128_channels_fp32_map_bf16x3_head_form():
+    """The bf16x3 head keeps conv 1's output as an fp32 map (its bilinear upsample reads fp32): 128 channels, fp32 store only."""
+    from muggled_dpt_amd import native
+    lib = native.load()
+    B, H, W, Cin = 1, 32, 32, 256
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(128, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    bias = torch.randn(128, generator=g)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    xh, xl = _split(x)
+    wh, wl = _split(_pack(w))
+    o32, _ = _run(lib, native, 1, 0, xh.cuda(), wh.cuda(), bias.cuda(), None, None, True, False, x_lo=xl.cuda(), wp_lo=wl.cuda(), want_bf=False)
+    err = float((o32.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 1e-5, f"rel err {err:.3e}"
+    r32, _ = _run(lib, native, 0, 6, xh.cuda(), wh.cuda(), bias.cuda(), None, None, True, False, x_lo=xl.cuda(), wp_lo=wl.cuda(), want_bf=False)
+    assert torch.equal(r32.view(torch.int32), o32.view(torch.int32))

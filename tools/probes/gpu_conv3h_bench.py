@@ -30,7 +30,7 @@ for (B, H, W, Cin, Cout) in shapes:
             native.check(lib, lib.mdpt_debug_conv3(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), skip.data_ptr() if has_skip else None,
                                                    up.data_ptr() if has_up else None, H // 2 if has_up else 0, W // 2 if has_up else 0,
                                                    o32.data_ptr() if want_f32 else None, obf.data_ptr(), int(relu), B, H, W, Cin, Cout, path, 0, iters, stream,
-                                                   dbg.data_ptr() if dbg is not None else None))
+                                                   dbg.data_ptr() if dbg is not None else None, None, None, None))
         res = {0: [], 1: []}
         for path in (0, 1):
             launch(path, 2)
