@@ -36,6 +36,7 @@
 #include "mdpt_kernels.h"
 #include "mdpt_prof.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 // Results must not depend on which tile instantiation a launch picks (the tile is chosen from the batch size, and
 // data-parallel sharding must reproduce the single-GPU result bit for bit): with the default fp-contract=fast the
@@ -618,13 +619,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
 // half-tile and every 128-column B half-tile of a K tile is therefore read in exactly one phase,
 //     P1: B0, A0 -> MFMA(0,0)    P2: B1 -> MFMA(0,1)    P3: A1 -> MFMA(1,1)    P4: (none) -> MFMA(1,0)
 // and can be re-staged early. DMA schedule (e/o = even/odd LDS buffer, t = this iteration's first K tile):
-//     P1: A1o(t+1)  P2: B0e(t+2)  P3: A0e(t+2)  P4: B1e(t+2) + vmcnt(6)
-//     P5: A1e(t+2)  P6: B0o(t+3)  P7: A0o(t+3)  P8: B1o(t+3) + vmcnt(6)
-// vmcnt(6) (3 half-tiles x 2 DMA instructions stay in flight) at P4 retires the odd buffer, which is read in P5-P7, and at
-// P8 the even buffer, read in P1-P3 of the next iteration: the wait sits one phase (>= one workgroup barrier that both
-// groups have passed) before the first read. WAR: a half-tile is re-staged two phases after the phase that read it; B0 is
-// re-staged ONE phase later, which is safe because the reading phase retires its 4 B reads (issued first, order pinned)
-// with lgkmcnt(8) BEFORE its first barrier.
+//     P1: -          P2: B0e(t+2)  P3: A0e(t+2)  P4: B1e(t+2), A1e(t+2) + vmcnt(8)
+//     P5: -          P6: B0o(t+3)  P7: A0o(t+3)  P8: B1o(t+3), A1o(t+3) + vmcnt(8)
+// (round 3: A1 moved out of the 12-read phases P1 / P5 into P4 / P8, which read nothing - QKV 243.9 -> 240.3 us, fc1 372.0 -> 368.0 us on
+// one box, profiles/r03_gemm8_schedule_ab.txt.) vmcnt(8) (the 4 half-tiles x 2 DMA instructions issued since the last wait stay in
+// flight) at P4 retires the odd buffer, which is read in P5-P7, and at P8 the even buffer, read in P1-P3 of the next iteration: the
+// wait sits one phase (>= one workgroup barrier that both groups have passed) before the first read. WAR: a half-tile is re-staged two
+// phases after the phase that read it; B0 and A1 are re-staged ONE phase later, which is safe because the reading phase retires those
+// reads BEFORE its first barrier (P1 / P5: lgkmcnt(8) for the 4 B reads, issued first, order pinned; P3 / P7: lgkmcnt(0)).
 // ------------------------------------------------------------------------------------------------------------
 // Direct (register -> global) epilogues of the 8-phase kernel for tiles computed with SWAPPED MFMA operands
 // (acc = mfma(B frag, A frag)): a lane then owns, for output row m = 16-row block + (lane & 15), four CONSECUTIVE columns
@@ -1077,7 +1079,8 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
                 src = a_ptr[i];
                 a_ptr[i] += 64;
             }
-            glds16(src, buf + (wave + 8 * i) * 1024);
+            if (p.dbg_flags & 1) src = p.W_hi + (threadIdx.x & 63) * 8;  // timing experiment: every A DMA re-reads one hot 1 KiB
+            if (!(p.dbg_flags & 2)) glds16(src, buf + (wave + 8 * i) * 1024);  // timing experiment 2: no A DMA at all (counts below assume it)
         }
         if (H == 1) {  // both halves of this K tile are on their way: advance K (and the bf16x3 operand planes at roll-over)
             a_k0 += 64;
@@ -1199,7 +1202,7 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
                  :                                                                                                                       \
                  : "memory")
 
-    // ---- prologue: K tile 0 complete (even buffer), K tile 1 minus A1 (odd buffer); T >= 2 and even (checked by the launcher)
+    // ---- prologue: K tiles 0 and 1 complete (even / odd buffer); T >= 2 and even (checked by the launcher)
     const int T = (p.K / 64) * p.npass;
     char* const bufE = smem;
     char* const bufO = smem + BUF;
@@ -1242,49 +1245,50 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
         st.template issue_b<0>(p, bufO, wave);
         st.template issue_a<0>(p, bufO, wave);
         st.template issue_b<1>(p, bufO, wave);
+        st.template issue_a<1>(p, bufO, wave);
         load_quadrant(0, 1);
         load_quadrant(1, 1);
         load_quadrant(1, 0);
-        WAIT_VM(38);  // K tile 0 has landed: 8 (quadrant (0,0)) + 6 (K tile 1) + 24 younger operations may still be in flight
+        WAIT_VM(40);  // K tile 0 has landed: 8 (quadrant (0,0)) + 8 (K tile 1) + 24 younger operations may still be in flight
     } else {
         st.template issue_b<0>(p, bufO, wave);
         st.template issue_a<0>(p, bufO, wave);
         st.template issue_b<1>(p, bufO, wave);
-        WAIT_VM(6);
+        st.template issue_a<1>(p, bufO, wave);
+        WAIT_VM(8);
     }
     BAR();
     if (p.dbg_times) t_first = memtime_now();
     if (grp == 1) BAR();  // stagger: group 1 runs one barrier behind group 0
 
+
 #define GEMM8_ITER(MORE_, FIRST_)                                                                                           \
     do {                                                                                                              \
         /* P1 */                                                                                                      \
         LOAD_B(fb0, 0, 0); PIN(); LOAD_A(0, 0); PIN();                                                                \
-        st.template issue_a<1>(p, bufO, wave);                                                                        \
-        PIN(); WAIT_LGKM(8); BAR(); WAIT_LGKM(0); PIN();                                                              \
-        if (FIRST_) { ACC_READY(0, 0, 32); PIN(); } /* younger: 6 (K tile 1) + 24 + 2 (this phase) */                  \
+        WAIT_LGKM(8); BAR(); WAIT_LGKM(0); PIN();                                                                     \
+        if (FIRST_) { ACC_READY(0, 0, 32); PIN(); } /* younger: 8 (K tile 1) + 24 */                                   \
         MFMA_Q(0, 0, fb0); BAR();                                                                                     \
         /* P2 */                                                                                                      \
         LOAD_B(fb1, 1, 0); PIN();                                                                                     \
         if (MORE_) st.template issue_b<0>(p, bufE, wave);                                                             \
         BAR(); WAIT_LGKM(0); PIN();                                                                                   \
-        if (FIRST_) { ACC_READY(0, 1, 20); PIN(); } /* younger: 16 + 4 */                                             \
+        if (FIRST_) { ACC_READY(0, 1, 18); PIN(); } /* younger: 16 + 2 */                                             \
         MFMA_Q(0, 1, fb1); BAR();                                                                                     \
         /* P3 */                                                                                                      \
         LOAD_A(1, 0); PIN();                                                                                          \
         if (MORE_) st.template issue_a<0>(p, bufE, wave);                                                             \
-        BAR(); WAIT_LGKM(0); PIN();                                                                                   \
-        if (FIRST_) { ACC_READY(1, 1, 14); PIN(); } /* younger: 8 + 6 */                                              \
+        PIN(); WAIT_LGKM(0); BAR(); PIN();                                                                            \
+        if (FIRST_) { ACC_READY(1, 1, 12); PIN(); } /* younger: 8 + 4 */                                              \
         MFMA_Q(1, 1, fb1); BAR();                                                                                     \
         /* P4 */                                                                                                      \
-        if (MORE_) { st.template issue_b<1>(p, bufE, wave); PIN(); WAIT_VM(6); } else { WAIT_VM(0); }                 \
+        if (MORE_) { st.template issue_b<1>(p, bufE, wave); st.template issue_a<1>(p, bufE, wave); PIN(); if (p.dbg_flags & 2) WAIT_VM(4); else WAIT_VM(8); } else { WAIT_VM(0); } \
         BAR();                                                                                                        \
-        if (FIRST_) { ACC_READY(1, 0, 6); PIN(); } /* the phase's own vmcnt(6) already covers the last 8 loads */     \
+        if (FIRST_) { ACC_READY(1, 0, 8); PIN(); } /* the phase's own vmcnt(8) already covers the last 8 loads */     \
         MFMA_Q(1, 0, fb0); BAR();                                                                                     \
         /* P5 */                                                                                                      \
         LOAD_B(fb0, 0, 1); PIN(); LOAD_A(0, 1); PIN();                                                                \
-        if (MORE_) st.template issue_a<1>(p, bufE, wave);                                                             \
-        PIN(); WAIT_LGKM(8); BAR(); WAIT_LGKM(0); PIN();                                                              \
+        WAIT_LGKM(8); BAR(); WAIT_LGKM(0); PIN();                                                                     \
         MFMA_Q(0, 0, fb0); BAR();                                                                                     \
         /* P6 */                                                                                                      \
         LOAD_B(fb1, 1, 1); PIN();                                                                                     \
@@ -1294,10 +1298,10 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
         /* P7 */                                                                                                      \
         LOAD_A(1, 1); PIN();                                                                                          \
         if (MORE_) st.template issue_a<0>(p, bufO, wave);                                                             \
-        BAR(); WAIT_LGKM(0); PIN();                                                                                   \
+        PIN(); WAIT_LGKM(0); BAR(); PIN();                                                                            \
         MFMA_Q(1, 1, fb1); BAR();                                                                                     \
         /* P8 */                                                                                                      \
-        if (MORE_) { st.template issue_b<1>(p, bufO, wave); PIN(); WAIT_VM(6); }                                      \
+        if (MORE_) { st.template issue_b<1>(p, bufO, wave); st.template issue_a<1>(p, bufO, wave); PIN(); if (p.dbg_flags & 2) WAIT_VM(4); else WAIT_VM(8); } \
         BAR();                                                                                                        \
         MFMA_Q(1, 0, fb0); BAR();                                                                                     \
     } while (0)
@@ -1436,7 +1440,10 @@ int launch_pp_mode(const GemmParams& p, hipStream_t stream) {
     static char prof_name[64] = "";
     if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "gemm8_kernel<%d, %d, %d>", AMODE, EKIND, DMODE);
     MdptProfScope prof(prof_name, 2.0 * p.M * p.N * p.K, stream);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, p);
+    static const int dbg_flags = getenv("MDPT_GEMM8_DBG") ? atoi(getenv("MDPT_GEMM8_DBG")) : 0;  // timing experiments (wrong results)
+    GemmParams q = p;
+    q.dbg_flags = dbg_flags;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, q);
     return (int)hipGetLastError();
 }
 

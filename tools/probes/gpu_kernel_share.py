@@ -11,6 +11,9 @@ _, model = make_depthanythingv2_dpt_from_original_state_dict(make_synthetic_orig
 model = model.to("cuda", torch.bfloat16)
 x = torch.randn(32, 3, 504, 504, generator=torch.Generator().manual_seed(1)).to("cuda", torch.bfloat16)
 native.check(lib, lib.mdpt_set_batch_split(model._get_engine().handle, 0))
+if os.environ.get("X3"):
+    model = model.to(torch.float32); x = x.float()
+    native.check(lib, lib.mdpt_set_batch_split(model._get_engine().handle, 0))
 if os.environ.get("TILE"):
     model.set_gemm_tile(int(os.environ["TILE"]))  # force one tile variant for every GEMM (MDPT_TILE_*)
 with torch.inference_mode():
@@ -25,6 +28,12 @@ buf = ctypes.create_string_buffer(1 << 16)
 lib.mdpt_profile_report(buf, len(buf)); lib.mdpt_profile_enable(0)
 pr = json.loads(buf.value.decode())
 out = [f"forward {e0.elapsed_time(e1)/5:7.3f} ms"]
+if "ALL" in sys.argv[1:]:  # the whole table: per-forward milliseconds and fraction of the dense bf16 MFMA peak of every kernel
+    print(out[0])
+    for k in pr["kernels"]:
+        print(f"  {k['name']:52s} {k['launches'] / 5:5.1f} launches/fwd  avg {k['avg_us']:8.1f} us  {k['total_ms'] / 5:7.3f} ms/fwd  "
+              f"{(k['tflops'] / 2500 if k['gflop'] > 0 else float('nan')):6.3f} of peak")
+    sys.exit(0)
 for pat in sys.argv[1:]:
     for k in pr["kernels"]:
         if pat in k["name"]:
