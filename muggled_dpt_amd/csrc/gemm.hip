@@ -1079,8 +1079,7 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
                 src = a_ptr[i];
                 a_ptr[i] += 64;
             }
-            if (p.dbg_flags & 1) src = p.W_hi + (threadIdx.x & 63) * 8;  // timing experiment: every A DMA re-reads one hot 1 KiB
-            if (!(p.dbg_flags & 2)) glds16(src, buf + (wave + 8 * i) * 1024);  // timing experiment 2: no A DMA at all (counts below assume it)
+            glds16(src, buf + (wave + 8 * i) * 1024);
         }
         if (H == 1) {  // both halves of this K tile are on their way: advance K (and the bf16x3 operand planes at roll-over)
             a_k0 += 64;
@@ -1134,10 +1133,18 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
     }
 };
 
-template <int AMODE, int EKIND, bool SW, bool RI = false>
+// FAST (dense rows, one pass - every encoder GEMM of the bf16 mode): operand staging without ANY per-K-tile state. A phase's MFMA block is
+// 16 x 16 = 256 cycles and the other wave group's whole load phase has to fit under it, so every instruction of a load phase is on the
+// critical path (profiles/r03_gemm8_loop_experiments.txt: ~10 scalar instructions + 4 branches per K tile cost 7 %). Here the operands go
+// through buffer descriptors over this tile's rows (LDS-DMA, buffer_load ... lds): ONE per-lane byte offset per operand for the whole
+// kernel, the K position and the 64-row step between a wave's DMA instructions are scalar offsets computed from the loop counter, rows past
+// M / N fail the bounds check and are staged as zeros, and the last iteration (which issues nothing) is peeled off the loop instead of
+// being tested for in every phase.
+template <int AMODE, int EKIND, bool SW, bool RI = false, bool FAST = false>
 __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, const int dmode, const int m0, const int n0,
                                            const unsigned long long t_start) {
     static_assert(!RI || SW, "residual-initialised accumulators use the swapped operand order (4 consecutive columns per lane)");
+    static_assert(!FAST || AMODE == MDPT_A_DENSE, "the stateless staging is for dense rows");
     constexpr int A_BYTES = 256 * 128, BUF = 2 * A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1145,7 +1152,41 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
     unsigned long long t_first = 0, t_loop = 0;
     constexpr bool swapped = SW;
     HalfStager<AMODE> st;
-    st.init(p, m0, n0, wave, lane);
+    if constexpr (!FAST) st.init(p, m0, n0, wave, lane);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __amdgpu_buffer_rsrc_t rs_a, rs_w;
+    unsigned fa_voff = 0, fb_voff = 0;
+    int fa_step = 0, fb_step = 0;
+    if constexpr (FAST) {
+        const int rows_here = p.M - m0 < 256 ? p.M - m0 : 256, cols_here = p.N - n0 < 256 ? p.N - n0 : 256;
+        rs_a = tile_rsrc(p.A_hi + (size_t)m0 * p.lda, (size_t)rows_here * p.lda * 2);
+        rs_w = tile_rsrc(p.W_hi + (size_t)n0 * p.K, (size_t)cols_here * p.K * 2);
+        const int r = wave * 8 + (lane >> 3);  // DMA instruction i of this wave stages rows r + 64 i (same swizzle key for all four)
+        const int koff = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+        fa_voff = (unsigned)(r * p.lda + koff) * 2u;
+        fb_voff = (unsigned)(r * p.K + koff) * 2u;
+        fa_step = 64 * p.lda * 2;
+        fb_step = 64 * p.K * 2;
+    }
+    // half-tile H of the K tile at byte offset KB_ (FAST) / of the stager's next K tile (state machine) -> ring buffer BUF_
+#define ISSUE_A(H_, BUF_, KB_)                                                                                          \
+    do {                                                                                                                \
+        if constexpr (FAST) {                                                                                           \
+            _Pragma("unroll") for (int i = 2 * (H_); i < 2 * (H_) + 2; ++i)                                             \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)((BUF_) + (wave + 8 * i) * 1024), 16, fa_voff, (KB_) + i * fa_step, 0, 0); \
+        } else {                                                                                                        \
+            st.template issue_a<H_>(p, BUF_, wave);                                                                     \
+        }                                                                                                               \
+    } while (0)
+#define ISSUE_B(H_, BUF_, KB_)                                                                                          \
+    do {                                                                                                                \
+        if constexpr (FAST) {                                                                                           \
+            _Pragma("unroll") for (int i = 2 * (H_); i < 2 * (H_) + 2; ++i)                                             \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)((BUF_) + 256 * 128 + (wave + 8 * i) * 1024), 16, fb_voff, (KB_) + i * fb_step, 0, 0); \
+        } else {                                                                                                        \
+            st.template issue_b<H_>(p, BUF_, wave);                                                                     \
+        }                                                                                                               \
+    } while (0)
 
     // fragment read offsets (16x16x32 MFMA: lane = (row l&15, 16-byte k-chunk l>>4)); key(row) = (row >> 1) & 7 as staged
     const int l15 = lane & 15, lh = lane >> 4, key = (l15 >> 1) & 7;
@@ -1206,10 +1247,10 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
     const int T = (p.K / 64) * p.npass;
     char* const bufE = smem;
     char* const bufO = smem + BUF;
-    st.template issue_a<0>(p, bufE, wave);
-    st.template issue_b<0>(p, bufE, wave);
-    st.template issue_b<1>(p, bufE, wave);
-    st.template issue_a<1>(p, bufE, wave);
+    ISSUE_A(0, bufE, 0);
+    ISSUE_B(0, bufE, 0);
+    ISSUE_B(1, bufE, 0);
+    ISSUE_A(1, bufE, 0);
     if constexpr (RI) {
         // Accumulators start at the residual tile (out = resid + A W^T + bias, in place): 32 x 16-byte loads per lane in the order the
         // quadrants are first used (P1 (0,0), P2 (0,1), P3 (1,1), P4 (1,0)), issued between the DMAs of K tile 0 and K tile 1. vmcnt retires
@@ -1242,19 +1283,19 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
             }
         };
         load_quadrant(0, 0);
-        st.template issue_b<0>(p, bufO, wave);
-        st.template issue_a<0>(p, bufO, wave);
-        st.template issue_b<1>(p, bufO, wave);
-        st.template issue_a<1>(p, bufO, wave);
+        ISSUE_B(0, bufO, 128);
+        ISSUE_A(0, bufO, 128);
+        ISSUE_B(1, bufO, 128);
+        ISSUE_A(1, bufO, 128);
         load_quadrant(0, 1);
         load_quadrant(1, 1);
         load_quadrant(1, 0);
         WAIT_VM(40);  // K tile 0 has landed: 8 (quadrant (0,0)) + 8 (K tile 1) + 24 younger operations may still be in flight
     } else {
-        st.template issue_b<0>(p, bufO, wave);
-        st.template issue_a<0>(p, bufO, wave);
-        st.template issue_b<1>(p, bufO, wave);
-        st.template issue_a<1>(p, bufO, wave);
+        ISSUE_B(0, bufO, 128);
+        ISSUE_A(0, bufO, 128);
+        ISSUE_B(1, bufO, 128);
+        ISSUE_A(1, bufO, 128);
         WAIT_VM(8);
     }
     BAR();
@@ -1264,6 +1305,7 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
 
 #define GEMM8_ITER(MORE_, FIRST_)                                                                                           \
     do {                                                                                                              \
+        const int kE = t * 128 + 256, kO = kE + 128; /* byte offsets of K tiles t + 2 / t + 3 (FAST staging) */        \
         /* P1 */                                                                                                      \
         LOAD_B(fb0, 0, 0); PIN(); LOAD_A(0, 0); PIN();                                                                \
         WAIT_LGKM(8); BAR(); WAIT_LGKM(0); PIN();                                                                     \
@@ -1271,18 +1313,18 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
         MFMA_Q(0, 0, fb0); BAR();                                                                                     \
         /* P2 */                                                                                                      \
         LOAD_B(fb1, 1, 0); PIN();                                                                                     \
-        if (MORE_) st.template issue_b<0>(p, bufE, wave);                                                             \
+        if (MORE_) ISSUE_B(0, bufE, kE);                                                             \
         BAR(); WAIT_LGKM(0); PIN();                                                                                   \
         if (FIRST_) { ACC_READY(0, 1, 18); PIN(); } /* younger: 16 + 2 */                                             \
         MFMA_Q(0, 1, fb1); BAR();                                                                                     \
         /* P3 */                                                                                                      \
         LOAD_A(1, 0); PIN();                                                                                          \
-        if (MORE_) st.template issue_a<0>(p, bufE, wave);                                                             \
+        if (MORE_) ISSUE_A(0, bufE, kE);                                                             \
         PIN(); WAIT_LGKM(0); BAR(); PIN();                                                                            \
         if (FIRST_) { ACC_READY(1, 1, 12); PIN(); } /* younger: 8 + 4 */                                              \
         MFMA_Q(1, 1, fb1); BAR();                                                                                     \
         /* P4 */                                                                                                      \
-        if (MORE_) { st.template issue_b<1>(p, bufE, wave); st.template issue_a<1>(p, bufE, wave); PIN(); if (p.dbg_flags & 2) WAIT_VM(4); else WAIT_VM(8); } else { WAIT_VM(0); } \
+        if (MORE_) { ISSUE_B(1, bufE, kE); ISSUE_A(1, bufE, kE); PIN(); WAIT_VM(8); } else { WAIT_VM(0); }                      \
         BAR();                                                                                                        \
         if (FIRST_) { ACC_READY(1, 0, 8); PIN(); } /* the phase's own vmcnt(8) already covers the last 8 loads */     \
         MFMA_Q(1, 0, fb0); BAR();                                                                                     \
@@ -1292,27 +1334,41 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
         MFMA_Q(0, 0, fb0); BAR();                                                                                     \
         /* P6 */                                                                                                      \
         LOAD_B(fb1, 1, 1); PIN();                                                                                     \
-        if (MORE_) st.template issue_b<0>(p, bufO, wave);                                                             \
+        if (MORE_) ISSUE_B(0, bufO, kO);                                                             \
         BAR(); WAIT_LGKM(0); PIN();                                                                                   \
         MFMA_Q(0, 1, fb1); BAR();                                                                                     \
         /* P7 */                                                                                                      \
         LOAD_A(1, 1); PIN();                                                                                          \
-        if (MORE_) st.template issue_a<0>(p, bufO, wave);                                                             \
+        if (MORE_) ISSUE_A(0, bufO, kO);                                                             \
         PIN(); WAIT_LGKM(0); BAR(); PIN();                                                                            \
         MFMA_Q(1, 1, fb1); BAR();                                                                                     \
         /* P8 */                                                                                                      \
-        if (MORE_) { st.template issue_b<1>(p, bufO, wave); st.template issue_a<1>(p, bufO, wave); PIN(); if (p.dbg_flags & 2) WAIT_VM(4); else WAIT_VM(8); } \
+        if (MORE_) { ISSUE_B(1, bufO, kO); ISSUE_A(1, bufO, kO); PIN(); WAIT_VM(8); }                                          \
         BAR();                                                                                                        \
         MFMA_Q(1, 0, fb0); BAR();                                                                                     \
     } while (0)
     // RI: the residual loads are waited for in the first iteration only (t == 0: T >= 4 is checked by the launcher, so that iteration's
     // DMA issues all happen and the younger-operation counts of ACC_READY are exact); the accumulators stay in the loop-carried registers
-    for (int t = 0; t < T; t += 2) {
-        const bool more = t + 2 < T;  // wave-uniform: the last iteration issues nothing after P1 and drains at P4
-        GEMM8_ITER(more, (RI && t == 0));
+    if constexpr (FAST) {
+        // compile-time MORE / FIRST: the first iteration (RI: counted waits for the residual loads) and the last one (issues nothing,
+        // drains) are peeled; T >= 4 when RI (launcher)
+        int t = 0;
+        if constexpr (RI) {
+            GEMM8_ITER(true, true);
+            t = 2;
+        }
+        for (; t + 2 < T; t += 2) GEMM8_ITER(true, false);
+        GEMM8_ITER(false, false);
+    } else {
+        for (int t = 0; t < T; t += 2) {
+            const bool more = t + 2 < T;  // wave-uniform: the last iteration issues nothing after P1 and drains at P4
+            GEMM8_ITER(more, (RI && t == 0));
+        }
     }
 #undef GEMM8_ITER
 #undef ACC_READY
+#undef ISSUE_A
+#undef ISSUE_B
     if (grp == 0) BAR();  // re-join the two groups
 #undef LOAD_A
 #undef LOAD_B
@@ -1417,10 +1473,36 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
     if (EKIND == MDPT_E_QKV) {
         // per tile: Q / K columns only -> swapped order + head-major direct epilogue; V columns only -> plain order + transposed
         // direct epilogue; a tile that straddles 2F (odd head counts) or planes beyond 32-bit offsets -> plain order + LDS strip
-        if (n0 + 256 <= 2 * p.F && (size_t)p.M * p.F * 2 < 0xFFFFFFF0ull) gemm8_body<AMODE, EKIND, true>(p, smem, DM_QK, m0, n0, t_start);
-        else if (n0 >= 2 * p.F && n0 + 256 <= p.N && (size_t)(p.M / p.npad) * p.F * p.npadv * 2 < 0xFFFFFFF0ull)
-            gemm8_body<AMODE, EKIND, false>(p, smem, DM_VT, m0, n0, t_start);
-        else gemm8_body<AMODE, EKIND, false>(p, smem, DM_NONE, m0, n0, t_start);
+#ifdef MDPT_GEMM8_NO_FAST
+        const bool fast = false;
+#else
+        const bool fast = AMODE == MDPT_A_DENSE && p.npass == 1;  // bf16 mode: stateless operand staging
+#endif
+        if (n0 + 256 <= 2 * p.F && (size_t)p.M * p.F * 2 < 0xFFFFFFF0ull) {
+            if constexpr (AMODE == MDPT_A_DENSE) {
+                if (fast) gemm8_body<AMODE, EKIND, true, false, true>(p, smem, DM_QK, m0, n0, t_start);
+                else gemm8_body<AMODE, EKIND, true>(p, smem, DM_QK, m0, n0, t_start);
+            } else {
+                gemm8_body<AMODE, EKIND, true>(p, smem, DM_QK, m0, n0, t_start);
+            }
+        } else if (n0 >= 2 * p.F && n0 + 256 <= p.N && (size_t)(p.M / p.npad) * p.F * p.npadv * 2 < 0xFFFFFFF0ull) {
+            if constexpr (AMODE == MDPT_A_DENSE) {
+                if (fast) gemm8_body<AMODE, EKIND, false, false, true>(p, smem, DM_VT, m0, n0, t_start);
+                else gemm8_body<AMODE, EKIND, false>(p, smem, DM_VT, m0, n0, t_start);
+            } else {
+                gemm8_body<AMODE, EKIND, false>(p, smem, DM_VT, m0, n0, t_start);
+            }
+        } else {
+            gemm8_body<AMODE, EKIND, false>(p, smem, DM_NONE, m0, n0, t_start);
+        }
+    } else if constexpr (AMODE == MDPT_A_DENSE && DMODE != DM_NONE) {
+        // the encoder's hot forms: stateless staging when there is one pass (bf16 mode), the state-machine stager for bf16x3
+#ifdef MDPT_GEMM8_NO_FAST  // A/B builds only
+        if (false) {}
+#else
+        if (p.npass == 1) gemm8_body<AMODE, EKIND, true, DMODE == DM_RINIT, true>(p, smem, DMODE, m0, n0, t_start);
+#endif
+        else gemm8_body<AMODE, EKIND, true, DMODE == DM_RINIT, false>(p, smem, DMODE, m0, n0, t_start);
     } else {
         gemm8_body<AMODE, EKIND, DMODE != DM_NONE, DMODE == DM_RINIT>(p, smem, DMODE, m0, n0, t_start);
     }
@@ -1440,10 +1522,7 @@ int launch_pp_mode(const GemmParams& p, hipStream_t stream) {
     static char prof_name[64] = "";
     if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "gemm8_kernel<%d, %d, %d>", AMODE, EKIND, DMODE);
     MdptProfScope prof(prof_name, 2.0 * p.M * p.N * p.K, stream);
-    static const int dbg_flags = getenv("MDPT_GEMM8_DBG") ? atoi(getenv("MDPT_GEMM8_DBG")) : 0;  // timing experiments (wrong results)
-    GemmParams q = p;
-    q.dbg_flags = dbg_flags;
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, q);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, p);
     return (int)hipGetLastError();
 }
 

@@ -52,7 +52,6 @@ struct GemmParams {
     // test hook: per-workgroup phase timestamps (s_memtime): [start, first barrier passed, main loop done, epilogue done]
     int throughput_mode;  // 1: another stream runs the other half batch concurrently -> pick tiles by CU-time efficiency, not latency
     unsigned long long* dbg_times;
-    int dbg_flags;        // set by the 8-phase launcher from MDPT_GEMM8_DBG (timing experiments that skip / redirect operand DMAs; results are wrong)
 };
 
 int mdpt_launch_gemm(const GemmParams& p, hipStream_t stream);   // returns hipError_t as int

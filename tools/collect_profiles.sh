@@ -12,7 +12,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/split" -- python "$R/bench.py" --steps 10 --warmup 3 > "$OUT/bench_under_rocprof.json" 2> "$OUT/split.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/split" -- python "$R/bench.py" --steps 10 --warmup 3 --no-secondary > "$OUT/bench_under_rocprof.json" 2> "$OUT/split.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/nosplit" -- python "$R/bench.py" --no-split --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_nosplit_under_rocprof.json" 2> "$OUT/nosplit.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/x3" -- python "$R/bench.py" --precision bf16x3 --no-split --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_x3_nosplit_under_rocprof.json" 2> "$OUT/x3.log"
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/timeline" -- python "$R/bench.py" --no-split --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> "$OUT/timeline.log"
