@@ -30,6 +30,7 @@
 
 #include "mdpt_kernels.h"
 #include "mdpt_prof.h"
+#include "up_bf16.h"
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -69,8 +70,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* base, s
 // A_lo * W_hi, A_hi * W_lo, A_hi * W_hi, into the same fp32 accumulators - the pass order of the implicit-GEMM kernels. A pass is just
 // ncb more channel blocks whose halo patches / weight tiles come from the other operand planes ("virtual" channel block vcb = pass * ncb + cb).
 // BFOUT: bf16 output planes (false: fp32 map only - the bf16x3 head keeps the fp32 map for its bilinear upsample).
-template <int NQN, bool X3, bool SKIP, bool F32OUT, bool RELU, bool UP, bool BFOUT>
+// UPIN (128-channel bf16 form only): the conv's input is the x2 bilinear upsample (align_corners=True) of a bf16 map `up_in` that never
+// exists in memory - the 18x18 halo patch of a channel block is INTERPOLATED in LDS from the <= 11x11 source pixels it touches (arithmetic
+// of up_bf16.h, rounded to bf16 like the stand-alone upsample kernel): SpatialUpsampleLayer + head conv 1, fusion_model.py:182 ->
+// head_model.py:74-76 fused.
+template <int NQN, bool X3, bool SKIP, bool F32OUT, bool RELU, bool UP, bool BFOUT, bool UPIN = false>
 __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
+    static_assert(!UPIN || (NQN == 1 && !X3 && BFOUT && !F32OUT), "the upsampled-input form exists for the bf16 head conv");
     constexpr int COUT = 128 * NQN;  // output channels: 256 (two 128-column halves per wave) or 128
     static_assert(NQN == 2 || (!SKIP && !UP && !RELU), "the 128-channel form has the bias-only epilogues");
     static_assert(BFOUT || F32OUT, "no output");
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     const int img = tile / (tiles_x * tiles_y), trem = tile - img * (tiles_x * tiles_y);
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const int Y0 = ty * 16, X0 = tx * 16;
-    const bf16_t* const in_img = p.in + (size_t)img * p.H * p.W * p.Cin;
+    const bf16_t* const in_img = UPIN ? p.up_in + (size_t)img * p.Hs * p.Ws * p.Cin : p.in + (size_t)img * p.H * p.W * p.Cin;
     const int ncb = p.Cin >> 6;
 
     // ---- operand staging: LDS-DMA through BUFFER descriptors (buffer_load_dwordx4 ... offen lds). The per-lane byte offsets are
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     const int Kw = p.Cin * 9;
     const __amdgpu_buffer_rsrc_t rs_w_hi = plane_rsrc(p.w, (size_t)COUT * Kw * 2);
     const __amdgpu_buffer_rsrc_t rs_w_lo = plane_rsrc(X3 ? p.w_lo : p.w, (size_t)COUT * Kw * 2);
-    const __amdgpu_buffer_rsrc_t rs_in_hi = plane_rsrc(in_img, (size_t)p.H * p.W * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rs_in_hi = plane_rsrc(in_img, UPIN ? (size_t)p.Hs * p.Ws * p.Cin * 2 : (size_t)p.H * p.W * p.Cin * 2);
     const __amdgpu_buffer_rsrc_t rs_in_lo = plane_rsrc(X3 ? p.in_lo + (size_t)img * p.H * p.W * p.Cin : in_img, (size_t)p.H * p.W * p.Cin * 2);
     const int nvcb = X3 ? 3 * ncb : ncb;  // channel blocks of all passes
     const int T = 9 * ncb;                // K tiles per pass; ncb is even (the launcher checks Cin % 128 == 0)
@@ -220,6 +226,110 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 #define WAIT_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory")
 #define WAIT_VM_IMM(N_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory")
 
+    if constexpr (UPIN) {
+        // ---- 128 output channels, input = x2 upsample of p.up_in, interpolated per channel block:
+        //   * source patch of block cb+1 (<= 11x11 pixels x 64 channels bf16, dense [ph * pw][128 B]): two DMA instructions per wave at tap 0 of
+        //     block cb into the 16 KB behind a THREE-deep weight ring (K tile kt in slot kt % 3, staged two K tiles ahead, in P1);
+        //   * halo patch of block cb+1: 2592 items of 8 channels (pixel, 16-byte chunk), item tid + 512 r is built at tap 3 + r of block cb:
+        //     its four corner reads are issued in P1 behind the fragment reads, the arithmetic and the 16-byte LDS store run in P2;
+        //     per-item constants (corner offsets, weights, destination) are tile constants held in registers;
+        //   * everything else as in the plain 128-channel form. vmcnt at P2: the weights of tile kt+2 and the patch instructions issued in
+        //     this and the previous K tile may stay in flight.
+        constexpr int PATCH_OFF = 3 * (BTILE / 2);  // the fourth 16 KB of the weight region
+        const float sy = (float)(p.Hs - 1) / (float)(p.H - 1), sx = (float)(p.Ws - 1) / (float)(p.W - 1);
+        const int oy_first = Y0 == 0 ? 0 : Y0 - 1, ox_first = X0 == 0 ? 0 : X0 - 1;
+        const int oy_last = min(Y0 + 16, p.H - 1), ox_last = min(X0 + 16, p.W - 1);
+        const int py0 = (int)(sy * (float)oy_first), px0 = (int)(sx * (float)ox_first);
+        const int ph = min((int)(sy * (float)oy_last) + 1, p.Hs - 1) - py0 + 1;
+        const int pw = min((int)(sx * (float)ox_last) + 1, p.Ws - 1) - px0 + 1;  // <= 11 (launcher's scale check)
+        unsigned pt_voff[2];  // patch DMA instruction c = wave + 8 j: patch pixels 8 c .. 8 c + 7, lane / 8 = pixel, lane % 8 = chunk
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pp = (wave + 8 * j) * 8 + (lane >> 3);
+            const int yy = pp / pw, xx = pp - yy * pw;
+            pt_voff[j] = pp < ph * pw ? ((unsigned)((py0 + yy) * p.Ws + px0 + xx) * (unsigned)p.Cin + (unsigned)((lane & 7) << 3)) * 2u : OOB;
+        }
+        auto issue_patch = [&](int cbn) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in_hi, (lds_ptr_t)(smem + PATCH_OFF + (wave + 8 * j) * 1024), 16, pt_voff[j], cbn * 128, 0, 0);
+        };
+        // item r of this thread: halo pixel (hy, hx), chunk; corner offsets inside the patch, weights, destination in the halo image
+        int it_src[6], it_dst[6];
+        float it_lx[6], it_ly[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int item = tid + 512 * r, pix = item >> 3, chunk = item & 7;
+            const int hy = (pix * 3641) >> 16, hx = pix - hy * 18;
+            const int oy = Y0 + hy - 1, ox = X0 + hx - 1;
+            const bool inside = item < 2592 && (unsigned)oy < (unsigned)p.H && (unsigned)ox < (unsigned)p.W;
+            const int oyc = min(max(oy, 0), p.H - 1), oxc = min(max(ox, 0), p.W - 1);
+            const float fy = sy * (float)oyc, fx = sx * (float)oxc;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int dy = y0 < p.Hs - 1 ? 1 : 0, dx = x0 < p.Ws - 1 ? 1 : 0;
+            it_ly[r] = fy - (float)y0; it_lx[r] = fx - (float)x0;
+            // corner (0,0) byte offset | dx << 28 | dy << 29 | outside-the-image (zero padding) << 30 | no such item << 31
+            it_src[r] = (((y0 - py0) * pw + (x0 - px0)) * 128 + chunk * 16) | (dx << 28) | (dy << 29) | (inside ? 0 : 1 << 30) | (item < 2592 ? 0 : 1 << 31);
+            it_dst[r] = hy * HROW + hx * 128 + ((chunk ^ (hx & 7)) << 4);
+        }
+        mdpt_u32x4 cq[4];  // the four corners of the item in flight
+        auto item_reads = [&](int r) {
+            const int o = it_src[r] & 0xFFFFFF, ddx = ((it_src[r] >> 28) & 1) * 128, ddy = ((it_src[r] >> 29) & 1) * pw * 128;
+            cq[0] = *(const mdpt_u32x4*)(smem + PATCH_OFF + o);
+            cq[1] = *(const mdpt_u32x4*)(smem + PATCH_OFF + o + ddx);
+            cq[2] = *(const mdpt_u32x4*)(smem + PATCH_OFF + o + ddy);
+            cq[3] = *(const mdpt_u32x4*)(smem + PATCH_OFF + o + ddx + ddy);
+        };
+        auto item_write = [&](int r, int hbn) {
+            mdpt_u32x4 v = mdpt_up_bf16x8(cq[0], cq[1], cq[2], cq[3], it_lx[r], it_ly[r]);
+            if (it_src[r] & (1 << 30)) v = mdpt_u32x4{0u, 0u, 0u, 0u};
+            if (it_src[r] >= 0) *(mdpt_u32x4*)(smem + OFF_H + hbn * HALO_BYTES + it_dst[r]) = v;
+        };
+
+        // prologue: patch 0 and K tiles 0, 1; then every thread builds its items of halo patch 0
+        issue_patch(0);
+        issue_b128(0, 0);
+        issue_b128(1, 1);
+        WAIT_VM_IMM(0);
+        BAR();
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            item_reads(r);
+            item_write(r, 0);
+        }
+        WAIT_LGKM(0);
+        BAR();
+        if (p.dbg_times) t_first = memtime_now();
+        if (grp == 1) BAR();
+#define CONV_KT128U(U_)                                                                                               \
+        do {                                                                                                          \
+            constexpr int cbl = (U_) / 9, t9 = (U_) % 9, ky = t9 / 3, kx = t9 % 3;                                     \
+            constexpr int p_now = t9 == 0 ? 2 : 0, p_prev = t9 == 1 ? 2 : 0;  /* patch DMA instructions of this / the previous K tile */ \
+            constexpr int slot = (U_) % 3, slot2 = ((U_) + 2) % 3, ritem = t9 - 3;                                     \
+            const int kt = cbp * 9 + (U_);                                                                            \
+            const bool more = (U_) < 16 || !last;            /* K tile kt + 2 exists */                               \
+            const bool next_cb = cbl == 0 || !last;          /* channel block cb + 1 exists */                        \
+            const int va = a_lane[kx] + cbl * HALO_BYTES;                                                             \
+            LOAD_B_AT(fb0, slot * (BTILE / 2)); PIN(); LOAD_A(0, va, ky); PIN();                                      \
+            if (more) issue_b128(slot2, kt + 2);                                                                      \
+            if constexpr (p_now != 0) { if (next_cb) issue_patch(cbp + cbl + 1); }                                    \
+            if constexpr (ritem >= 0) { if (next_cb) item_reads(ritem); }                                             \
+            BAR(); WAIT_LGKM(0); PIN();                                                                               \
+            MFMA_Q(0, 0, fb0); BAR();                                                                                 \
+            LOAD_A(1, va, ky); PIN();                                                                                 \
+            if constexpr (ritem >= 0) { if (next_cb) item_write(ritem, cbl ^ 1); }                                    \
+            if (more) { if (next_cb) WAIT_VM_IMM(2 + p_now + p_prev); else WAIT_VM_IMM(2); } else { WAIT_VM_IMM(0); }  \
+            if constexpr (t9 == 8) WAIT_LGKM(0);  /* the last halo stores are complete before the barrier both groups pass */ \
+            BAR(); WAIT_LGKM(0); PIN();                                                                               \
+            MFMA_Q(1, 0, fb0); BAR();                                                                                 \
+        } while (0)
+        for (int cbp = 0; cbp < nvcb; cbp += 2) {
+            const bool last = cbp + 2 >= nvcb;
+            CONV_KT128U(0); CONV_KT128U(1); CONV_KT128U(2); CONV_KT128U(3); CONV_KT128U(4); CONV_KT128U(5); CONV_KT128U(6); CONV_KT128U(7); CONV_KT128U(8);
+            CONV_KT128U(9); CONV_KT128U(10); CONV_KT128U(11); CONV_KT128U(12); CONV_KT128U(13); CONV_KT128U(14); CONV_KT128U(15); CONV_KT128U(16); CONV_KT128U(17);
+        }
+#undef CONV_KT128U
+    } else
     if constexpr (NQN == 1) {
         // ---- COUT = 128 (head conv 1, head_model.py:74-76): a K tile of weights is 16 KB, a wave owns two 64 x 32 quadrants (qm = 0, 1), so a
         //      K tile has TWO phases of 16 MFMAs and the weights live in a four-deep ring (K tile kt in slot kt & 3, staged three K tiles ahead):
@@ -503,9 +613,9 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 #undef WAIT_LGKM
 #undef WAIT_VM_IMM
 
-template <int NQN, bool X3, bool SKIP, bool F32OUT, bool RELU, bool UP, bool BFOUT = true>
+template <int NQN, bool X3, bool SKIP, bool F32OUT, bool RELU, bool UP, bool BFOUT = true, bool UPIN = false>
 int launch_variant(const Conv3hParams& p, hipStream_t stream) {
-    auto kern = conv3h_kernel<NQN, X3, SKIP, F32OUT, RELU, UP, BFOUT>;
+    auto kern = conv3h_kernel<NQN, X3, SKIP, F32OUT, RELU, UP, BFOUT, UPIN>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -515,7 +625,8 @@ int launch_variant(const Conv3hParams& p, hipStream_t stream) {
     const int tiles = p.B * ((p.H + 15) / 16) * ((p.W + 15) / 16);
     static char prof_name[80] = "";
     if (!prof_name[0])
-        snprintf(prof_name, sizeof(prof_name), "conv3h_kernel<%d, %s, %d, %d, %d, %d>", 128 * NQN, X3 ? "x3" : "bf16", (int)SKIP, (int)F32OUT, (int)RELU, (int)UP);
+        snprintf(prof_name, sizeof(prof_name), "conv3h_kernel<%d, %s, %d, %d, %d, %d>", 128 * NQN, UPIN ? "bf16 up2-in" : (X3 ? "x3" : "bf16"), (int)SKIP, (int)F32OUT, (int)RELU,
+                 (int)UP);
     MdptProfScope prof(prof_name, 2.0 * p.B * p.H * p.W * (128.0 * NQN) * 9.0 * p.Cin, stream);  // algorithmic flops (one pass, whatever the mode)
     static const int dbg_flags = getenv("MDPT_CONV3H_DBG") ? atoi(getenv("MDPT_CONV3H_DBG")) : 0;  // timing experiments (wrong results)
     Conv3hParams q = p;
@@ -529,6 +640,9 @@ template <bool X3>
 int launch_mode(const Conv3hParams& p, hipStream_t stream) {
     const bool skip = p.skip != nullptr, f32 = p.out_f32 != nullptr, up = p.up_src != nullptr;
     if (p.Cout == 128) {
+        if constexpr (!X3) {
+            if (p.up_in) return launch_variant<1, false, false, false, false, false, true, true>(p, stream);
+        }
         if (p.out_bf) return launch_variant<1, X3, false, false, false, false>(p, stream);
         return launch_variant<1, X3, false, true, false, false, false>(p, stream);
     }
@@ -542,7 +656,14 @@ int launch_mode(const Conv3hParams& p, hipStream_t stream) {
 
 // the combinations the decoder uses (anything else runs the implicit-GEMM path of gemm.hip)
 bool mdpt_conv3h_supported(const Conv3hParams& p) {
-    if (p.B <= 0 || p.H < 2 || p.W < 2 || p.Cin <= 0 || (p.Cin & 127) || !p.in || !p.w) return false;
+    if (p.B <= 0 || p.H < 2 || p.W < 2 || p.Cin <= 0 || (p.Cin & 127) || !p.w) return false;
+    if ((p.in != nullptr) == (p.up_in != nullptr)) return false;  // exactly one input form
+    if (p.up_in) {
+        // upsampled input: 128 output channels, bf16 planes out, bias only; 18 halo pixels must interpolate from <= 11 source pixels
+        if (p.Cout != 128 || p.in_lo || !p.out_bf || p.out_f32 || p.skip || p.up_src || p.relu_bf || p.Hs < 2 || p.Ws < 2) return false;
+        if ((long)17 * (p.Hs - 1) >= (long)9 * (p.H - 1) || (long)17 * (p.Ws - 1) >= (long)9 * (p.W - 1)) return false;
+        if ((size_t)p.Hs * p.Ws * p.Cin * 2 >= 0xFFFFFFF0ull) return false;
+    }
     if (p.Cout != 256 && p.Cout != 128) return false;
     if ((size_t)p.H * p.W * p.Cout * 4 >= 0xFFFFFFF0ull || (size_t)p.H * p.W * p.Cin * 2 >= 0xFFFFFFF0ull) return false;  // 32-bit byte offsets inside one image plane
     const bool x3 = p.in_lo != nullptr;

@@ -3,6 +3,7 @@
 // conversion. All are coalesced 8/16-byte-per-lane streaming kernels; none reshapes work into a GEMM.
 
 #include "mdpt_kernels.h"
+#include "up_bf16.h"
 #include "mdpt_prof.h"
 #include "ln_row.h"
 
@@ -620,6 +621,31 @@ int mdpt_launch_zero_vt_pad(bf16_t* vt_hi, bf16_t* vt_lo, int rows, int N, int n
     LAUNCH_RET();
 }
 
+// bf16 NHWC -> bf16 NHWC bilinear (align_corners=True) resize, 8 channels (16 bytes) per thread: the stand-alone form of the upsample in
+// front of the head's first conv for launches too small for the halo-staged conv kernel that interpolates its own input (conv3h.hip).
+// Same arithmetic (up_bf16.h), so both forms give the same bits.
+__global__ __launch_bounds__(256) void upsample_bf16src_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B, int Hi, int Wi, int Ho,
+                                                               int Wo, int C) {
+#pragma clang fp contract(off)  // the source coordinates and weights must be the bits conv3h.hip computes (no fma(sx, x, -x0))
+    const int c8 = C >> 3;
+    const size_t total = (size_t)B * Ho * Wo * c8;
+    const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.0f;
+    const float sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.0f;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % c8);
+        const size_t pix = idx / c8;
+        const int x = (int)(pix % Wo), y = (int)((pix / Wo) % Ho), b = (int)(pix / ((size_t)Wo * Ho));
+        const float fy = sy * (float)y, fx = sx * (float)x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hi - 1), x1 = x0 + (x0 < Wi - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const bf16_t* base = in + (size_t)b * Hi * Wi * C + ch * 8;
+        const mdpt_u32x4 v00 = *(const mdpt_u32x4*)(base + ((size_t)y0 * Wi + x0) * C), v01 = *(const mdpt_u32x4*)(base + ((size_t)y0 * Wi + x1) * C);
+        const mdpt_u32x4 v10 = *(const mdpt_u32x4*)(base + ((size_t)y1 * Wi + x0) * C), v11 = *(const mdpt_u32x4*)(base + ((size_t)y1 * Wi + x1) * C);
+        *(mdpt_u32x4*)(out + pix * C + ch * 8) = mdpt_up_bf16x8(v00, v01, v10, v11, lx, ly);
+    }
+}
+
 int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float* out_f32, int B, int Hi, int Wi, int Ho, int Wo,
                          int C, hipStream_t stream) {
     if (C & 3) return (int)hipErrorInvalidValue;
@@ -649,6 +675,13 @@ int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float*
         hipLaunchKernelGGL(upsample_kernel<8>, dim3(grid_for(total / 2)), dim3(256), 0, stream, in, out_hi, out_lo, out_f32, B, Hi, Wi, Ho, Wo, C);
     else
         hipLaunchKernelGGL(upsample_kernel<4>, dim3(grid_for(total)), dim3(256), 0, stream, in, out_hi, out_lo, out_f32, B, Hi, Wi, Ho, Wo, C);
+    LAUNCH_RET();
+}
+
+int mdpt_launch_upsample_bf16(const bf16_t* in, bf16_t* out, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t stream) {
+    if (C & 7) return (int)hipErrorInvalidValue;
+    MdptProfScope prof("upsample_bf16src_kernel", 0.0, stream);
+    hipLaunchKernelGGL(upsample_bf16src_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 8))), dim3(256), 0, stream, in, out, B, Hi, Wi, Ho, Wo, C);
     LAUNCH_RET();
 }
 

@@ -398,8 +398,12 @@ void plan_decoder(Bump& bump, const mdpt_handle* h, Plan& p, size_t min_scratch_
     }
     const size_t fpx = (size_t)64 * p.Np;  // (8gh)*(8gw)
     take_planes(bump, x3, (size_t)B * fpx * h->Cp, p.fused);
-    p.h1 = bump.take((size_t)B * fpx * h->C2p * 4);
-    take_planes(bump, x3, (size_t)B * p.H * p.W * h->C2p, p.h1u);
+    // bf16 mode with the fused head tail (run_head): conv 1 writes a bf16 map and the full-resolution upsampled map never exists (ViT-L,
+    // 504x504, batch 32: 2.1 GB + 0.7 GB of workspace that used to be reserved and never touched)
+    const bool bf16_head = !x3 && mdpt_head_tail_supported(h->C2p) && mdpt_head_tail_scale_ok(8 * p.gh, 8 * p.gw, p.H, p.W);
+    p.h1 = bump.take((size_t)B * fpx * h->C2p * (bf16_head ? 2 : 4));
+    if (bf16_head) p.h1u[0] = p.h1u[1] = SIZE_MAX;
+    else take_planes(bump, x3, (size_t)B * p.H * p.W * h->C2p, p.h1u);
     p.scratch_floats = (size_t)B * fpx * h->Cp;
     if (min_scratch_floats > p.scratch_floats) p.scratch_floats = min_scratch_floats;
     p.scratch = bump.take(p.scratch_floats * 4);
@@ -736,7 +740,12 @@ int rcu_conv(const Ctx& c, const std::string& wname, Planes in, int sh, int sw, 
 
 // ---- stage: fusion. Level index i: 3 = coarsest (gh/2), 0 = finest (4gh). Output: flo[0] (fp32, 4gh x 4gw, before the
 //      final x2 upsample) and `fused` planes (8gh x 8gw).
-int run_fusion(const Ctx& c) {
+// bf16 mode, forward path (for_head): the last projection (level 0) writes its output as bf16 and the x2 upsample in front of the head is
+// left to run_head, which either interpolates it inside the head's first conv (halo-staged kernel, big launches) or runs the stand-alone
+// bf16 upsample - same arithmetic, same bits (up_bf16.h). The stage-level API and the bf16x3 mode keep the fp32 map + fp32 upsample.
+bool head_upsamples_bf16(const mdpt_handle* h) { return !h->x3 && (h->Cp & 7) == 0; }
+
+int run_fusion(const Ctx& c, bool for_head = false) {
     const mdpt_handle* h = c.h;
     const Plan& p = c.p;
     const int sh[4] = {4 * p.gh, 2 * p.gh, p.gh, p.gh / 2}, sw[4] = {4 * p.gw, 2 * p.gw, p.gw, p.gw / 2};
@@ -765,20 +774,30 @@ int run_fusion(const Ctx& c) {
             // sum to 1) and is applied by the consumer (next level's epilogue / final upsample kernel)
             GemmParams g = base_params(c, h->M(blk + "." + proj_seq(h) + ".2.weight"), b2, p.B * sh[i] * sw[i], h->Cp);
             g.bias = h->V(blk + "." + proj_seq(h) + ".2.bias");
-            g.out_f32 = c.at<float>(p.flo[i]); g.ldc = h->Cp;
+            if (i == 0 && for_head && head_upsamples_bf16(h)) g.out_hi = c.at<bf16_t>(p.flo[0]);  // bf16 map in the fp32 map's buffer
+            else g.out_f32 = c.at<float>(p.flo[i]);
+            g.ldc = h->Cp;
             CHK(mdpt_launch_gemm(g, c.s));
         }
     }
+    if (for_head && head_upsamples_bf16(h)) return 0;
     Planes fu = c.pl(p.fused);
     CHK(mdpt_launch_upsample(c.at<float>(p.flo[0]), fu.hi, fu.lo, nullptr, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
     return 0;
 }
 
 // ---- stage: head
-int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32) {
+// from_flo0b: the head's input is still the bf16 output of the last fusion projection at half resolution (run_fusion(c, true))
+int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool from_flo0b = false) {
     const mdpt_handle* h = c.h;
     const Plan& p = c.p;
     const int fh = 8 * p.gh, fw = 8 * p.gw;
+    bool fused_ready = !from_flo0b;
+    auto materialise_fused = [&]() -> int {  // stand-alone bf16 upsample (small launches / shapes the fused kernel does not cover)
+        if (!fused_ready) CHK(mdpt_launch_upsample_bf16(c.at<bf16_t>(p.flo[0]), c.pl(p.fused).hi, p.B, fh / 2, fw / 2, fh, fw, h->Cp, c.s));
+        fused_ready = true;
+        return 0;
+    };
     if (!h->x3 && mdpt_head_tail_supported(h->C2p) && mdpt_head_tail_scale_ok(fh, fw, p.H, p.W)) {
         // bf16 mode: the first conv writes bf16 (the buffer of the fp32 map is reused), everything behind it is ONE kernel that keeps the
         // upsampled map in LDS tiles: upsample + 3x3 conv + ReLU + 1x1 conv + ReLU | sigmoid (head.hip). The bf16x3 mode keeps the
@@ -788,15 +807,29 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32) {
         if (h->C2p == 128 && conv3h_shape_ok(h, fh, fw, h->Cp) && h->gemm_tile == MDPT_TILE_AUTO) {  // halo-staged form, 128 output channels
             Conv3hParams q;
             memset(&q, 0, sizeof(q));
-            q.in = c.pl(p.fused).hi; q.w = h->M("head.spatial_upsampler.0.weight").hi; q.bias = h->V("head.spatial_upsampler.0.bias");
+            q.w = h->M("head.spatial_upsampler.0.weight").hi; q.bias = h->V("head.spatial_upsampler.0.bias");
             q.out_bf = h1b; q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
             const long tiles256 = ((long)p.B * fh * fw + 255) / 256;
-            if (tiles256 >= (c.split ? 24 : 140) && mdpt_conv3h_supported(q)) {
-                CHK(mdpt_launch_conv3h(q, c.s));
-                done = true;
+            const bool big = tiles256 >= (c.split ? 24 : 140);
+            if (big && !fused_ready) {  // the x2 upsample folded into the conv's halo interpolation
+                q.up_in = c.at<bf16_t>(p.flo[0]); q.Hs = fh / 2; q.Ws = fw / 2;
+                if (mdpt_conv3h_supported(q)) {
+                    CHK(mdpt_launch_conv3h(q, c.s));
+                    done = true;
+                }
+                q.up_in = nullptr;
+            }
+            if (big && !done) {
+                CHK(materialise_fused());
+                q.in = c.pl(p.fused).hi;
+                if (mdpt_conv3h_supported(q)) {
+                    CHK(mdpt_launch_conv3h(q, c.s));
+                    done = true;
+                }
             }
         }
         if (!done) {
+            CHK(materialise_fused());
             GemmParams g = base_params(c, h->M("head.spatial_upsampler.0.weight"), c.pl(p.fused), p.B * fh * fw, h->Cp);
             as_conv(g, fh, fw, h->Cp, fh, fw, 1);
             g.bias = h->V("head.spatial_upsampler.0.bias");
@@ -812,6 +845,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32) {
         CHK(mdpt_launch_head_tail(t, h->C2p, c.s));
         return 0;
     }
+    CHK(materialise_fused());
     {
         bool done = false;
         if (h->C2p == 128 && conv3h_shape_ok(h, fh, fw, h->Cp) && h->gemm_tile == MDPT_TILE_AUTO) {  // halo-staged form, fp32 map out
@@ -1115,8 +1149,8 @@ static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, int
         h->has_last = true;
         CHK(run_encoder_swin(c, nullptr));
         CHK(run_reassemble_swin(c));
-        CHK(run_fusion(c));
-        CHK(run_head(c, depth_bhw, depth_dtype));
+        CHK(run_fusion(c, true));
+        CHK(run_head(c, depth_bhw, depth_dtype, head_upsamples_bf16(h)));
         return 0;
     }
     CHK(run_patch_embed_fused(c, image_bchw, image_dtype));
@@ -1125,8 +1159,8 @@ static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, int
     CHK(run_encoder(c, nullptr));
     if (h->dbg_block >= 0) return 0;  // test hook: encoder truncated, skip the decoder
     CHK(run_reassemble(c));
-    CHK(run_fusion(c));
-    CHK(run_head(c, depth_bhw, depth_dtype));
+    CHK(run_fusion(c, true));
+    CHK(run_head(c, depth_bhw, depth_dtype, head_upsamples_bf16(h)));
     return 0;
 }
 
@@ -1388,8 +1422,13 @@ int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspac
         CHK(mdpt_launch_nhwc_to_nchw(c.at<float>(p.r_f32[i]), nullptr, nullptr, (float*)out_f32, p.B, sh[i], sw[i], h->C, h->Cp, c.s));
     } else if (which == 8) {
         float* tmp = c.at<float>(p.scratch);
-        CHK(mdpt_launch_upsample(c.at<float>(p.flo[0]), nullptr, nullptr, tmp, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
-        CHK(mdpt_launch_nhwc_to_nchw(tmp, nullptr, nullptr, (float*)out_f32, p.B, 8 * p.gh, 8 * p.gw, h->C, h->Cp, c.s));
+        if (head_upsamples_bf16(h)) {  // the forward left the last projection as a bf16 map (run_fusion(c, true)): same upsample as the head's
+            CHK(mdpt_launch_upsample_bf16(c.at<bf16_t>(p.flo[0]), (bf16_t*)tmp, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
+            CHK(mdpt_launch_nhwc_to_nchw(nullptr, (const bf16_t*)tmp, nullptr, (float*)out_f32, p.B, 8 * p.gh, 8 * p.gw, h->C, h->Cp, c.s));
+        } else {
+            CHK(mdpt_launch_upsample(c.at<float>(p.flo[0]), nullptr, nullptr, tmp, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
+            CHK(mdpt_launch_nhwc_to_nchw(tmp, nullptr, nullptr, (float*)out_f32, p.B, 8 * p.gh, 8 * p.gw, h->C, h->Cp, c.s));
+        }
     } else {
         return fail(MDPT_E_INVALID, "unknown tap %d", which);
     }
@@ -1451,6 +1490,8 @@ int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_
     const std::string n = name;
     const size_t* planes = nullptr;
     size_t f32_off = SIZE_MAX, elems = 0;
+    size_t bf16_only[2] = {SIZE_MAX, SIZE_MAX};  // a bf16 map without a lo plane
+    const bool bf16_head = !h->x3 && mdpt_head_tail_supported(h->C2p) && mdpt_head_tail_scale_ok(8 * p.gh, 8 * p.gw, p.H, p.W);
     const size_t px[4] = {(size_t)16 * p.Np, (size_t)4 * p.Np, (size_t)p.Np, (size_t)p.Np / 4};
     if (n == "im2col") { planes = p.im2col; elems = (size_t)p.B * p.Np * h->Kpatch; }
     else if (n == "pos") { f32_off = p.pos; elems = (size_t)p.Np * h->F; }
@@ -1461,14 +1502,30 @@ int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_
     else if (n == "vt") { planes = p.vt; elems = (size_t)p.B * h->heads * 64 * p.npadv; }
     else if (n == "att") { planes = p.att; elems = rows * h->F; }
     else if (n == "hbuf") { planes = p.hbuf; elems = rows * 4 * h->F; }
-    else if (n == "h1") { f32_off = p.h1; elems = (size_t)p.B * 64 * p.Np * h->C2p; }
-    else if (n == "h1u") { planes = p.h1u; elems = (size_t)p.B * p.H * p.W * h->C2p; }
-    else if (n == "fused") { planes = p.fused; elems = (size_t)p.B * 64 * p.Np * h->Cp; }
+    else if (n == "h1") {
+        // bf16 mode with the fused head tail: the first conv writes a bf16 map into the fp32 map's buffer (run_head)
+        elems = (size_t)p.B * 64 * p.Np * h->C2p;
+        if (bf16_head) { bf16_only[0] = p.h1; planes = bf16_only; } else { f32_off = p.h1; }
+    }
+    else if (n == "h1u") {
+        if (bf16_head) return fail(MDPT_E_STATE, "h1u does not exist on the fused head-tail path (the upsampled map only ever lives in LDS tiles)");
+        planes = p.h1u; elems = (size_t)p.B * p.H * p.W * h->C2p;
+    }
+    else if (n == "fused") {
+        // bf16 mode: the forward may have folded the x2 upsample into the head's first conv; rebuild the map the head saw (same arithmetic)
+        if (head_upsamples_bf16(h))
+            CHK(mdpt_launch_upsample_bf16(c.at<bf16_t>(p.flo[0]), c.pl(p.fused).hi, p.B, 4 * p.gh, 4 * p.gw, 8 * p.gh, 8 * p.gw, h->Cp, c.s));
+        planes = p.fused; elems = (size_t)p.B * 64 * p.Np * h->Cp;
+    }
     else if (n == "u0") { planes = p.u0; elems = (size_t)p.B * px[0] * h->hidp[0]; }
     else if (n == "u1") { planes = p.u1; elems = (size_t)p.B * px[1] * h->hidp[1]; }
     else if (n == "d3") { planes = p.d3; elems = (size_t)p.B * px[3] * h->hidp[3]; }
     else if (n.size() == 2 && n[0] == 't' && n[1] >= '0' && n[1] <= '3') { const int i = n[1] - '0'; planes = p.t[i]; elems = (size_t)p.B * p.Np * h->hidp[i]; }
-    else if (n.size() == 4 && n.compare(0, 3, "flo") == 0 && n[3] >= '0' && n[3] <= '3') { const int i = n[3] - '0'; f32_off = p.flo[i]; elems = (size_t)p.B * px[i] * h->Cp; }
+    else if (n.size() == 4 && n.compare(0, 3, "flo") == 0 && n[3] >= '0' && n[3] <= '3') {
+        const int i = n[3] - '0';
+        elems = (size_t)p.B * px[i] * h->Cp;
+        if (i == 0 && head_upsamples_bf16(h)) { bf16_only[0] = p.flo[0]; planes = bf16_only; } else { f32_off = p.flo[i]; }  // level 0: bf16 map (run_fusion(c, true))
+    }
     else if (n.size() == 3 && n.compare(0, 2, "xf") == 0 && n[2] >= '0' && n[2] <= '3') { const int i = n[2] - '0'; f32_off = p.x_f32[i]; elems = (size_t)p.B * px[i] * h->Cp; }
     else if (n.size() == 3 && n.compare(0, 2, "a1") == 0 && n[2] >= '0' && n[2] <= '3') { const int i = n[2] - '0'; planes = p.a1[i]; elems = (size_t)p.B * px[i] * h->Cp; }
     else if (n.size() == 3 && n.compare(0, 2, "b2") == 0 && n[2] >= '0' && n[2] <= '3') { const int i = n[2] - '0'; planes = p.b2[i]; elems = (size_t)p.B * px[i] * h->Cp; }
@@ -1522,6 +1579,35 @@ int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void*
     static bf16_t* zero_page = nullptr;  // test hook only: allocated once, never freed
     if (!zero_page) {
         if (hipMalloc((void**)&zero_page, 256) != hipSuccess || hipMemset(zero_page, 0, 256) != hipSuccess) return fail(MDPT_E_STATE, "zero page allocation failed");
+    }
+    if (path == 2 || path == 3) {
+        // upsampled input: in_bf16 is the SOURCE map [B, Hu, Wu, Cin]; the conv runs on its bilinear upsample to H x W.
+        // path 2 = interpolated inside the halo-staged kernel; path 3 = stand-alone bf16 upsample into out_lo_bf16 (scratch [B, H, W, Cin])
+        // followed by the implicit-GEMM conv (tile) - the two must agree bit for bit
+        if (Cout != 128 || !out_bf16 || Hu < 2 || Wu < 2) return fail(MDPT_E_INVALID, "upsampled-input form: 128 output channels, bf16 output");
+        if (path == 2) {
+            Conv3hParams q;
+            memset(&q, 0, sizeof(q));
+            q.up_in = (const bf16_t*)in_bf16; q.Hs = Hu; q.Ws = Wu; q.w = (const bf16_t*)w_packed_bf16; q.bias = (const float*)bias_f32;
+            q.out_bf = (bf16_t*)out_bf16; q.B = B; q.H = H; q.W = W; q.Cin = Cin; q.Cout = 128;
+            q.dbg_times = (unsigned long long*)dbg_times;
+            if (!mdpt_conv3h_supported(q)) return fail(MDPT_E_UNSUPPORTED, "conv3h does not cover this combination");
+            for (int i = 0; i < iters; ++i) CHK(mdpt_launch_conv3h(q, (hipStream_t)stream));
+            return 0;
+        }
+        if (!out_lo_bf16) return fail(MDPT_E_INVALID, "path 3 needs a scratch map in out_lo_bf16");
+        for (int i = 0; i < iters; ++i) {
+            CHK(mdpt_launch_upsample_bf16((const bf16_t*)in_bf16, (bf16_t*)out_lo_bf16, B, Hu, Wu, H, W, Cin, (hipStream_t)stream));
+            GemmParams g;
+            memset(&g, 0, sizeof(g));
+            g.A_hi = (const bf16_t*)out_lo_bf16; g.W_hi = (const bf16_t*)w_packed_bf16;
+            g.M = B * H * W; g.N = 128; g.K = 9 * Cin; g.lda = Cin; g.npass = 1; g.zero_page = zero_page;
+            g.amode = MDPT_A_CONV3; g.ekind = MDPT_E_GENERIC; g.tile = tile;
+            g.Hi = H; g.Wi = W; g.Cin = Cin; g.Ho = H; g.Wo = W; g.cstride = 1;
+            g.bias = (const float*)bias_f32; g.out_hi = (bf16_t*)out_bf16; g.ldc = 128; g.ldr = 128;
+            CHK(mdpt_launch_gemm(g, (hipStream_t)stream));
+        }
+        return 0;
     }
     if (path == 1) {
         Conv3hParams q;

@@ -63,6 +63,8 @@ int mdpt_launch_gemm(const GemmParams& p, hipStream_t stream);   // returns hipE
 // ------------------------------------------------------------------------------------------------
 struct Conv3hParams {
     const bf16_t* in;          // NHWC [B, H, W, Cin] bf16 (hi plane), Cin % 128 == 0
+    const bf16_t* up_in; int Hs, Ws;  // instead of `in` (Cout = 128, bf16 only): bf16 NHWC [B, Hs, Ws, Cin]; the conv input is its bilinear
+                               // (align_corners) upsample to H x W, interpolated inside the kernel (up_bf16.h arithmetic)
     const bf16_t* in_lo;       // lo plane of the input: non-null selects the bf16x3 mode (then w_lo and, with out_bf, out_bf_lo are required)
     const bf16_t* w;           // [Cout][9 * Cin] bf16, MDPT_PACK_CONV3 order (hi plane)
     const bf16_t* w_lo;
@@ -125,6 +127,8 @@ int mdpt_launch_zero_vt_pad(bf16_t* vt_hi, bf16_t* vt_lo, int rows, int N, int n
 // bilinear align_corners=True resize of fp32 NHWC [B,Hi,Wi,C] -> [B,Ho,Wo,C] as bf16 hi (+lo) and/or fp32
 int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float* out_f32, int B, int Hi, int Wi, int Ho,
                          int Wo, int C, hipStream_t stream);
+// the same resize of a bf16 NHWC map to a bf16 NHWC map (C % 8 == 0), arithmetic of up_bf16.h
+int mdpt_launch_upsample_bf16(const bf16_t* in, bf16_t* out, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t stream);
 // weight repack: source (fp32 / bf16 / fp16: src_dtype) in PyTorch layout -> bf16 hi (+lo) [Np][Kp] rows, zero padded. Layout kinds:
 enum { MDPT_PACK_LINEAR = 0,   // src [N][K]
        MDPT_PACK_CONV3 = 1,    // src [Cout][Cin][3][3] -> k = (cb*9 + ky*3+kx)*64 + c, ci = cb*64 + c (64-channel block outer, tap inner)

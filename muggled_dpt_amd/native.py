@@ -18,7 +18,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(CSRC, "libmdpt.so")
 SOURCES = ("gemm.hip", "conv3h.hip", "attention.hip", "elementwise.hip", "swin.hip", "postprocess.hip", "head.hip", "mdpt_api.cpp", "mdpt_prof.cpp")
-HEADERS = ("mdpt_kernels.h", "mdpt_prof.h", "mdpt_swin.inc", "ln_row.h", os.path.join(REPO, "include", "mdpt.h"))
+HEADERS = ("mdpt_kernels.h", "mdpt_prof.h", "mdpt_swin.inc", "ln_row.h", "up_bf16.h", os.path.join(REPO, "include", "mdpt.h"))
 
 ABI_VERSION = 3  # MDPT_ABI_VERSION in include/mdpt.h
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2

@@ -178,3 +178,41 @@ def test_conv3h_128_channels_fp32_map_bf16x3_head_form():
     assert err < 1e-5, f"rel err {err:.3e}"
     r32, _ = _run(lib, native, 0, 6, xh.cuda(), wh.cuda(), bias.cuda(), None, None, True, False, x_lo=xl.cuda(), wp_lo=wl.cuda(), want_bf=False)
     assert torch.equal(r32.view(torch.int32), o32.view(torch.int32))
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 256), (1, 48, 64, 128), (1, 34, 18, 128)])
+def test_conv3h_with_the_x2_upsample_folded_into_its_halo_interpolation(shape):
+    """Head conv 1 on the x2 bilinear upsample (align_corners=True) of the last fusion projection (fusion_model.py:182 -> head_model.py:74-76):
+    the halo-staged kernel interpolates its 18x18 input patches in LDS from the half-resolution bf16 map (no upsampled map in memory).
+    Checked against an fp64 upsample + conv on the bf16 source, and bit for bit against the stand-alone bf16 upsample kernel followed by
+    the implicit-GEMM conv (the small-launch path of the same model)."""
+    from muggled_dpt_amd import native
+    lib = native.load()
+    B, H, W, Cin = shape
+    Hs, Ws = H // 2, W // 2
+    g = torch.Generator().manual_seed(H * 31 + W)
+    src = torch.randn(B, Hs, Ws, Cin, generator=g).to(torch.bfloat16)
+    w = (torch.randn(128, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).to(torch.bfloat16)
+    bias = torch.randn(128, generator=g)
+    up = F.interpolate(src.double().permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=True).to(torch.bfloat16).double()
+    ref = F.conv2d(up, w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    sd, wp, bd = src.cuda(), _pack(w.float()).to(torch.bfloat16).cuda(), bias.cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(path, tile):
+        out = torch.full((B, H, W, 128), float("nan"), device="cuda", dtype=torch.bfloat16)
+        scratch = torch.full((B, H, W, Cin), float("nan"), device="cuda", dtype=torch.bfloat16)
+        native.check(lib, lib.mdpt_debug_conv3(sd.data_ptr(), wp.data_ptr(), bd.data_ptr(), None, None, Hs, Ws, None, out.data_ptr(), 0, B, H, W, Cin, 128,
+                                               path, tile, 1, stream, None, None, None, scratch.data_ptr()))
+        torch.cuda.synchronize()
+        return out, scratch
+
+    got, _ = run(2, 0)
+    err = float((got.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 1.2e-2, f"rel err {err:.3e}"  # bf16 rounding of the interpolated input (may differ by one bf16 ulp from the fp64 interpolation) and of the output
+    for tile in (6, 1, 0):
+        want, scratch = run(3, tile)
+        assert torch.equal(want.view(torch.int16), got.view(torch.int16)), f"differs from upsample + implicit GEMM (tile {tile})"
+    # the stand-alone upsample itself vs torch (one bf16 ulp: fp32 vs fp64 interpolation before the rounding)
+    e_up = float((scratch.double().cpu() - up.permute(0, 2, 3, 1)).abs().max()) / float(up.abs().max())
+    assert e_up < 8e-3, f"upsample rel err {e_up:.3e}"
