@@ -811,6 +811,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool f
             q.out_bf = h1b; q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
             const long tiles256 = ((long)p.B * fh * fw + 255) / 256;
             const bool big = tiles256 >= (c.split ? 24 : 140);
+#ifndef MDPT_NO_UPIN  // (A/B builds: -DMDPT_NO_UPIN keeps the stand-alone upsample in front of the halo-staged conv)
             if (big && !fused_ready) {  // the x2 upsample folded into the conv's halo interpolation
                 q.up_in = c.at<bf16_t>(p.flo[0]); q.Hs = fh / 2; q.Ws = fw / 2;
                 if (mdpt_conv3h_supported(q)) {
@@ -819,6 +820,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool f
                 }
                 q.up_in = nullptr;
             }
+#endif
             if (big && !done) {
                 CHK(materialise_fused());
                 q.in = c.pl(p.fused).hi;
