@@ -221,34 +221,43 @@ __global__ __launch_bounds__(256) void swin_qk_prep_kernel(const float* __restri
 }
 
 // V preparation: Vt[(p*H + h)*32 + d][npadv], token-contiguous, pad columns [wa, npadv) written as zero.
-// Consecutive lanes = consecutive tokens so the 2-byte transposed stores coalesce.
+// One workgroup per (window p, head h): the window's [wa tokens][32 d] fp32 block is read with 128-byte rows (8 lanes x 16 B per token),
+// transposed through an LDS tile [32][npadv + 8] bf16 (hi, and lo in bf16x3 mode) and written out as whole 16-byte runs of the
+// token-contiguous rows. (Round 2 wrote every element with its own 2-byte global store: 74 us per block for Q, K and V at SwinV2-L
+// stage 2 where the bytes moved take ~30 us.)
 __global__ __launch_bounds__(256) void swin_v_prep_kernel(const float* __restrict__ qkv, const int* __restrict__ rowmap, bf16_t* vt_hi,
                                                           bf16_t* vt_lo, int B, int N, int nw, int wa, int npadv, int heads) {
-    const int F = heads * 32;
-    const size_t total = (size_t)B * nw * heads * 8 * npadv;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int i = (int)(idx % npadv);
-        const size_t r = idx / npadv;
-        const int g = (int)(r & 7);
-        const size_t ph = r >> 3;  // p*heads + h
-        const int h = (int)(ph % heads);
-        const size_t p = ph / heads;
+    extern __shared__ __attribute__((aligned(16))) bf16_t vtile[];  // [planes][32][pitch]
+    const int F = heads * 32, pitch = npadv + 8;
+    const size_t ph = blockIdx.x;  // p * heads + h
+    const int h = (int)(ph % heads);
+    const size_t p = ph / heads;
+    const int w = (int)(p % nw);
+    const size_t img = p / nw;
+    const int g = threadIdx.x & 7;
+    bf16_t* t_hi = vtile;
+    bf16_t* t_lo = vtile + 32 * pitch;
+    for (int i = threadIdx.x >> 3; i < npadv; i += 32) {
         f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (i < wa) {
-            const int w = (int)(p % nw);
-            const size_t img = p / nw;
-            v = *(const f32x4*)(qkv + (img * N + rowmap[(size_t)w * wa + i]) * (size_t)(3 * F) + 2 * F + h * 32 + g * 4);
-        }
+        if (i < wa) v = *(const f32x4*)(qkv + (img * N + rowmap[(size_t)w * wa + i]) * (size_t)(3 * F) + 2 * F + h * 32 + g * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const size_t o = (ph * 32 + g * 4 + e) * npadv + i;
             const __bf16 hi = (__bf16)v[e];
-            vt_hi[o] = __builtin_bit_cast(bf16_t, hi);
+            t_hi[(g * 4 + e) * pitch + i] = __builtin_bit_cast(bf16_t, hi);
             if (vt_lo) {
                 const __bf16 lo = (__bf16)(v[e] - (float)hi);
-                vt_lo[o] = __builtin_bit_cast(bf16_t, lo);
+                t_lo[(g * 4 + e) * pitch + i] = __builtin_bit_cast(bf16_t, lo);
             }
         }
+    }
+    __syncthreads();
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    const int chunks = npadv >> 3;  // 16-byte runs per row (npadv % 64 == 0)
+    for (int idx = threadIdx.x; idx < 32 * chunks; idx += 256) {
+        const int d = idx / chunks, c = idx - d * chunks;
+        const size_t o = (ph * 32 + d) * (size_t)npadv + c * 8;
+        *(u32x4_t*)(vt_hi + o) = *(const u32x4_t*)(t_hi + d * pitch + c * 8);
+        if (vt_lo) *(u32x4_t*)(vt_lo + o) = *(const u32x4_t*)(t_lo + d * pitch + c * 8);
     }
 }
 
@@ -332,11 +341,22 @@ int mdpt_launch_swin_cpb_batch(const SwinCpbBatch& b, hipStream_t stream) {
 int mdpt_launch_swin_qkv_prep(const float* qkv, const int* rowmap, const float* logit_scale, bf16_t* q_hi, bf16_t* q_lo, bf16_t* k_hi,
                               bf16_t* k_lo, bf16_t* vt_hi, bf16_t* vt_lo, int B, int N, int nw, int wa, int npad, int npadv, int heads,
                               hipStream_t stream) {
-    MdptProfScope prof("swin_qkv_prep", 0.0, stream);
-    hipLaunchKernelGGL(swin_qk_prep_kernel, dim3(grid_for((size_t)B * nw * wa * 2 * heads * 8)), dim3(256), 0, stream, qkv, rowmap, logit_scale,
-                       q_hi, q_lo, k_hi, k_lo, B, N, nw, wa, npad, heads);
-    hipLaunchKernelGGL(swin_v_prep_kernel, dim3(grid_for((size_t)B * nw * heads * 8 * npadv)), dim3(256), 0, stream, qkv, rowmap, vt_hi, vt_lo,
-                       B, N, nw, wa, npadv, heads);
+    {
+        MdptProfScope prof_qk("swin_qk_prep", 0.0, stream);
+        hipLaunchKernelGGL(swin_qk_prep_kernel, dim3(grid_for((size_t)B * nw * wa * 2 * heads * 8)), dim3(256), 0, stream, qkv, rowmap, logit_scale,
+                           q_hi, q_lo, k_hi, k_lo, B, N, nw, wa, npad, heads);
+    }
+    MdptProfScope prof("swin_v_prep", 0.0, stream);
+    const size_t v_lds = (size_t)(vt_lo ? 2 : 1) * 32 * (npadv + 8) * 2;
+    if (v_lds > 160 * 1024 || (npadv & 63)) return (int)hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)swin_v_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(swin_v_prep_kernel, dim3((unsigned)((size_t)B * nw * heads)), dim3(256), v_lds, stream, qkv, rowmap, vt_hi, vt_lo, B, N, nw, wa,
+                       npadv, heads);
     LAUNCH_RET();
 }
 
