@@ -643,7 +643,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
 //              fc2 with the layer scale folded into the packed weights and bias): out = (resid + A W'^T) + bias'. The 256 KB residual
 //              read of a tile streams in under the first K tiles instead of sitting exposed in the epilogue.
 //   DM_VT    : V transposed, token-contiguous (epilogue_direct_vt: PLAIN operand order, a lane owns 4 consecutive tokens)
-enum { DM_NONE = 0, DM_BF16 = 1, DM_RESID = 2, DM_QK = 3, DM_VT = 4, DM_F32 = 5, DM_RINIT = 6 };
+//   DM_SWQK  : SwinV2 cosine-attention Q / K (heads of 32): L2-normalised, Q times the head's logit scale, scattered to window order
+//              (QKV tiles without V columns when GemmParams::swin_tokmap is set; the V tiles of that GEMM use DM_F32)
+enum { DM_NONE = 0, DM_BF16 = 1, DM_RESID = 2, DM_QK = 3, DM_VT = 4, DM_F32 = 5, DM_RINIT = 6, DM_SWQK = 7 };
 
 // Everything that selects code is a template parameter (MODE, X3 = hi+lo output planes, ACT) and every memory access is a raw
 // buffer op whose out-of-range lanes (tail rows: offset beyond num_records; tail columns: offset forced to ~0) are dropped by
@@ -876,6 +878,113 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc
                 }
             }
         }
+    }
+}
+
+// SwinV2 window-attention operands straight out of a Q / K tile of the QKV GEMM (windowed_attention.py:100-123: F.normalize(q), F.normalize(k),
+// q * exp(clamped logit scale)). Heads are 32 wide = the 32 columns one wave owns in a quadrant: a lane holds two 4-column groups of a row (groups
+// lh and 4 + lh of the head), the four lanes lane, lane^16, lane^32, lane^48 hold the row's whole head. |.|^2 is summed in the order
+// swin_qk_prep_kernel (swin.hip) uses on the fp32 QKV rows - (a^2 + b^2) + (c^2 + d^2) per group, group c with group c+4, then the neighbour
+// group pair, then the other half - with unfused multiplies, so the fused and the unfused form of a block give the same bits whichever tile
+// rule picks which. Rows scatter through the token map: image token t -> swin_tokmap[t] = w*heads*npad + i, + img*swin_img_rows + h*npad.
+template <bool X3>
+__device__ __forceinline__ void epilogue_swin_qk(const GemmParams& p, f32x4 (&acc)[2][2][4][2], int m0, int n0, int grp, int wc, int lane) {
+#pragma clang fp contract(off)
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const int l15 = lane & 15, lh = lane >> 4;
+    const size_t plane = (size_t)(p.M / p.swin_N) * p.swin_img_rows * 64;  // bytes of a Q / K plane (< 4 GiB: checked by the caller)
+    // everything that is loaded comes before the first store (a wait after a store also waits for the store)
+    f32x4 bias_q[2][2];
+    float scale_q[2];
+    int head_q[2], which_q[2];
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn) {
+        const int nq = n0 + qn * 128 + wc * 32;
+        which_q[qn] = __builtin_amdgcn_readfirstlane(nq >= p.F);
+        head_q[qn] = (nq - which_q[qn] * p.F) >> 5;
+        scale_q[qn] = which_q[qn] ? 1.0f : p.swin_logit_scale[head_q[qn]];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bias_q[qn][j] = p.bias ? *(const f32x4*)(p.bias + nq + j * 16 + 4 * lh) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    int dst[2][4];
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm) {
+        const int r0 = m0 + qm * 128 + grp * 64 + l15;
+        int img = r0 / p.swin_N, t = r0 - img * p.swin_N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dst[qm][i] = r0 + 16 * i < p.M ? img * p.swin_img_rows + p.swin_tokmap[t] : -1;
+            t += 16;
+            while (t >= p.swin_N) { t -= p.swin_N; ++img; }
+        }
+    }
+    const int d8 = (lh & 1) * 16 + (lh >> 1) * 8;  // first of the 8 head columns this lane stores (after the lane^16 exchange)
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn) {
+        const __amdgpu_buffer_rsrc_t rs_hi = tile_rsrc(which_q[qn] ? p.k_hi : p.q_hi, plane);
+        const __amdgpu_buffer_rsrc_t rs_lo = tile_rsrc(X3 ? (which_q[qn] ? p.k_lo : p.q_lo) : p.q_hi, X3 ? plane : 0);
+        const int hrow = head_q[qn] * p.npad;
+#pragma unroll
+        for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v[2];
+                float sg[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    v[j] = acc[qm][qn][i][j] + bias_q[qn][j];
+                    sg[j] = (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
+                }
+                float ss = sg[0] + sg[1];
+                // cross-lane sums with the swap instructions: swap(x, x) leaves [R0 R0 R2 R2] / [R1 R1 R3 R3] (rows of 16 lanes) resp.
+                // [lo lo] / [hi hi] in the two registers. The results go through scalars: __builtin_bit_cast applied to an element of the
+                // returned vector reads element 0 both times (DESIGN.md bug 4)
+                {
+                    const unsigned u = __builtin_bit_cast(unsigned, ss);
+                    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+                    const unsigned r0 = r[0], r1 = r[1];
+                    ss = __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+                }
+                {
+                    const unsigned u = __builtin_bit_cast(unsigned, ss);
+                    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                    const unsigned r0 = r[0], r1 = r[1];
+                    ss = __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+                }
+                float scale = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+                scale *= scale_q[qn];
+                unsigned hw_[2][2], lw_[2][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int w2 = 0; w2 < 2; ++w2) {
+                        const f32x2 pp = {v[j][2 * w2] * scale, v[j][2 * w2 + 1] * scale};
+                        const bf16x2 hh = __builtin_convertvector(pp, bf16x2);
+                        hw_[j][w2] = __builtin_bit_cast(unsigned, hh);
+                        if (X3) {
+                            const f32x2 rr = pp - __builtin_convertvector(hh, f32x2);
+                            lw_[j][w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                        }
+                    }
+                unsigned ph[4], pl[4];
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2) {
+                    auto r = __builtin_amdgcn_permlane16_swap(hw_[0][w2], hw_[1][w2], false, false);
+                    ph[w2] = r[0];
+                    ph[w2 + 2] = r[1];
+                    if (X3) {
+                        auto rl = __builtin_amdgcn_permlane16_swap(lw_[0][w2], lw_[1][w2], false, false);
+                        pl[w2] = rl[0];
+                        pl[w2 + 2] = rl[1];
+                    }
+                }
+                const unsigned off = dst[qm][i] < 0 ? OOB : (unsigned)(((size_t)(dst[qm][i] + hrow) * 32 + d8) * 2);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{ph[0], ph[1], ph[2], ph[3]}, rs_hi, off, 0, 0);
+                if (X3) __builtin_amdgcn_raw_buffer_store_b128(u32x4{pl[0], pl[1], pl[2], pl[3]}, rs_lo, off, 0, 0);
+            }
     }
 }
 
@@ -1376,8 +1485,16 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
     if (p.dbg_times) t_loop = memtime_now();
     if constexpr (SW) {
         if (EKIND == MDPT_E_QKV) {
-            if (p.q_lo) epilogue_direct<DM_QK, true, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
-            else epilogue_direct<DM_QK, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+            if (dmode == DM_SWQK) {
+                if (p.q_lo) epilogue_swin_qk<true>(p, acc, m0, n0, grp, wc, lane);
+                else epilogue_swin_qk<false>(p, acc, m0, n0, grp, wc, lane);
+            } else if (dmode == DM_F32) {  // V columns of the SwinV2 form
+                epilogue_direct<DM_F32, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+            } else if (p.q_lo) {
+                epilogue_direct<DM_QK, true, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+            } else {
+                epilogue_direct<DM_QK, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+            }
         } else if (dmode == DM_BF16) {
             const int sel = (p.out_lo ? 3 : 0) + (p.act == MDPT_ACT_GELU ? 2 : (p.act == MDPT_ACT_RELU || p.relu_bf16) ? 1 : 0);
             switch (sel) {
@@ -1478,12 +1595,15 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
 #else
         const bool fast = AMODE == MDPT_A_DENSE && p.npass == 1;  // bf16 mode: stateless operand staging
 #endif
-        if (n0 + 256 <= 2 * p.F && (size_t)p.M * p.F * 2 < 0xFFFFFFF0ull) {
+        // SwinV2 form (host guarantees 2F % 256 == 0 and 32-bit plane offsets): Q / K tiles -> DM_SWQK, V tiles -> fp32 rows for swin_v_prep
+        const bool swin = p.swin_tokmap != nullptr;
+        if (swin || (n0 + 256 <= 2 * p.F && (size_t)p.M * p.F * 2 < 0xFFFFFFF0ull)) {
+            const int dm = swin ? (n0 + 256 <= 2 * p.F ? DM_SWQK : DM_F32) : DM_QK;
             if constexpr (AMODE == MDPT_A_DENSE) {
-                if (fast) gemm8_body<AMODE, EKIND, true, false, true>(p, smem, DM_QK, m0, n0, t_start);
-                else gemm8_body<AMODE, EKIND, true>(p, smem, DM_QK, m0, n0, t_start);
+                if (fast) gemm8_body<AMODE, EKIND, true, false, true>(p, smem, dm, m0, n0, t_start);
+                else gemm8_body<AMODE, EKIND, true>(p, smem, dm, m0, n0, t_start);
             } else {
-                gemm8_body<AMODE, EKIND, true>(p, smem, DM_QK, m0, n0, t_start);
+                gemm8_body<AMODE, EKIND, true>(p, smem, dm, m0, n0, t_start);
             }
         } else if (n0 >= 2 * p.F && n0 + 256 <= p.N && (size_t)(p.M / p.npad) * p.F * p.npadv * 2 < 0xFFFFFFF0ull) {
             if constexpr (AMODE == MDPT_A_DENSE) {
@@ -1563,8 +1683,8 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-template <int AMODE, int EKIND>
-int launch_tile(const GemmParams& p, hipStream_t stream) {
+// the tile mdpt_launch_gemm runs for p (MDPT_TILE_AUTO resolved); -1: the 128x64 form of narrow outputs
+int resolve_tile(const GemmParams& p) {
     int tile = p.tile;
     if (tile == MDPT_TILE_AUTO) {
         // measured on MI355X, kernel alone on the GPU (tests/gpu_gemm_tile_sweep.py): the 8-phase 256x256 tile wins from ~140
@@ -1581,7 +1701,17 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
         tile = big ? MDPT_TILE_PP256 : (tiles128 <= 330 ? MDPT_TILE_64x64 : MDPT_TILE_128x128);
         // narrow outputs with many rows (64-channel decoder convs of the small models): a 128-wide tile would spend half of its
         // MFMAs on padding columns. 128x64, four waves stacked in M: ViT-S B=32 +8.4 %
-        if (!big && tiles128 > 330 && p.N <= 64) return launch_cfg<128, 64, 4, 1, 64, 2, 2, AMODE, EKIND>(p, stream);
+        if (!big && tiles128 > 330 && p.N <= 64) return -1;
+    }
+    if (tile == MDPT_TILE_PP256 && (((p.K / 64) * p.npass) & 1)) tile = MDPT_TILE_256x256;  // odd number of K tiles: the 8-phase loop handles pairs
+    return tile;
+}
+template <int AMODE, int EKIND>
+int launch_tile(const GemmParams& p, hipStream_t stream) {
+    int tile = resolve_tile(p);
+    if (tile < 0) return launch_cfg<128, 64, 4, 1, 64, 2, 2, AMODE, EKIND>(p, stream);
+    if constexpr (EKIND == MDPT_E_QKV) {
+        if (p.swin_tokmap && tile != MDPT_TILE_PP256) return (int)hipErrorInvalidValue;  // the SwinV2 form exists in the 8-phase kernel only
     }
     if constexpr (EKIND == MDPT_E_GENERIC) {
         // residual-initialised accumulators: the 8-phase kernel has them in its DM_RINIT form only (dense A, >= 4 K tiles, 32-bit tile
@@ -1591,14 +1721,15 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
             tile = MDPT_TILE_256x256;
     }
     if (tile == MDPT_TILE_64x64) return launch_cfg<64, 64, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);
-    if (tile == MDPT_TILE_PP256 && (((p.K / 64) * p.npass) & 1) == 0) return launch_pp<AMODE, EKIND>(p, stream);
-    if (tile == MDPT_TILE_PP256) tile = MDPT_TILE_256x256;  // odd number of K tiles: the 8-phase loop handles pairs
+    if (tile == MDPT_TILE_PP256) return launch_pp<AMODE, EKIND>(p, stream);
     if (tile == MDPT_TILE_256x128) return launch_cfg<256, 128, 2, 2, 32, 3, 2, AMODE, EKIND>(p, stream);
     if (tile == MDPT_TILE_256x256) return launch_cfg<256, 256, 2, 4, 64, 2, 1, AMODE, EKIND>(p, stream);
     return launch_cfg<128, 128, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);
 }
 
 }  // namespace
+
+bool mdpt_gemm_resolves_to_pp256(const GemmParams& p) { return p.M > 0 && p.N > 0 && p.K > 0 && !(p.K & 63) && resolve_tile(p) == MDPT_TILE_PP256; }
 
 int mdpt_launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0) return 0;

@@ -43,6 +43,10 @@ struct GemmParams {
     // E_QKV: scatter to head-major Q (pre-scaled), K and transposed V
     bf16_t* q_hi; bf16_t* q_lo; bf16_t* k_hi; bf16_t* k_lo; bf16_t* vt_hi; bf16_t* vt_lo;
     int F, heads, npad, npadv; float qscale;
+    // E_QKV, SwinV2 form (swin_tokmap != nullptr; 8-phase tile only, 2F % 256 == 0): Q / K column tiles are written as the window
+    // attention's operands - q / max(|q|, 1e-12) * logit_scale[h], k / max(|k|, 1e-12), heads of 32, row (img*swin_img_rows +
+    // swin_tokmap[t] + h*npad) for image token t - and V column tiles as fp32 into out_f32 (ldc = 3F) for swin_v_prep
+    const int* swin_tokmap; const float* swin_logit_scale; int swin_N, swin_img_rows;
     // E_PATCH: out_f32[(b*npad + 1 + p), n] = acc + bias[n] + pos[p, n]   (m = b*tok_np + p)
     const float* pos;
     // E_D2S: transposed conv k==s as GEMM: n = (ky*k + kx)*Cout + co ; out NHWC [B, Ho*k, Wo*k, Cout]
@@ -55,6 +59,7 @@ struct GemmParams {
 };
 
 int mdpt_launch_gemm(const GemmParams& p, hipStream_t stream);   // returns hipError_t as int
+bool mdpt_gemm_resolves_to_pp256(const GemmParams& p);          // would mdpt_launch_gemm run the 8-phase 256x256 kernel for p?
 
 // ------------------------------------------------------------------------------------------------
 // halo-staged 3x3 convolution, stride 1, pad 1, Cout = 256 (conv3h.hip): the 256-channel convs of the DPT decoder at large batch.
@@ -199,8 +204,9 @@ int mdpt_launch_head_tail(const HeadTailParams& p, int cin, hipStream_t stream);
 int mdpt_launch_ln_res(const float* x, const float* add, const float* gamma, const float* beta, float eps, float* out_f32,
                        bf16_t* out_hi, bf16_t* out_lo, int rows, int F, hipStream_t stream, int ld_planes = 0);
 // window -> image token map (with cyclic shift sh, sw), shifted-window region ids [nW][region_ld], window-local tq / tk terms
+// tokmap (optional): the inverse, image token -> w * tok_stride + i
 int mdpt_launch_swin_window_map(int* rowmap, int* region, int* tq, int* tk, int gh, int gw, int wh, int ww, int sh, int sw,
-                                int region_ld, int ntok_pad, hipStream_t stream);
+                                int region_ld, int ntok_pad, hipStream_t stream, int* tokmap = nullptr, int tok_stride = 0);
 // continuous position bias LUT [heads][(2wh-1)(2ww-1)] = 16*sigmoid(MLP(log-coords)); pretrained = 0 means "None"
 int mdpt_launch_swin_cpb(const float* w1, const float* b1, const float* w2, float* lut, int heads, int hidden, int wh, int ww,
                          int pretrained, hipStream_t stream);
@@ -214,7 +220,7 @@ int mdpt_launch_swin_cpb_batch(const SwinCpbBatch& b, hipStream_t stream);
 // fp32 qkv [B*N, 3F] -> normalised/scaled window operands Q,K [B*nw, heads, npad, 32] and Vt [B*nw, heads, 32, npadv]
 int mdpt_launch_swin_qkv_prep(const float* qkv, const int* rowmap, const float* logit_scale, bf16_t* q_hi, bf16_t* q_lo,
                               bf16_t* k_hi, bf16_t* k_lo, bf16_t* vt_hi, bf16_t* vt_lo, int B, int N, int nw, int wa, int npad,
-                              int npadv, int heads, hipStream_t stream);
+                              int npadv, int heads, hipStream_t stream, bool qk = true);  // qk = false: V only (Q, K came out of the GEMM)
 // fp32 [B,gh,gw,C] -> bf16 rows [B*(gh/2)*(gw/2), 4C] = cat(TL, BL, TR, BR)
 int mdpt_launch_swin_merge_gather(const float* tok, bf16_t* out_hi, bf16_t* out_lo, int B, int gh, int gw, int C,
                                   hipStream_t stream);

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void ln_res_kernel(const float* __restrict__ x
 // one dimension makes that dimension's LAST slice cover everything (Python slice(-0, None)).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void swin_window_map_kernel(int* rowmap, int* region, int* tq, int* tk, int gh, int gw, int wh, int ww,
-                                                              int sh, int sw, int region_ld, int ntok_pad) {
+                                                              int sh, int sw, int region_ld, int ntok_pad, int* tokmap, int tok_stride) {
     const int wa = wh * ww, nwx = gw / ww, nw = (gh / wh) * nwx;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < ntok_pad) {
@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256) void swin_window_map_kernel(int* rowmap, int* 
     const int w = gid / wa, i = gid - w * wa;
     const int wy = w / nwx, wx = w - wy * nwx, iy = i / ww, ix = i - iy * ww;
     const int yr = wy * wh + iy, xr = wx * ww + ix;
-    rowmap[gid] = ((yr + sh) % gh) * gw + (xr + sw) % gw;
+    const int tok = ((yr + sh) % gh) * gw + (xr + sw) % gw;
+    rowmap[gid] = tok;
+    if (tokmap) tokmap[tok] = w * tok_stride + i;
     const int rh = sh == 0 ? 2 : (yr < gh - wh ? 0 : (yr < gh - sh ? 1 : 2));
     const int rw = sw == 0 ? 2 : (xr < gw - ww ? 0 : (xr < gw - sw ? 1 : 2));
     region[(size_t)w * region_ld + i] = 3 * rh + rw;
@@ -187,11 +189,14 @@ __global__ __launch_bounds__(256) void swin_cpb_batch_kernel(const SwinCpbBatch 
 // Q / K preparation. qkv fp32 [B*N, 3F] (biases already added by the GEMM epilogue) -> head-major window operands
 //   Q[(p*H + h)*npad + i][32] = logit_scale[h] * q / max(|q|, 1e-12),  K likewise without the scale   (F.normalize eps)
 // p = image*nW + window, i = token inside the window. One thread = 4 consecutive d of one (token, q|k, head);
-// the 8 lanes of a head reduce |.|^2 with three xor-shuffles.
+// the 8 lanes of a head reduce |.|^2 with three xor-shuffles: group c with group c+4 first, then neighbours, then pairs - the order
+// (and the unfused multiplies: fp contraction off) of epilogue_swin_qk in gemm.hip, which produces the same bits straight out of the
+// QKV GEMM's accumulators when the 8-phase tile runs.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void swin_qk_prep_kernel(const float* __restrict__ qkv, const int* __restrict__ rowmap,
                                                            const float* __restrict__ logit_scale, bf16_t* q_hi, bf16_t* q_lo, bf16_t* k_hi,
                                                            bf16_t* k_lo, int B, int N, int nw, int wa, int npad, int heads) {
+#pragma clang fp contract(off)
     const int F = heads * 32;
     const size_t per_tok = (size_t)2 * heads * 8;
     const size_t total = (size_t)B * nw * wa * per_tok;
@@ -207,11 +212,11 @@ __global__ __launch_bounds__(256) void swin_qk_prep_kernel(const float* __restri
         const size_t src = (img * N + rowmap[(size_t)w * wa + i]) * (size_t)(3 * F) + (size_t)which * F + h * 32 + g * 4;
         f32x4 v = *(const f32x4*)(qkv + src);
         float ss = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        ss += __shfl_xor(ss, 4);
         ss += __shfl_xor(ss, 1);
         ss += __shfl_xor(ss, 2);
-        ss += __shfl_xor(ss, 4);
         float scale = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-        if (which == 0) scale *= logit_scale[h];
+        scale *= which == 0 ? logit_scale[h] : 1.0f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= scale;
         const size_t dst = ((p * heads + h) * npad + i) * 32 + g * 4;
@@ -312,11 +317,11 @@ int mdpt_launch_ln_res(const float* x, const float* add, const float* gamma, con
 }
 
 int mdpt_launch_swin_window_map(int* rowmap, int* region, int* tq, int* tk, int gh, int gw, int wh, int ww, int sh, int sw, int region_ld,
-                                int ntok_pad, hipStream_t stream) {
+                                int ntok_pad, hipStream_t stream, int* tokmap, int tok_stride) {
     if (wh <= 0 || ww <= 0 || gh % wh || gw % ww || region_ld < wh * ww) return (int)hipErrorInvalidValue;
     const size_t work = (size_t)gh * gw > (size_t)ntok_pad ? (size_t)gh * gw : (size_t)ntok_pad;
     hipLaunchKernelGGL(swin_window_map_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, rowmap, region, tq, tk, gh, gw, wh,
-                       ww, sh, sw, region_ld, ntok_pad);
+                       ww, sh, sw, region_ld, ntok_pad, tokmap, tok_stride);
     LAUNCH_RET();
 }
 
@@ -340,8 +345,8 @@ int mdpt_launch_swin_cpb_batch(const SwinCpbBatch& b, hipStream_t stream) {
 
 int mdpt_launch_swin_qkv_prep(const float* qkv, const int* rowmap, const float* logit_scale, bf16_t* q_hi, bf16_t* q_lo, bf16_t* k_hi,
                               bf16_t* k_lo, bf16_t* vt_hi, bf16_t* vt_lo, int B, int N, int nw, int wa, int npad, int npadv, int heads,
-                              hipStream_t stream) {
-    {
+                              hipStream_t stream, bool qk) {
+    if (qk) {
         MdptProfScope prof_qk("swin_qk_prep", 0.0, stream);
         hipLaunchKernelGGL(swin_qk_prep_kernel, dim3(grid_for((size_t)B * nw * wa * 2 * heads * 8)), dim3(256), 0, stream, qkv, rowmap, logit_scale,
                            q_hi, q_lo, k_hi, k_lo, B, N, nw, wa, npad, heads);

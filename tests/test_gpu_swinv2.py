@@ -102,6 +102,25 @@ def test_swin_window_that_does_not_tile_the_grid():
     assert rel_err(model.to("cuda")(x.to("cuda")).cpu(), dpt_oracle.forward(w, cfg, x)) <= REL_TOL_X3
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_swin_fused_qk_epilogue_is_bitwise_identical_to_the_prep_kernel(dtype):
+    """With the 8-phase GEMM tile the cosine-attention Q / K operands come straight out of the QKV GEMM's accumulators
+    (gemm.hip epilogue_swin_qk); every other tile writes fp32 QKV rows and runs swin_qk_prep. Same arithmetic in the same order:
+    the depth maps must be the same bits whichever form each block took (the tile rule makes that depend on the batch size).
+    swin2_base widths (128 .. 1024) put every stage on the fused form when tile 5 is forced; shifted and unshifted blocks both run."""
+    model, cfg, w = _build("swin2_base_384", 3, dtype)
+    x = seeded_input((2, 3, 384, 384), 9).to("cuda", dtype)
+    model.set_gemm_tile(1)   # 128x128 lockstep everywhere: unfused
+    y_unfused = model(x)
+    model.set_gemm_tile(5)   # 8-phase everywhere it can run: fused
+    y_fused = model(x)
+    model.set_gemm_tile(0)   # the shipped rule: a mix
+    y_auto = model(x)
+    assert torch.isfinite(y_fused.float()).all() and float(y_fused.float().abs().max()) > 0
+    assert torch.equal(y_fused, y_unfused), float((y_fused.float() - y_unfused.float()).abs().max())
+    assert torch.equal(y_auto, y_unfused)
+
+
 @pytest.mark.parametrize("dtype,tol", MODES)
 def test_swin_large_384_vs_golden_fixture(golden_dir, dtype, tol):
     """BASELINE.json configs[5]: SwinV2-L @384, batch 1 (compact fixture: strided depth, crops, per-boundary stats)."""
