@@ -645,7 +645,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
 //   DM_VT    : V transposed, token-contiguous (epilogue_direct_vt: PLAIN operand order, a lane owns 4 consecutive tokens)
 //   DM_SWQK  : SwinV2 cosine-attention Q / K (heads of 32): L2-normalised, Q times the head's logit scale, scattered to window order
 //              (QKV tiles without V columns when GemmParams::swin_tokmap is set; the V tiles of that GEMM use DM_F32)
-enum { DM_NONE = 0, DM_BF16 = 1, DM_RESID = 2, DM_QK = 3, DM_VT = 4, DM_F32 = 5, DM_RINIT = 6, DM_SWQK = 7 };
+//   DM_SWVT  : SwinV2 V columns written as the transposed window operand (4-token runs, plain operand order like DM_VT)
+enum { DM_NONE = 0, DM_BF16 = 1, DM_RESID = 2, DM_QK = 3, DM_VT = 4, DM_F32 = 5, DM_RINIT = 6, DM_SWQK = 7, DM_SWVT = 8 };
 
 // Everything that selects code is a template parameter (MODE, X3 = hi+lo output planes, ACT) and every memory access is a raw
 // buffer op whose out-of-range lanes (tail rows: offset beyond num_records; tail columns: offset forced to ~0) are dropped by
@@ -986,6 +987,69 @@ __device__ __forceinline__ void epilogue_swin_qk(const GemmParams& p, f32x4 (&ac
                 if (X3) __builtin_amdgcn_raw_buffer_store_b128(u32x4{pl[0], pl[1], pl[2], pl[3]}, rs_lo, off, 0, 0);
             }
     }
+}
+
+// SwinV2 V columns as the window attention's transposed operand Vt[(img*nw + w)*heads + h][d][npadv] (what swin_v_prep_kernel builds from
+// fp32 rows: bf16(acc + bias), lo = bf16(v - hi) in bf16x3 mode - the same two conversions). Plain operand order: a lane owns 4 consecutive
+// rows = image tokens t .. t+3 (t % 4 == 0) of one column; the caller guarantees grid width, window width and shift are multiples of 4,
+// so the four tokens are consecutive positions of one window: one 8-byte store per lane, row block and column. Pad positions [wa, npadv)
+// are zeroed by the caller once per stage.
+template <bool X3>
+__device__ __forceinline__ void epilogue_swin_vt(const GemmParams& p, f32x4 (&acc)[2][2][4][2], int m0, int n0, int grp, int wc, int lane) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const int l15 = lane & 15, lh = lane >> 4;
+    const size_t plane = (size_t)(p.M / p.swin_N) * p.swin_img_velems * 2;  // bytes; < 4 GiB checked by the caller
+    const __amdgpu_buffer_rsrc_t rs_hi = tile_rsrc(p.vt_hi, plane);
+    const __amdgpu_buffer_rsrc_t rs_lo = tile_rsrc(X3 ? p.vt_lo : p.vt_hi, X3 ? plane : 0);
+    float bias_q[2][2];
+    int col_q[2][2];
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + qn * 128 + wc * 32 + j * 16 + l15;
+            bias_q[qn][j] = p.bias ? p.bias[n < p.N ? n : p.N - 1] : 0.0f;
+            col_q[qn][j] = n < p.N ? (n - 2 * p.F) * p.npadv : -1;  // (h*32 + d) * npadv
+        }
+    int dst[2][4];
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm) {
+        const int r0 = m0 + qm * 128 + grp * 64 + 4 * lh;
+        int img = r0 / p.swin_N, t = r0 - img * p.swin_N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dst[qm][i] = r0 + 16 * i < p.M ? img * p.swin_img_velems + p.swin_vtokmap[t] : -1;
+            t += 16;
+            while (t >= p.swin_N) { t -= p.swin_N; ++img; }
+        }
+    }
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 v = acc[qm][qn][i][j] + bias_q[qn][j];
+                    unsigned hw_[2], lw_[2];
+#pragma unroll
+                    for (int w2 = 0; w2 < 2; ++w2) {
+                        const f32x2 pp = {v[2 * w2], v[2 * w2 + 1]};
+                        const bf16x2 hb = __builtin_convertvector(pp, bf16x2);
+                        hw_[w2] = __builtin_bit_cast(unsigned, hb);
+                        if (X3) {
+                            const f32x2 rr = pp - __builtin_convertvector(hb, f32x2);
+                            lw_[w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                        }
+                    }
+                    const unsigned off = dst[qm][i] < 0 || col_q[qn][j] < 0 ? OOB : (unsigned)(dst[qm][i] + col_q[qn][j]) * 2u;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{hw_[0], hw_[1]}, rs_hi, off, 0, 0);
+                    if (X3) __builtin_amdgcn_raw_buffer_store_b64(u32x2{lw_[0], lw_[1]}, rs_lo, off, 0, 0);
+                }
 }
 
 // V columns of the QKV GEMM, written transposed: Vt[(b, h, d)][token]. With the PLAIN MFMA operand order a lane owns 4 consecutive
@@ -1520,9 +1584,15 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
         }
         return;
     }
-    if (EKIND == MDPT_E_QKV && dmode == DM_VT) {
-        if (p.vt_lo) epilogue_direct_vt<true>(p, acc, m0, n0, grp, wc, lane);
-        else epilogue_direct_vt<false>(p, acc, m0, n0, grp, wc, lane);
+    if (EKIND == MDPT_E_QKV && (dmode == DM_VT || dmode == DM_SWVT)) {
+        if (dmode == DM_SWVT) {
+            if (p.vt_lo) epilogue_swin_vt<true>(p, acc, m0, n0, grp, wc, lane);
+            else epilogue_swin_vt<false>(p, acc, m0, n0, grp, wc, lane);
+        } else if (p.vt_lo) {
+            epilogue_direct_vt<true>(p, acc, m0, n0, grp, wc, lane);
+        } else {
+            epilogue_direct_vt<false>(p, acc, m0, n0, grp, wc, lane);
+        }
         if (p.dbg_times && tid == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned long long* d = p.dbg_times + (size_t)blockIdx.x * 6;
@@ -1597,7 +1667,14 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
 #endif
         // SwinV2 form (host guarantees 2F % 256 == 0 and 32-bit plane offsets): Q / K tiles -> DM_SWQK, V tiles -> fp32 rows for swin_v_prep
         const bool swin = p.swin_tokmap != nullptr;
-        if (swin || (n0 + 256 <= 2 * p.F && (size_t)p.M * p.F * 2 < 0xFFFFFFF0ull)) {
+        if (swin && p.swin_vtokmap && n0 >= 2 * p.F) {  // SwinV2 V tile, transposed direct form (plain operand order)
+            if constexpr (AMODE == MDPT_A_DENSE) {
+                if (fast) gemm8_body<AMODE, EKIND, false, false, true>(p, smem, DM_SWVT, m0, n0, t_start);
+                else gemm8_body<AMODE, EKIND, false>(p, smem, DM_SWVT, m0, n0, t_start);
+            } else {
+                gemm8_body<AMODE, EKIND, false>(p, smem, DM_SWVT, m0, n0, t_start);
+            }
+        } else if (swin || (n0 + 256 <= 2 * p.F && (size_t)p.M * p.F * 2 < 0xFFFFFFF0ull)) {
             const int dm = swin ? (n0 + 256 <= 2 * p.F ? DM_SWQK : DM_F32) : DM_QK;
             if constexpr (AMODE == MDPT_A_DENSE) {
                 if (fast) gemm8_body<AMODE, EKIND, true, false, true>(p, smem, dm, m0, n0, t_start);

@@ -103,7 +103,7 @@ struct Plan {
     // window operands, window maps (plain / shifted) and the position-bias LUT
     struct {
         int g0h, g0w;
-        size_t resid[4], x, xn[2], q[2], k[2], vt[2], att[2], hb[2], lut, lut_stride, tq, tk, rowmap[2], region[2], tokmap[2];
+        size_t resid[4], x, xn[2], q[2], k[2], vt[2], att[2], hb[2], lut, lut_stride, tq, tk, rowmap[2], region[2], tokmap[2], vtokmap[2];
     } sw;
 };
 

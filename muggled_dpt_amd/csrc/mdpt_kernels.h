@@ -47,6 +47,9 @@ struct GemmParams {
     // attention's operands - q / max(|q|, 1e-12) * logit_scale[h], k / max(|k|, 1e-12), heads of 32, row (img*swin_img_rows +
     // swin_tokmap[t] + h*npad) for image token t - and V column tiles as fp32 into out_f32 (ldc = 3F) for swin_v_prep
     const int* swin_tokmap; const float* swin_logit_scale; int swin_N, swin_img_rows;
+    // ... and, when swin_vtokmap != nullptr (token runs of 4 stay together: gw, ww, shift % 4 == 0), the V column tiles are written as the
+    // transposed window operand Vt[(img*nw + w)*heads + h][d][npadv] directly: element img*swin_img_velems + swin_vtokmap[t] + (h*32 + d)*npadv
+    const int* swin_vtokmap; int swin_img_velems;
     // E_PATCH: out_f32[(b*npad + 1 + p), n] = acc + bias[n] + pos[p, n]   (m = b*tok_np + p)
     const float* pos;
     // E_D2S: transposed conv k==s as GEMM: n = (ky*k + kx)*Cout + co ; out NHWC [B, Ho*k, Wo*k, Cout]
@@ -204,9 +207,10 @@ int mdpt_launch_head_tail(const HeadTailParams& p, int cin, hipStream_t stream);
 int mdpt_launch_ln_res(const float* x, const float* add, const float* gamma, const float* beta, float eps, float* out_f32,
                        bf16_t* out_hi, bf16_t* out_lo, int rows, int F, hipStream_t stream, int ld_planes = 0);
 // window -> image token map (with cyclic shift sh, sw), shifted-window region ids [nW][region_ld], window-local tq / tk terms
-// tokmap (optional): the inverse, image token -> w * tok_stride + i
+// tokmap / vtokmap (optional): the inverse, image token -> w * tok_stride + i resp. w * vtok_stride + i
 int mdpt_launch_swin_window_map(int* rowmap, int* region, int* tq, int* tk, int gh, int gw, int wh, int ww, int sh, int sw,
-                                int region_ld, int ntok_pad, hipStream_t stream, int* tokmap = nullptr, int tok_stride = 0);
+                                int region_ld, int ntok_pad, hipStream_t stream, int* tokmap = nullptr, int tok_stride = 0, int* vtokmap = nullptr,
+                                int vtok_stride = 0);
 // continuous position bias LUT [heads][(2wh-1)(2ww-1)] = 16*sigmoid(MLP(log-coords)); pretrained = 0 means "None"
 int mdpt_launch_swin_cpb(const float* w1, const float* b1, const float* w2, float* lut, int heads, int hidden, int wh, int ww,
                          int pretrained, hipStream_t stream);

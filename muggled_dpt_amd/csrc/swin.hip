@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void ln_res_kernel(const float* __restrict__ x
 // one dimension makes that dimension's LAST slice cover everything (Python slice(-0, None)).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void swin_window_map_kernel(int* rowmap, int* region, int* tq, int* tk, int gh, int gw, int wh, int ww,
-                                                              int sh, int sw, int region_ld, int ntok_pad, int* tokmap, int tok_stride) {
+                                                              int sh, int sw, int region_ld, int ntok_pad, int* tokmap, int tok_stride,
+                                                              int* vtokmap, int vtok_stride) {
     const int wa = wh * ww, nwx = gw / ww, nw = (gh / wh) * nwx;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < ntok_pad) {
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256) void swin_window_map_kernel(int* rowmap, int* 
     const int tok = ((yr + sh) % gh) * gw + (xr + sw) % gw;
     rowmap[gid] = tok;
     if (tokmap) tokmap[tok] = w * tok_stride + i;
+    if (vtokmap) vtokmap[tok] = w * vtok_stride + i;
     const int rh = sh == 0 ? 2 : (yr < gh - wh ? 0 : (yr < gh - sh ? 1 : 2));
     const int rw = sw == 0 ? 2 : (xr < gw - ww ? 0 : (xr < gw - sw ? 1 : 2));
     region[(size_t)w * region_ld + i] = 3 * rh + rw;
@@ -317,11 +319,11 @@ int mdpt_launch_ln_res(const float* x, const float* add, const float* gamma, con
 }
 
 int mdpt_launch_swin_window_map(int* rowmap, int* region, int* tq, int* tk, int gh, int gw, int wh, int ww, int sh, int sw, int region_ld,
-                                int ntok_pad, hipStream_t stream, int* tokmap, int tok_stride) {
+                                int ntok_pad, hipStream_t stream, int* tokmap, int tok_stride, int* vtokmap, int vtok_stride) {
     if (wh <= 0 || ww <= 0 || gh % wh || gw % ww || region_ld < wh * ww) return (int)hipErrorInvalidValue;
     const size_t work = (size_t)gh * gw > (size_t)ntok_pad ? (size_t)gh * gw : (size_t)ntok_pad;
     hipLaunchKernelGGL(swin_window_map_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, rowmap, region, tq, tk, gh, gw, wh,
-                       ww, sh, sw, region_ld, ntok_pad, tokmap, tok_stride);
+                       ww, sh, sw, region_ld, ntok_pad, tokmap, tok_stride, vtokmap, vtok_stride);
     LAUNCH_RET();
 }
 
