@@ -900,13 +900,12 @@ __device__ __forceinline__ void epilogue_swin_qk(const GemmParams& p, f32x4 (&ac
     // everything that is loaded comes before the first store (a wait after a store also waits for the store)
     f32x4 bias_q[2][2];
     float scale_q[2];
-    int head_q[2], which_q[2];
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn) {
         const int nq = n0 + qn * 128 + wc * 32;
-        which_q[qn] = __builtin_amdgcn_readfirstlane(nq >= p.F);
-        head_q[qn] = (nq - which_q[qn] * p.F) >> 5;
-        scale_q[qn] = which_q[qn] ? 1.0f : p.swin_logit_scale[head_q[qn]];
+        const int which = __builtin_amdgcn_readfirstlane(nq >= p.F);
+        const float ls = p.swin_logit_scale[(nq - which * p.F) >> 5];
+        scale_q[qn] = which ? 1.0f : ls;
 #pragma unroll
         for (int j = 0; j < 2; ++j) bias_q[qn][j] = p.bias ? *(const f32x4*)(p.bias + nq + j * 16 + 4 * lh) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
@@ -925,9 +924,12 @@ __device__ __forceinline__ void epilogue_swin_qk(const GemmParams& p, f32x4 (&ac
     const int d8 = (lh & 1) * 16 + (lh >> 1) * 8;  // first of the 8 head columns this lane stores (after the lane^16 exchange)
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn) {
-        const __amdgpu_buffer_rsrc_t rs_hi = tile_rsrc(which_q[qn] ? p.k_hi : p.q_hi, plane);
-        const __amdgpu_buffer_rsrc_t rs_lo = tile_rsrc(X3 ? (which_q[qn] ? p.k_lo : p.q_lo) : p.q_hi, X3 ? plane : 0);
-        const int hrow = head_q[qn] * p.npad;
+        // (Q | K plane and head recomputed here, wave-uniform scalars: kept in arrays across the loops above they became a pointer table in scratch)
+        const int nq = n0 + qn * 128 + wc * 32;
+        const int which = __builtin_amdgcn_readfirstlane(nq >= p.F);
+        const __amdgpu_buffer_rsrc_t rs_hi = tile_rsrc(which ? p.k_hi : p.q_hi, plane);
+        const __amdgpu_buffer_rsrc_t rs_lo = tile_rsrc(X3 ? (which ? p.k_lo : p.q_lo) : p.q_hi, X3 ? plane : 0);
+        const int hrow = ((nq - which * p.F) >> 5) * p.npad;
 #pragma unroll
         for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
@@ -1548,17 +1550,17 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
 #undef MFMA_Q
     if (p.dbg_times) t_loop = memtime_now();
     if constexpr (SW) {
-        if (EKIND == MDPT_E_QKV) {
-            if (dmode == DM_SWQK) {
-                if (p.q_lo) epilogue_swin_qk<true>(p, acc, m0, n0, grp, wc, lane);
-                else epilogue_swin_qk<false>(p, acc, m0, n0, grp, wc, lane);
-            } else if (dmode == DM_F32) {  // V columns of the SwinV2 form
+        if (EKIND == MDPT_E_SWQKV) {
+            if (dmode == DM_F32) {  // V columns as fp32 rows (swin_v_prep follows)
                 epilogue_direct<DM_F32, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
             } else if (p.q_lo) {
-                epilogue_direct<DM_QK, true, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+                epilogue_swin_qk<true>(p, acc, m0, n0, grp, wc, lane);
             } else {
-                epilogue_direct<DM_QK, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+                epilogue_swin_qk<false>(p, acc, m0, n0, grp, wc, lane);
             }
+        } else if (EKIND == MDPT_E_QKV) {
+            if (p.q_lo) epilogue_direct<DM_QK, true, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+            else epilogue_direct<DM_QK, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
         } else if (dmode == DM_BF16) {
             const int sel = (p.out_lo ? 3 : 0) + (p.act == MDPT_ACT_GELU ? 2 : (p.act == MDPT_ACT_RELU || p.relu_bf16) ? 1 : 0);
             switch (sel) {
@@ -1584,8 +1586,8 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
         }
         return;
     }
-    if (EKIND == MDPT_E_QKV && (dmode == DM_VT || dmode == DM_SWVT)) {
-        if (dmode == DM_SWVT) {
+    if ((EKIND == MDPT_E_QKV && dmode == DM_VT) || (EKIND == MDPT_E_SWQKV && dmode == DM_SWVT)) {
+        if (EKIND == MDPT_E_SWQKV) {
             if (p.vt_lo) epilogue_swin_vt<true>(p, acc, m0, n0, grp, wc, lane);
             else epilogue_swin_vt<false>(p, acc, m0, n0, grp, wc, lane);
         } else if (p.vt_lo) {
@@ -1657,7 +1659,19 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
     if (p.dbg_times) t_start = memtime_now();
     int m0, n0;
     tile_coords((p.N + 255) / 256, 256, 256, m0, n0);
-    if (EKIND == MDPT_E_QKV) {
+    if constexpr (EKIND == MDPT_E_SWQKV) {
+        // SwinV2 QKV projection (the host guarantees dense A, 2F % 256 == 0 and 32-bit plane offsets): Q / K tiles -> DM_SWQK; V tiles ->
+        // transposed window operand (DM_SWVT, plain operand order) when token runs of 4 stay together, else fp32 rows for swin_v_prep
+        const bool fast = p.npass == 1;
+        if (n0 >= 2 * p.F && p.swin_vtokmap) {
+            if (fast) gemm8_body<AMODE, EKIND, false, false, true>(p, smem, DM_SWVT, m0, n0, t_start);
+            else gemm8_body<AMODE, EKIND, false>(p, smem, DM_SWVT, m0, n0, t_start);
+        } else {
+            const int dm = n0 >= 2 * p.F ? DM_F32 : DM_SWQK;
+            if (fast) gemm8_body<AMODE, EKIND, true, false, true>(p, smem, dm, m0, n0, t_start);
+            else gemm8_body<AMODE, EKIND, true>(p, smem, dm, m0, n0, t_start);
+        }
+    } else if (EKIND == MDPT_E_QKV) {
         // per tile: Q / K columns only -> swapped order + head-major direct epilogue; V columns only -> plain order + transposed
         // direct epilogue; a tile that straddles 2F (odd head counts) or planes beyond 32-bit offsets -> plain order + LDS strip
 #ifdef MDPT_GEMM8_NO_FAST
@@ -1665,22 +1679,12 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
 #else
         const bool fast = AMODE == MDPT_A_DENSE && p.npass == 1;  // bf16 mode: stateless operand staging
 #endif
-        // SwinV2 form (host guarantees 2F % 256 == 0 and 32-bit plane offsets): Q / K tiles -> DM_SWQK, V tiles -> fp32 rows for swin_v_prep
-        const bool swin = p.swin_tokmap != nullptr;
-        if (swin && p.swin_vtokmap && n0 >= 2 * p.F) {  // SwinV2 V tile, transposed direct form (plain operand order)
+        if (n0 + 256 <= 2 * p.F && (size_t)p.M * p.F * 2 < 0xFFFFFFF0ull) {
             if constexpr (AMODE == MDPT_A_DENSE) {
-                if (fast) gemm8_body<AMODE, EKIND, false, false, true>(p, smem, DM_SWVT, m0, n0, t_start);
-                else gemm8_body<AMODE, EKIND, false>(p, smem, DM_SWVT, m0, n0, t_start);
+                if (fast) gemm8_body<AMODE, EKIND, true, false, true>(p, smem, DM_QK, m0, n0, t_start);
+                else gemm8_body<AMODE, EKIND, true>(p, smem, DM_QK, m0, n0, t_start);
             } else {
-                gemm8_body<AMODE, EKIND, false>(p, smem, DM_SWVT, m0, n0, t_start);
-            }
-        } else if (swin || (n0 + 256 <= 2 * p.F && (size_t)p.M * p.F * 2 < 0xFFFFFFF0ull)) {
-            const int dm = swin ? (n0 + 256 <= 2 * p.F ? DM_SWQK : DM_F32) : DM_QK;
-            if constexpr (AMODE == MDPT_A_DENSE) {
-                if (fast) gemm8_body<AMODE, EKIND, true, false, true>(p, smem, dm, m0, n0, t_start);
-                else gemm8_body<AMODE, EKIND, true>(p, smem, dm, m0, n0, t_start);
-            } else {
-                gemm8_body<AMODE, EKIND, true>(p, smem, dm, m0, n0, t_start);
+                gemm8_body<AMODE, EKIND, true>(p, smem, DM_QK, m0, n0, t_start);
             }
         } else if (n0 >= 2 * p.F && n0 + 256 <= p.N && (size_t)(p.M / p.npad) * p.F * p.npadv * 2 < 0xFFFFFFF0ull) {
             if constexpr (AMODE == MDPT_A_DENSE) {
@@ -1736,6 +1740,8 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
         return launch_pp_mode<AMODE, EKIND, DM_NONE>(p, stream);
     } else if constexpr (EKIND == MDPT_E_QKV) {
         return launch_pp_mode<AMODE, EKIND, DM_QK>(p, stream);
+    } else if constexpr (EKIND == MDPT_E_SWQKV) {
+        return launch_pp_mode<AMODE, EKIND, DM_SWQK>(p, stream);
     } else {
         return launch_pp_mode<AMODE, EKIND, DM_NONE>(p, stream);
     }
@@ -1787,9 +1793,6 @@ template <int AMODE, int EKIND>
 int launch_tile(const GemmParams& p, hipStream_t stream) {
     int tile = resolve_tile(p);
     if (tile < 0) return launch_cfg<128, 64, 4, 1, 64, 2, 2, AMODE, EKIND>(p, stream);
-    if constexpr (EKIND == MDPT_E_QKV) {
-        if (p.swin_tokmap && tile != MDPT_TILE_PP256) return (int)hipErrorInvalidValue;  // the SwinV2 form exists in the 8-phase kernel only
-    }
     if constexpr (EKIND == MDPT_E_GENERIC) {
         // residual-initialised accumulators: the 8-phase kernel has them in its DM_RINIT form only (dense A, >= 4 K tiles, 32-bit tile
         // offsets); anything else runs the lockstep 256x256 tile, whose prologue loads the residual the same way
@@ -1821,6 +1824,11 @@ int mdpt_launch_gemm(const GemmParams& p, hipStream_t stream) {
         case MDPT_E_QKV:
             if (p.amode == MDPT_A_DENSE && (p.F & 63) == 0 && (p.npad & 7) == 0 && (p.npadv & 7) == 0)
                 return launch_tile<MDPT_A_DENSE, MDPT_E_QKV>(p, stream);
+            break;
+        case MDPT_E_SWQKV:  // exists in the 8-phase kernel only: the caller asks mdpt_gemm_resolves_to_pp256() first
+            if (p.amode == MDPT_A_DENSE && p.swin_tokmap && (2 * p.F) % 256 == 0 && p.N == 3 * p.F && (p.npadv & 3) == 0 &&
+                resolve_tile(p) == MDPT_TILE_PP256)
+                return launch_pp<MDPT_A_DENSE, MDPT_E_SWQKV>(p, stream);
             break;
         case MDPT_E_PATCH:
             if (p.amode == MDPT_A_DENSE) return launch_tile<MDPT_A_DENSE, MDPT_E_PATCH>(p, stream);

@@ -15,7 +15,7 @@ enum { MDPT_DT_F32 = 0, MDPT_DT_BF16 = 1, MDPT_DT_F16 = 2 };
 // A and W are bf16 "hi" planes plus optional "lo" planes (x = hi + lo, bf16x3 split precision).
 // ------------------------------------------------------------------------------------------------
 enum { MDPT_A_DENSE = 0, MDPT_A_TOKENS = 1, MDPT_A_CONV3 = 2 };
-enum { MDPT_E_GENERIC = 0, MDPT_E_QKV = 1, MDPT_E_PATCH = 2, MDPT_E_D2S = 3, MDPT_E_HEAD = 4 };
+enum { MDPT_E_GENERIC = 0, MDPT_E_QKV = 1, MDPT_E_PATCH = 2, MDPT_E_D2S = 3, MDPT_E_HEAD = 4, MDPT_E_SWQKV = 5 };
 enum { MDPT_ACT_NONE = 0, MDPT_ACT_RELU = 1, MDPT_ACT_GELU = 2 };
 enum { MDPT_TILE_AUTO = 0, MDPT_TILE_128x128 = 1, MDPT_TILE_256x256 = 2, MDPT_TILE_128x32 = 3, MDPT_TILE_256x128 = 4, MDPT_TILE_PP256 = 5, MDPT_TILE_64x64 = 6 };
 
@@ -43,7 +43,7 @@ struct GemmParams {
     // E_QKV: scatter to head-major Q (pre-scaled), K and transposed V
     bf16_t* q_hi; bf16_t* q_lo; bf16_t* k_hi; bf16_t* k_lo; bf16_t* vt_hi; bf16_t* vt_lo;
     int F, heads, npad, npadv; float qscale;
-    // E_QKV, SwinV2 form (swin_tokmap != nullptr; 8-phase tile only, 2F % 256 == 0): Q / K column tiles are written as the window
+    // E_SWQKV, the SwinV2 QKV projection (its own kernel; 8-phase tile only, 2F % 256 == 0): Q / K column tiles are written as the window
     // attention's operands - q / max(|q|, 1e-12) * logit_scale[h], k / max(|k|, 1e-12), heads of 32, row (img*swin_img_rows +
     // swin_tokmap[t] + h*npad) for image token t - and V column tiles as fp32 into out_f32 (ldc = 3F) for swin_v_prep
     const int* swin_tokmap; const float* swin_logit_scale; int swin_N, swin_img_rows;
