@@ -147,6 +147,13 @@ int mdpt_fusion(mdpt_handle* h, const void* const maps_in[4], int32_t B, int32_t
 int mdpt_encoder_probe(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, int32_t gw, void* const stage_out[4],
                        void* const* attn_out, void* workspace, size_t workspace_bytes, void* stream);
 int mdpt_attn_probe_shape(const mdpt_handle* h, int32_t B, int32_t gh, int32_t gw, int32_t block, int64_t shape[4]);
+/* The same pass with, in addition or instead, the OUTPUT TOKENS of selected transformer blocks: what a forward hook on a block module of
+ * the reference receives (demo_helpers/model_capture.py:54-59, used by experiments/block_norm_visualization.py:282 on
+ * v2_depthanything/components/transformer_block.py:41-62; SwinV2: v31_swinv2/image_encoder_model.py:213-225). block_out has one entry
+ * per block (SwinV2: stage-major); every non-NULL entry receives fp32 [B, 1 + gh*gw, F] (ViT / BEiT families, cls row first) or
+ * [B, tokens of the block's stage, features of the stage] (SwinV2). attn_out and block_out may each be NULL. */
+int mdpt_encoder_probe_blocks(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, int32_t gw, void* const stage_out[4],
+                              void* const* attn_out, void* const* block_out, void* workspace, size_t workspace_bytes, void* stream);
 /* FusionModel.blocks[index].forward (fusion_model.py:89-114 top-most block, :148-154 regular blocks; called one by one by
  * experiments/fusion_scaling.py:330-334): reassembly map [B,C,sh,sw] (+ the previous block's output [B,C,sh,sw]; NULL for index 3,
  * the top-most block) -> [B,C,2sh,2sw]. */

@@ -463,6 +463,7 @@ struct Ctx {
     hipStream_t s;
     bool split = false;  // this context is one half of a two-stream batch split
     void* const* attn_dump = nullptr;  // per block: where to write softmax(q k^T) as fp32 [B,H,N,N] (null entries: skip)
+    void* const* block_dump = nullptr; // per block: where to write the block's output tokens as fp32 [B,N,F] (null entries: skip)
     template <class T> T* at(size_t off) const { return off == SIZE_MAX ? nullptr : (T*)(ws + off); }
     Planes pl(const size_t o[2]) const {
         Planes r;
@@ -611,6 +612,8 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             CHK(mdpt_launch_gemm(g, c.s));
         }
         DBG_STOP(6);
+        if (c.block_dump && c.block_dump[b])  // TransformerBlock output (transformer_block.py:61-62), pad rows dropped
+            CHK(mdpt_launch_tokens_export(nullptr, nullptr, resid, (float*)c.block_dump[b], p.B, p.N, p.npad, F, 0, c.s));
         const bool v1 = h->cfg.family == MDPT_FAMILY_DAV1;
         if (v1 ? b >= h->nblocks - 4 : (b + 1) % h->bps == 0) {
             const int st = v1 ? b - (h->nblocks - 4) : b / h->bps;
@@ -1234,14 +1237,22 @@ int mdpt_encoder(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, 
 // entries; a non-null entry receives that block's softmax(q k^T / sqrt(d) [+ bias]) as fp32 [B, heads, N, N].
 int mdpt_encoder_probe(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, int32_t gw, void* const stage_out[4],
                        void* const* attn_out, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!h || !tokens_bnf || !stage_out || !attn_out) return fail(MDPT_E_INVALID, "null argument");
+    if (!attn_out) return fail(MDPT_E_INVALID, "null argument");
+    return mdpt_encoder_probe_blocks(h, tokens_bnf, B, gh, gw, stage_out, attn_out, nullptr, workspace, workspace_bytes, stream);
+}
+
+// ... and / or the output tokens of selected blocks (what a forward hook on a TransformerBlock sees: demo_helpers/model_capture.py:54-59
+// used by experiments/block_norm_visualization.py:282)
+int mdpt_encoder_probe_blocks(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, int32_t gw, void* const stage_out[4],
+                              void* const* attn_out, void* const* block_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !tokens_bnf || !stage_out) return fail(MDPT_E_INVALID, "null argument");
     for (int i = 0; i < 4; ++i)
         if (!stage_out[i]) return fail(MDPT_E_INVALID, "null stage output %d", i);
     if (gh <= 0 || gw <= 0) return fail(MDPT_E_INVALID, "bad grid");
     Ctx c;
     if (h->swin) {  // as mdpt_encoder, plus the window-attention weights of the listed blocks (stage-major block order)
         CHK(make_ctx(h, B, gh * h->P, gw * h->P, workspace, workspace_bytes, stream, &c));
-        c.attn_dump = attn_out;
+        c.attn_dump = attn_out; c.block_dump = block_out;
         const size_t n = (size_t)B * gh * gw * h->F;
         Planes xn = c.pl(c.p.sw.xn);
         CHK(hipMemcpyAsync(c.at<float>(c.p.sw.resid[0]), tokens_bnf, n * 4, hipMemcpyDeviceToDevice, c.s));
@@ -1255,7 +1266,7 @@ int mdpt_encoder_probe(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_
     c.p.gh = gh; c.p.gw = gw; c.p.Np = gh * gw; c.p.N = c.p.Np + 1;
     if (rup(c.p.N, 8) > c.p.npad) return fail(MDPT_E_INVALID, "internal: plan too small");
     c.p.npad = rup(c.p.N, 8); c.p.npadv = rup(c.p.N, 64);
-    c.attn_dump = attn_out;
+    c.attn_dump = attn_out; c.block_dump = block_out;
     if (is_beit(h)) {
         CHK(mdpt_launch_memset_f32(c.at<float>(c.p.pos), 0.0f, (size_t)c.p.Np * h->F, c.s));
     } else {

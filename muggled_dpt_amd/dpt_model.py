@@ -67,6 +67,16 @@ class _SoftmaxProbe(nn.Softmax):
         return attention_weights
 
 
+class _BlockProbe(_Node):
+    """A transformer block of the encoder. The whole encoder is one C call, so the block is never *called* on the hot path; when a
+    forward hook is registered on it (demo_helpers/model_capture.py:54-59 does that for experiments/block_norm_visualization.py:282)
+    the encoder also writes this block's output tokens (mdpt_encoder_probe_blocks) and passes them through this module so the hook
+    fires with them as the output, like a hook on the reference's TransformerBlock (transformer_block.py:41-62)."""
+
+    def forward(self, block_output_tokens: Tensor) -> Tensor:
+        return block_output_tokens
+
+
 def _register_tree(root: nn.Module, shapes: dict[str, tuple]) -> None:
     for key, shape in shapes.items():
         parts = key.split(".")
@@ -172,8 +182,10 @@ class ImageEncoder(_Stage):
         b = x.shape[0]
         assert x.shape[1] == gh * gw and x.shape[2] == eng.F, f"tokens {tuple(x.shape)} do not match grid {gh}x{gw}, F={eng.F}"
         probes = self.__dict__.get("_softmax_probes") or []
+        blocks = self.__dict__.get("_block_probes") or []
         hooked = [i for i, pr in enumerate(probes) if len(pr._forward_hooks) > 0]
-        if hooked:  # hooks on the softmax modules (enable_optimizations=False; SwinV2: always there): same encoder pass, plus weight dumps
+        hooked_blocks = [i for i, (node, _) in enumerate(blocks) if len(node._forward_hooks) > 0]
+        if hooked or hooked_blocks:  # hooks on softmax modules (enable_optimizations=False; SwinV2: always there) / on blocks: same pass + dumps
             if eng.swin:
                 outs = [torch.empty((b, (gh >> s) * (gw >> s), eng.stage_features[s]), device=x.device, dtype=torch.float32) for s in range(4)]
                 size_hw = (gh * eng.P, gw * eng.P)
@@ -185,10 +197,18 @@ class ImageEncoder(_Stage):
                 shp = (ctypes.c_int64 * 4)()
                 native.check(eng.lib, eng.lib.mdpt_attn_probe_shape(eng.handle, b, gh, gw, i, shp))
                 dumps[i] = torch.empty(tuple(shp), device=x.device, dtype=torch.float32)
-            arr = (ctypes.c_void_p * len(probes))(*[dumps[i].data_ptr() if i in dumps else None for i in range(len(probes))])
-            eng.call_checked("mdpt_encoder_probe", x, b, gh, gw, eng.ptr_array(outs), arr, size_hw=size_hw, batch=b)
+            arr = (ctypes.c_void_p * len(probes))(*[dumps[i].data_ptr() if i in dumps else None for i in range(len(probes))]) if probes else None
+            bdumps = {}
+            for i in hooked_blocks:  # block output tokens: [B, 1 + gh*gw, F]; SwinV2: [B, tokens of the block's stage, its features]
+                st = blocks[i][1]
+                shape = (b, (gh >> st) * (gw >> st), eng.stage_features[st]) if eng.swin else (b, gh * gw + 1, eng.F)
+                bdumps[i] = torch.empty(shape, device=x.device, dtype=torch.float32)
+            barr = (ctypes.c_void_p * len(blocks))(*[bdumps[i].data_ptr() if i in bdumps else None for i in range(len(blocks))]) if blocks else None
+            eng.call_checked("mdpt_encoder_probe_blocks", x, b, gh, gw, eng.ptr_array(outs), arr, barr, size_hw=size_hw, batch=b)
             for i in hooked:
                 probes[i](eng.as_output(dumps[i]))  # fires the registered forward hooks with the weights as module output
+            for i in hooked_blocks:
+                blocks[i][0](eng.as_output(bdumps[i]))  # ... with the block's output tokens
             return tuple(eng.as_output(o) for o in outs)
         if eng.swin:  # stage s: [B, (gh >> s) * (gw >> s), F_s] (v31_swinv2/image_encoder_model.py:77-98)
             outs = [torch.empty((b, (gh >> s) * (gw >> s), eng.stage_features[s]), device=x.device, dtype=torch.float32) for s in range(4)]
@@ -462,6 +482,19 @@ class DPTModel(nn.Module):
                     node.attn.add_module("softmax", _SoftmaxProbe(dim=-1))
                     probes.append(node.attn.softmax)
             self.imgencoder.__dict__["_softmax_probes"] = probes
+        # every transformer block is hookable (output tokens), in block order; SwinV2 stage-major, with the stage of each block
+        block_nodes = []
+        if family == "swinv2":
+            for s, nl in enumerate(self.config["layers_per_stage"]):
+                block_nodes += [(self.imgencoder.stages[s].blocks[l], s) for l in range(int(nl))]
+        elif family == "v1":
+            block_nodes = [(self.imgencoder.blocks[i], 0) for i in range(self.config["num_blocks"])]
+        else:
+            bps = max(1, self.config["num_blocks"] // 4)
+            block_nodes = [(self.imgencoder.stages[i // bps].blocks[i % bps], i // bps) for i in range(self.config["num_blocks"])]
+        for node, _ in block_nodes:
+            node.__class__ = _BlockProbe
+        self.imgencoder.__dict__["_block_probes"] = block_nodes
         self.__dict__["_engine_obj"] = None
         self.__dict__["_gemm_tile"] = 0
         self.eval()  # inference only (dpt_model.py:57)
@@ -518,8 +551,9 @@ class DPTModel(nn.Module):
     def forward(self, image_rgb_normalized_bchw: Tensor) -> Tensor:
         """[B,3,H,W] normalised RGB -> inverse depth [B,H,W] (dpt_model.py:61-83), one fused C-ABI call."""
         probes = self.imgencoder.__dict__.get("_softmax_probes") or []
-        if any(len(pr._forward_hooks) > 0 for pr in probes):
-            # somebody is listening on the attention softmax modules: go stage by stage so the encoder can dump the weights
+        blocks = self.imgencoder.__dict__.get("_block_probes") or []
+        if any(len(pr._forward_hooks) > 0 for pr in probes) or any(len(node._forward_hooks) > 0 for node, _ in blocks):
+            # somebody is listening on attention softmax modules or on blocks: go stage by stage so the encoder can dump what they see
             tokens, hw = self.patch_embed(image_rgb_normalized_bchw)
             return self.head(self.fusion(*self.reassemble(*self.imgencoder(tokens, hw), hw)))
         eng = self._get_engine()

@@ -142,6 +142,7 @@ SYMBOLS = {
     "mdpt_fusion": (ctypes.c_int, [_VP, _VP4, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_encoder_probe": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP4, _VP4, _VP, _SZ, _VP]),
     "mdpt_attn_probe_shape": (ctypes.c_int, [_VP, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int64)]),
+    "mdpt_encoder_probe_blocks": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP4, _VP, _VP, _VP, _SZ, _VP]),
     "mdpt_fusion_block": (ctypes.c_int, [_VP, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_head": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_prepare_image": (ctypes.c_int, [_VP, _I, _I, _VP, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _I, _VP]),

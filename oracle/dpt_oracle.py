@@ -126,7 +126,8 @@ def transformer_block(w: dict, pre: str, x: torch.Tensor, num_heads: int, captur
     return x + w[f"{pre}.scale_mlp"] * m
 
 
-def image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple[int, int], capture: list | None = None) -> list[torch.Tensor]:
+def image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple[int, int], capture: list | None = None,
+                  block_outputs: list | None = None) -> list[torch.Tensor]:
     """+pos-embed, prepend cls(+cls_embedding), 4 stages of round(num_blocks/4) blocks, shared out-norm on
     each stage output (image_encoder_model.py:80-94, :69, :136-147; position_encoder.py:55-76)."""
     b = patch_tokens.shape[0]
@@ -139,6 +140,8 @@ def image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple
         n = cfg["num_blocks"]
         for i in range(n):
             tokens = transformer_block(w, f"imgencoder.blocks.{i}", tokens, cfg["num_heads"], capture)
+            if block_outputs is not None:
+                block_outputs.append(tokens)  # what a forward hook on the block sees (tests of mdpt_encoder_probe_blocks)
             if i >= n - 4:
                 taps.append(tokens)
     else:
@@ -146,6 +149,8 @@ def image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple
         for s in range(4):
             for i in range(per_stage):
                 tokens = transformer_block(w, f"imgencoder.stages.{s}.blocks.{i}", tokens, cfg["num_heads"], capture)
+                if block_outputs is not None:
+                    block_outputs.append(tokens)
             taps.append(tokens)
     return [layernorm(t, w["imgencoder.outnorm.weight"], w["imgencoder.outnorm.bias"]) for t in taps]
 
@@ -209,7 +214,8 @@ def beit_attention(w: dict, pre: str, x: torch.Tensor, cfg: dict, grid_hw: tuple
     return F.linear(y, w[f"{pre}.proj.weight"], w[f"{pre}.proj.bias"])
 
 
-def beit_image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple[int, int], capture: list | None = None) -> list[torch.Tensor]:
+def beit_image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: tuple[int, int], capture: list | None = None,
+                       block_outputs: list | None = None) -> list[torch.Tensor]:
     """cls ++ patch tokens (no absolute position embedding), 4 stages, raw stage outputs are the taps (no out-norm)
     (image_encoder_model.py:80-99, block :241-251)."""
     tokens = torch.cat((w["imgencoder.cls_token"].expand(patch_tokens.shape[0], -1, -1), patch_tokens), dim=1)
@@ -222,6 +228,8 @@ def beit_image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw: 
             tokens = tokens + w[f"{pre}.scale_attn"] * a
             m = mlp(w, f"{pre}.mlp", layernorm(tokens, w[f"{pre}.norm2.weight"], w[f"{pre}.norm2.bias"]))
             tokens = tokens + w[f"{pre}.scale_mlp"] * m
+            if block_outputs is not None:
+                block_outputs.append(tokens)
         taps.append(tokens)
     return taps
 
@@ -376,7 +384,8 @@ def swin_patch_merge(w: dict, pre: str, tokens: torch.Tensor, grid_hw):
     return F.layer_norm(x, (x.shape[-1],), w[f"{pre}.norm.weight"], w[f"{pre}.norm.bias"], 1e-5), out_hw
 
 
-def swin_image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw, capture: list | None = None) -> list[torch.Tensor]:
+def swin_image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw, capture: list | None = None,
+                       block_outputs: list | None = None) -> list[torch.Tensor]:
     """4 stages of (plain, shifted) post-norm block pairs with a patch merge between stages; taps = stage outputs
     (image_encoder_model.py:77-98, :155-161, :213-225)."""
     tokens, hw, taps = patch_tokens, tuple(grid_hw), []
@@ -387,6 +396,8 @@ def swin_image_encoder(w: dict, cfg: dict, patch_tokens: torch.Tensor, grid_hw, 
             tokens = tokens + F.layer_norm(a, (a.shape[-1],), w[f"{pre}.norm1.weight"], w[f"{pre}.norm1.bias"], 1e-5)
             m = mlp(w, f"{pre}.mlp", tokens)
             tokens = tokens + F.layer_norm(m, (m.shape[-1],), w[f"{pre}.norm2.weight"], w[f"{pre}.norm2.bias"], 1e-5)
+            if block_outputs is not None:
+                block_outputs.append(tokens)
         taps.append(tokens)
         if s < 3:
             tokens, hw = swin_patch_merge(w, f"imgencoder.patch_merge_layers.{s}", tokens, hw)

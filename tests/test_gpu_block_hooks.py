@@ -1,0 +1,103 @@
+"""Forward hooks on the encoder's transformer-block modules receive the block's output tokens - what the reference's
+demo_helpers/model_capture.py:54-59 captures for experiments/block_norm_visualization.py:282 (hooks on TransformerBlock,
+v2_depthanything/components/transformer_block.py:41-62; SwinV2 blocks v31_swinv2/image_encoder_model.py:213-225). The encoder is one C
+call here, so the tokens come from mdpt_encoder_probe_blocks; they are checked against the oracle's per-block capture. `pytest -m gpu`."""
+import pytest
+import torch
+
+from tests.helpers import rel_err, seeded_input, synthetic_model
+
+pytestmark = pytest.mark.gpu
+
+MODES = [(torch.float32, 1e-4), (torch.bfloat16, 4e-2)]  # relative to the block output's range (bf16: depth of the toy models)
+
+
+def _oracle():
+    from oracle import dpt_oracle
+    return dpt_oracle
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu_and_native_lib():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from muggled_dpt_amd import native
+    native.load()
+
+
+def _build(family, name, dtype):
+    import muggled_dpt_amd as mda
+    from muggled_dpt_amd.state_dict_conversion import flatten_components
+    if family == "beit":
+        from muggled_dpt_amd import state_dict_conversion_beit as conv
+        from muggled_dpt_amd.synthetic import make_synthetic_beit_state_dict
+        osd = make_synthetic_beit_state_dict(name, 3)
+        cfg, model = mda.make_beit_dpt_from_midas_v31_state_dict(osd)
+        w = flatten_components(conv.convert_state_dict_keys(cfg, osd))
+    elif family == "swinv2":
+        from muggled_dpt_amd import state_dict_conversion_swinv2 as conv
+        from muggled_dpt_amd.synthetic import make_synthetic_swinv2_state_dict
+        osd = make_synthetic_swinv2_state_dict(name, 5)
+        cfg, model = mda.make_swinv2_dpt_from_midas_v31_state_dict(osd)
+        w = flatten_components(conv.convert_state_dict_keys(cfg, osd))
+    else:
+        osd, cfg, w = synthetic_model(name, 0)
+        cfg, model = mda.make_depthanythingv2_dpt_from_original_state_dict(osd)
+    return model.to("cuda", dtype), cfg, w
+
+
+def _blocks(model, cfg, family):
+    if family == "swinv2":
+        return [model.imgencoder.stages[s].blocks[l] for s, nl in enumerate(cfg["layers_per_stage"]) for l in range(int(nl))]
+    bps = cfg["num_blocks"] // 4
+    return [model.imgencoder.stages[i // bps].blocks[i % bps] for i in range(cfg["num_blocks"])]
+
+
+@pytest.mark.parametrize("dtype,tol", MODES)
+@pytest.mark.parametrize("family,name,hw", [("v2", "tiny", (56, 84)), ("beit", "beit_tiny", (64, 96)), ("swinv2", "swin2_tiny", (64, 96))])
+def test_block_hooks_receive_the_block_output_tokens(family, name, hw, dtype, tol):
+    orc = _oracle()
+    model, cfg, w = _build(family, name, dtype)
+    x = seeded_input((2, 3, *hw), seed=13)
+    blocks = _blocks(model, cfg, family)
+    picked = sorted({0, len(blocks) // 2, len(blocks) - 1})  # a first, a middle and the last block (SwinV2: three different stages)
+    got, handles = {}, []
+    for i in picked:
+        handles.append(blocks[i].register_forward_hook(lambda mod, args, out, i=i: got.__setitem__(i, out)))
+    y = model(x.to("cuda", dtype))
+    assert sorted(got) == picked
+
+    tokens, grid = orc.patch_embed(w, x)
+    ref = []
+    enc = {"beit": orc.beit_image_encoder, "swinv2": orc.swin_image_encoder}.get(family, orc.image_encoder)
+    enc(w, cfg, tokens, grid, block_outputs=ref)
+    assert len(ref) == len(blocks)
+    for i in picked:
+        g, want = got[i].float().cpu(), ref[i]
+        assert got[i].dtype == dtype and tuple(g.shape) == tuple(want.shape), (i, tuple(g.shape), tuple(want.shape))
+        assert rel_err(g, want) <= tol, f"block {i}: {rel_err(g, want):.3e}"
+    # the prediction is the usual one with listeners attached, and the fused single-call path is back once they are gone
+    ref_y = orc.forward(w, cfg, x)
+    assert rel_err(y.float().cpu(), ref_y) <= (1e-4 if dtype == torch.float32 else 6e-2)
+    for h in handles:
+        h.remove()
+    n_before = len(got)
+    y2 = model(x.to("cuda", dtype))
+    assert len(got) == n_before
+    if dtype == torch.float32:
+        assert rel_err(y2.float().cpu(), y.float().cpu()) <= 1e-6
+
+
+def test_stage_level_call_fires_block_hooks_too():
+    """simple_examples/internal_features.py style: patch_embed -> imgencoder called directly, hook on one block."""
+    model, cfg, w = _build("v2", "tiny", torch.float32)
+    x = seeded_input((1, 3, 56, 56), seed=4).cuda()
+    blk = _blocks(model, cfg, "v2")[-1]
+    got = []
+    blk.register_forward_hook(lambda mod, args, out: got.append(out))
+    tk, hw = model.patch_embed(x)
+    taps = model.imgencoder(tk, hw)
+    assert len(got) == 1 and tuple(got[0].shape) == (1, hw[0] * hw[1] + 1, cfg["features_per_token"])
+    # the last block's output, through the shared out-norm, is the last encoder tap (image_encoder_model.py:136-147)
+    orc = _oracle()
+    want = orc.layernorm(got[0].float().cpu(), w["imgencoder.outnorm.weight"], w["imgencoder.outnorm.bias"])
+    assert rel_err(taps[3].float().cpu(), want) <= 1e-5
