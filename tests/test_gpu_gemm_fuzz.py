@@ -71,6 +71,22 @@ def test_gemm_variants_on_ragged_shapes(lib, tile, mode):
         assert torch.all(out[M:] == 7.0), f"tile {tile} mode {mode} M={M} N={N} K={K}: wrote past row M"
 
 
+def test_gemm_against_a_cpu_float64_product(lib):
+    """The fuzz above takes its reference from a GPU matmul (rocBLAS through torch); this one does not depend on another GPU library
+    being right: one ragged shape, every tile variant, against numpy float64 on the CPU (bf16 operands are exact in float64, so the
+    only error left is the kernel's fp32 accumulation order: measured < 1e-6 of the output range)."""
+    M, N, K = 777, 1024, 1024
+    rng = np.random.default_rng(5)
+    a = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(torch.bfloat16)
+    w = torch.from_numpy(rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).to(torch.bfloat16)
+    ref = a.float().numpy().astype(np.float64) @ w.float().numpy().astype(np.float64).T
+    scale = float(np.abs(ref).max())
+    for tile in (5, 2, 1, 6, 4):
+        out, _ = _run(lib, a.cuda(), w.cuda(), "f32", tile)
+        err = float(np.abs(out[:M].cpu().numpy().astype(np.float64) - ref).max())
+        assert err <= 2e-6 * scale, f"tile {tile}: max err {err:.3e} (range {scale:.3f})"
+
+
 def test_residual_initialised_accumulators_are_bitwise_identical_across_tile_variants(lib):
     """out = (resid + A W^T) + bias with the accumulators STARTING at the residual: the 8-phase kernel (16-byte loads, swapped MFMA operands)
     and the lockstep kernels (dword loads, plain order) must agree bit for bit - batch invariance of the encoder rests on it."""
