@@ -153,6 +153,41 @@ def test_enable_optimizations_false_adds_hookable_softmax_modules_only():
     assert float((cap[-1].sum(-1) - 1).abs().max()) < 1e-5
 
 
+def test_every_transformer_block_is_a_hookable_module_and_the_oracle_captures_block_outputs():
+    """A forward hook on a block module is how the reference's tooling reads block outputs (demo_helpers/model_capture.py:54-59,
+    experiments/block_norm_visualization.py:282). The block modules are parameter containers that pass a tensor through when called
+    (so registered hooks fire with the tokens mdpt_encoder_probe_blocks dumped); making them hookable must not change the key set."""
+    import torch
+    import muggled_dpt_amd as mda
+    from muggled_dpt_amd.dpt_model import _BlockProbe
+    from muggled_dpt_amd.synthetic import make_synthetic_beit_state_dict, make_synthetic_swinv2_state_dict
+    from tests.helpers import synthetic_model
+    osd, _, _ = synthetic_model("tiny", 0)
+    cfg, model = mda.make_depthanythingv2_dpt_from_original_state_dict(osd)
+    blocks = [m for m in model.modules() if isinstance(m, _BlockProbe)]
+    assert len(blocks) == cfg["num_blocks"]
+    assert [n for n, m in model.named_modules() if isinstance(m, _BlockProbe)] == [f"imgencoder.stages.{b}.blocks.0" for b in range(cfg["num_blocks"])]
+    seen = []
+    h = blocks[1].register_forward_hook(lambda mod, args, out: seen.append(out))
+    t = torch.arange(6.0).reshape(1, 2, 3)
+    assert blocks[1](t) is t and len(seen) == 1 and seen[0] is t
+    h.remove()
+    assert all(k.count("_BlockProbe") == 0 for k in model.state_dict())
+    _, beit = mda.make_beit_dpt_from_midas_v31_state_dict(make_synthetic_beit_state_dict("beit_tiny", 1))
+    scfg, swin = mda.make_swinv2_dpt_from_midas_v31_state_dict(make_synthetic_swinv2_state_dict("swin2_tiny", 1))
+    assert sum(isinstance(m, _BlockProbe) for m in beit.modules()) == 4
+    assert sum(isinstance(m, _BlockProbe) for m in swin.modules()) == sum(scfg["layers_per_stage"])
+    # the oracle's per-block capture: one [B, 1 + gh*gw, F] tensor per block, the last one out-normed is the last tap
+    from oracle import dpt_oracle as orc
+    from muggled_dpt_amd.state_dict_conversion import convert_state_dict_keys, flatten_components
+    w = flatten_components(convert_state_dict_keys(cfg, osd))
+    tokens, grid = orc.patch_embed(w, torch.randn(1, 3, 56, 56, generator=torch.Generator().manual_seed(0)))
+    outs = []
+    taps = orc.image_encoder(w, cfg, tokens, grid, block_outputs=outs)
+    assert len(outs) == cfg["num_blocks"] and tuple(outs[0].shape) == (1, 17, cfg["features_per_token"])
+    assert torch.equal(taps[3], orc.layernorm(outs[-1], w["imgencoder.outnorm.weight"], w["imgencoder.outnorm.bias"]))
+
+
 def test_parameter_snapshot_key_works_for_inference_tensors_and_sees_replaced_parameters():
     """reading p._version of an inference tensor raises, so a model built under torch.inference_mode() failed on
     every call; and a Parameter replaced by attribute assignment kept the old packed snapshot alive."""
