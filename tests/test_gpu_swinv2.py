@@ -103,13 +103,16 @@ def test_swin_window_that_does_not_tile_the_grid():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_swin_fused_qk_epilogue_is_bitwise_identical_to_the_prep_kernel(dtype):
-    """With the 8-phase GEMM tile the cosine-attention Q / K operands come straight out of the QKV GEMM's accumulators
-    (gemm.hip epilogue_swin_qk); every other tile writes fp32 QKV rows and runs swin_qk_prep. Same arithmetic in the same order:
-    the depth maps must be the same bits whichever form each block took (the tile rule makes that depend on the batch size).
-    swin2_base widths (128 .. 1024) put every stage on the fused form when tile 5 is forced; shifted and unshifted blocks both run."""
+@pytest.mark.parametrize("hw", [(384, 384), (384, 416)])
+def test_swin_fused_qk_epilogue_is_bitwise_identical_to_the_prep_kernel(dtype, hw):
+    """With the 8-phase GEMM tile the cosine-attention Q / K / V operands come straight out of the QKV GEMM's accumulators
+    (gemm.hip epilogue_swin_qk / epilogue_swin_vt); every other tile writes fp32 QKV rows and runs swin_qk_prep / swin_v_prep. Same
+    arithmetic in the same order: the depth maps must be the same bits whichever form each block took (the tile rule makes that depend
+    on the batch size). swin2_base widths (128 .. 1024) put every stage on the fused form when tile 5 is forced; shifted and unshifted
+    blocks both run. 384x416: a 96x104 grid whose window width becomes 26 (shift 13) - token runs of 4 do not stay together, so V takes
+    the fp32-rows + swin_v_prep route while Q / K stay fused."""
     model, cfg, w = _build("swin2_base_384", 3, dtype)
-    x = seeded_input((2, 3, 384, 384), 9).to("cuda", dtype)
+    x = seeded_input((2, 3, *hw), 9).to("cuda", dtype)
     model.set_gemm_tile(1)   # 128x128 lockstep everywhere: unfused
     y_unfused = model(x)
     model.set_gemm_tile(5)   # 8-phase everywhere it can run: fused
