@@ -36,6 +36,9 @@ GFLOP_PER_MAP = {("vitl", 504): 1224.9, ("vitl", 532): 1385.8, ("vitl", 1036): 7
                  ("vits", 504): 107.3, ("vits", 532): 123.5, ("vits", 1036): 875.2,
                  ("beitl", 384): 516.4, ("swinl", 384): 343.7}
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+# what a loop of nothing but bf16 MFMAs on random operands sustains on this part (power limit: 1.93 GHz of the 2.4 GHz the nominal peak is
+# quoted at; tools/probes/mfma_power.hip, profiles/r03_mfma_power_probe.txt). Context for `roofline.frac`, never its denominator.
+SUSTAINED_BF16_TFLOPS = 2030.0
 FAMILY = {"vitl": "Depth-Anything-V2 ViT-L", "vits": "Depth-Anything-V2 ViT-S", "vitb": "Depth-Anything-V2 ViT-B",
           "beitl": "MiDaS v3.1 BEiT-L-384", "swinl": "MiDaS v3.1 SwinV2-L-384"}
 SYNTH_NAME = {"beitl": "beit_large_384", "swinl": "swin2_large_384"}
@@ -156,6 +159,8 @@ def roofline(args, pr, how):
     r = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
          "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic(args, dom["name"]), "kernel": dom["name"],
          "launches": dom["launches"], "avg_us": dom["avg_us"], "gflop_per_launch": round(dom["gflop"] / dom["launches"], 3), "measured": how}
+    r["sustained_mfma_tflops"] = SUSTAINED_BF16_TFLOPS  # measured ceiling for random-data bf16 MFMA; frac stays against the nominal peak
+    r["frac_of_sustained"] = round((3 if args.precision == "bf16x3" else 1) * dom["tflops"] / SUSTAINED_BF16_TFLOPS, 4)
     if args.precision == "bf16x3":
         r["executed_mfma_tflops"] = round(3 * dom["tflops"], 2)
         r["executed_mfma_frac"] = round(3 * dom["tflops"] / PEAK_BF16_TFLOPS, 4)
