@@ -522,9 +522,15 @@ int mdpt_launch_attention(const AttnParams& p, hipStream_t stream) {
     const bool swin = p.rowmap != nullptr;
     if (swin && (hd != 32 || !p.bias_lut || p.win_nw <= 0 || p.B % p.win_nw)) return (int)hipErrorInvalidValue;
     if (!swin && hd != 64) return (int)hipErrorInvalidValue;
-    // 64 queries per wave (256 per workgroup) when that still gives >= 2 workgroups per CU, else 128-query workgroups
+    // 64 queries per wave (256 per workgroup: K / V fragments read once per 64 queries) when that still gives >= 2 workgroups per CU and,
+    // at head dim 64, when the query count fills its last 256-query workgroup reasonably: N = 1297 pads to 1536 (+18 %) and N = 577 to 768
+    // (+33 %), where 128-query workgroups (11 resp. 5 per head, 116 VGPRs: four waves per SIMD) measure +0.7 % on the ViT-L step and
+    // +1.0 % on BEiT-L; N = 5477 (1036x1036) pads by 3 % and stays wide (+1.4 %), and so does the d = 32 window attention (+4.7 %:
+    // profiles/r03_attention_queries_per_wave_ab.txt). Both forms give a query the same bits (per-lane softmax state, same key order).
     const long blocks256 = (long)((p.npad + 255) / 256) * p.heads * p.B;
-    const bool wide = !p.x3 && blocks256 >= 512;
+    static const int wide_env = getenv("MDPT_ATTN_WIDE") ? atoi(getenv("MDPT_ATTN_WIDE")) : -1;  // A/B switch
+    const bool fills = hd == 32 || (long)((p.N + 255) / 256) * 256 * 100 <= (long)p.N * 108;
+    const bool wide = !p.x3 && (wide_env >= 0 ? wide_env != 0 : (blocks256 >= 512 && fills));
     const bool bias = p.bias_lut != nullptr;
     const int ntk = ((p.N + 63) / 64) * 64;
     const size_t extra = bias ? (size_t)p.bias_elen * 4 + (size_t)ntk * 4 * (swin ? 2 : 1) : 0;
