@@ -1774,13 +1774,16 @@ int resolve_tile(const GemmParams& p) {
         // tiles (0.55 rounds; one tile takes ~25 us at K = 1024 whatever the count), 64x64 tiles win the latency race while
         // there are <= ~330 128x128 tiles, 128x128 (2 workgroups per CU) in between. When the other half batch runs on a second
         // stream (throughput_mode) idle CUs are not wasted, so the tile with the best CU-time per flop - the big one - is taken
-        // much earlier.
+        // earlier.
         const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         // a partial last column tile is accepted while it wastes <= 1/4 of the padded columns (N = 384 -> 2 tiles: measured +1 % on ViT-S)
         const long ncol = (p.N + 255) / 256 * 256;
         const bool cols_ok = (ncol - p.N) * 4 <= ncol;
-        const bool big = cols_ok && tiles256 >= (p.throughput_mode ? 24 : 140);
+        // (round 3: 70, i.e. the same ~140 big tiles in flight as when alone, now counted over both streams; it was 24. A 54-tile launch
+        // of each half - SwinV2-L stage 2 proj / fc2 at batch 16 - fills 42 % of the CUs with big tiles and 84 % with 128x128 ones:
+        // SwinV2-L +1.1 ... 1.6 %, ViT-S batch 32 +0.3 %, ViT-L / BEiT-L (76 tiles) unchanged, profiles/r03_gemm_tile_threshold_ab.txt)
+        const bool big = cols_ok && tiles256 >= (p.throughput_mode ? 70 : 140);
         tile = big ? MDPT_TILE_PP256 : (tiles128 <= 330 ? MDPT_TILE_64x64 : MDPT_TILE_128x128);
         // narrow outputs with many rows (64-channel decoder convs of the small models): a 128-wide tile would spend half of its
         // MFMAs on padding columns. 128x64, four waves stacked in M: ViT-S B=32 +8.4 %
