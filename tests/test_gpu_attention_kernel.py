@@ -63,3 +63,20 @@ def test_attention_kernel_rows_do_not_depend_on_their_wave_partners():
     q2[:, :, 1::2] *= 7.0  # every other query becomes a very different row (much larger maxima)
     out_b, *_ = _run(q2, k, v, N)
     assert torch.equal(out_a[:, :, 0::2], out_b[:, :, 0::2])
+
+
+def test_attention_kernel_64_and_32_queries_per_wave_give_the_same_bits():
+    """The launcher runs 256-query workgroups (64 queries per wave) when there are >= 512 of them AND the query count pads by <= 8 % to a
+    multiple of 256, else 128-query workgroups - so the form depends on the batch size. N = 1024 fills: one image x 16 heads takes the
+    narrow form (64 wide workgroups), eight images the wide one (512). Image 0 must come out identical, and both must match fp64."""
+    g = torch.Generator().manual_seed(23)
+    N = 1024
+    q = torch.randn(8, 16, N, 64, generator=g) * 0.25
+    k = torch.randn(8, 16, N, 64, generator=g)
+    v = torch.randn(8, 16, N, 64, generator=g)
+    k[:, :, 900] *= 6.0  # an outlier key late in the sequence: the deferred-maximum branch runs in both forms
+    wide, qd, kd, vd = _run(q, k, v, N)
+    narrow, *_ = _run(q[:1], k[:1], v[:1], N)
+    assert torch.equal(wide[:1], narrow)
+    ref = _ref(qd[:1], kd[:1], vd[:1])
+    assert float((narrow.double() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
