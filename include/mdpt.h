@@ -32,11 +32,30 @@
 extern "C" {
 #endif
 
-#define MDPT_ABI_VERSION 3
+#define MDPT_ABI_VERSION 4
 
 /* arithmetic modes (all accumulate in fp32; residual stream, LayerNorm and softmax statistics are fp32) */
 #define MDPT_PREC_BF16 0   /* bf16 MFMA operands - the reference's GPU default dtype (demo_helpers/misc.py:73-77) */
 #define MDPT_PREC_BF16X3 1 /* split-bf16 (hi+lo) operands, 3 MFMA passes: fp32-class accuracy (parity mode)        */
+#define MDPT_PREC_FP16 2   /* fp16 MFMA operands (v_mfma_*_f16: the bf16 rate, 11 instead of 8 significand bits; converts saturate at
+                              +-65504) - what the reference's device policy hands the model when bf16 is not preferred
+                              (demo_helpers/misc.py:61-77: float16)                                                  */
+#define MDPT_PREC_FP16X3 3 /* split-fp16 (hi+lo) operands, 3 passes                                                 */
+#define MDPT_PREC_MIXED 4  /* fp16 operands; the op classes listed in mdpt_default_mixed_passes() run 3 passes, the others 1:
+                              the cheapest per-class assignment that keeps the depth map within 1e-3 of the fp32 reference
+                              (profiles/r04_precision_budget.md)                                                     */
+
+/* op classes of the path (what mdpt_set_class_passes / MDPT_PREC_MIXED address) */
+#define MDPT_CLASS_PATCH 0  /* patch-embed projection                    patch_embed.py:92                         */
+#define MDPT_CLASS_QKV 1    /* attention QKV projection                  transformer_block.py:160                  */
+#define MDPT_CLASS_ATTN 2   /* q k^T and p v inside the attention kernel transformer_block.py:164                  */
+#define MDPT_CLASS_PROJ 3   /* attention output projection (+ SwinV2 patch merge)   transformer_block.py:168       */
+#define MDPT_CLASS_FC1 4    /* MLP first linear                          misc_helpers.py:111                       */
+#define MDPT_CLASS_FC2 5    /* MLP second linear                         misc_helpers.py:115                       */
+#define MDPT_CLASS_REASM 6  /* reassembly convs (incl. BEiT readout)     reassembly_model.py:139-149               */
+#define MDPT_CLASS_FUSION 7 /* RefineNet fusion convs                    fusion_model.py:148-154,178-182           */
+#define MDPT_CLASS_HEAD 8   /* depth head 3x3 convs                      head_model.py:74-85                       */
+#define MDPT_NUM_CLASSES 9
 
 #define MDPT_FAMILY_DAV2 0
 #define MDPT_FAMILY_DAV1 1
@@ -88,6 +107,13 @@ const char* mdpt_last_error(void);
  * derives the list of parameters the model needs. */
 int mdpt_create(const mdpt_config* cfg, mdpt_handle** out);
 void mdpt_destroy(mdpt_handle* h);
+
+/* Per-class MFMA pass count (1 or 3) on top of whatever mdpt_config.precision chose. Changes the packed-weight layout and the workspace
+ * plan: call it after mdpt_create and BEFORE mdpt_packed_bytes / mdpt_finalize / mdpt_workspace_bytes (bound pointers are kept).
+ * mdpt_get_class_passes reads the current assignment; mdpt_default_mixed_passes fills the table MDPT_PREC_MIXED uses. */
+int mdpt_set_class_passes(mdpt_handle* h, int32_t op_class, int32_t passes);
+int mdpt_get_class_passes(const mdpt_handle* h, int32_t op_class, int32_t* passes);
+void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]);
 
 /* Parameter inventory, named with the reference's converted ("new format") keys, prefixed by component:
  * "patch_embed.proj.weight", "imgencoder.stages.0.blocks.0.attn.qkv.weight", "reassemble.spatial_upx4.resample.1.weight",
@@ -216,6 +242,10 @@ int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspac
 int mdpt_debug_set_stop(mdpt_handle* h, int32_t block, int32_t step);
 int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_floats, void* workspace, size_t workspace_bytes,
                     void* stream);
+
+/* The handle-less kernel hooks below (mdpt_debug_gemm / _attention / _conv3) take their 16-bit operands as bf16 (0, default) or fp16 (1):
+ * process-wide switch, tests only. */
+int mdpt_debug_set_operand_format(int32_t fp16);
 
 /* Kernel micro-benchmark hook: `iters` launches of the dense GEMM kernel, out[M,N] = A[M,K] * W[N,K]^T (bf16 operands,
  * fp32 and/or bf16 output), tile as in mdpt_set_gemm_tile. */

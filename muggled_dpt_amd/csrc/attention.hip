@@ -28,11 +28,8 @@
 #include "mdpt_kernels.h"
 #include "mdpt_prof.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 namespace {
 
@@ -49,8 +46,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ bf16x8 cat44(bf16x4 a, bf16x4 b) {
-    bf16x8 r;
+__device__ __forceinline__ opx8 cat44(opx4 a, opx4 b) {
+    opx8 r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { r[e] = a[e]; r[e + 4] = b[e]; }
     return r;
@@ -111,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const bool active = q0 < p.npad;  // tail waves of the last q-tile only help with DMA and barriers
 
     // ---- Q fragments (B operand of S^T = K Q^T): Q[q][d = 16*ks + 8*half .. +8]
-    bf16x8 qh[QB][KS], ql[QB][KS];
+    opx8 qh[QB][KS], ql[QB][KS];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int q = q0 + qb * 32 + l31;
@@ -119,8 +116,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const size_t o = (bh * p.npad + q_ld) * HD + ks * 16 + half * 8;
-            qh[qb][ks] = *(const bf16x8*)(p.q_hi + o);
-            if (X3) ql[qb][ks] = *(const bf16x8*)(p.q_lo + o);
+            qh[qb][ks] = *(const opx8*)(p.q_hi + o);
+            if (X3) ql[qb][ks] = *(const opx8*)(p.q_lo + o);
         }
     }
 
@@ -216,17 +213,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             for (int ks = 0; ks < KS; ++ks) {
                 const int off = HD == 64 ? (blk * 32 + l31) * 128 + (((ks * 2 + half) ^ sw_frag) << 4)
                                          : (blk * 16 + (l31 >> 1)) * 128 + ((((l31 & 1) * 4 + ks * 2 + half) ^ ((l31 >> 2) & 7)) << 4);
-                const bf16x8 kh = *(const bf16x8*)(sK + off);
-                bf16x8 kl;
-                if (X3) kl = *(const bf16x8*)(sK + TILE + off);
+                const opx8 kh = *(const opx8*)(sK + off);
+                opx8 kl;
+                if (X3) kl = *(const opx8*)(sK + TILE + off);
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
                     if (X3) {
-                        s[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[qb][ks], ks == 0 ? zero16 : s[qb][blk], 0, 0, 0);
-                        s[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[qb][ks], s[qb][blk], 0, 0, 0);
-                        s[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[qb][ks], s[qb][blk], 0, 0, 0);
+                        s[qb][blk] = MDPT_MFMA_32x32x16(kl, qh[qb][ks], ks == 0 ? zero16 : s[qb][blk], 0, 0, 0);
+                        s[qb][blk] = MDPT_MFMA_32x32x16(kh, ql[qb][ks], s[qb][blk], 0, 0, 0);
+                        s[qb][blk] = MDPT_MFMA_32x32x16(kh, qh[qb][ks], s[qb][blk], 0, 0, 0);
                     } else {
-                        s[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[qb][ks], ks == 0 ? zero16 : s[qb][blk], 0, 0, 0);
+                        s[qb][blk] = MDPT_MFMA_32x32x16(kh, qh[qb][ks], ks == 0 ? zero16 : s[qb][blk], 0, 0, 0);
                     }
                 }
             }
@@ -312,18 +309,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int kb2 = 0; kb2 < 2; ++kb2) {
-                bf16x8 ph[QB], pl[QB];
+                opx8 ph[QB], pl[QB];
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
-                    unsigned hw[4], lw[4];  // packed bf16x2: [0],[1] = keys (0,1),(2,3)+4hi ; [2],[3] = keys (8,9),(10,11)+4hi
+                    unsigned hw[4], lw[4];  // packed opx2: [0],[1] = keys (0,1),(2,3)+4hi ; [2],[3] = keys (8,9),(10,11)+4hi
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) {
                         const f32x2 pp = {s[qb][blk][kb2 * 8 + 2 * w2], s[qb][blk][kb2 * 8 + 2 * w2 + 1]};
-                        const bf16x2 hh = __builtin_convertvector(pp, bf16x2);   // one v_cvt_pk_bf16_f32
+                        const opx2 hh = to_op2_bounded(pp);   // one v_cvt_pk_bf16_f32
                         hw[w2] = __builtin_bit_cast(unsigned, hh);
                         if (X3) {
                             const f32x2 rr = pp - __builtin_convertvector(hh, f32x2);
-                            lw[w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                            lw[w2] = __builtin_bit_cast(unsigned, to_op2_bounded(rr));
                         }
                     }
                     unsigned pw[4], qw[4];
@@ -338,23 +335,23 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                             qw[w2 + 2] = rl[1];
                         }
                     }
-                    ph[qb] = __builtin_bit_cast(bf16x8, (u32x4){pw[0], pw[1], pw[2], pw[3]});
-                    if (X3) pl[qb] = __builtin_bit_cast(bf16x8, (u32x4){qw[0], qw[1], qw[2], qw[3]});
+                    ph[qb] = __builtin_bit_cast(opx8, (u32x4){pw[0], pw[1], pw[2], pw[3]});
+                    if (X3) pl[qb] = __builtin_bit_cast(opx8, (u32x4){qw[0], qw[1], qw[2], qw[3]});
                 }
                 const int kb = blk * 2 + kb2;
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
                     const int off = (db * 32 + l31) * 128 + (((2 * kb + half) ^ sw_frag) << 4);
-                    const bf16x8 vh = *(const bf16x8*)(sV + off);
-                    bf16x8 vl;
-                    if (X3) vl = *(const bf16x8*)(sV + TILE + off);
+                    const opx8 vh = *(const opx8*)(sV + off);
+                    opx8 vl;
+                    if (X3) vl = *(const opx8*)(sV + TILE + off);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
                         if (X3) {
-                            o_acc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[qb], o_acc[qb][db], 0, 0, 0);
-                            o_acc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[qb], o_acc[qb][db], 0, 0, 0);
+                            o_acc[qb][db] = MDPT_MFMA_32x32x16(vl, ph[qb], o_acc[qb][db], 0, 0, 0);
+                            o_acc[qb][db] = MDPT_MFMA_32x32x16(vh, pl[qb], o_acc[qb][db], 0, 0, 0);
                         }
-                        o_acc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[qb], o_acc[qb][db], 0, 0, 0);
+                        o_acc[qb][db] = MDPT_MFMA_32x32x16(vh, ph[qb], o_acc[qb][db], 0, 0, 0);
                     }
                 }
             }
@@ -426,11 +423,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 #pragma unroll
                         for (int w2 = 0; w2 < 2; ++w2) {
                             const f32x2 pp = {o_acc[qb][db][(2 * gp + gi) * 4 + 2 * w2] * inv, o_acc[qb][db][(2 * gp + gi) * 4 + 2 * w2 + 1] * inv};
-                            const bf16x2 hh = __builtin_convertvector(pp, bf16x2);
+                            const opx2 hh = to_op2_bounded(pp);
                             hx[gi][w2] = __builtin_bit_cast(unsigned, hh);
                             if (X3) {
                                 const f32x2 rr = pp - __builtin_convertvector(hh, f32x2);
-                                lx[gi][w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                                lx[gi][w2] = __builtin_bit_cast(unsigned, to_op2_bounded(rr));
                             }
                         }
                     unsigned oh[4], ol[4];
@@ -461,8 +458,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 // window attention has the same hookable nn.Softmax (v31_swinv2/components/windowed_attention.py:60-61,119): HD = 32 form below.
 // ------------------------------------------------------------------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(256) void attn_weights_kernel(const bf16_t* __restrict__ q_hi, const bf16_t* __restrict__ q_lo,
-                                                           const bf16_t* __restrict__ k_hi, const bf16_t* __restrict__ k_lo,
+__global__ __launch_bounds__(256) void attn_weights_kernel(const op_t* __restrict__ q_hi, const op_t* __restrict__ q_lo,
+                                                           const op_t* __restrict__ k_hi, const op_t* __restrict__ k_lo,
                                                            const float* __restrict__ bias_lut, int bias_elen, const int* tq, const int* tk,
                                                            const int* __restrict__ region, int region_ld, int win_nw,
                                                            float* __restrict__ out, int heads, int N, int npad) {
@@ -472,8 +469,8 @@ __global__ __launch_bounds__(256) void attn_weights_kernel(const bf16_t* __restr
     extern __shared__ float sc[];  // [N] scores, then 8 floats of reduction scratch
     const int row = blockIdx.x, bh = blockIdx.y, h = bh % heads, tid = threadIdx.x;
     float q[HD];
-    const bf16_t* qp = q_hi + ((size_t)bh * npad + row) * HD;
-    const bf16_t* qlp = q_lo ? q_lo + ((size_t)bh * npad + row) * HD : nullptr;
+    const op_t* qp = q_hi + ((size_t)bh * npad + row) * HD;
+    const op_t* qlp = q_lo ? q_lo + ((size_t)bh * npad + row) * HD : nullptr;
 #pragma unroll
     for (int d = 0; d < HD; ++d) q[d] = (float)qp[d] + (qlp ? (float)qlp[d] : 0.0f);
     const float* lut = bias_lut ? bias_lut + (size_t)h * bias_elen : nullptr;
@@ -482,8 +479,8 @@ __global__ __launch_bounds__(256) void attn_weights_kernel(const bf16_t* __restr
     const int rq = reg ? reg[row] : 0;
     float lmax = -3.0e38f;
     for (int key = tid; key < N; key += 256) {
-        const bf16_t* kp = k_hi + ((size_t)bh * npad + key) * HD;
-        const bf16_t* klp = k_lo ? k_lo + ((size_t)bh * npad + key) * HD : nullptr;
+        const op_t* kp = k_hi + ((size_t)bh * npad + key) * HD;
+        const op_t* klp = k_lo ? k_lo + ((size_t)bh * npad + key) * HD : nullptr;
         float s = 0.0f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) s += q[d] * ((float)kp[d] + (klp ? (float)klp[d] : 0.0f));
@@ -515,7 +512,7 @@ __global__ __launch_bounds__(256) void attn_weights_kernel(const bf16_t* __restr
 
 }  // namespace
 
-int mdpt_launch_attention(const AttnParams& p, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_attention)(const AttnParams& p, hipStream_t stream) {
     const int hd = p.head_dim ? p.head_dim : 64;
     if ((hd != 64 && hd != 32) || p.F != p.heads * hd || (p.npadv & 63) || p.npadv < ((p.N + 63) & ~63) || p.npad < p.N)
         return (int)hipErrorInvalidValue;
@@ -605,7 +602,7 @@ int mdpt_launch_attention(const AttnParams& p, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-int mdpt_launch_attn_weights(const AttnParams& p, float* out_bhnn, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_attn_weights)(const AttnParams& p, float* out_bhnn, hipStream_t stream) {
     const bool swin = p.rowmap != nullptr;
     const int hd = p.head_dim ? p.head_dim : 64;
     if ((swin && (hd != 32 || p.win_nw <= 0)) || (!swin && hd != 64)) return (int)hipErrorInvalidValue;

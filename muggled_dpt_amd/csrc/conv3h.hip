@@ -36,7 +36,6 @@
 
 #pragma clang fp contract(off)
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -102,7 +101,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     const int img = tile / (tiles_x * tiles_y), trem = tile - img * (tiles_x * tiles_y);
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const int Y0 = ty * 16, X0 = tx * 16;
-    const bf16_t* const in_img = UPIN ? p.up_in + (size_t)img * p.Hs * p.Ws * p.Cin : p.in + (size_t)img * p.H * p.W * p.Cin;
+    const op_t* const in_img = UPIN ? p.up_in + (size_t)img * p.Hs * p.Ws * p.Cin : p.in + (size_t)img * p.H * p.W * p.Cin;
     const int ncb = p.Cin >> 6;
 
     // ---- operand staging: LDS-DMA through BUFFER descriptors (buffer_load_dwordx4 ... offen lds). The per-lane byte offsets are
@@ -190,28 +189,28 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    opx8 fa[4][2], fb0[2][2], fb1[2][2];
 #define PIN() __builtin_amdgcn_sched_barrier(0)
 #define BAR() do { PIN(); __builtin_amdgcn_s_barrier(); PIN(); } while (0)
 #define LOAD_A(QM_, VA_, ROW0_)                                                                                       \
     do {                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
-            fa[i][0] = *(const bf16x8*)(smem + (VA_) + ((ROW0_) + (QM_) * 8 + i) * HROW);                              \
-            fa[i][1] = *(const bf16x8*)(smem + ((VA_) ^ 64) + ((ROW0_) + (QM_) * 8 + i) * HROW);                       \
+            fa[i][0] = *(const opx8*)(smem + (VA_) + ((ROW0_) + (QM_) * 8 + i) * HROW);                              \
+            fa[i][1] = *(const opx8*)(smem + ((VA_) ^ 64) + ((ROW0_) + (QM_) * 8 + i) * HROW);                       \
         }                                                                                                             \
     } while (0)
 #define LOAD_B(DST_, QN_, BUF_)                                                                                       \
     do {                                                                                                              \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                               \
-            DST_[j][0] = *(const bf16x8*)(smem + (BUF_) * BTILE + (QN_) * 16384 + j * 2048 + b_off0);                  \
-            DST_[j][1] = *(const bf16x8*)(smem + (BUF_) * BTILE + (QN_) * 16384 + j * 2048 + b_off1);                  \
+            DST_[j][0] = *(const opx8*)(smem + (BUF_) * BTILE + (QN_) * 16384 + j * 2048 + b_off0);                  \
+            DST_[j][1] = *(const opx8*)(smem + (BUF_) * BTILE + (QN_) * 16384 + j * 2048 + b_off1);                  \
         }                                                                                                             \
     } while (0)
 #define LOAD_B_AT(DST_, BYTES_) /* COUT = 128: ring slot at a run-time byte offset */                                 \
     do {                                                                                                              \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                               \
-            DST_[j][0] = *(const bf16x8*)(smem + (BYTES_) + j * 2048 + b_off0);                                        \
-            DST_[j][1] = *(const bf16x8*)(smem + (BYTES_) + j * 2048 + b_off1);                                        \
+            DST_[j][0] = *(const opx8*)(smem + (BYTES_) + j * 2048 + b_off0);                                        \
+            DST_[j][1] = *(const opx8*)(smem + (BYTES_) + j * 2048 + b_off1);                                        \
         }                                                                                                             \
     } while (0)
 #define MFMA_Q(QM_, QN_, FB_)                                                                                         \
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                              \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
-                    acc[QM_][QN_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB_[j][kk], fa[i][kk], acc[QM_][QN_][i][j], 0, 0, 0); \
+                    acc[QM_][QN_][i][j] = MDPT_MFMA_16x16x32(FB_[j][kk], fa[i][kk], acc[QM_][QN_][i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                                \
     } while (0)
 #define WAIT_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory")
@@ -430,7 +429,6 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     // ---- epilogue. Lane (l15, lh) of wave (grp, wc) holds, for tile row y = 8 qm + 4 grp + i, pixel x = l15, the four consecutive channels
     //      n = 128 qn + 32 wc + 16 j + 4 lh .. +3 in acc[qm][qn][i][j].
     typedef __attribute__((ext_vector_type(2))) float f32x2;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     const size_t plane_px = (size_t)p.H * p.W;
     const __amdgpu_buffer_rsrc_t rs_f = plane_rsrc(F32OUT ? p.out_f32 + (size_t)img * plane_px * COUT : nullptr, F32OUT ? plane_px * COUT * 4 : 0);
     const __amdgpu_buffer_rsrc_t rs_b = plane_rsrc(BFOUT ? p.out_bf + (size_t)img * plane_px * COUT : nullptr, BFOUT ? plane_px * COUT * 2 : 0);
@@ -549,11 +547,11 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 #pragma unroll
                     for (int w2 = 0; w2 < 2; ++w2) {
                         const f32x2 pp = {v[j][2 * w2], v[j][2 * w2 + 1]};
-                        const bf16x2 hh = __builtin_convertvector(pp, bf16x2);
+                        const opx2 hh = to_op2(pp);
                         hw_[j][w2] = __builtin_bit_cast(unsigned, hh);
                         if constexpr (X3) {
                             const f32x2 rr = pp - __builtin_convertvector(hh, f32x2);
-                            lw_[j][w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                            lw_[j][w2] = __builtin_bit_cast(unsigned, to_op2(rr));
                         }
                     }
                 unsigned ph[4], pl[4];
@@ -655,7 +653,7 @@ int launch_mode(const Conv3hParams& p, hipStream_t stream) {
 }  // namespace
 
 // the combinations the decoder uses (anything else runs the implicit-GEMM path of gemm.hip)
-bool mdpt_conv3h_supported(const Conv3hParams& p) {
+bool MDPT_FN(mdpt_conv3h_supported)(const Conv3hParams& p) {
     if (p.B <= 0 || p.H < 2 || p.W < 2 || p.Cin <= 0 || (p.Cin & 127) || !p.w) return false;
     if ((p.in != nullptr) == (p.up_in != nullptr)) return false;  // exactly one input form
     if (p.up_in) {
@@ -683,7 +681,7 @@ bool mdpt_conv3h_supported(const Conv3hParams& p) {
     return false;
 }
 
-int mdpt_launch_conv3h(const Conv3hParams& p, hipStream_t stream) {
-    if (!mdpt_conv3h_supported(p)) return (int)hipErrorInvalidValue;
+int MDPT_FN(mdpt_launch_conv3h)(const Conv3hParams& p, hipStream_t stream) {
+    if (!MDPT_FN(mdpt_conv3h_supported)(p)) return (int)hipErrorInvalidValue;
     return p.in_lo ? launch_mode<true>(p, stream) : launch_mode<false>(p, stream);
 }

@@ -7,21 +7,20 @@
 #include "mdpt_prof.h"
 #include "ln_row.h"
 
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 
-__device__ __forceinline__ void split_store4(bf16_t* hi, bf16_t* lo, size_t off, f32x4 v) {
-    bf16x4 h;
+__device__ __forceinline__ void split_store4(op_t* hi, op_t* lo, size_t off, f32x4 v) {
+    opx4 h;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
-    *(bf16x4*)(hi + off) = h;
+    for (int e = 0; e < 4; ++e) h[e] = to_op(v[e]);
+    *(opx4*)(hi + off) = h;
     if (lo) {
-        bf16x4 l;
+        opx4 l;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) l[e] = (__bf16)(v[e] - (float)h[e]);
-        *(bf16x4*)(lo + off) = l;
+        for (int e = 0; e < 4; ++e) l[e] = to_op(v[e] - (float)h[e]);
+        *(opx4*)(lo + off) = l;
     }
 }
 
@@ -39,7 +38,7 @@ constexpr int LN_MAXV = 8;  // up to F = 2048
 
 template <int NV>  // NV float4 per lane: F <= 256*NV
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, bf16_t* out_hi, bf16_t* out_lo,
+                                                        const float* __restrict__ beta, op_t* out_hi, op_t* out_lo,
                                                         float* out_f32, int rows, int F) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -58,7 +57,7 @@ __device__ __forceinline__ float ld_typed(const void* p, size_t i, int dt) {
     return ((const float*)p)[i];
 }
 
-__global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ img, int img_dt, bf16_t* out_hi, bf16_t* out_lo, int B,
+__global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ img, int img_dt, op_t* out_hi, op_t* out_lo, int B,
                                                        int H, int W, int P, int Kp) {
     const int gw = W / P, gh = H / P;
     const int K = 3 * P * P;
@@ -143,13 +142,13 @@ __global__ __launch_bounds__(256) void init_tokens_kernel(float* resid, const fl
     }
 }
 
-__global__ __launch_bounds__(256) void zero_vt_pad_kernel(bf16_t* vt_hi, bf16_t* vt_lo, int rows, int N, int npadv) {
+__global__ __launch_bounds__(256) void zero_vt_pad_kernel(op_t* vt_hi, op_t* vt_lo, int rows, int N, int npadv) {
     const int padw = npadv - N;
     const size_t total = (size_t)rows * padw;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const size_t o = (idx / padw) * npadv + N + (idx % padw);
-        vt_hi[o] = (__bf16)0.0f;
-        if (vt_lo) vt_lo[o] = (__bf16)0.0f;
+        vt_hi[o] = to_op(0.0f);
+        if (vt_lo) vt_lo[o] = to_op(0.0f);
     }
 }
 
@@ -159,7 +158,7 @@ __global__ __launch_bounds__(256) void zero_vt_pad_kernel(bf16_t* vt_hi, bf16_t*
 // about one store instruction per 64 cycles whatever its width, so the bf16 output wants 16-byte (8-channel) stores.
 // ---------------------------------------------------------------------------------------------------
 template <int CPT>
-__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, bf16_t* out_hi, bf16_t* out_lo,
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, op_t* out_hi, op_t* out_lo,
                                                        float* out_f32, int B, int Hi, int Wi, int Ho, int Wo, int C) {
 #pragma clang fp contract(off)  // the direct and the tiled kernel must round identically (batch-size independent bits)
     const int cq = C / CPT;
@@ -190,19 +189,18 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
         }
         if (out_hi) {
             if (CPT == 8) {
-                bf16x4 h0, h1;
+                opx4 h0, h1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { h0[e] = (__bf16)v[0][e]; h1[e] = (__bf16)v[CPT / 4 - 1][e]; }
-                typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-                bf16x8_t h;
+                for (int e = 0; e < 4; ++e) { h0[e] = to_op(v[0][e]); h1[e] = to_op(v[CPT / 4 - 1][e]); }
+                opx8 h;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { h[e] = h0[e]; h[e + 4] = h1[e]; }
-                *(bf16x8_t*)(out_hi + o) = h;
+                *(opx8*)(out_hi + o) = h;
                 if (out_lo) {
-                    bf16x8_t l;
+                    opx8 l;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { l[e] = (__bf16)(v[0][e] - (float)h0[e]); l[e + 4] = (__bf16)(v[CPT / 4 - 1][e] - (float)h1[e]); }
-                    *(bf16x8_t*)(out_lo + o) = l;
+                    for (int e = 0; e < 4; ++e) { l[e] = to_op(v[0][e] - (float)h0[e]); l[e + 4] = to_op(v[CPT / 4 - 1][e] - (float)h1[e]); }
+                    *(opx8*)(out_lo + o) = l;
                 }
             } else {
                 split_store4(out_hi, out_lo, o, v[0]);
@@ -219,7 +217,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
 // Same arithmetic, same operation order as upsample_kernel (bit-identical results).
 // ---------------------------------------------------------------------------------------------------
 template <int C8>  // channels / 8 (lanes per pixel): 32 -> C = 256, 16 -> C = 128, 8 -> C = 64
-__global__ __launch_bounds__(256) void upsample_tiled_kernel(const float* __restrict__ in, bf16_t* out_hi, bf16_t* out_lo, int B, int Hi,
+__global__ __launch_bounds__(256) void upsample_tiled_kernel(const float* __restrict__ in, op_t* out_hi, op_t* out_lo, int B, int Hi,
                                                              int Wi, int Ho, int Wo) {
 #pragma clang fp contract(off)
     constexpr int C = C8 * 8, TS = 8, PS = 7;  // tile side, max patch side
@@ -265,15 +263,14 @@ __global__ __launch_bounds__(256) void upsample_tiled_kernel(const float* __rest
             v[q] = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
         }
         const size_t o = (((size_t)b * Ho + y) * Wo + x) * C + lane_c;
-        typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-        bf16x8_t h, l;
+        opx8 h, l;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v[0][e]; h[e + 4] = (__bf16)v[1][e]; }
-        *(bf16x8_t*)(out_hi + o) = h;
+        for (int e = 0; e < 4; ++e) { h[e] = to_op(v[0][e]); h[e + 4] = to_op(v[1][e]); }
+        *(opx8*)(out_hi + o) = h;
         if (out_lo) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { l[e] = (__bf16)(v[0][e] - (float)h[e]); l[e + 4] = (__bf16)(v[1][e] - (float)h[e + 4]); }
-            *(bf16x8_t*)(out_lo + o) = l;
+            for (int e = 0; e < 4; ++e) { l[e] = to_op(v[0][e] - (float)h[e]); l[e + 4] = to_op(v[1][e] - (float)h[e + 4]); }
+            *(opx8*)(out_lo + o) = l;
         }
     }
 }
@@ -281,7 +278,7 @@ __global__ __launch_bounds__(256) void upsample_tiled_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------------
 // one-time weight repack: fp32 PyTorch layouts -> bf16 hi(/lo) [Np][Kp], zero padded
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_weight_kernel(const void* __restrict__ src, int sdt, bf16_t* dst_hi, bf16_t* dst_lo, int kind,
+__global__ __launch_bounds__(256) void pack_weight_kernel(const void* __restrict__ src, int sdt, op_t* dst_hi, op_t* dst_lo, int kind,
                                                           int N, int K, int Np, int Kp, int ksz, int src_ld, int src_col0,
                                                           const void* __restrict__ row_scale, int rdt) {
     const size_t total = (size_t)Np * Kp;
@@ -310,9 +307,9 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const void* __restrict
             const int kidx = nrow / coutp, co = nrow - kidx * coutp;
             if (co < N && kcol < K) v = ld_typed(src, ((size_t)kcol * N + co) * (ksz * ksz) + kidx, sdt);
         }
-        const __bf16 h = (__bf16)v;
+        const op_t h = to_op(v);
         dst_hi[idx] = h;
-        if (dst_lo) dst_lo[idx] = (__bf16)(v - (float)h);
+        if (dst_lo) dst_lo[idx] = to_op(v - (float)h);
     }
 }
 
@@ -332,7 +329,7 @@ __global__ __launch_bounds__(256) void add_f32_kernel(float* dst, const float* _
 // ---------------------------------------------------------------------------------------------------
 // layout conversion (stage-level API and debug taps; not on the fused forward path)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in_f32, const bf16_t* in_hi, const bf16_t* in_lo,
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in_f32, const op_t* in_hi, const op_t* in_lo,
                                                            float* __restrict__ out, int B, int H, int W, int C, int Cp) {
     const size_t total = (size_t)B * C * H * W;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -348,8 +345,8 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in_f32, 
     }
 }
 
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* out_f32, bf16_t* out_hi,
-                                                           bf16_t* out_lo, int relu_bf16, int B, int H, int W, int C, int Cp) {
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* out_f32, op_t* out_hi,
+                                                           op_t* out_lo, int relu_bf16, int B, int H, int W, int C, int Cp) {
     const size_t total = (size_t)B * H * W * Cp;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % Cp);
@@ -361,14 +358,14 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         if (out_f32) out_f32[idx] = v;
         if (out_hi) {
             if (relu_bf16) v = fmaxf(v, 0.0f);
-            const __bf16 h = (__bf16)v;
+            const op_t h = to_op(v);
             out_hi[idx] = h;
-            if (out_lo) out_lo[idx] = (__bf16)(v - (float)h);
+            if (out_lo) out_lo[idx] = to_op(v - (float)h);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void tokens_export_kernel(const bf16_t* in_hi, const bf16_t* in_lo, const float* in_f32,
+__global__ __launch_bounds__(256) void tokens_export_kernel(const op_t* in_hi, const op_t* in_lo, const float* in_f32,
                                                             float* __restrict__ out, int B, int N, int npad, int F, int skip_cls) {
     const int nout = N - skip_cls;
     const size_t total = (size_t)B * nout * F;
@@ -384,7 +381,7 @@ __global__ __launch_bounds__(256) void tokens_export_kernel(const bf16_t* in_hi,
     }
 }
 
-__global__ __launch_bounds__(256) void tokens_import_kernel(const float* __restrict__ in, bf16_t* out_hi, bf16_t* out_lo, int B,
+__global__ __launch_bounds__(256) void tokens_import_kernel(const float* __restrict__ in, op_t* out_hi, op_t* out_lo, int B,
                                                             int N, int npad, int F) {
     const size_t total = (size_t)B * npad * F;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -392,9 +389,9 @@ __global__ __launch_bounds__(256) void tokens_import_kernel(const float* __restr
         const int t = (int)((idx / F) % npad);
         const int b = (int)(idx / ((size_t)F * npad));
         const float v = t < N ? in[((size_t)b * N + t) * F + f] : 0.0f;
-        const __bf16 h = (__bf16)v;
+        const op_t h = to_op(v);
         out_hi[idx] = h;
-        if (out_lo) out_lo[idx] = (__bf16)(v - (float)h);
+        if (out_lo) out_lo[idx] = to_op(v - (float)h);
     }
 }
 
@@ -545,7 +542,7 @@ __global__ __launch_bounds__(256) void beit_relpos_batch_kernel(const BeitRelpos
 // ViT-G SwiGLU gate (reference components/misc_helpers.py:182-185): in fp32 [rows, 2h] = (a | b) -> silu(a) * b as
 // bf16 hi (+lo) [rows, hp], columns [h, hp) zero (K padding of the outer GEMM). One thread = 4 columns.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ in, bf16_t* out_hi, bf16_t* out_lo, size_t rows, int h, int hp) {
+__global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ in, op_t* out_hi, op_t* out_lo, size_t rows, int h, int hp) {
     const int cq = hp / 4;
     const size_t total = rows * cq;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -570,7 +567,7 @@ inline int grid_for(size_t total, int block = 256) {
 
 #define LAUNCH_RET() return (int)hipGetLastError()
 
-int mdpt_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* out_hi, bf16_t* out_lo, float* out_f32,
+int MDPT_FN(mdpt_launch_layernorm)(const float* x, const float* gamma, const float* beta, op_t* out_hi, op_t* out_lo, float* out_f32,
                           int rows, int F, hipStream_t stream) {
     if ((F & 3) || F > 64 * 4 * LN_MAXV) return (int)hipErrorInvalidValue;
     if (rows <= 0) return 0;
@@ -586,27 +583,27 @@ int mdpt_launch_layernorm(const float* x, const float* gamma, const float* beta,
     LAUNCH_RET();
 }
 
-int mdpt_launch_swiglu(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t rows, int h, int hp, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_swiglu)(const float* in, op_t* out_hi, op_t* out_lo, size_t rows, int h, int hp, hipStream_t stream) {
     if ((h & 3) || (hp & 3) || hp < h) return (int)hipErrorInvalidValue;
     MdptProfScope prof("swiglu_kernel", 0.0, stream);
     hipLaunchKernelGGL(swiglu_kernel, dim3(grid_for(rows * (hp / 4))), dim3(256), 0, stream, in, out_hi, out_lo, rows, h, hp);
     LAUNCH_RET();
 }
 
-int mdpt_launch_patchify(const void* img, int img_dtype, bf16_t* out_hi, bf16_t* out_lo, int B, int H, int W, int P, int Kp, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_patchify)(const void* img, int img_dtype, op_t* out_hi, op_t* out_lo, int B, int H, int W, int P, int Kp, hipStream_t stream) {
     const size_t total = (size_t)B * (H / P) * (W / P) * (Kp / 4);
     MdptProfScope prof("patchify_kernel", 0.0, stream);
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, stream, img, img_dtype, out_hi, out_lo, B, H, W, P, Kp);
     LAUNCH_RET();
 }
 
-int mdpt_launch_posembed(const float* base, float* out, int Gh, int Gw, int gh, int gw, int F, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_posembed)(const float* base, float* out, int Gh, int Gw, int gh, int gw, int F, hipStream_t stream) {
     MdptProfScope prof("posembed_kernel", 0.0, stream);
     hipLaunchKernelGGL(posembed_kernel, dim3(grid_for((size_t)gh * gw * F)), dim3(256), 0, stream, base, out, Gh, Gw, gh, gw, F);
     LAUNCH_RET();
 }
 
-int mdpt_launch_init_tokens(float* resid, const float* cls_token, const float* cls_embed, int B, int N, int npad, int F,
+int MDPT_FN(mdpt_launch_init_tokens)(float* resid, const float* cls_token, const float* cls_embed, int B, int N, int npad, int F,
                             hipStream_t stream) {
     const size_t total = (size_t)B * (1 + npad - N) * F;
     MdptProfScope prof("init_tokens_kernel", 0.0, stream);
@@ -614,7 +611,7 @@ int mdpt_launch_init_tokens(float* resid, const float* cls_token, const float* c
     LAUNCH_RET();
 }
 
-int mdpt_launch_zero_vt_pad(bf16_t* vt_hi, bf16_t* vt_lo, int rows, int N, int npadv, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_zero_vt_pad)(op_t* vt_hi, op_t* vt_lo, int rows, int N, int npadv, hipStream_t stream) {
     if (npadv == N) return 0;
     MdptProfScope prof("zero_vt_pad_kernel", 0.0, stream);
     hipLaunchKernelGGL(zero_vt_pad_kernel, dim3(grid_for((size_t)rows * (npadv - N))), dim3(256), 0, stream, vt_hi, vt_lo, rows, N, npadv);
@@ -624,7 +621,7 @@ int mdpt_launch_zero_vt_pad(bf16_t* vt_hi, bf16_t* vt_lo, int rows, int N, int n
 // bf16 NHWC -> bf16 NHWC bilinear (align_corners=True) resize, 8 channels (16 bytes) per thread: the stand-alone form of the upsample in
 // front of the head's first conv for launches too small for the halo-staged conv kernel that interpolates its own input (conv3h.hip).
 // Same arithmetic (up_bf16.h), so both forms give the same bits.
-__global__ __launch_bounds__(256) void upsample_bf16src_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B, int Hi, int Wi, int Ho,
+__global__ __launch_bounds__(256) void upsample_bf16src_kernel(const op_t* __restrict__ in, op_t* __restrict__ out, int B, int Hi, int Wi, int Ho,
                                                                int Wo, int C) {
 #pragma clang fp contract(off)  // the source coordinates and weights must be the bits conv3h.hip computes (no fma(sx, x, -x0))
     const int c8 = C >> 3;
@@ -639,14 +636,14 @@ __global__ __launch_bounds__(256) void upsample_bf16src_kernel(const bf16_t* __r
         const int y0 = (int)fy, x0 = (int)fx;
         const int y1 = y0 + (y0 < Hi - 1), x1 = x0 + (x0 < Wi - 1);
         const float ly = fy - (float)y0, lx = fx - (float)x0;
-        const bf16_t* base = in + (size_t)b * Hi * Wi * C + ch * 8;
+        const op_t* base = in + (size_t)b * Hi * Wi * C + ch * 8;
         const mdpt_u32x4 v00 = *(const mdpt_u32x4*)(base + ((size_t)y0 * Wi + x0) * C), v01 = *(const mdpt_u32x4*)(base + ((size_t)y0 * Wi + x1) * C);
         const mdpt_u32x4 v10 = *(const mdpt_u32x4*)(base + ((size_t)y1 * Wi + x0) * C), v11 = *(const mdpt_u32x4*)(base + ((size_t)y1 * Wi + x1) * C);
         *(mdpt_u32x4*)(out + pix * C + ch * 8) = mdpt_up_bf16x8(v00, v01, v10, v11, lx, ly);
     }
 }
 
-int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float* out_f32, int B, int Hi, int Wi, int Ho, int Wo,
+int MDPT_FN(mdpt_launch_upsample)(const float* in, op_t* out_hi, op_t* out_lo, float* out_f32, int B, int Hi, int Wi, int Ho, int Wo,
                          int C, hipStream_t stream) {
     if (C & 3) return (int)hipErrorInvalidValue;
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
@@ -678,66 +675,66 @@ int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float*
     LAUNCH_RET();
 }
 
-int mdpt_launch_upsample_bf16(const bf16_t* in, bf16_t* out, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_upsample_bf16)(const op_t* in, op_t* out, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t stream) {
     if (C & 7) return (int)hipErrorInvalidValue;
     MdptProfScope prof("upsample_bf16src_kernel", 0.0, stream);
     hipLaunchKernelGGL(upsample_bf16src_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 8))), dim3(256), 0, stream, in, out, B, Hi, Wi, Ho, Wo, C);
     LAUNCH_RET();
 }
 
-int mdpt_launch_pack_weight(const void* src, int src_dtype, bf16_t* dst_hi, bf16_t* dst_lo, int kind, int N, int K, int Np, int Kp, int ksz,
+int MDPT_FN(mdpt_launch_pack_weight)(const void* src, int src_dtype, op_t* dst_hi, op_t* dst_lo, int kind, int N, int K, int Np, int Kp, int ksz,
                             hipStream_t stream, int src_ld, int src_col0, const void* row_scale, int scale_dtype) {
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)Np * Kp)), dim3(256), 0, stream, src, src_dtype, dst_hi, dst_lo, kind, N, K, Np, Kp,
                        ksz, src_ld > 0 ? src_ld : K, src_col0, kind == MDPT_PACK_LINEAR ? row_scale : nullptr, scale_dtype);
     LAUNCH_RET();
 }
 
-int mdpt_launch_pad_copy_f32(const void* src, int src_dtype, float* dst, int n, int np, hipStream_t stream, const void* scale, int scale_dtype) {
+int MDPT_FN(mdpt_launch_pad_copy_f32)(const void* src, int src_dtype, float* dst, int n, int np, hipStream_t stream, const void* scale, int scale_dtype) {
     hipLaunchKernelGGL(pad_copy_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, src, src_dtype, dst, n, np, scale, scale_dtype);
     LAUNCH_RET();
 }
 
-int mdpt_launch_memset_f32(float* dst, float value, size_t n, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_memset_f32)(float* dst, float value, size_t n, hipStream_t stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(memset_f32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dst, value, n);
     LAUNCH_RET();
 }
 
-int mdpt_launch_add_f32(float* dst, const float* src, size_t n, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_add_f32)(float* dst, const float* src, size_t n, hipStream_t stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dst, src, n);
     LAUNCH_RET();
 }
 
-int mdpt_launch_nhwc_to_nchw(const float* in_f32, const bf16_t* in_hi, const bf16_t* in_lo, float* out, int B, int H, int W, int C,
+int MDPT_FN(mdpt_launch_nhwc_to_nchw)(const float* in_f32, const op_t* in_hi, const op_t* in_lo, float* out, int B, int H, int W, int C,
                              int Cp, hipStream_t stream) {
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)B * C * H * W)), dim3(256), 0, stream, in_f32, in_hi, in_lo, out, B, H, W, C, Cp);
     LAUNCH_RET();
 }
 
-int mdpt_launch_nchw_to_nhwc(const float* in, float* out_f32, bf16_t* out_hi, bf16_t* out_lo, int relu_bf16, int B, int H, int W,
+int MDPT_FN(mdpt_launch_nchw_to_nhwc)(const float* in, float* out_f32, op_t* out_hi, op_t* out_lo, int relu_bf16, int B, int H, int W,
                              int C, int Cp, hipStream_t stream) {
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)B * H * W * Cp)), dim3(256), 0, stream, in, out_f32, out_hi, out_lo, relu_bf16, B, H, W, C, Cp);
     LAUNCH_RET();
 }
 
-int mdpt_launch_tokens_export(const bf16_t* in_hi, const bf16_t* in_lo, const float* in_f32, float* out, int B, int N, int npad,
+int MDPT_FN(mdpt_launch_tokens_export)(const op_t* in_hi, const op_t* in_lo, const float* in_f32, float* out, int B, int N, int npad,
                               int F, int skip_cls, hipStream_t stream) {
     hipLaunchKernelGGL(tokens_export_kernel, dim3(grid_for((size_t)B * (N - skip_cls) * F)), dim3(256), 0, stream, in_hi, in_lo, in_f32, out, B, N, npad, F, skip_cls);
     LAUNCH_RET();
 }
 
-int mdpt_launch_tokens_import(const float* in, bf16_t* out_hi, bf16_t* out_lo, int B, int N, int npad, int F, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_tokens_import)(const float* in, op_t* out_hi, op_t* out_lo, int B, int N, int npad, int F, hipStream_t stream) {
     hipLaunchKernelGGL(tokens_import_kernel, dim3(grid_for((size_t)B * npad * F)), dim3(256), 0, stream, in, out_hi, out_lo, B, N, npad, F);
     LAUNCH_RET();
 }
 
-int mdpt_launch_tokens_to_resid(const float* tokens, const float* pos, float* resid, int B, int Np, int npad, int F, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_tokens_to_resid)(const float* tokens, const float* pos, float* resid, int B, int Np, int npad, int F, hipStream_t stream) {
     hipLaunchKernelGGL(tokens_to_resid_kernel, dim3(grid_for((size_t)B * Np * F)), dim3(256), 0, stream, tokens, pos, resid, B, Np, npad, F);
     LAUNCH_RET();
 }
 
-int mdpt_launch_prepare_image(const unsigned char* bgr, float* out, int ih, int iw, int oh, int ow, const float mean[3],
+int MDPT_FN(mdpt_launch_prepare_image)(const unsigned char* bgr, float* out, int ih, int iw, int oh, int ow, const float mean[3],
                               const float inv_std[3], int interp, hipStream_t stream) {
     if (ih <= 0 || iw <= 0 || oh <= 0 || ow <= 0 || (interp != 0 && interp != 1)) return (int)hipErrorInvalidValue;
     MdptProfScope prof("prepare_image_kernel", 0.0, stream);
@@ -750,22 +747,22 @@ int mdpt_launch_prepare_image(const unsigned char* bgr, float* out, int ih, int 
     LAUNCH_RET();
 }
 
-int mdpt_beit_relpos_elen(int gh, int gw) {
+int MDPT_FN(mdpt_beit_relpos_elen)(int gh, int gw) {
     const int rw = 2 * gw - 1, R = (2 * gh - 1) * rw, T = (gh - 1) * rw + gw - 1;
     return 2 * R + 2 * T + 2;
 }
 
-int mdpt_launch_beit_relpos_batch(const BeitRelposBatch& b, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_beit_relpos_batch)(const BeitRelposBatch& b, hipStream_t stream) {
     if (b.n < 1 || b.n > 32) return (int)hipErrorInvalidValue;
-    const size_t total = (size_t)b.heads * mdpt_beit_relpos_elen(b.gh, b.gw);
+    const size_t total = (size_t)b.heads * MDPT_FN(mdpt_beit_relpos_elen)(b.gh, b.gw);
     const size_t work = total > (size_t)b.ntok_pad ? total : (size_t)b.ntok_pad;
     hipLaunchKernelGGL(beit_relpos_batch_kernel, dim3(grid_for(work), b.n), dim3(256), 0, stream, b);
     LAUNCH_RET();
 }
 
-int mdpt_launch_beit_relpos(const float* ref_lut, float* ext_lut, int* tq, int* tk, int heads, int Gh, int Gw, int gh, int gw, int N,
+int MDPT_FN(mdpt_launch_beit_relpos)(const float* ref_lut, float* ext_lut, int* tq, int* tk, int heads, int Gh, int Gw, int gh, int gw, int N,
                             int ntok_pad, hipStream_t stream) {
-    const size_t total = (size_t)heads * mdpt_beit_relpos_elen(gh, gw);
+    const size_t total = (size_t)heads * MDPT_FN(mdpt_beit_relpos_elen)(gh, gw);
     size_t work = total > (size_t)ntok_pad ? total : (size_t)ntok_pad;
     hipLaunchKernelGGL(beit_relpos_kernel, dim3(grid_for(work)), dim3(256), 0, stream, ref_lut, ext_lut, tq, tk, heads, Gh, Gw, gh, gw, N, ntok_pad);
     LAUNCH_RET();

@@ -44,8 +44,6 @@
 // bilinear-add epilogue between the 128x128 and 256x256 kernels). Epilogue arithmetic is a negligible cost.
 #pragma clang fp contract(off)
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -103,29 +101,29 @@ __device__ __forceinline__ gelu_f32x2 gelu_erf2(gelu_f32x2 v) {
     return __builtin_elementwise_fma(h, sgn, h);
 }
 
-__device__ __forceinline__ void split_store4(bf16_t* hi, bf16_t* lo, size_t off, f32x4 v) {
-    bf16x4 h;
+__device__ __forceinline__ void split_store4(op_t* hi, op_t* lo, size_t off, f32x4 v) {
+    opx4 h;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
-    *(bf16x4*)(hi + off) = h;
+    for (int e = 0; e < 4; ++e) h[e] = to_op(v[e]);
+    *(opx4*)(hi + off) = h;
     if (lo) {
-        bf16x4 l;
+        opx4 l;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) l[e] = (__bf16)(v[e] - (float)h[e]);
-        *(bf16x4*)(lo + off) = l;
+        for (int e = 0; e < 4; ++e) l[e] = to_op(v[e] - (float)h[e]);
+        *(opx4*)(lo + off) = l;
     }
 }
 
-__device__ __forceinline__ void split_store8(bf16_t* hi, bf16_t* lo, size_t off, f32x4 v0, f32x4 v1) {
-    bf16x8 h;
+__device__ __forceinline__ void split_store8(op_t* hi, op_t* lo, size_t off, f32x4 v0, f32x4 v1) {
+    opx8 h;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v0[e]; h[e + 4] = (__bf16)v1[e]; }
-    *(bf16x8*)(hi + off) = h;
+    for (int e = 0; e < 4; ++e) { h[e] = to_op(v0[e]); h[e + 4] = to_op(v1[e]); }
+    *(opx8*)(hi + off) = h;
     if (lo) {
-        bf16x8 l;
+        opx8 l;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { l[e] = (__bf16)(v0[e] - (float)h[e]); l[e + 4] = (__bf16)(v1[e] - (float)h[e + 4]); }
-        *(bf16x8*)(lo + off) = l;
+        for (int e = 0; e < 4; ++e) { l[e] = to_op(v0[e] - (float)h[e]); l[e + 4] = to_op(v1[e] - (float)h[e + 4]); }
+        *(opx8*)(lo + off) = l;
     }
 }
 
@@ -145,16 +143,16 @@ struct Stager {
     static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, SLAB = A_BYTES + B_BYTES;
     static_assert(BM % (RPC * NW) == 0 && BN % (RPC * NW) == 0, "chunk split");
 
-    const bf16_t* a_ptr[CA];
+    const op_t* a_ptr[CA];
     int a_pix[CA], a_y[CA], a_x[CA], a_ko[CA];
-    const bf16_t* b_ptr[CB];
+    const op_t* b_ptr[CB];
     ptrdiff_t a_hi_minus_lo, w_lo_minus_hi;
-    const bf16_t* conv_plane;
+    const op_t* conv_plane;
     int st_pass, st_k0, st_tap, st_ci, st_sub;  // conv K order: 64-channel block (st_ci) outer, tap, then the BK-wide part of the block (st_sub)
 
     __device__ __forceinline__ void init(const GemmParams& p, int m0, int n0, int wave, int lane) {
         const int lrow = lane / CPR, slot = lane % CPR;
-        const bf16_t* A0 = p.npass == 3 ? p.A_lo : p.A_hi;  // operand plane of pass 0
+        const op_t* A0 = p.npass == 3 ? p.A_lo : p.A_hi;  // operand plane of pass 0
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
             const int r = (wave + NW * i) * RPC + lrow;
@@ -199,7 +197,7 @@ struct Stager {
         char* sB = slab_base + A_BYTES;
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
-            const bf16_t* src;
+            const op_t* src;
             if (AMODE == MDPT_A_CONV3) {
                 const int ky = (st_tap * 11) >> 5, kx = st_tap - 3 * ky;
                 const int iy = a_y[i] + ky, ix = a_x[i] + kx;
@@ -263,7 +261,7 @@ __device__ __forceinline__ void tile_coords(int tiles_n, int BM, int BN, int& m0
 // ------------------------------------------------------------------------------------------------------------
 // Epilogue shared by both main-loop variants: per 32-row block, accumulators -> wave-private LDS strip [32][WTN] fp32
 // -> row-major vectors. The vector-memory path moves 64 B/clk per CU and a store instruction costs about the same address
-// processing whatever its width, so every store is 16 bytes per lane: each lane owns 8 consecutive columns (one bf16x8 store,
+// processing whatever its width, so every store is 16 bytes per lane: each lane owns 8 consecutive columns (one opx8 store,
 // two fp32x4 stores). Stores here sit behind per-lane bounds checks (divergent branches), which makes hipcc wait for every
 // store's acknowledgement before the next one (see epilogue_direct for the branch-free form used on the big GEMMs).
 // ------------------------------------------------------------------------------------------------------------
@@ -554,16 +552,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
         if (t + NST - 1 < total) st.issue(p, smem + wr * STAGE, wave);
         const char* sA = smem + rd * STAGE + wm * WTM * ROWB;
         const char* sB = smem + rd * STAGE + A_BYTES + wn * WTN * ROWB;
-        bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+        opx8 a0[TM], b0[TN], a1[TM], b1[TN];
 #define LOAD_FRAGS(A_, B_, KK_)                                                                           \
     do {                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) A_[i] = *(const bf16x8*)(sA + i * 32 * ROWB + frag_off[KK_]); \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) B_[j] = *(const bf16x8*)(sB + j * 32 * ROWB + frag_off[KK_]); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) A_[i] = *(const opx8*)(sA + i * 32 * ROWB + frag_off[KK_]); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) B_[j] = *(const opx8*)(sB + j * 32 * ROWB + frag_off[KK_]); \
     } while (0)
 #define MFMA_RANGE(A_, B_, LO_, HI_)                                                                      \
     do {                                                                                                  \
         _Pragma("unroll") for (int ij = LO_; ij < HI_; ++ij)                                              \
-            acc[ij / TN][ij % TN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[ij / TN], B_[ij % TN], acc[ij / TN][ij % TN], 0, 0, 0); \
+            acc[ij / TN][ij % TN] = MDPT_MFMA_32x32x16(A_[ij / TN], B_[ij % TN], acc[ij / TN][ij % TN], 0, 0, 0); \
     } while (0)
 #define PIN() __builtin_amdgcn_sched_barrier(0)
         // Fragment reads are double-buffered in registers and the issue order is pinned (hipcc would otherwise sink
@@ -662,7 +660,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, si
 template <int MODE, bool X3, int ACT>
 __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc)[2][2][4][2], int m0, int n0, int grp, int wc, int lane) {
     typedef __attribute__((ext_vector_type(2))) float f32x2;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     constexpr unsigned OOB = 0xFFFFFFF0u;
     const int l15 = lane & 15, lh = lane >> 4;
@@ -844,11 +841,11 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc
 #pragma unroll
                     for (int w2 = 0; w2 < 2; ++w2) {
                         const f32x2 pp = {v[j][2 * w2], v[j][2 * w2 + 1]};
-                        const bf16x2 hh = __builtin_convertvector(pp, bf16x2);
+                        const opx2 hh = to_op2(pp);
                         hw_[j][w2] = __builtin_bit_cast(unsigned, hh);
                         if (X3) {
                             const f32x2 rr = pp - __builtin_convertvector(hh, f32x2);
-                            lw_[j][w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                            lw_[j][w2] = __builtin_bit_cast(unsigned, to_op2(rr));
                         }
                     }
                 unsigned ph[4], pl[4];
@@ -892,7 +889,6 @@ template <bool X3>
 __device__ __forceinline__ void epilogue_swin_qk(const GemmParams& p, f32x4 (&acc)[2][2][4][2], int m0, int n0, int grp, int wc, int lane) {
 #pragma clang fp contract(off)
     typedef __attribute__((ext_vector_type(2))) float f32x2;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     constexpr unsigned OOB = 0xFFFFFFF0u;
     const int l15 = lane & 15, lh = lane >> 4;
@@ -965,11 +961,11 @@ __device__ __forceinline__ void epilogue_swin_qk(const GemmParams& p, f32x4 (&ac
 #pragma unroll
                     for (int w2 = 0; w2 < 2; ++w2) {
                         const f32x2 pp = {v[j][2 * w2] * scale, v[j][2 * w2 + 1] * scale};
-                        const bf16x2 hh = __builtin_convertvector(pp, bf16x2);
+                        const opx2 hh = to_op2(pp);
                         hw_[j][w2] = __builtin_bit_cast(unsigned, hh);
                         if (X3) {
                             const f32x2 rr = pp - __builtin_convertvector(hh, f32x2);
-                            lw_[j][w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                            lw_[j][w2] = __builtin_bit_cast(unsigned, to_op2(rr));
                         }
                     }
                 unsigned ph[4], pl[4];
@@ -999,7 +995,6 @@ __device__ __forceinline__ void epilogue_swin_qk(const GemmParams& p, f32x4 (&ac
 template <bool X3>
 __device__ __forceinline__ void epilogue_swin_vt(const GemmParams& p, f32x4 (&acc)[2][2][4][2], int m0, int n0, int grp, int wc, int lane) {
     typedef __attribute__((ext_vector_type(2))) float f32x2;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
     constexpr unsigned OOB = 0xFFFFFFF0u;
     const int l15 = lane & 15, lh = lane >> 4;
@@ -1041,11 +1036,11 @@ __device__ __forceinline__ void epilogue_swin_vt(const GemmParams& p, f32x4 (&ac
 #pragma unroll
                     for (int w2 = 0; w2 < 2; ++w2) {
                         const f32x2 pp = {v[2 * w2], v[2 * w2 + 1]};
-                        const bf16x2 hb = __builtin_convertvector(pp, bf16x2);
+                        const opx2 hb = to_op2(pp);
                         hw_[w2] = __builtin_bit_cast(unsigned, hb);
                         if (X3) {
                             const f32x2 rr = pp - __builtin_convertvector(hb, f32x2);
-                            lw_[w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                            lw_[w2] = __builtin_bit_cast(unsigned, to_op2(rr));
                         }
                     }
                     const unsigned off = dst[qm][i] < 0 || col_q[qn][j] < 0 ? OOB : (unsigned)(dst[qm][i] + col_q[qn][j]) * 2u;
@@ -1061,7 +1056,6 @@ __device__ __forceinline__ void epilogue_swin_vt(const GemmParams& p, f32x4 (&ac
 template <bool X3>
 __device__ __forceinline__ void epilogue_direct_vt(const GemmParams& p, f32x4 (&acc)[2][2][4][2], int m0, int n0, int grp, int wc, int lane) {
     typedef __attribute__((ext_vector_type(2))) float f32x2;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     constexpr unsigned OOB = 0xFFFFFFF0u;
     const int l15 = lane & 15, lh = lane >> 4;
@@ -1094,11 +1088,11 @@ __device__ __forceinline__ void epilogue_direct_vt(const GemmParams& p, f32x4 (&
 #pragma unroll
                     for (int w2 = 0; w2 < 2; ++w2) {
                         const f32x2 pp = {v[2 * w2], v[2 * w2 + 1]};
-                        const bf16x2 hb = __builtin_convertvector(pp, bf16x2);
+                        const opx2 hb = to_op2(pp);
                         hw_[j][w2] = __builtin_bit_cast(unsigned, hb);
                         if (X3) {
                             const f32x2 rr = pp - __builtin_convertvector(hb, f32x2);
-                            lw_[j][w2] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+                            lw_[j][w2] = __builtin_bit_cast(unsigned, to_op2(rr));
                         }
                     }
                 }
@@ -1145,13 +1139,13 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
     __amdgpu_buffer_rsrc_t rs_a, rs_w;
     unsigned a_voff[4], b_voff;
     int a_soff, b_soff, a_row_step, b_row_step;
-    const bf16_t* a_base_hi; const bf16_t* a_base_lo; const bf16_t* w_base_hi; const bf16_t* w_base_lo;
+    const op_t* a_base_hi; const op_t* a_base_lo; const op_t* w_base_hi; const op_t* w_base_lo;
     size_t a_bytes, w_bytes;
-    const bf16_t* a_ptr[4];
+    const op_t* a_ptr[4];
     int a_pix[4], a_y[4], a_x[4], a_ko[4];
-    const bf16_t* b_ptr[4];
+    const op_t* b_ptr[4];
     ptrdiff_t a_hi_minus_lo, w_lo_minus_hi;
-    const bf16_t* conv_plane;
+    const op_t* conv_plane;
     int a_pass, a_k0, a_tap, a_ci, b_pass, b_k0;
 
     static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, size_t bytes) {
@@ -1160,7 +1154,7 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
 
     __device__ __forceinline__ void init(const GemmParams& p, int m0, int n0, int wave, int lane) {
         const int lrow = lane >> 3, slot = lane & 7;
-        const bf16_t* A0 = p.npass == 3 ? p.A_lo : p.A_hi;
+        const op_t* A0 = p.npass == 3 ? p.A_lo : p.A_hi;
         a_pass = a_k0 = a_tap = a_ci = b_pass = b_k0 = 0;
         if constexpr (BUFFERED) {
             constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -1244,7 +1238,7 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
         }
 #pragma unroll
         for (int i = 2 * H; i < 2 * H + 2; ++i) {
-            const bf16_t* src;
+            const op_t* src;
             if (AMODE == MDPT_A_CONV3) {
                 const int ky = (a_tap * 11) >> 5, kx = a_tap - 3 * ky;
                 const int iy = a_y[i] + ky, ix = a_x[i] + kx;
@@ -1380,21 +1374,21 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
                     for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
 
-    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    opx8 fa[4][2], fb0[2][2], fb1[2][2];
 #define PIN() __builtin_amdgcn_sched_barrier(0)
 #define BAR() do { PIN(); __builtin_amdgcn_s_barrier(); PIN(); } while (0)
 #define LOAD_A(QM_, BUF_)                                                                                             \
     do {                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
-            fa[i][0] = *(const bf16x8*)(smem + (BUF_) * BUF + (QM_) * 16384 + i * 2048 + a_off0);                      \
-            fa[i][1] = *(const bf16x8*)(smem + (BUF_) * BUF + (QM_) * 16384 + i * 2048 + a_off1);                      \
+            fa[i][0] = *(const opx8*)(smem + (BUF_) * BUF + (QM_) * 16384 + i * 2048 + a_off0);                      \
+            fa[i][1] = *(const opx8*)(smem + (BUF_) * BUF + (QM_) * 16384 + i * 2048 + a_off1);                      \
         }                                                                                                             \
     } while (0)
 #define LOAD_B(DST_, QN_, BUF_)                                                                                       \
     do {                                                                                                              \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                               \
-            DST_[j][0] = *(const bf16x8*)(smem + (BUF_) * BUF + (QN_) * 16384 + j * 2048 + b_off0);                    \
-            DST_[j][1] = *(const bf16x8*)(smem + (BUF_) * BUF + (QN_) * 16384 + j * 2048 + b_off1);                    \
+            DST_[j][0] = *(const opx8*)(smem + (BUF_) * BUF + (QN_) * 16384 + j * 2048 + b_off0);                    \
+            DST_[j][1] = *(const opx8*)(smem + (BUF_) * BUF + (QN_) * 16384 + j * 2048 + b_off1);                    \
         }                                                                                                             \
     } while (0)
 #define MFMA_Q(QM_, QN_, FB_)                                                                                         \
@@ -1403,8 +1397,8 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                              \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
-                    acc[QM_][QN_][i][j] = swapped ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB_[j][kk], fa[i][kk], acc[QM_][QN_][i][j], 0, 0, 0) \
-                                                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kk], FB_[j][kk], acc[QM_][QN_][i][j], 0, 0, 0); \
+                    acc[QM_][QN_][i][j] = swapped ? MDPT_MFMA_16x16x32(FB_[j][kk], fa[i][kk], acc[QM_][QN_][i][j], 0, 0, 0) \
+                                                  : MDPT_MFMA_16x16x32(fa[i][kk], FB_[j][kk], acc[QM_][QN_][i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                                \
     } while (0)
 #define WAIT_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory")
@@ -1812,9 +1806,9 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-bool mdpt_gemm_resolves_to_pp256(const GemmParams& p) { return p.M > 0 && p.N > 0 && p.K > 0 && !(p.K & 63) && resolve_tile(p) == MDPT_TILE_PP256; }
+bool MDPT_FN(mdpt_gemm_resolves_to_pp256)(const GemmParams& p) { return p.M > 0 && p.N > 0 && p.K > 0 && !(p.K & 63) && resolve_tile(p) == MDPT_TILE_PP256; }
 
-int mdpt_launch_gemm(const GemmParams& p, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_gemm)(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0) return 0;
     if (p.K <= 0 || (p.K & 63) || (p.N & 7)) return (int)hipErrorInvalidValue;
     if (p.npass != 1 && p.npass != 3) return (int)hipErrorInvalidValue;

@@ -31,7 +31,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -65,7 +64,6 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
     static_assert((PIXP / 16) % 2 == 1 && ROWB % 256 == 0, "halo pitches");
     constexpr int HALO_BYTES = HS * ROWB, PATCH_BYTES = PS * PS * PIXB, XCH_BYTES = 8 * 16 * 64 * 4;
     typedef __attribute__((ext_vector_type(2))) float f32x2;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sH = smem;
     char* const sP = smem + HALO_BYTES;
@@ -83,13 +81,13 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
 
     // ---- this wave's weight fragments -> registers, once: W[n = l31][k = tap*CIN + (2*kg + grp)*16 + half*8 .. +8]
     //      (w_kc image: chunk (k/8), row n, 8 elements: 16 consecutive bytes per lane, 512 per fragment and half)
-    bf16x8 wreg[9][KG];
+    opx8 wreg[9][KG];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
             const int chunk = tap * NCH + (2 * kg + grp) * 2 + half;
-            wreg[tap][kg] = *(const bf16x8*)((const char*)p.w_kc + ((size_t)chunk * 32 + l31) * 16);
+            wreg[tap][kg] = *(const opx8*)((const char*)p.w_kc + ((size_t)chunk * 32 + l31) * 16);
         }
 
     const float sy = p.Ho > 1 ? (float)(p.Hi - 1) / (float)(p.Ho - 1) : 0.0f;
@@ -114,7 +112,7 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
     };
     // source patch global -> LDS by LDS-DMA, dense [ph*pw][CIN] image (pixel pitch pw): 1 KiB = PPI pixels per wave instruction
     auto issue_patch = [&](const TileGeom& g) {
-        const bf16_t* src = p.src + (size_t)g.b * p.Hi * p.Wi * CIN;
+        const op_t* src = p.src + (size_t)g.b * p.Hi * p.Wi * CIN;
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));  // opaque: keeps hipcc from hoisting the lane's address part to kernel entry (it gets spilled there)
         const int npix = g.ph * g.pw, c = lane_o % NCH;
@@ -164,7 +162,11 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
         //      lerp (the branches depend on the row only: wave-uniform). bf16 -> fp32 is a shift for the even element of a packed pair;
         //      the odd one is used IN PLACE (its low 16 bits are the neighbour's bits: a relative perturbation below 2^-16, two
         //      hundred times finer than the bf16 rounding of the result)
+#if MDPT_OP_IS_F16
+        auto to_f2 = [](unsigned d) { return op2_to_f32(d); };  // fp16 operands: two v_cvt_f32_f16
+#else
         auto to_f2 = [](unsigned d) { return f32x2{__builtin_bit_cast(float, d << 16), __builtin_bit_cast(float, d)}; };
+#endif
         if (tid < 2 * TS * NCH) {
             // strips: halo columns 0..15, chunk c, rows 9 part .. 9 part + 8
             const int part = tid / (TS * NCH), rem = tid - part * (TS * NCH);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
                         const f32x2 o2 = t0[w] + ly * (t1[w] - t0[w]);
-                        outw[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(o2, bf16x2));
+                        outw[w] = __builtin_bit_cast(unsigned, to_op2(o2));
                     }
                 }
                 *(u32x4*)(hcol + hy * ROWB) = outw;
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
                     const f32x2 u0 = a00 + lx * (a01 - a00);
                     const f32x2 u1 = a10 + lx * (a11 - a10);
                     const f32x2 o2 = u0 + ly * (u1 - u0);
-                    outw[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(o2, bf16x2));
+                    outw[w] = __builtin_bit_cast(unsigned, to_op2(o2));
                 }
             }
             *(u32x4*)(sH + hy * ROWB + hx * PIXP + c * 16) = outw;
@@ -265,30 +267,30 @@ __global__ __launch_bounds__(512, 1) void head_tail_kernel(const HeadTailParams 
         // fragment reads run a PAIR of k-steps ahead of the MFMAs (register double buffer, issue order pinned: hipcc's own waits are
         // always lgkmcnt(0), so each one is placed four MFMAs behind the newest reads)
         const char* const hbase = sH + prow * ROWB + px * PIXP + ((2 * grp + half) << 4);
-        auto frag = [&](int step, int blk) -> bf16x8 {
+        auto frag = [&](int step, int blk) -> opx8 {
             const int tap = step / KG, kg = step - tap * KG;
             const int ky = tap / 3, kx = tap - 3 * ky;
-            return *(const bf16x8*)(hbase + (ky + 2 * blk) * ROWB + kx * PIXP + kg * 64);
+            return *(const opx8*)(hbase + (ky + 2 * blk) * ROWB + kx * PIXP + kg * 64);
         };
         constexpr int NSTEP = 9 * KG;
         static_assert(NSTEP % 2 == 0, "k-steps are consumed in pairs");
-        bf16x8 xf[2][2][2];  // [buffer][step of the pair][block]
+        opx8 xf[2][2][2];  // [buffer][step of the pair][block]
 #pragma unroll
         for (int u = 0; u < 2; ++u) { xf[0][u][0] = frag(u, 0); xf[0][u][1] = frag(u, 1); }
 #pragma unroll
         for (int pair = 0; pair < NSTEP / 2; ++pair) {
             const int cur = pair & 1;
             // first MFMA of the pair (its lgkmcnt(0) retires the reads issued during the previous pair), THEN the next pair's reads
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(2 * pair) / KG][(2 * pair) % KG], xf[cur][0][0], acc[0], 0, 0, 0);
+            acc[0] = MDPT_MFMA_32x32x16(wreg[(2 * pair) / KG][(2 * pair) % KG], xf[cur][0][0], acc[0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (pair + 1 < NSTEP / 2) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) { xf[cur ^ 1][u][0] = frag(2 * pair + 2 + u, 0); xf[cur ^ 1][u][1] = frag(2 * pair + 2 + u, 1); }
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(2 * pair) / KG][(2 * pair) % KG], xf[cur][0][1], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(2 * pair + 1) / KG][(2 * pair + 1) % KG], xf[cur][1][0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(2 * pair + 1) / KG][(2 * pair + 1) % KG], xf[cur][1][1], acc[1], 0, 0, 0);
+            acc[1] = MDPT_MFMA_32x32x16(wreg[(2 * pair) / KG][(2 * pair) % KG], xf[cur][0][1], acc[1], 0, 0, 0);
+            acc[0] = MDPT_MFMA_32x32x16(wreg[(2 * pair + 1) / KG][(2 * pair + 1) % KG], xf[cur][1][0], acc[0], 0, 0, 0);
+            acc[1] = MDPT_MFMA_32x32x16(wreg[(2 * pair + 1) / KG][(2 * pair + 1) % KG], xf[cur][1][1], acc[1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -376,16 +378,16 @@ int launch_cin(const HeadTailParams& p, hipStream_t stream) {
 
 }  // namespace
 
-bool mdpt_head_tail_supported(int cin) { return cin == 64 || cin == 128; }
+bool MDPT_FN(mdpt_head_tail_supported)(int cin) { return cin == 64 || cin == 128; }
 
 // the 18 halo pixels of a tile side must interpolate from at most PS source pixels: floor(17 * scale) + 2 <= PS with
 // scale = (in - 1) / (out - 1) (x1.75 for patch 14: 11, x2 for patch 16: 10)
-bool mdpt_head_tail_scale_ok(int Hi, int Wi, int Ho, int Wo) {
+bool MDPT_FN(mdpt_head_tail_scale_ok)(int Hi, int Wi, int Ho, int Wo) {
     return Ho > 1 && Wo > 1 && (long)17 * (Hi - 1) < (long)(PS - 1) * (Ho - 1) && (long)17 * (Wi - 1) < (long)(PS - 1) * (Wo - 1);
 }
 
-int mdpt_launch_head_tail(const HeadTailParams& p, int cin, hipStream_t stream) {
-    if (p.B <= 0 || p.Hi <= 0 || p.Wi <= 0 || p.Ho <= 0 || p.Wo <= 0 || !mdpt_head_tail_scale_ok(p.Hi, p.Wi, p.Ho, p.Wo)) return (int)hipErrorInvalidValue;
+int MDPT_FN(mdpt_launch_head_tail)(const HeadTailParams& p, int cin, hipStream_t stream) {
+    if (p.B <= 0 || p.Hi <= 0 || p.Wi <= 0 || p.Ho <= 0 || p.Wo <= 0 || !MDPT_FN(mdpt_head_tail_scale_ok)(p.Hi, p.Wi, p.Ho, p.Wo)) return (int)hipErrorInvalidValue;
     if (cin == 128) return launch_cin<128>(p, stream);
     if (cin == 64) return launch_cin<64>(p, stream);
     return (int)hipErrorInvalidValue;

@@ -8,7 +8,6 @@
 #include "mdpt_kernels.h"
 
 typedef __attribute__((ext_vector_type(4))) float ln_f32x4;
-typedef __attribute__((ext_vector_type(4))) __bf16 ln_bf16x4;
 
 __device__ __forceinline__ float ln_wave_sum(float v) {
 #pragma unroll
@@ -18,7 +17,7 @@ __device__ __forceinline__ float ln_wave_sum(float v) {
 
 template <int NV>
 __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       bf16_t* out_hi, bf16_t* out_lo, float* out_f32, size_t out_off, int F, int lane) {
+                                       op_t* out_hi, op_t* out_lo, float* out_f32, size_t out_off, int F, int lane) {
 #pragma clang fp contract(off)
     ln_f32x4 v[NV];
     float s = 0.0f;
@@ -53,15 +52,15 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((v[i][e] - mean) * rstd, g[e], bt[e]);
             if (out_hi) {
-                ln_bf16x4 h;
+                opx4 h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (__bf16)y[e];
-                *(ln_bf16x4*)(out_hi + out_off + c) = h;
+                for (int e = 0; e < 4; ++e) h[e] = to_op(y[e]);
+                *(opx4*)(out_hi + out_off + c) = h;
                 if (out_lo) {
-                    ln_bf16x4 l;
+                    opx4 l;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) l[e] = (__bf16)(y[e] - (float)h[e]);
-                    *(ln_bf16x4*)(out_lo + out_off + c) = l;
+                    for (int e = 0; e < 4; ++e) l[e] = to_op(y[e] - (float)h[e]);
+                    *(opx4*)(out_lo + out_off + c) = l;
                 }
             }
             if (out_f32) *(ln_f32x4*)(out_f32 + out_off + c) = y;

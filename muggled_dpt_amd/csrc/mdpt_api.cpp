@@ -23,9 +23,30 @@
 #include "../../include/mdpt.h"
 #include "mdpt_kernels.h"
 
+// Every operand-format dependent launcher exists twice (op_types.h): mdpt_kernels.h declared the *_bf16 set, here is the *_f16 one.
+// The host side never looks inside an operand plane - `op_t*` is an opaque 2-byte-element pointer here - and picks the set per handle.
+#undef MDPT_FN
+#define MDPT_FN(name) name##_f16
+extern "C" {
+#include "mdpt_launchers.inc"
+}
+#undef MDPT_FN
+#define MDPT_FN(name) name##_bf16
+#define OPL_(f16, fn, ...) ((f16) ? fn##_f16(__VA_ARGS__) : fn##_bf16(__VA_ARGS__))
+#define OPLC(fn, ...) OPL_(c.h->f16, fn, __VA_ARGS__)   // inside a stage driver (a Ctx named c)
+#define OPLH(fn, ...) OPL_(h->f16, fn, __VA_ARGS__)     // with only the handle in scope
+#define OPLG(fn, ...) OPL_(g_debug_f16, fn, __VA_ARGS__)  // handle-less test hooks (mdpt_debug_set_operand_format)
+// host-only predicates of the kernel files: the same answer in both builds
+#define mdpt_head_tail_supported mdpt_head_tail_supported_bf16
+#define mdpt_head_tail_scale_ok mdpt_head_tail_scale_ok_bf16
+#define mdpt_beit_relpos_elen mdpt_beit_relpos_elen_bf16
+#define mdpt_gemm_resolves_to_pp256 mdpt_gemm_resolves_to_pp256_bf16
+#define mdpt_conv3h_supported mdpt_conv3h_supported_bf16
+
 namespace {
 
 thread_local std::string g_err = "";
+int g_debug_f16 = 0;
 
 int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -62,13 +83,32 @@ struct WeightSpec {
     }
 };
 
-struct Mat {  // packed bf16 panel [Np][Kp]
+// Op classes: every contraction of the path belongs to one; a class runs 1 MFMA pass (operands rounded to one 16-bit plane) or 3 (hi + lo
+// split planes). The uniform modes set all classes alike; MDPT_PREC_MIXED / mdpt_set_class_passes choose per class (include/mdpt.h).
+enum { CLS_PATCH = MDPT_CLASS_PATCH, CLS_QKV = MDPT_CLASS_QKV, CLS_ATTN = MDPT_CLASS_ATTN, CLS_PROJ = MDPT_CLASS_PROJ, CLS_FC1 = MDPT_CLASS_FC1,
+       CLS_FC2 = MDPT_CLASS_FC2, CLS_REASM = MDPT_CLASS_REASM, CLS_FUSION = MDPT_CLASS_FUSION, CLS_HEAD = MDPT_CLASS_HEAD, NCLS = MDPT_NUM_CLASSES };
+
+int mat_class(const std::string& src) {
+    if (src.compare(0, 12, "patch_embed.") == 0) return CLS_PATCH;
+    if (src.compare(0, 11, "reassemble.") == 0) return CLS_REASM;
+    if (src.compare(0, 7, "fusion.") == 0) return CLS_FUSION;
+    if (src.compare(0, 5, "head.") == 0) return CLS_HEAD;
+    if (src.find(".attn.qkv.") != std::string::npos) return CLS_QKV;
+    if (src.find(".attn.proj.") != std::string::npos) return CLS_PROJ;
+    if (src.find(".mlp.layers.0.") != std::string::npos || src.find("inner_linear_doubled") != std::string::npos) return CLS_FC1;
+    if (src.find(".mlp.layers.2.") != std::string::npos || src.find("outer_linear") != std::string::npos) return CLS_FC2;
+    if (src.find("patch_merge_layers") != std::string::npos) return CLS_PROJ;  // SwinV2 patch merge: a token-mixing projection
+    return CLS_PROJ;
+}
+
+struct Mat {  // packed operand panel [Np][Kp]
     std::string src;
+    int cls;  // CLS_*
     std::string row_scale;  // name of a per-output-feature fp32 parameter folded into the rows at pack time ("" = none)
     int kind, N, K, Np, Kp, ksz;
     size_t off_hi, off_lo;
-    bf16_t* hi;
-    bf16_t* lo;
+    op_t* hi;
+    op_t* lo;
 };
 
 struct Vec {  // packed fp32 vector (zero padded)
@@ -80,8 +120,8 @@ struct Vec {  // packed fp32 vector (zero padded)
 };
 
 struct Planes {
-    bf16_t* hi = nullptr;
-    bf16_t* lo = nullptr;
+    op_t* hi = nullptr;
+    op_t* lo = nullptr;
 };
 
 const char* kStageNames[4] = {"spatial_upx4", "spatial_upx2", "spatial_noscale", "spatial_downx2"};
@@ -117,7 +157,9 @@ struct mdpt_handle {
     int Pv;  // patch size seen by fusion/head: the finest reassembly map is (4H/Pv) x (4W/Pv); = P except SwinV2 (16)
     int gh_hidden, gh_hidden_p;  // ViT-G SwiGLU hidden width (and padded to 64), 0 otherwise
     int sH[4], sL[4], swh, sww, spre[4];  // SwinV2: heads / layers per stage, target window, pretrained window sizes (0 = None)
-    bool x3;
+    bool f16;       // operand format: fp16 (v_mfma_*_f16, *_f16 launchers) instead of bf16
+    int np[NCLS];   // MFMA passes per op class: 1 or 3
+    bool x3c(int cls) const { return np[cls] == 3; }
     int gemm_tile;
     std::vector<WeightSpec> specs;
     std::map<std::string, int> spec_index;
@@ -127,7 +169,7 @@ struct mdpt_handle {
     std::map<std::string, int> vec_index;
     size_t packed_total;
     size_t zero_off;
-    bf16_t* zero_page;
+    op_t* zero_page;
     bool finalized;
     // last forward (for export taps)
     Plan last_plan;
@@ -160,10 +202,11 @@ struct mdpt_handle {
     void add_mat(const std::string& src, int kind, int N, int K, int Np, int Kp, int ksz) {
         Mat m;
         m.src = src; m.kind = kind; m.N = N; m.K = K; m.Np = Np; m.Kp = Kp; m.ksz = ksz;
+        m.cls = mat_class(src);
         m.off_hi = packed_total;
         packed_total += rup256((size_t)Np * Kp * 2);
         m.off_lo = SIZE_MAX;
-        if (x3) { m.off_lo = packed_total; packed_total += rup256((size_t)Np * Kp * 2); }
+        if (x3c(m.cls)) { m.off_lo = packed_total; packed_total += rup256((size_t)Np * Kp * 2); }
         m.hi = m.lo = nullptr;
         mat_index[src] = (int)mats.size();
         mats.push_back(m);
@@ -355,7 +398,7 @@ int build_inventory_decoder(mdpt_handle* h) {
     h->add_mat("head.spatial_upsampler.0.weight", MDPT_PACK_CONV3, h->C2, C, h->C2p, 9 * h->Cp, 3);
     h->add_vec("head.spatial_upsampler.0.bias", h->C2, h->C2p);
     h->add_mat("head.proj_1ch.0.weight", MDPT_PACK_CONV3, 32, h->C2, 32, 9 * h->C2p, 3);
-    if (!h->x3 && mdpt_head_tail_supported(h->C2p))  // LDS image of the same weights for the fused head tail (head.hip)
+    if (!h->x3c(CLS_HEAD) && mdpt_head_tail_supported(h->C2p))  // LDS image of the same weights for the fused head tail (head.hip)
         h->add_mat("head.proj_1ch.0.weight@kc32", MDPT_PACK_CONV3_KC32, 32, h->C2, 32, 9 * h->C2p, 3);
     h->add_vec("head.proj_1ch.0.bias", 32, 32);
     h->add_vec("head.proj_1ch.2.weight", 32, 32);
@@ -382,7 +425,7 @@ void take_planes(Bump& bump, bool x3, size_t elems, size_t out[2]) {
 
 // reassembly outputs, fusion and head buffers; p.Np / p.gh / p.gw = the "noscale" level (1/Pv of the image)
 void plan_decoder(Bump& bump, const mdpt_handle* h, Plan& p, size_t min_scratch_floats) {
-    const bool x3 = h->x3;
+    const bool x3 = h->x3c(CLS_FUSION), x3h = h->x3c(CLS_HEAD);  // lo planes exist where the CONSUMING class runs three passes
     const int B = p.B;
     const size_t px[4] = {(size_t)16 * p.Np, (size_t)4 * p.Np, (size_t)p.Np, (size_t)p.Np / 4};
     for (int i = 0; i < 4; ++i) {
@@ -397,13 +440,13 @@ void plan_decoder(Bump& bump, const mdpt_handle* h, Plan& p, size_t min_scratch_
         p.flo[i] = bump.take(e * 4);
     }
     const size_t fpx = (size_t)64 * p.Np;  // (8gh)*(8gw)
-    take_planes(bump, x3, (size_t)B * fpx * h->Cp, p.fused);
+    take_planes(bump, x3h, (size_t)B * fpx * h->Cp, p.fused);
     // bf16 mode with the fused head tail (run_head): conv 1 writes a bf16 map and the full-resolution upsampled map never exists (ViT-L,
     // 504x504, batch 32: 2.1 GB + 0.7 GB of workspace that used to be reserved and never touched)
-    const bool bf16_head = !x3 && mdpt_head_tail_supported(h->C2p) && mdpt_head_tail_scale_ok(8 * p.gh, 8 * p.gw, p.H, p.W);
+    const bool bf16_head = !x3h && mdpt_head_tail_supported(h->C2p) && mdpt_head_tail_scale_ok(8 * p.gh, 8 * p.gw, p.H, p.W);
     p.h1 = bump.take((size_t)B * fpx * h->C2p * (bf16_head ? 2 : 4));
     if (bf16_head) p.h1u[0] = p.h1u[1] = SIZE_MAX;
-    else take_planes(bump, x3, (size_t)B * p.H * p.W * h->C2p, p.h1u);
+    else take_planes(bump, x3h, (size_t)B * p.H * p.W * h->C2p, p.h1u);
     p.scratch_floats = (size_t)B * fpx * h->Cp;
     if (min_scratch_floats > p.scratch_floats) p.scratch_floats = min_scratch_floats;
     p.scratch = bump.take(p.scratch_floats * 4);
@@ -419,23 +462,23 @@ int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
     const int gh = H / h->P, gw = W / h->P;
     if ((gh & 1) || (gw & 1))
         return fail(MDPT_E_GRID, "patch grid %dx%d must be even in both dimensions (the reference fails in fusion_model.py:151)", gh, gw);
-    const bool x3 = h->x3;
     const int F = h->F;
     Plan& p = *pl;
     p.B = B; p.H = H; p.W = W; p.gh = gh; p.gw = gw;
     p.Np = gh * gw; p.N = p.Np + 1; p.npad = rup(p.N, 8); p.npadv = rup(p.N, 64);
     Bump bump;
     const size_t rows = (size_t)B * p.npad;
-    take_planes(bump, x3, (size_t)B * p.Np * h->Kpatch, p.im2col);
+    take_planes(bump, h->x3c(CLS_PATCH), (size_t)B * p.Np * h->Kpatch, p.im2col);
     p.pos = bump.take((size_t)p.Np * F * 4);
     p.resid = bump.take(rows * F * 4);
-    take_planes(bump, x3, rows * F, p.xn);
-    take_planes(bump, x3, (size_t)B * h->heads * p.npad * 64, p.q);
-    take_planes(bump, x3, (size_t)B * h->heads * p.npad * 64, p.k);
-    take_planes(bump, x3, (size_t)B * h->heads * 64 * p.npadv, p.vt);
-    take_planes(bump, x3, rows * F, p.att);
-    take_planes(bump, x3, rows * 4 * F, p.hbuf);
+    take_planes(bump, h->x3c(CLS_QKV) || h->x3c(CLS_FC1), rows * F, p.xn);
+    take_planes(bump, h->x3c(CLS_ATTN), (size_t)B * h->heads * p.npad * 64, p.q);
+    take_planes(bump, h->x3c(CLS_ATTN), (size_t)B * h->heads * p.npad * 64, p.k);
+    take_planes(bump, h->x3c(CLS_ATTN), (size_t)B * h->heads * 64 * p.npadv, p.vt);
+    take_planes(bump, h->x3c(CLS_PROJ), rows * F, p.att);
+    take_planes(bump, h->x3c(CLS_FC2), rows * 4 * F, p.hbuf);
     p.swi = h->gh_hidden ? bump.take(rows * 2 * h->gh_hidden * 4) : SIZE_MAX;
+    const bool x3 = h->x3c(CLS_REASM);
     for (int i = 0; i < 4; ++i) take_planes(bump, x3, rows * F, p.tap[i]);
     p.tapf32 = bump.take(rows * F * 4);
     const size_t px[4] = {(size_t)16 * p.Np, (size_t)4 * p.Np, (size_t)p.Np, (size_t)p.Np / 4};
@@ -467,8 +510,8 @@ struct Ctx {
     template <class T> T* at(size_t off) const { return off == SIZE_MAX ? nullptr : (T*)(ws + off); }
     Planes pl(const size_t o[2]) const {
         Planes r;
-        r.hi = at<bf16_t>(o[0]);
-        r.lo = at<bf16_t>(o[1]);
+        r.hi = at<op_t>(o[0]);
+        r.lo = at<op_t>(o[1]);
         return r;
     }
 };
@@ -476,10 +519,10 @@ struct Ctx {
 GemmParams base_params(const Ctx& c, const Mat& w, Planes a, int M, int lda) {
     GemmParams g;
     memset(&g, 0, sizeof(g));
-    g.A_hi = a.hi; g.A_lo = a.lo;
-    g.W_hi = w.hi; g.W_lo = w.lo;
+    g.npass = c.h->np[w.cls];  // the class of the weight matrix decides; an A buffer shared with a 3-pass class may carry an unused lo plane
+    g.A_hi = a.hi; g.A_lo = g.npass == 3 ? a.lo : nullptr;
+    g.W_hi = w.hi; g.W_lo = g.npass == 3 ? w.lo : nullptr;
     g.M = M; g.N = w.Np; g.K = w.Kp; g.lda = lda;
-    g.npass = c.h->x3 ? 3 : 1;
     g.zero_page = c.h->zero_page;
     g.amode = MDPT_A_DENSE; g.ekind = MDPT_E_GENERIC; g.tile = c.h->gemm_tile;
     g.throughput_mode = c.split ? 1 : 0;
@@ -502,7 +545,7 @@ int check_ws(const mdpt_handle* h, const Plan& p, const void* ws, size_t bytes) 
 // ---- stage: patch embed (fused form: writes the residual stream incl. position embedding)
 int run_pos(const Ctx& c) {
     const mdpt_handle* h = c.h;
-    return mdpt_launch_posembed(h->V("imgencoder.posenc.base_patch_embedding"), c.at<float>(c.p.pos), h->cfg.base_patch_grid_h,
+    return OPLC(mdpt_launch_posembed, h->V("imgencoder.posenc.base_patch_embedding"), c.at<float>(c.p.pos), h->cfg.base_patch_grid_h,
                                 h->cfg.base_patch_grid_w, c.p.gh, c.p.gw, h->F, c.s);
 }
 
@@ -510,10 +553,10 @@ int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype) {
     const mdpt_handle* h = c.h;
     const Plan& p = c.p;
     Planes im = c.pl(p.im2col);
-    CHK(mdpt_launch_patchify(image, image_dtype, im.hi, im.lo, p.B, p.H, p.W, h->P, h->Kpatch, c.s));
+    CHK(OPLC(mdpt_launch_patchify, image, image_dtype, im.hi, im.lo, p.B, p.H, p.W, h->P, h->Kpatch, c.s));
     const bool beit = is_beit(h);
     if (!beit) CHK(run_pos(c));
-    CHK(mdpt_launch_init_tokens(c.at<float>(p.resid), h->V("imgencoder.cls_token"), beit ? nullptr : h->V("imgencoder.posenc.cls_embedding"),
+    CHK(OPLC(mdpt_launch_init_tokens, c.at<float>(p.resid), h->V("imgencoder.cls_token"), beit ? nullptr : h->V("imgencoder.posenc.cls_embedding"),
                                 p.B, p.N, p.npad, h->F, c.s));
     GemmParams g = base_params(c, h->M("patch_embed.proj.weight"), im, p.B * p.Np, h->Kpatch);
     g.ekind = MDPT_E_PATCH;
@@ -521,7 +564,7 @@ int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype) {
     g.pos = beit ? nullptr : c.at<float>(p.pos);
     g.out_f32 = c.at<float>(p.resid);
     g.tok_np = p.Np; g.npad = p.npad; g.ldc = h->F;
-    CHK(mdpt_launch_gemm(g, c.s));
+    CHK(OPLC(mdpt_launch_gemm, g, c.s));
     return 0;
 }
 
@@ -532,7 +575,11 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
     const int F = h->F, rows = p.B * p.npad;
     float* resid = c.at<float>(p.resid);
     Planes xn = c.pl(p.xn), q = c.pl(p.q), k = c.pl(p.k), vt = c.pl(p.vt), att = c.pl(p.att), hb = c.pl(p.hbuf);
-    CHK(mdpt_launch_zero_vt_pad(vt.hi, vt.lo, p.B * h->heads * 64, p.N, p.npadv, c.s));
+    CHK(OPLC(mdpt_launch_zero_vt_pad, vt.hi, vt.lo, p.B * h->heads * 64, p.N, p.npadv, c.s));
+    // a 3-pass projection behind a 1-pass attention kernel (which writes no lo plane): the plane is zero, i.e. the projection keeps
+    // the rounding of its A operand and loses only that of its weights
+    if (att.lo && !h->x3c(CLS_ATTN)) CHK(hipMemsetAsync(att.lo, 0, (size_t)rows * F * 2, c.s));
+    const Planes xn_qkv = {xn.hi, h->x3c(CLS_QKV) ? xn.lo : nullptr}, xn_fc1 = {xn.hi, h->x3c(CLS_FC1) ? xn.lo : nullptr};
 #define DBG_STOP(step) if (h->dbg_block == b && h->dbg_step == (step)) return 0
     const size_t relpos_stride = is_beit(h) ? (size_t)h->heads * mdpt_beit_relpos_elen(p.gh, p.gw) : 0;
     const bool relpos_batched = is_beit(h) && h->nblocks <= 32;
@@ -544,11 +591,11 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
         rb.tq = c.at<int>(p.relpos_tq); rb.tk = c.at<int>(p.relpos_tk);
         rb.n = h->nblocks; rb.heads = h->heads; rb.Gh = h->cfg.base_patch_grid_h; rb.Gw = h->cfg.base_patch_grid_w;
         rb.gh = p.gh; rb.gw = p.gw; rb.N = p.N; rb.ntok_pad = p.npadv;
-        CHK(mdpt_launch_beit_relpos_batch(rb, c.s));
+        CHK(OPLC(mdpt_launch_beit_relpos_batch, rb, c.s));
     }
     for (int b = 0; b < h->nblocks; ++b) {
         const std::string n = blk_name(h, b);
-        CHK(mdpt_launch_layernorm(resid, h->V(n + ".norm1.weight"), h->V(n + ".norm1.bias"), xn.hi, xn.lo, nullptr, rows, F, c.s));
+        CHK(OPLC(mdpt_launch_layernorm, resid, h->V(n + ".norm1.weight"), h->V(n + ".norm1.bias"), xn_qkv.hi, xn_qkv.lo, nullptr, rows, F, c.s));
         DBG_STOP(0);
         {
             GemmParams g = base_params(c, h->M(n + ".attn.qkv.weight"), xn, rows, F);
@@ -556,7 +603,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             g.bias = h->V(is_beit(h) ? n + ".attn.qkv.bias@qv" : n + ".attn.qkv.bias");
             g.q_hi = q.hi; g.q_lo = q.lo; g.k_hi = k.hi; g.k_lo = k.lo; g.vt_hi = vt.hi; g.vt_lo = vt.lo;
             g.F = F; g.heads = h->heads; g.npad = p.npad; g.npadv = p.npadv; g.qscale = 0.125f;
-            CHK(mdpt_launch_gemm(g, c.s));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         DBG_STOP(1);
         {
@@ -564,18 +611,18 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             memset(&a, 0, sizeof(a));
             a.q_hi = q.hi; a.q_lo = q.lo; a.k_hi = k.hi; a.k_lo = k.lo; a.vt_hi = vt.hi; a.vt_lo = vt.lo;
             a.out_hi = att.hi; a.out_lo = att.lo;
-            a.B = p.B; a.heads = h->heads; a.N = p.N; a.npad = p.npad; a.npadv = p.npadv; a.F = F; a.x3 = h->x3;
+            a.B = p.B; a.heads = h->heads; a.N = p.N; a.npad = p.npad; a.npadv = p.npadv; a.F = F; a.x3 = h->x3c(CLS_ATTN);
             a.allow_split_kv = h->latency_mode;
             if (is_beit(h)) {
                 float* lut_b = c.at<float>(p.relpos_lut) + (relpos_batched ? (size_t)b * relpos_stride : 0);
                 if (!relpos_batched)  // more than 32 blocks: this layer's table on its own (tiny kernel)
-                    CHK(mdpt_launch_beit_relpos(h->V(n + ".attn.relpos_enc.ref_bias_lut"), lut_b, c.at<int>(p.relpos_tq), c.at<int>(p.relpos_tk),
+                    CHK(OPLC(mdpt_launch_beit_relpos, h->V(n + ".attn.relpos_enc.ref_bias_lut"), lut_b, c.at<int>(p.relpos_tq), c.at<int>(p.relpos_tk),
                                                 h->heads, h->cfg.base_patch_grid_h, h->cfg.base_patch_grid_w, p.gh, p.gw, p.N, p.npadv, c.s));
                 a.bias_lut = lut_b; a.bias_elen = mdpt_beit_relpos_elen(p.gh, p.gw);
                 a.tq = c.at<int>(p.relpos_tq); a.tk = c.at<int>(p.relpos_tk);
             }
-            if (c.attn_dump && c.attn_dump[b]) CHK(mdpt_launch_attn_weights(a, (float*)c.attn_dump[b], c.s));
-            CHK(mdpt_launch_attention(a, c.s));
+            if (c.attn_dump && c.attn_dump[b]) CHK(OPLC(mdpt_launch_attn_weights, a, (float*)c.attn_dump[b], c.s));
+            CHK(OPLC(mdpt_launch_attention, a, c.s));
         }
         DBG_STOP(2);
         {
@@ -583,23 +630,23 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             g.bias = h->V(n + ".attn.proj.bias@ls");  // layer scale folded into W and the bias at pack time
             g.acc_init = 1;
             g.resid = resid; g.out_f32 = resid; g.ldr = F; g.ldc = F;
-            CHK(mdpt_launch_gemm(g, c.s));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         DBG_STOP(3);
-        CHK(mdpt_launch_layernorm(resid, h->V(n + ".norm2.weight"), h->V(n + ".norm2.bias"), xn.hi, xn.lo, nullptr, rows, F, c.s));
+        CHK(OPLC(mdpt_launch_layernorm, resid, h->V(n + ".norm2.weight"), h->V(n + ".norm2.bias"), xn_fc1.hi, xn_fc1.lo, nullptr, rows, F, c.s));
         DBG_STOP(4);
         if (h->gh_hidden) {  // ViT-G: (a | b) = x W12^T + b12 ; hidden = silu(a) * b
             GemmParams g = base_params(c, h->M(n + ".mlp.inner_linear_doubled.weight"), xn, rows, F);
             g.bias = h->V(n + ".mlp.inner_linear_doubled.bias");
             g.out_f32 = c.at<float>(p.swi); g.ldc = 2 * h->gh_hidden;
-            CHK(mdpt_launch_gemm(g, c.s));
-            CHK(mdpt_launch_swiglu(c.at<float>(p.swi), hb.hi, hb.lo, (size_t)rows, h->gh_hidden, h->gh_hidden_p, c.s));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
+            CHK(OPLC(mdpt_launch_swiglu, c.at<float>(p.swi), hb.hi, hb.lo, (size_t)rows, h->gh_hidden, h->gh_hidden_p, c.s));
         } else {
             GemmParams g = base_params(c, h->M(n + ".mlp.layers.0.weight"), xn, rows, F);
             g.bias = h->V(n + ".mlp.layers.0.bias");
             g.act = MDPT_ACT_GELU;
             g.out_hi = hb.hi; g.out_lo = hb.lo; g.ldc = 4 * F;
-            CHK(mdpt_launch_gemm(g, c.s));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         DBG_STOP(5);
         {
@@ -609,23 +656,23 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             g.bias = h->V(giant ? n + ".mlp.outer_linear.bias@ls" : n + ".mlp.layers.2.bias@ls");
             g.acc_init = 1;
             g.resid = resid; g.out_f32 = resid; g.ldr = F; g.ldc = F;
-            CHK(mdpt_launch_gemm(g, c.s));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         DBG_STOP(6);
         if (c.block_dump && c.block_dump[b])  // TransformerBlock output (transformer_block.py:61-62), pad rows dropped
-            CHK(mdpt_launch_tokens_export(nullptr, nullptr, resid, (float*)c.block_dump[b], p.B, p.N, p.npad, F, 0, c.s));
+            CHK(OPLC(mdpt_launch_tokens_export, nullptr, nullptr, resid, (float*)c.block_dump[b], p.B, p.N, p.npad, F, 0, c.s));
         const bool v1 = h->cfg.family == MDPT_FAMILY_DAV1;
         if (v1 ? b >= h->nblocks - 4 : (b + 1) % h->bps == 0) {
             const int st = v1 ? b - (h->nblocks - 4) : b / h->bps;
             Planes tp = c.pl(p.tap[st]);
             float* f32 = taps_f32 ? c.at<float>(p.tapf32) : nullptr;
             if (is_beit(h)) {  // BEiT taps the raw residual stream (no out-norm, v31_beit/image_encoder_model.py:84-91)
-                CHK(mdpt_launch_tokens_import(resid, tp.hi, tp.lo, p.B, p.npad, p.npad, F, c.s));
-                if (taps_f32) CHK(mdpt_launch_tokens_export(nullptr, nullptr, resid, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
+                CHK(OPLC(mdpt_launch_tokens_import, resid, tp.hi, tp.lo, p.B, p.npad, p.npad, F, c.s));
+                if (taps_f32) CHK(OPLC(mdpt_launch_tokens_export, nullptr, nullptr, resid, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
             } else {
-                CHK(mdpt_launch_layernorm(resid, h->V("imgencoder.outnorm.weight"), h->V("imgencoder.outnorm.bias"), tp.hi, tp.lo, f32, rows, F, c.s));
+                CHK(OPLC(mdpt_launch_layernorm, resid, h->V("imgencoder.outnorm.weight"), h->V("imgencoder.outnorm.bias"), tp.hi, tp.lo, f32, rows, F, c.s));
                 if (taps_f32)
-                    CHK(mdpt_launch_tokens_export(nullptr, nullptr, f32, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
+                    CHK(OPLC(mdpt_launch_tokens_export, nullptr, nullptr, f32, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
             }
         }
     }
@@ -651,7 +698,7 @@ int run_reassemble(const Ctx& c) {
                 GemmParams g = base_params(c, h->M(n + ".readout_proj.1.weight@cls"), tp, p.B, p.npad * F);  // row b = cls token of image b
                 g.bias = h->V(n + ".readout_proj.1.bias");
                 g.out_f32 = c.at<float>(p.cbuf); g.ldc = F;
-                CHK(mdpt_launch_gemm(g, c.s));
+                CHK(OPLC(mdpt_launch_gemm, g, c.s));
             }
             Planes tr = c.pl(p.tokr);
             {
@@ -660,7 +707,7 @@ int run_reassemble(const Ctx& c) {
                 g.bias = c.at<float>(p.cbuf); g.bias_img_stride = F;
                 g.act = MDPT_ACT_GELU;
                 g.out_hi = tr.hi; g.out_lo = tr.lo; g.ldc = F;
-                CHK(mdpt_launch_gemm(g, c.s));
+                CHK(OPLC(mdpt_launch_gemm, g, c.s));
             }
             tp = tr;
             tokens_mode = false;
@@ -670,7 +717,7 @@ int run_reassemble(const Ctx& c) {
             if (tokens_mode) { g.amode = MDPT_A_TOKENS; g.tok_np = p.Np; g.tok_stride = p.npad; }
             g.bias = h->V(n + ".resample.0.bias");
             g.out_hi = t.hi; g.out_lo = t.lo; g.ldc = hp;
-            CHK(mdpt_launch_gemm(g, c.s));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         Planes src = t;
         int sh = gh, sw = gw;
@@ -682,7 +729,7 @@ int run_reassemble(const Ctx& c) {
             g.bias = h->V(n + ".resample.1.bias");
             g.Ho = gh; g.Wo = gw; g.d2s_k = kk; g.d2s_cout = hp;
             g.out_hi = u.hi; g.out_lo = u.lo;
-            CHK(mdpt_launch_gemm(g, c.s));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
             src = u; sh = gh * kk; sw = gw * kk;
         } else if (i == 3) {  // 3x3 stride-2
             Planes d = c.pl(p.d3);
@@ -690,7 +737,7 @@ int run_reassemble(const Ctx& c) {
             as_conv(g, gh, gw, hp, gh / 2, gw / 2, 2);
             g.bias = h->V(n + ".resample.1.bias");
             g.out_hi = d.hi; g.out_lo = d.lo; g.ldc = hp;
-            CHK(mdpt_launch_gemm(g, c.s));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
             src = d; sh = gh / 2; sw = gw / 2;
         }
         {   // 3x3 projection to the fusion width (no bias): fp32 copy (skip path) + ReLU'd bf16 (next conv input)
@@ -723,7 +770,7 @@ int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int 
         q.out_f32 = out_f32; q.out_bf = out.hi; q.out_bf_lo = out.lo; q.relu_bf = relu_bf16;
         q.B = c.p.B; q.H = sh; q.W = sw; q.Cin = Cin; q.Cout = 256; q.zero_page = h->zero_page;
         const long tiles256 = ((long)c.p.B * sh * sw + 255) / 256;
-        if (tiles256 >= (c.split ? 24 : 140) && mdpt_conv3h_supported(q)) return mdpt_launch_conv3h(q, c.s);
+        if (tiles256 >= (c.split ? 24 : 140) && mdpt_conv3h_supported(q)) return OPLC(mdpt_launch_conv3h, q, c.s);
     }
     GemmParams g = base_params(c, w, in, c.p.B * sh * sw, Cin);
     as_conv(g, sh, sw, Cin, sh, sw, 1);
@@ -731,7 +778,7 @@ int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int 
     g.resid = skip; g.ldr = h->Cp;
     g.up_src = up_src; g.Hu = Hu; g.Wu = Wu;
     g.out_f32 = out_f32; g.out_hi = out.hi; g.out_lo = out.lo; g.relu_bf16 = relu_bf16; g.ldc = h->Cp;
-    return mdpt_launch_gemm(g, c.s);
+    return OPLC(mdpt_launch_gemm, g, c.s);
 }
 
 // one 3x3 conv C->C of a residual conv unit at level `lv` (spatial sh x sw)
@@ -746,7 +793,7 @@ int rcu_conv(const Ctx& c, const std::string& wname, Planes in, int sh, int sw, 
 // bf16 mode, forward path (for_head): the last projection (level 0) writes its output as bf16 and the x2 upsample in front of the head is
 // left to run_head, which either interpolates it inside the head's first conv (halo-staged kernel, big launches) or runs the stand-alone
 // bf16 upsample - same arithmetic, same bits (up_bf16.h). The stage-level API and the bf16x3 mode keep the fp32 map + fp32 upsample.
-bool head_upsamples_bf16(const mdpt_handle* h) { return !h->x3 && (h->Cp & 7) == 0; }
+bool head_upsamples_bf16(const mdpt_handle* h) { return !h->x3c(CLS_HEAD) && (h->Cp & 7) == 0; }
 
 int run_fusion(const Ctx& c, bool for_head = false) {
     const mdpt_handle* h = c.h;
@@ -777,15 +824,15 @@ int run_fusion(const Ctx& c, bool for_head = false) {
             // sum to 1) and is applied by the consumer (next level's epilogue / final upsample kernel)
             GemmParams g = base_params(c, h->M(blk + "." + proj_seq(h) + ".2.weight"), b2, p.B * sh[i] * sw[i], h->Cp);
             g.bias = h->V(blk + "." + proj_seq(h) + ".2.bias");
-            if (i == 0 && for_head && head_upsamples_bf16(h)) g.out_hi = c.at<bf16_t>(p.flo[0]);  // bf16 map in the fp32 map's buffer
+            if (i == 0 && for_head && head_upsamples_bf16(h)) g.out_hi = c.at<op_t>(p.flo[0]);  // bf16 map in the fp32 map's buffer
             else g.out_f32 = c.at<float>(p.flo[i]);
             g.ldc = h->Cp;
-            CHK(mdpt_launch_gemm(g, c.s));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
     }
     if (for_head && head_upsamples_bf16(h)) return 0;
     Planes fu = c.pl(p.fused);
-    CHK(mdpt_launch_upsample(c.at<float>(p.flo[0]), fu.hi, fu.lo, nullptr, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
+    CHK(OPLC(mdpt_launch_upsample, c.at<float>(p.flo[0]), fu.hi, fu.lo, nullptr, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
     return 0;
 }
 
@@ -797,15 +844,15 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool f
     const int fh = 8 * p.gh, fw = 8 * p.gw;
     bool fused_ready = !from_flo0b;
     auto materialise_fused = [&]() -> int {  // stand-alone bf16 upsample (small launches / shapes the fused kernel does not cover)
-        if (!fused_ready) CHK(mdpt_launch_upsample_bf16(c.at<bf16_t>(p.flo[0]), c.pl(p.fused).hi, p.B, fh / 2, fw / 2, fh, fw, h->Cp, c.s));
+        if (!fused_ready) CHK(OPLC(mdpt_launch_upsample_bf16, c.at<op_t>(p.flo[0]), c.pl(p.fused).hi, p.B, fh / 2, fw / 2, fh, fw, h->Cp, c.s));
         fused_ready = true;
         return 0;
     };
-    if (!h->x3 && mdpt_head_tail_supported(h->C2p) && mdpt_head_tail_scale_ok(fh, fw, p.H, p.W)) {
+    if (!h->x3c(CLS_HEAD) && mdpt_head_tail_supported(h->C2p) && mdpt_head_tail_scale_ok(fh, fw, p.H, p.W)) {
         // bf16 mode: the first conv writes bf16 (the buffer of the fp32 map is reused), everything behind it is ONE kernel that keeps the
         // upsampled map in LDS tiles: upsample + 3x3 conv + ReLU + 1x1 conv + ReLU | sigmoid (head.hip). The bf16x3 mode keeps the
         // unfused form below (its hi + lo operand planes do not fit the LDS tile next to the weights).
-        bf16_t* h1b = c.at<bf16_t>(p.h1);
+        op_t* h1b = c.at<op_t>(p.h1);
         bool done = false;
         if (h->C2p == 128 && conv3h_shape_ok(h, fh, fw, h->Cp) && h->gemm_tile == MDPT_TILE_AUTO) {  // halo-staged form, 128 output channels
             Conv3hParams q;
@@ -816,9 +863,9 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool f
             const bool big = tiles256 >= (c.split ? 24 : 140);
 #ifndef MDPT_NO_UPIN  // (A/B builds: -DMDPT_NO_UPIN keeps the stand-alone upsample in front of the halo-staged conv)
             if (big && !fused_ready) {  // the x2 upsample folded into the conv's halo interpolation
-                q.up_in = c.at<bf16_t>(p.flo[0]); q.Hs = fh / 2; q.Ws = fw / 2;
+                q.up_in = c.at<op_t>(p.flo[0]); q.Hs = fh / 2; q.Ws = fw / 2;
                 if (mdpt_conv3h_supported(q)) {
-                    CHK(mdpt_launch_conv3h(q, c.s));
+                    CHK(OPLC(mdpt_launch_conv3h, q, c.s));
                     done = true;
                 }
                 q.up_in = nullptr;
@@ -828,7 +875,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool f
                 CHK(materialise_fused());
                 q.in = c.pl(p.fused).hi;
                 if (mdpt_conv3h_supported(q)) {
-                    CHK(mdpt_launch_conv3h(q, c.s));
+                    CHK(OPLC(mdpt_launch_conv3h, q, c.s));
                     done = true;
                 }
             }
@@ -839,7 +886,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool f
             as_conv(g, fh, fw, h->Cp, fh, fw, 1);
             g.bias = h->V("head.spatial_upsampler.0.bias");
             g.out_hi = h1b; g.ldc = h->C2p;
-            CHK(mdpt_launch_gemm(g, c.s));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         HeadTailParams t;
         memset(&t, 0, sizeof(t));
@@ -847,7 +894,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool f
         t.bias = h->V("head.proj_1ch.0.bias"); t.head_w = h->V("head.proj_1ch.2.weight"); t.head_b = h->V("head.proj_1ch.2.bias");
         t.out = depth; t.out_dtype = depth_dtype; t.sigmoid = h->cfg.is_metric;
         t.B = p.B; t.Hi = fh; t.Wi = fw; t.Ho = p.H; t.Wo = p.W;
-        CHK(mdpt_launch_head_tail(t, h->C2p, c.s));
+        CHK(OPLC(mdpt_launch_head_tail, t, h->C2p, c.s));
         return 0;
     }
     CHK(materialise_fused());
@@ -862,7 +909,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool f
             q.out_f32 = c.at<float>(p.h1); q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
             const long tiles256 = ((long)p.B * fh * fw + 255) / 256;
             if (tiles256 >= (c.split ? 24 : 140) && mdpt_conv3h_supported(q)) {
-                CHK(mdpt_launch_conv3h(q, c.s));
+                CHK(OPLC(mdpt_launch_conv3h, q, c.s));
                 done = true;
             }
         }
@@ -871,11 +918,11 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool f
             as_conv(g, fh, fw, h->Cp, fh, fw, 1);
             g.bias = h->V("head.spatial_upsampler.0.bias");
             g.out_f32 = c.at<float>(p.h1); g.ldc = h->C2p;
-            CHK(mdpt_launch_gemm(g, c.s));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
     }
     Planes hu = c.pl(p.h1u);
-    CHK(mdpt_launch_upsample(c.at<float>(p.h1), hu.hi, hu.lo, nullptr, p.B, fh, fw, p.H, p.W, h->C2p, c.s));
+    CHK(OPLC(mdpt_launch_upsample, c.at<float>(p.h1), hu.hi, hu.lo, nullptr, p.B, fh, fw, p.H, p.W, h->C2p, c.s));
     {
         GemmParams g = base_params(c, h->M("head.proj_1ch.0.weight"), hu, p.B * p.H * p.W, h->C2p);
         as_conv(g, p.H, p.W, h->C2p, p.H, p.W, 1);
@@ -885,7 +932,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool f
         g.head_b = h->V("head.proj_1ch.2.bias");
         g.head_sigmoid = h->cfg.is_metric;
         g.head_out = depth; g.head_out_dtype = depth_dtype;
-        CHK(mdpt_launch_gemm(g, c.s));
+        CHK(OPLC(mdpt_launch_gemm, g, c.s));
     }
     return 0;
 }
@@ -939,7 +986,7 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     if (cfg->fusion_channels <= 0 || cfg->fusion_channels % 8) return fail(MDPT_E_INVALID, "fusion_channels must be a multiple of 8");
     if (cfg->patch_size_px <= 0 || cfg->patch_size_px % 2) return fail(MDPT_E_INVALID, "patch_size_px must be even (head scale = patch/8)");
     if (cfg->base_patch_grid_h <= 0 || cfg->base_patch_grid_w <= 0) return fail(MDPT_E_INVALID, "bad base patch grid");
-    if (cfg->precision != MDPT_PREC_BF16 && cfg->precision != MDPT_PREC_BF16X3) return fail(MDPT_E_INVALID, "unknown precision %d", cfg->precision);
+    if (cfg->precision < MDPT_PREC_BF16 || cfg->precision > MDPT_PREC_MIXED) return fail(MDPT_E_INVALID, "unknown precision %d", cfg->precision);
     for (int i = 0; i < 4; ++i)
         if (cfg->reassembly_features[i] <= 0 || cfg->reassembly_features[i] % 4) return fail(MDPT_E_INVALID, "reassembly_features[%d] must be a multiple of 4", i);
     mdpt_handle* h = new mdpt_handle();
@@ -956,7 +1003,13 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     h->gh_hidden_p = rup(h->gh_hidden, 64);
     for (int i = 0; i < 4; ++i) { h->sH[i] = cfg->swin_heads[i]; h->sL[i] = cfg->swin_layers[i]; h->spre[i] = cfg->swin_pretrained_window[i]; }
     h->swh = cfg->swin_window_h; h->sww = cfg->swin_window_w;
-    h->x3 = cfg->precision == MDPT_PREC_BF16X3;
+    h->f16 = cfg->precision == MDPT_PREC_FP16 || cfg->precision == MDPT_PREC_FP16X3 || cfg->precision == MDPT_PREC_MIXED;
+    {
+        int32_t mixed[NCLS];
+        mdpt_default_mixed_passes(mixed);
+        const bool all3 = cfg->precision == MDPT_PREC_BF16X3 || cfg->precision == MDPT_PREC_FP16X3;
+        for (int i = 0; i < NCLS; ++i) h->np[i] = cfg->precision == MDPT_PREC_MIXED ? mixed[i] : (all3 ? 3 : 1);
+    }
     h->gemm_tile = MDPT_TILE_AUTO;
     h->finalized = false;
     h->has_last = false;
@@ -971,6 +1024,46 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
 }
 
 void mdpt_destroy(mdpt_handle* h) { delete h; }
+
+// MDPT_PREC_MIXED: which classes pay for three passes. From the per-class error budget (profiles/r04_precision_budget.md; the CPU
+// emulation tests/precision_budget/emulate_operand_rounding.py reproduces it): the decoder's convs feed the depth map directly - no
+// LayerNorm or residual stream between them and the output averages their operand rounding away - and carry ~85 % of the squared error.
+void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]) {
+    for (int i = 0; i < NCLS; ++i) passes[i] = 1;
+    passes[CLS_PATCH] = 3;  // 0.13 % of the FLOPs
+    passes[CLS_REASM] = 3;
+    passes[CLS_FUSION] = 3;
+    passes[CLS_HEAD] = 3;
+}
+
+int mdpt_get_class_passes(const mdpt_handle* h, int32_t op_class, int32_t* passes) {
+    if (!h || !passes || op_class < 0 || op_class >= NCLS) return fail(MDPT_E_INVALID, "bad argument");
+    *passes = h->np[op_class];
+    return 0;
+}
+
+int mdpt_set_class_passes(mdpt_handle* h, int32_t op_class, int32_t passes) {
+    if (!h || op_class < 0 || op_class >= NCLS) return fail(MDPT_E_INVALID, "bad op class %d", op_class);
+    if (passes != 1 && passes != 3) return fail(MDPT_E_INVALID, "passes must be 1 or 3, got %d", passes);
+    if (h->np[op_class] == passes) return 0;
+    h->np[op_class] = passes;
+    // the packed-weight inventory depends on the pass counts (lo planes): rebuild it, keeping what was bound
+    std::vector<WeightSpec> bound = h->specs;
+    h->specs.clear(); h->spec_index.clear(); h->mats.clear(); h->mat_index.clear(); h->vecs.clear(); h->vec_index.clear();
+    build_inventory(h);
+    for (const WeightSpec& b : bound) {
+        auto it = h->spec_index.find(b.name);
+        if (it != h->spec_index.end()) { h->specs[it->second].ptr = b.ptr; h->specs[it->second].dtype = b.dtype; }
+    }
+    h->finalized = false;
+    h->has_last = false;
+    return 0;
+}
+
+int mdpt_debug_set_operand_format(int32_t fp16) {
+    g_debug_f16 = fp16 ? 1 : 0;
+    return 0;
+}
 
 int mdpt_num_weights(const mdpt_handle* h) { return h ? (int)h->specs.size() : 0; }
 
@@ -1021,10 +1114,10 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
     hipStream_t st = (hipStream_t)stream;
     char* base = (char*)packed_dev;
     CHK(hipMemsetAsync(base + h->zero_off, 0, 256, st));
-    h->zero_page = (bf16_t*)(base + h->zero_off);
+    h->zero_page = (op_t*)(base + h->zero_off);
     for (Mat& m : h->mats) {
-        m.hi = (bf16_t*)(base + m.off_hi);
-        m.lo = m.off_lo == SIZE_MAX ? nullptr : (bf16_t*)(base + m.off_lo);
+        m.hi = (op_t*)(base + m.off_hi);
+        m.lo = m.off_lo == SIZE_MAX ? nullptr : (op_t*)(base + m.off_lo);
         std::string src_name = m.src;
         int src_ld = 0, src_col0 = 0;
         const size_t kc = src_name.find("@kc32");
@@ -1036,7 +1129,7 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
         }
         const WeightSpec& sp = h->specs[h->spec_index.at(src_name)];
         const WeightSpec* rs = m.row_scale.empty() ? nullptr : &h->specs[h->spec_index.at(m.row_scale)];
-        CHK(mdpt_launch_pack_weight(sp.ptr, sp.dtype, m.hi, m.lo, m.kind, m.N, m.K, m.Np, m.Kp, m.ksz, st, src_ld, src_col0, rs ? rs->ptr : nullptr,
+        CHK(OPLH(mdpt_launch_pack_weight, sp.ptr, sp.dtype, m.hi, m.lo, m.kind, m.N, m.K, m.Np, m.Kp, m.ksz, st, src_ld, src_col0, rs ? rs->ptr : nullptr,
                                     rs ? rs->dtype : 0));
     }
     for (Vec& v : h->vecs) {
@@ -1048,19 +1141,19 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
             CHK(hipMemsetAsync(v.ptr, 0, (size_t)v.np * 4, st));
             const WeightSpec& qb = h->specs[h->spec_index.at(blk + ".attn.q_bias")];
             const WeightSpec& vb = h->specs[h->spec_index.at(blk + ".attn.v_bias")];
-            CHK(mdpt_launch_pad_copy_f32(qb.ptr, qb.dtype, v.ptr, Fq, Fq, st));
-            CHK(mdpt_launch_pad_copy_f32(vb.ptr, vb.dtype, v.ptr + 2 * Fq, Fq, Fq, st));
+            CHK(OPLH(mdpt_launch_pad_copy_f32, qb.ptr, qb.dtype, v.ptr, Fq, Fq, st));
+            CHK(OPLH(mdpt_launch_pad_copy_f32, vb.ptr, vb.dtype, v.ptr + 2 * Fq, Fq, Fq, st));
             continue;
         }
         const size_t ls = v.src.find("@ls");
         if (ls != std::string::npos) {  // bias * layer scale (see build_inventory)
             const WeightSpec& bs = h->specs[h->spec_index.at(v.src.substr(0, ls))];
             const WeightSpec& sc = h->specs[h->spec_index.at(v.scale)];
-            CHK(mdpt_launch_pad_copy_f32(bs.ptr, bs.dtype, v.ptr, v.n, v.np, st, sc.ptr, sc.dtype));
+            CHK(OPLH(mdpt_launch_pad_copy_f32, bs.ptr, bs.dtype, v.ptr, v.n, v.np, st, sc.ptr, sc.dtype));
             continue;
         }
         const WeightSpec& vs = h->specs[h->spec_index.at(v.src)];
-        CHK(mdpt_launch_pad_copy_f32(vs.ptr, vs.dtype, v.ptr, v.n, v.np, st));
+        CHK(OPLH(mdpt_launch_pad_copy_f32, vs.ptr, vs.dtype, v.ptr, v.n, v.np, st));
     }
     h->finalized = true;
     h->has_last = false;
@@ -1187,11 +1280,11 @@ int mdpt_patch_embed(mdpt_handle* h, const void* image_bchw, int32_t B, int32_t 
     CHK(make_ctx(h, B, He, We, workspace, workspace_bytes, stream, &c));
     const int Np = (H / h->P) * (W / h->P);
     Planes im = c.pl(c.p.im2col);
-    CHK(mdpt_launch_patchify(image_bchw, MDPT_DTYPE_F32, im.hi, im.lo, B, H, W, h->P, h->Kpatch, c.s));
+    CHK(OPLC(mdpt_launch_patchify, image_bchw, MDPT_DTYPE_F32, im.hi, im.lo, B, H, W, h->P, h->Kpatch, c.s));
     GemmParams g = base_params(c, h->M("patch_embed.proj.weight"), im, B * Np, h->Kpatch);
     g.bias = h->V("patch_embed.proj.bias");
     g.out_f32 = (float*)tokens_bnf; g.ldc = h->F;
-    CHK(mdpt_launch_gemm(g, c.s));
+    CHK(OPLC(mdpt_launch_gemm, g, c.s));
     h->has_last = false;
     return 0;
 }
@@ -1209,7 +1302,7 @@ int mdpt_encoder(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, 
         Planes xn = c.pl(c.p.sw.xn);
         CHK(hipMemcpyAsync(c.at<float>(c.p.sw.resid[0]), tokens_bnf, n * 4, hipMemcpyDeviceToDevice, c.s));
         CHK(swin_zero_pad_planes(c, B * gh * gw));
-        CHK(mdpt_launch_f32_to_planes((const float*)tokens_bnf, xn.hi, xn.lo, (size_t)B * gh * gw, h->F, rup(h->F, 64), c.s));
+        CHK(OPLC(mdpt_launch_f32_to_planes, (const float*)tokens_bnf, xn.hi, xn.lo, (size_t)B * gh * gw, h->F, rup(h->F, 64), c.s));
         CHK(run_encoder_swin(c, stage_out));
         h->has_last = false;
         return 0;
@@ -1220,13 +1313,13 @@ int mdpt_encoder(mdpt_handle* h, const void* tokens_bnf, int32_t B, int32_t gh, 
     if (rup(c.p.N, 8) > c.p.npad) return fail(MDPT_E_INVALID, "internal: plan too small");
     c.p.npad = rup(c.p.N, 8); c.p.npadv = rup(c.p.N, 64);
     if (is_beit(h)) {
-        CHK(mdpt_launch_memset_f32(c.at<float>(c.p.pos), 0.0f, (size_t)c.p.Np * h->F, c.s));
+        CHK(OPLC(mdpt_launch_memset_f32, c.at<float>(c.p.pos), 0.0f, (size_t)c.p.Np * h->F, c.s));
     } else {
         CHK(run_pos(c));
     }
-    CHK(mdpt_launch_init_tokens(c.at<float>(c.p.resid), h->V("imgencoder.cls_token"), is_beit(h) ? nullptr : h->V("imgencoder.posenc.cls_embedding"),
+    CHK(OPLC(mdpt_launch_init_tokens, c.at<float>(c.p.resid), h->V("imgencoder.cls_token"), is_beit(h) ? nullptr : h->V("imgencoder.posenc.cls_embedding"),
                                 B, c.p.N, c.p.npad, h->F, c.s));
-    CHK(mdpt_launch_tokens_to_resid((const float*)tokens_bnf, c.at<float>(c.p.pos), c.at<float>(c.p.resid), B, c.p.Np, c.p.npad, h->F, c.s));
+    CHK(OPLC(mdpt_launch_tokens_to_resid, (const float*)tokens_bnf, c.at<float>(c.p.pos), c.at<float>(c.p.resid), B, c.p.Np, c.p.npad, h->F, c.s));
     CHK(run_encoder(c, stage_out));
     h->has_last = false;
     return 0;
@@ -1257,7 +1350,7 @@ int mdpt_encoder_probe_blocks(mdpt_handle* h, const void* tokens_bnf, int32_t B,
         Planes xn = c.pl(c.p.sw.xn);
         CHK(hipMemcpyAsync(c.at<float>(c.p.sw.resid[0]), tokens_bnf, n * 4, hipMemcpyDeviceToDevice, c.s));
         CHK(swin_zero_pad_planes(c, B * gh * gw));
-        CHK(mdpt_launch_f32_to_planes((const float*)tokens_bnf, xn.hi, xn.lo, (size_t)B * gh * gw, h->F, rup(h->F, 64), c.s));
+        CHK(OPLC(mdpt_launch_f32_to_planes, (const float*)tokens_bnf, xn.hi, xn.lo, (size_t)B * gh * gw, h->F, rup(h->F, 64), c.s));
         CHK(run_encoder_swin(c, stage_out));
         h->has_last = false;
         return 0;
@@ -1268,13 +1361,13 @@ int mdpt_encoder_probe_blocks(mdpt_handle* h, const void* tokens_bnf, int32_t B,
     c.p.npad = rup(c.p.N, 8); c.p.npadv = rup(c.p.N, 64);
     c.attn_dump = attn_out; c.block_dump = block_out;
     if (is_beit(h)) {
-        CHK(mdpt_launch_memset_f32(c.at<float>(c.p.pos), 0.0f, (size_t)c.p.Np * h->F, c.s));
+        CHK(OPLC(mdpt_launch_memset_f32, c.at<float>(c.p.pos), 0.0f, (size_t)c.p.Np * h->F, c.s));
     } else {
         CHK(run_pos(c));
     }
-    CHK(mdpt_launch_init_tokens(c.at<float>(c.p.resid), h->V("imgencoder.cls_token"), is_beit(h) ? nullptr : h->V("imgencoder.posenc.cls_embedding"),
+    CHK(OPLC(mdpt_launch_init_tokens, c.at<float>(c.p.resid), h->V("imgencoder.cls_token"), is_beit(h) ? nullptr : h->V("imgencoder.posenc.cls_embedding"),
                                 B, c.p.N, c.p.npad, h->F, c.s));
-    CHK(mdpt_launch_tokens_to_resid((const float*)tokens_bnf, c.at<float>(c.p.pos), c.at<float>(c.p.resid), B, c.p.Np, c.p.npad, h->F, c.s));
+    CHK(OPLC(mdpt_launch_tokens_to_resid, (const float*)tokens_bnf, c.at<float>(c.p.pos), c.at<float>(c.p.resid), B, c.p.Np, c.p.npad, h->F, c.s));
     CHK(run_encoder(c, stage_out));
     h->has_last = false;
     return 0;
@@ -1308,22 +1401,22 @@ int mdpt_reassemble(mdpt_handle* h, const void* const stage_in[4], int32_t B, in
         for (int i = 0; i < 4; ++i) {
             Planes tp = c.pl(p.tap[i]);
             if (i == 0) CHK(swin_zero_pad_planes(c, B * gh * gw));
-            CHK(mdpt_launch_f32_to_planes((const float*)stage_in[i], tp.hi, tp.lo, (size_t)B * (gh >> i) * (gw >> i), h->hid[i], h->hidp[i], c.s));
+            CHK(OPLC(mdpt_launch_f32_to_planes, (const float*)stage_in[i], tp.hi, tp.lo, (size_t)B * (gh >> i) * (gw >> i), h->hid[i], h->hidp[i], c.s));
         }
         CHK(run_reassemble_swin(c));
         for (int i = 0; i < 4; ++i)
-            CHK(mdpt_launch_nhwc_to_nchw(c.at<float>(p.r_f32[i]), nullptr, nullptr, (float*)maps_out[i], B, gh >> i, gw >> i, h->C, h->Cp, c.s));
+            CHK(OPLC(mdpt_launch_nhwc_to_nchw, c.at<float>(p.r_f32[i]), nullptr, nullptr, (float*)maps_out[i], B, gh >> i, gw >> i, h->C, h->Cp, c.s));
         h->has_last = false;
         return 0;
     }
     for (int i = 0; i < 4; ++i) {
         Planes tp = c.pl(p.tap[i]);
-        CHK(mdpt_launch_tokens_import((const float*)stage_in[i], tp.hi, tp.lo, B, p.N, p.npad, h->F, c.s));
+        CHK(OPLC(mdpt_launch_tokens_import, (const float*)stage_in[i], tp.hi, tp.lo, B, p.N, p.npad, h->F, c.s));
     }
     CHK(run_reassemble(c));
     const int sh[4] = {4 * gh, 2 * gh, gh, gh / 2}, sw[4] = {4 * gw, 2 * gw, gw, gw / 2};
     for (int i = 0; i < 4; ++i)
-        CHK(mdpt_launch_nhwc_to_nchw(c.at<float>(p.r_f32[i]), nullptr, nullptr, (float*)maps_out[i], B, sh[i], sw[i], h->C, h->Cp, c.s));
+        CHK(OPLC(mdpt_launch_nhwc_to_nchw, c.at<float>(p.r_f32[i]), nullptr, nullptr, (float*)maps_out[i], B, sh[i], sw[i], h->C, h->Cp, c.s));
     h->has_last = false;
     return 0;
 }
@@ -1338,12 +1431,12 @@ int mdpt_fusion(mdpt_handle* h, const void* const maps_in[4], int32_t B, int32_t
     for (int i = 0; i < 4; ++i) {
         if (!maps_in[i]) return fail(MDPT_E_INVALID, "null map %d", i);
         Planes rb = c.pl(p.r_bf[i]);
-        CHK(mdpt_launch_nchw_to_nhwc((const float*)maps_in[i], c.at<float>(p.r_f32[i]), rb.hi, rb.lo, 1, B, sh[i], sw[i], h->C, h->Cp, c.s));
+        CHK(OPLC(mdpt_launch_nchw_to_nhwc, (const float*)maps_in[i], c.at<float>(p.r_f32[i]), rb.hi, rb.lo, 1, B, sh[i], sw[i], h->C, h->Cp, c.s));
     }
     CHK(run_fusion(c));
     float* tmp = c.at<float>(p.scratch);
-    CHK(mdpt_launch_upsample(c.at<float>(p.flo[0]), nullptr, nullptr, tmp, B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
-    CHK(mdpt_launch_nhwc_to_nchw(tmp, nullptr, nullptr, (float*)fused_out, B, 8 * gh, 8 * gw, h->C, h->Cp, c.s));
+    CHK(OPLC(mdpt_launch_upsample, c.at<float>(p.flo[0]), nullptr, nullptr, tmp, B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
+    CHK(OPLC(mdpt_launch_nhwc_to_nchw, tmp, nullptr, nullptr, (float*)fused_out, B, 8 * gh, 8 * gw, h->C, h->Cp, c.s));
     h->has_last = false;
     return 0;
 }
@@ -1374,14 +1467,14 @@ int mdpt_fusion_block(mdpt_handle* h, int32_t index, const void* reasm_in, const
     const std::string blk = pb;
     const size_t elems = (size_t)B * sh * sw * h->Cp;
     Planes rb = c.pl(p.r_bf[i]);
-    CHK(mdpt_launch_nchw_to_nhwc((const float*)reasm_in, c.at<float>(p.r_f32[i]), rb.hi, rb.lo, 1, B, sh, sw, h->C, h->Cp, c.s));
+    CHK(OPLC(mdpt_launch_nchw_to_nhwc, (const float*)reasm_in, c.at<float>(p.r_f32[i]), rb.hi, rb.lo, 1, B, sh, sw, h->C, h->Cp, c.s));
     const float* x_f32 = c.at<float>(p.r_f32[i]);
     Planes x_bf = rb;
     if (i != 3) {
         // skip term of the reassembly RCU plus the previous fusion output: (r + prior), added in the second conv's epilogue
         float* skip = c.at<float>(p.scratch);
-        CHK(mdpt_launch_nchw_to_nhwc((const float*)prior_in, skip, nullptr, nullptr, 0, B, sh, sw, h->C, h->Cp, c.s));
-        CHK(mdpt_launch_add_f32(skip, c.at<float>(p.r_f32[i]), elems, c.s));
+        CHK(OPLC(mdpt_launch_nchw_to_nhwc, (const float*)prior_in, skip, nullptr, nullptr, 0, B, sh, sw, h->C, h->Cp, c.s));
+        CHK(OPLC(mdpt_launch_add_f32, skip, c.at<float>(p.r_f32[i]), elems, c.s));
         Planes a1 = c.pl(p.a1[i]);
         CHK(rcu_conv(c, blk + ".conv_reassembly." + rcu_seq(h) + ".1", rb, sh, sw, nullptr, nullptr, 0, 0, nullptr, a1, 1));
         x_bf = c.pl(p.x_bf[i]);
@@ -1395,11 +1488,11 @@ int mdpt_fusion_block(mdpt_handle* h, int32_t index, const void* reasm_in, const
         GemmParams g = base_params(c, h->M(blk + "." + proj_seq(h) + ".2.weight"), b2, B * sh * sw, h->Cp);
         g.bias = h->V(blk + "." + proj_seq(h) + ".2.bias");
         g.out_f32 = c.at<float>(p.flo[i]); g.ldc = h->Cp;
-        CHK(mdpt_launch_gemm(g, c.s));
+        CHK(OPLC(mdpt_launch_gemm, g, c.s));
     }
     float* tmp = c.at<float>(p.scratch);
-    CHK(mdpt_launch_upsample(c.at<float>(p.flo[i]), nullptr, nullptr, tmp, B, sh, sw, 2 * sh, 2 * sw, h->Cp, c.s));
-    CHK(mdpt_launch_nhwc_to_nchw(tmp, nullptr, nullptr, (float*)out, B, 2 * sh, 2 * sw, h->C, h->Cp, c.s));
+    CHK(OPLC(mdpt_launch_upsample, c.at<float>(p.flo[i]), nullptr, nullptr, tmp, B, sh, sw, 2 * sh, 2 * sw, h->Cp, c.s));
+    CHK(OPLC(mdpt_launch_nhwc_to_nchw, tmp, nullptr, nullptr, (float*)out, B, 2 * sh, 2 * sw, h->C, h->Cp, c.s));
     h->has_last = false;
     return 0;
 }
@@ -1410,7 +1503,7 @@ int mdpt_head(mdpt_handle* h, const void* fused_in, int32_t B, int32_t gh, int32
     Ctx c;
     CHK(make_ctx(h, B, gh * h->Pv, gw * h->Pv, workspace, workspace_bytes, stream, &c));
     Planes fu = c.pl(c.p.fused);
-    CHK(mdpt_launch_nchw_to_nhwc((const float*)fused_in, nullptr, fu.hi, fu.lo, 0, B, 8 * gh, 8 * gw, h->C, h->Cp, c.s));
+    CHK(OPLC(mdpt_launch_nchw_to_nhwc, (const float*)fused_in, nullptr, fu.hi, fu.lo, 0, B, 8 * gh, 8 * gw, h->C, h->Cp, c.s));
     CHK(run_head(c, (float*)depth_bhw));
     h->has_last = false;
     return 0;
@@ -1429,18 +1522,18 @@ int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspac
         CHK(hipMemcpyAsync(out_f32, c.at<float>(p.sw.resid[which]), n * 4, hipMemcpyDeviceToDevice, c.s));
     } else if (which >= 0 && which < 4) {
         Planes tp = c.pl(p.tap[which]);
-        CHK(mdpt_launch_tokens_export(tp.hi, tp.lo, nullptr, (float*)out_f32, p.B, p.N, p.npad, h->F, 0, c.s));
+        CHK(OPLC(mdpt_launch_tokens_export, tp.hi, tp.lo, nullptr, (float*)out_f32, p.B, p.N, p.npad, h->F, 0, c.s));
     } else if (which >= 4 && which < 8) {
         const int i = which - 4;
-        CHK(mdpt_launch_nhwc_to_nchw(c.at<float>(p.r_f32[i]), nullptr, nullptr, (float*)out_f32, p.B, sh[i], sw[i], h->C, h->Cp, c.s));
+        CHK(OPLC(mdpt_launch_nhwc_to_nchw, c.at<float>(p.r_f32[i]), nullptr, nullptr, (float*)out_f32, p.B, sh[i], sw[i], h->C, h->Cp, c.s));
     } else if (which == 8) {
         float* tmp = c.at<float>(p.scratch);
         if (head_upsamples_bf16(h)) {  // the forward left the last projection as a bf16 map (run_fusion(c, true)): same upsample as the head's
-            CHK(mdpt_launch_upsample_bf16(c.at<bf16_t>(p.flo[0]), (bf16_t*)tmp, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
-            CHK(mdpt_launch_nhwc_to_nchw(nullptr, (const bf16_t*)tmp, nullptr, (float*)out_f32, p.B, 8 * p.gh, 8 * p.gw, h->C, h->Cp, c.s));
+            CHK(OPLC(mdpt_launch_upsample_bf16, c.at<op_t>(p.flo[0]), (op_t*)tmp, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
+            CHK(OPLC(mdpt_launch_nhwc_to_nchw, nullptr, (const op_t*)tmp, nullptr, (float*)out_f32, p.B, 8 * p.gh, 8 * p.gw, h->C, h->Cp, c.s));
         } else {
-            CHK(mdpt_launch_upsample(c.at<float>(p.flo[0]), nullptr, nullptr, tmp, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
-            CHK(mdpt_launch_nhwc_to_nchw(tmp, nullptr, nullptr, (float*)out_f32, p.B, 8 * p.gh, 8 * p.gw, h->C, h->Cp, c.s));
+            CHK(OPLC(mdpt_launch_upsample, c.at<float>(p.flo[0]), nullptr, nullptr, tmp, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
+            CHK(OPLC(mdpt_launch_nhwc_to_nchw, tmp, nullptr, nullptr, (float*)out_f32, p.B, 8 * p.gh, 8 * p.gw, h->C, h->Cp, c.s));
         }
     } else {
         return fail(MDPT_E_INVALID, "unknown tap %d", which);
@@ -1456,7 +1549,7 @@ int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void*
         return fail(MDPT_E_UNSUPPORTED, "interpolation %d: antialiased resize exists for bilinear and bicubic only (as in torch)", interpolation);
     if (in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) return fail(MDPT_E_INVALID, "bad image size %dx%d -> %dx%d", in_h, in_w, out_h, out_w);
     const float inv_std[3] = {1.0f / rgb_std[0], 1.0f / rgb_std[1], 1.0f / rgb_std[2]};  // patch_embed.py:38-39,62
-    CHK(mdpt_launch_prepare_image((const unsigned char*)bgr_u8_hwc, (float*)out_chw_f32, in_h, in_w, out_h, out_w, rgb_mean, inv_std, interpolation, (hipStream_t)stream));
+    CHK(mdpt_launch_prepare_image_bf16((const unsigned char*)bgr_u8_hwc, (float*)out_chw_f32, in_h, in_w, out_h, out_w, rgb_mean, inv_std, interpolation, (hipStream_t)stream));
     return 0;
 }
 
@@ -1504,7 +1597,7 @@ int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_
     const size_t* planes = nullptr;
     size_t f32_off = SIZE_MAX, elems = 0;
     size_t bf16_only[2] = {SIZE_MAX, SIZE_MAX};  // a bf16 map without a lo plane
-    const bool bf16_head = !h->x3 && mdpt_head_tail_supported(h->C2p) && mdpt_head_tail_scale_ok(8 * p.gh, 8 * p.gw, p.H, p.W);
+    const bool bf16_head = !h->x3c(CLS_HEAD) && mdpt_head_tail_supported(h->C2p) && mdpt_head_tail_scale_ok(8 * p.gh, 8 * p.gw, p.H, p.W);
     const size_t px[4] = {(size_t)16 * p.Np, (size_t)4 * p.Np, (size_t)p.Np, (size_t)p.Np / 4};
     if (n == "im2col") { planes = p.im2col; elems = (size_t)p.B * p.Np * h->Kpatch; }
     else if (n == "pos") { f32_off = p.pos; elems = (size_t)p.Np * h->F; }
@@ -1527,7 +1620,7 @@ int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_
     else if (n == "fused") {
         // bf16 mode: the forward may have folded the x2 upsample into the head's first conv; rebuild the map the head saw (same arithmetic)
         if (head_upsamples_bf16(h))
-            CHK(mdpt_launch_upsample_bf16(c.at<bf16_t>(p.flo[0]), c.pl(p.fused).hi, p.B, 4 * p.gh, 4 * p.gw, 8 * p.gh, 8 * p.gw, h->Cp, c.s));
+            CHK(OPLC(mdpt_launch_upsample_bf16, c.at<op_t>(p.flo[0]), c.pl(p.fused).hi, p.B, 4 * p.gh, 4 * p.gw, 8 * p.gh, 8 * p.gw, h->Cp, c.s));
         planes = p.fused; elems = (size_t)p.B * 64 * p.Np * h->Cp;
     }
     else if (n == "u0") { planes = p.u0; elems = (size_t)p.B * px[0] * h->hidp[0]; }
@@ -1547,9 +1640,9 @@ int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_
     // reuse the token exporter as a flat converter: B=1, N=npad=elems/F' with F'=4 keeps indices simple
     if (planes) {
         Planes pl = c.pl(planes);
-        CHK(mdpt_launch_tokens_export(pl.hi, pl.lo, nullptr, (float*)out_f32, 1, (int)(elems / 4), (int)(elems / 4), 4, 0, c.s));
+        CHK(OPLC(mdpt_launch_tokens_export, pl.hi, pl.lo, nullptr, (float*)out_f32, 1, (int)(elems / 4), (int)(elems / 4), 4, 0, c.s));
     } else {
-        CHK(mdpt_launch_tokens_export(nullptr, nullptr, c.at<float>(f32_off), (float*)out_f32, 1, (int)(elems / 4), (int)(elems / 4), 4, 0, c.s));
+        CHK(OPLC(mdpt_launch_tokens_export, nullptr, nullptr, c.at<float>(f32_off), (float*)out_f32, 1, (int)(elems / 4), (int)(elems / 4), 4, 0, c.s));
     }
     return 0;
 }
@@ -1560,12 +1653,12 @@ int mdpt_debug_gemm(const void* a_bf16, const void* w_bf16, void* out_f32, void*
     if (!a_bf16 || !w_bf16 || (!out_f32 && !out_bf16)) return fail(MDPT_E_INVALID, "null argument");
     GemmParams g;
     memset(&g, 0, sizeof(g));
-    g.A_hi = (const bf16_t*)a_bf16; g.W_hi = (const bf16_t*)w_bf16;
+    g.A_hi = (const op_t*)a_bf16; g.W_hi = (const op_t*)w_bf16;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.npass = 1;
-    g.zero_page = (const bf16_t*)w_bf16;
+    g.zero_page = (const op_t*)w_bf16;
     g.amode = MDPT_A_DENSE; g.ekind = MDPT_E_GENERIC; g.tile = tile & 255;
     g.act = (tile >> 8) & 3;  // bits 8-9 of `tile`: epilogue activation (MDPT_ACT_*), for epilogue-cost measurements
-    g.out_f32 = (float*)out_f32; g.out_hi = (bf16_t*)out_bf16; g.ldc = N; g.ldr = N;
+    g.out_f32 = (float*)out_f32; g.out_hi = (op_t*)out_bf16; g.ldc = N; g.ldr = N;
     g.dbg_times = (unsigned long long*)dbg_times;
     if ((tile >> 10) & 1) {  // bit 10: in-place residual epilogue (proj / fc2 form); bias and gamma are read from the out_bf16 buffer
         if (!out_f32 || !out_bf16) return fail(MDPT_E_INVALID, "residual mode needs both output buffers");
@@ -1575,7 +1668,7 @@ int mdpt_debug_gemm(const void* a_bf16, const void* w_bf16, void* out_f32, void*
         if (!out_f32 || !out_bf16) return fail(MDPT_E_INVALID, "residual mode needs both output buffers");
         g.bias = (const float*)out_bf16; g.resid = (const float*)out_f32; g.out_hi = nullptr; g.acc_init = 1;
     }
-    for (int i = 0; i < iters; ++i) CHK(mdpt_launch_gemm(g, (hipStream_t)stream));
+    for (int i = 0; i < iters; ++i) CHK(OPLG(mdpt_launch_gemm, g, (hipStream_t)stream));
     return 0;
 }
 
@@ -1589,7 +1682,7 @@ int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void*
     if (Cout != 256 && Cout != 128) return fail(MDPT_E_INVALID, "Cout must be 256 or 128");
     if ((in_lo_bf16 != nullptr) != (w_lo_bf16 != nullptr)) return fail(MDPT_E_INVALID, "bf16x3 needs the lo planes of input and weights");
     if (!in_bf16 || !w_packed_bf16 || (!out_bf16 && !out_f32)) return fail(MDPT_E_INVALID, "null argument");
-    static bf16_t* zero_page = nullptr;  // test hook only: allocated once, never freed
+    static op_t* zero_page = nullptr;  // test hook only: allocated once, never freed
     if (!zero_page) {
         if (hipMalloc((void**)&zero_page, 256) != hipSuccess || hipMemset(zero_page, 0, 256) != hipSuccess) return fail(MDPT_E_STATE, "zero page allocation failed");
     }
@@ -1601,51 +1694,51 @@ int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void*
         if (path == 2) {
             Conv3hParams q;
             memset(&q, 0, sizeof(q));
-            q.up_in = (const bf16_t*)in_bf16; q.Hs = Hu; q.Ws = Wu; q.w = (const bf16_t*)w_packed_bf16; q.bias = (const float*)bias_f32;
-            q.out_bf = (bf16_t*)out_bf16; q.B = B; q.H = H; q.W = W; q.Cin = Cin; q.Cout = 128;
+            q.up_in = (const op_t*)in_bf16; q.Hs = Hu; q.Ws = Wu; q.w = (const op_t*)w_packed_bf16; q.bias = (const float*)bias_f32;
+            q.out_bf = (op_t*)out_bf16; q.B = B; q.H = H; q.W = W; q.Cin = Cin; q.Cout = 128;
             q.dbg_times = (unsigned long long*)dbg_times;
             if (!mdpt_conv3h_supported(q)) return fail(MDPT_E_UNSUPPORTED, "conv3h does not cover this combination");
-            for (int i = 0; i < iters; ++i) CHK(mdpt_launch_conv3h(q, (hipStream_t)stream));
+            for (int i = 0; i < iters; ++i) CHK(OPLG(mdpt_launch_conv3h, q, (hipStream_t)stream));
             return 0;
         }
         if (!out_lo_bf16) return fail(MDPT_E_INVALID, "path 3 needs a scratch map in out_lo_bf16");
         for (int i = 0; i < iters; ++i) {
-            CHK(mdpt_launch_upsample_bf16((const bf16_t*)in_bf16, (bf16_t*)out_lo_bf16, B, Hu, Wu, H, W, Cin, (hipStream_t)stream));
+            CHK(OPLG(mdpt_launch_upsample_bf16, (const op_t*)in_bf16, (op_t*)out_lo_bf16, B, Hu, Wu, H, W, Cin, (hipStream_t)stream));
             GemmParams g;
             memset(&g, 0, sizeof(g));
-            g.A_hi = (const bf16_t*)out_lo_bf16; g.W_hi = (const bf16_t*)w_packed_bf16;
+            g.A_hi = (const op_t*)out_lo_bf16; g.W_hi = (const op_t*)w_packed_bf16;
             g.M = B * H * W; g.N = 128; g.K = 9 * Cin; g.lda = Cin; g.npass = 1; g.zero_page = zero_page;
             g.amode = MDPT_A_CONV3; g.ekind = MDPT_E_GENERIC; g.tile = tile;
             g.Hi = H; g.Wi = W; g.Cin = Cin; g.Ho = H; g.Wo = W; g.cstride = 1;
-            g.bias = (const float*)bias_f32; g.out_hi = (bf16_t*)out_bf16; g.ldc = 128; g.ldr = 128;
-            CHK(mdpt_launch_gemm(g, (hipStream_t)stream));
+            g.bias = (const float*)bias_f32; g.out_hi = (op_t*)out_bf16; g.ldc = 128; g.ldr = 128;
+            CHK(OPLG(mdpt_launch_gemm, g, (hipStream_t)stream));
         }
         return 0;
     }
     if (path == 1) {
         Conv3hParams q;
         memset(&q, 0, sizeof(q));
-        q.in = (const bf16_t*)in_bf16; q.w = (const bf16_t*)w_packed_bf16; q.bias = (const float*)bias_f32; q.skip = (const float*)skip_f32;
-        q.in_lo = (const bf16_t*)in_lo_bf16; q.w_lo = (const bf16_t*)w_lo_bf16; q.out_bf_lo = (bf16_t*)out_lo_bf16;
-        q.up_src = (const float*)up_f32; q.Hu = Hu; q.Wu = Wu; q.out_f32 = (float*)out_f32; q.out_bf = (bf16_t*)out_bf16; q.relu_bf = relu_bf16;
+        q.in = (const op_t*)in_bf16; q.w = (const op_t*)w_packed_bf16; q.bias = (const float*)bias_f32; q.skip = (const float*)skip_f32;
+        q.in_lo = (const op_t*)in_lo_bf16; q.w_lo = (const op_t*)w_lo_bf16; q.out_bf_lo = (op_t*)out_lo_bf16;
+        q.up_src = (const float*)up_f32; q.Hu = Hu; q.Wu = Wu; q.out_f32 = (float*)out_f32; q.out_bf = (op_t*)out_bf16; q.relu_bf = relu_bf16;
         q.B = B; q.H = H; q.W = W; q.Cin = Cin; q.Cout = Cout; q.zero_page = zero_page;
         q.dbg_times = (unsigned long long*)dbg_times;
         if (!mdpt_conv3h_supported(q)) return fail(MDPT_E_UNSUPPORTED, "conv3h does not cover this combination");
-        for (int i = 0; i < iters; ++i) CHK(mdpt_launch_conv3h(q, (hipStream_t)stream));
+        for (int i = 0; i < iters; ++i) CHK(OPLG(mdpt_launch_conv3h, q, (hipStream_t)stream));
         return 0;
     }
     GemmParams g;
     memset(&g, 0, sizeof(g));
-    g.A_hi = (const bf16_t*)in_bf16; g.W_hi = (const bf16_t*)w_packed_bf16; g.A_lo = (const bf16_t*)in_lo_bf16; g.W_lo = (const bf16_t*)w_lo_bf16;
+    g.A_hi = (const op_t*)in_bf16; g.W_hi = (const op_t*)w_packed_bf16; g.A_lo = (const op_t*)in_lo_bf16; g.W_lo = (const op_t*)w_lo_bf16;
     g.M = B * H * W; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.npass = in_lo_bf16 ? 3 : 1;
     g.zero_page = zero_page;
     g.amode = MDPT_A_CONV3; g.ekind = MDPT_E_GENERIC; g.tile = tile;
     g.Hi = H; g.Wi = W; g.Cin = Cin; g.Ho = H; g.Wo = W; g.cstride = 1;
     g.bias = (const float*)bias_f32; g.resid = (const float*)skip_f32; g.ldr = Cout;
     g.up_src = (const float*)up_f32; g.Hu = Hu; g.Wu = Wu;
-    g.out_f32 = (float*)out_f32; g.out_hi = (bf16_t*)out_bf16; g.out_lo = (bf16_t*)out_lo_bf16; g.relu_bf16 = relu_bf16; g.ldc = Cout;
+    g.out_f32 = (float*)out_f32; g.out_hi = (op_t*)out_bf16; g.out_lo = (op_t*)out_lo_bf16; g.relu_bf16 = relu_bf16; g.ldc = Cout;
     g.dbg_times = (unsigned long long*)dbg_times;
-    for (int i = 0; i < iters; ++i) CHK(mdpt_launch_gemm(g, (hipStream_t)stream));
+    for (int i = 0; i < iters; ++i) CHK(OPLG(mdpt_launch_gemm, g, (hipStream_t)stream));
     return 0;
 }
 
@@ -1656,9 +1749,9 @@ int mdpt_debug_attention(const void* q_bf16, const void* k_bf16, const void* vt_
     if (!q_bf16 || !k_bf16 || !vt_bf16 || !out_bf16) return fail(MDPT_E_INVALID, "null argument");
     AttnParams a;
     memset(&a, 0, sizeof(a));
-    a.q_hi = (const bf16_t*)q_bf16; a.k_hi = (const bf16_t*)k_bf16; a.vt_hi = (const bf16_t*)vt_bf16; a.out_hi = (bf16_t*)out_bf16;
+    a.q_hi = (const op_t*)q_bf16; a.k_hi = (const op_t*)k_bf16; a.vt_hi = (const op_t*)vt_bf16; a.out_hi = (op_t*)out_bf16;
     a.B = B; a.heads = heads; a.N = N; a.npad = npad; a.npadv = npadv; a.F = heads * 64;
-    for (int i = 0; i < iters; ++i) CHK(mdpt_launch_attention(a, (hipStream_t)stream));
+    for (int i = 0; i < iters; ++i) CHK(OPLG(mdpt_launch_attention, a, (hipStream_t)stream));
     return 0;
 }
 

@@ -5,7 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-typedef __bf16 bf16_t;
+#include "op_types.h"
 
 // element types of tensors that cross the C ABI (= MDPT_DTYPE_* of include/mdpt.h)
 enum { MDPT_DT_F32 = 0, MDPT_DT_BF16 = 1, MDPT_DT_F16 = 2 };
@@ -21,12 +21,12 @@ enum { MDPT_TILE_AUTO = 0, MDPT_TILE_128x128 = 1, MDPT_TILE_256x256 = 2, MDPT_TI
 
 struct GemmParams {
     // operands
-    const bf16_t* A_hi; const bf16_t* A_lo;   // activations, row stride lda (elements)
-    const bf16_t* W_hi; const bf16_t* W_lo;   // weights [N][K]
+    const op_t* A_hi; const op_t* A_lo;   // activations, row stride lda (elements)
+    const op_t* W_hi; const op_t* W_lo;   // weights [N][K]
     int M, N, K;                              // K % 64 == 0 (conv: K = 9 * Cin)
     int lda;
     int npass;                                // 1 = bf16, 3 = bf16x3 (A_lo*W_hi + A_hi*W_lo + A_hi*W_hi)
-    const bf16_t* zero_page;                  // >= 256 B of zeros (source for padded conv taps)
+    const op_t* zero_page;                  // >= 256 B of zeros (source for padded conv taps)
     int amode, ekind, tile;
     // A_TOKENS: logical row m = (b, p) reads source row b*tok_stride + 1 + p (skips the cls row)
     int tok_np, tok_stride;
@@ -37,11 +37,11 @@ struct GemmParams {
     int bias_img_stride;                      // != 0: bias row (m / tok_np) * stride is used (per-image bias, BEiT readout)
     const float* up_src; int Hu, Wu;          // fp32 NHWC [B,Hu,Wu,N] added through x2 bilinear (align_corners)
     int act;
-    float* out_f32; bf16_t* out_hi; bf16_t* out_lo; int ldc;
+    float* out_f32; op_t* out_hi; op_t* out_lo; int ldc;
     int relu_bf16;                            // apply ReLU to the bf16 planes only (fp32 copy stays raw)
     int acc_init;                             // 1: accumulators start at resid[m,n] (resid == out_f32, gamma folded into W / bias): out = (resid + A W^T) + bias
     // E_QKV: scatter to head-major Q (pre-scaled), K and transposed V
-    bf16_t* q_hi; bf16_t* q_lo; bf16_t* k_hi; bf16_t* k_lo; bf16_t* vt_hi; bf16_t* vt_lo;
+    op_t* q_hi; op_t* q_lo; op_t* k_hi; op_t* k_lo; op_t* vt_hi; op_t* vt_lo;
     int F, heads, npad, npadv; float qscale;
     // E_SWQKV, the SwinV2 QKV projection (its own kernel; 8-phase tile only, 2F % 256 == 0): Q / K column tiles are written as the window
     // attention's operands - q / max(|q|, 1e-12) * logit_scale[h], k / max(|k|, 1e-12), heads of 32, row (img*swin_img_rows +
@@ -61,8 +61,6 @@ struct GemmParams {
     unsigned long long* dbg_times;
 };
 
-int mdpt_launch_gemm(const GemmParams& p, hipStream_t stream);   // returns hipError_t as int
-bool mdpt_gemm_resolves_to_pp256(const GemmParams& p);          // would mdpt_launch_gemm run the 8-phase 256x256 kernel for p?
 
 // ------------------------------------------------------------------------------------------------
 // halo-staged 3x3 convolution, stride 1, pad 1, Cout = 256 (conv3h.hip): the 256-channel convs of the DPT decoder at large batch.
@@ -70,35 +68,33 @@ bool mdpt_gemm_resolves_to_pp256(const GemmParams& p);          // would mdpt_la
 // Same K order (MDPT_PACK_CONV3 weights) and epilogue arithmetic as the MDPT_A_CONV3 path of mdpt_launch_gemm (generic epilogue, resid = skip).
 // ------------------------------------------------------------------------------------------------
 struct Conv3hParams {
-    const bf16_t* in;          // NHWC [B, H, W, Cin] bf16 (hi plane), Cin % 128 == 0
-    const bf16_t* up_in; int Hs, Ws;  // instead of `in` (Cout = 128, bf16 only): bf16 NHWC [B, Hs, Ws, Cin]; the conv input is its bilinear
+    const op_t* in;          // NHWC [B, H, W, Cin] bf16 (hi plane), Cin % 128 == 0
+    const op_t* up_in; int Hs, Ws;  // instead of `in` (Cout = 128, bf16 only): bf16 NHWC [B, Hs, Ws, Cin]; the conv input is its bilinear
                                // (align_corners) upsample to H x W, interpolated inside the kernel (up_bf16.h arithmetic)
-    const bf16_t* in_lo;       // lo plane of the input: non-null selects the bf16x3 mode (then w_lo and, with out_bf, out_bf_lo are required)
-    const bf16_t* w;           // [Cout][9 * Cin] bf16, MDPT_PACK_CONV3 order (hi plane)
-    const bf16_t* w_lo;
+    const op_t* in_lo;       // lo plane of the input: non-null selects the bf16x3 mode (then w_lo and, with out_bf, out_bf_lo are required)
+    const op_t* w;           // [Cout][9 * Cin] bf16, MDPT_PACK_CONV3 order (hi plane)
+    const op_t* w_lo;
     const float* bias;         // [Cout] or null
     const float* skip;         // fp32 NHWC [B, H, W, 256] or null
     const float* up_src; int Hu, Wu;  // fp32 NHWC [B, Hu, Wu, 256] or null
     float* out_f32;            // fp32 NHWC [B, H, W, 256] or null
-    bf16_t* out_bf;            // bf16 NHWC [B, H, W, Cout] (hi plane); Cout = 128 may write the fp32 map alone instead
-    bf16_t* out_bf_lo;
+    op_t* out_bf;            // bf16 NHWC [B, H, W, Cout] (hi plane); Cout = 128 may write the fp32 map alone instead
+    op_t* out_bf_lo;
     int relu_bf;
     int B, H, W, Cin;
     int Cout;                  // 256 (every epilogue form) or 128 (bias-only bf16 output: the head's first conv)
-    const bf16_t* zero_page;   // unused (out-of-image pixels are staged as zeros by the buffer bounds check)
+    const op_t* zero_page;   // unused (out-of-image pixels are staged as zeros by the buffer bounds check)
     unsigned long long* dbg_times;  // test hook: per-workgroup s_memtime stamps [start, first barrier, loop done, stores acknowledged, stores issued, XCC id]
     int dbg_flags;                  // set by the launcher from MDPT_CONV3H_DBG (timing experiments that skip parts of the loop; results are wrong)
 };
-bool mdpt_conv3h_supported(const Conv3hParams& p);
-int mdpt_launch_conv3h(const Conv3hParams& p, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // fused multi-head attention (head dim 64), Q/K head-major [B,H,npad,64], Vt [B,H,64,npadv]
 // ------------------------------------------------------------------------------------------------
 struct AttnParams {
-    const bf16_t* q_hi; const bf16_t* q_lo; const bf16_t* k_hi; const bf16_t* k_lo;
-    const bf16_t* vt_hi; const bf16_t* vt_lo;
-    bf16_t* out_hi; bf16_t* out_lo;           // [B*npad, F] token-major, column h*64 + d
+    const op_t* q_hi; const op_t* q_lo; const op_t* k_hi; const op_t* k_lo;
+    const op_t* vt_hi; const op_t* vt_lo;
+    op_t* out_hi; op_t* out_lo;           // [B*npad, F] token-major, column h*64 + d
     int B, heads, N, npad, npadv, F;
     int x3;
     // additive relative-position bias (BEiT): per-head extended LUT [heads][bias_elen] fp32, s[q][k] += lut[tq[q] - tk[k]]
@@ -111,83 +107,28 @@ struct AttnParams {
     int allow_split_kv;  // latency mode: small launches may split the key loop over the waves (not batch-invariant in the last bit)
     int tail_last;  // set by the launcher: dispatch nearly empty last q-tiles after all full ones
 };
-int mdpt_launch_attention(const AttnParams& p, hipStream_t stream);
-// diagnostic: explicit softmax(q k^T + bias [+ shift mask]) as fp32 [B, heads, N, N] from the same Q / K planes (head dim 64 families;
-// SwinV2 windows: B = images * windows, head dim 32)
-int mdpt_launch_attn_weights(const AttnParams& p, float* out_bhnn, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // bandwidth-bound helpers
 // ------------------------------------------------------------------------------------------------
-// LayerNorm over the last dim (eps 1e-6): fp32 rows -> bf16 hi (+lo) (+ optional fp32 copy)
-int mdpt_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* out_hi, bf16_t* out_lo,
-                          float* out_f32, int rows, int F, hipStream_t stream);
-// NCHW image (fp32 / bf16 / fp16: img_dtype) -> im2col rows [B*Np, Kp] bf16 hi (+lo), k = c*P*P + ky*P + kx, zero padded to Kp
-int mdpt_launch_patchify(const void* img, int img_dtype, bf16_t* out_hi, bf16_t* out_lo, int B, int H, int W, int P, int Kp,
-                         hipStream_t stream);
-// bicubic (A=-0.75, align_corners=False) resize of the [Gh*Gw, F] position grid to [gh*gw, F]
-int mdpt_launch_posembed(const float* base, float* out, int Gh, int Gw, int gh, int gw, int F, hipStream_t stream);
-// residual-stream init: cls rows = cls_token + cls_embedding, pad rows = 0 (patch rows are written by E_PATCH)
-int mdpt_launch_init_tokens(float* resid, const float* cls_token, const float* cls_embed, int B, int N, int npad, int F,
-                            hipStream_t stream);
-// zero the pad columns [N, npadv) of the transposed-V planes
-int mdpt_launch_zero_vt_pad(bf16_t* vt_hi, bf16_t* vt_lo, int rows, int N, int npadv, hipStream_t stream);
-// bilinear align_corners=True resize of fp32 NHWC [B,Hi,Wi,C] -> [B,Ho,Wo,C] as bf16 hi (+lo) and/or fp32
-int mdpt_launch_upsample(const float* in, bf16_t* out_hi, bf16_t* out_lo, float* out_f32, int B, int Hi, int Wi, int Ho,
-                         int Wo, int C, hipStream_t stream);
-// the same resize of a bf16 NHWC map to a bf16 NHWC map (C % 8 == 0), arithmetic of up_bf16.h
-int mdpt_launch_upsample_bf16(const bf16_t* in, bf16_t* out, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t stream);
 // weight repack: source (fp32 / bf16 / fp16: src_dtype) in PyTorch layout -> bf16 hi (+lo) [Np][Kp] rows, zero padded. Layout kinds:
 enum { MDPT_PACK_LINEAR = 0,   // src [N][K]
        MDPT_PACK_CONV3 = 1,    // src [Cout][Cin][3][3] -> k = (cb*9 + ky*3+kx)*64 + c, ci = cb*64 + c (64-channel block outer, tap inner)
        MDPT_PACK_CONVT = 2,    // src [Cin][Cout][k][k] -> row n = (ky*k+kx)*Coutp + co, col ci
        MDPT_PACK_CONV3_KC32 = 3 };  // src [32][Cin][3][3] -> [Kp/8][32][8] (k = (ky*3+kx)*Cinp + ci in 8-element chunks, Np = 32): the
                                     // LDS image of head_tail_kernel, where a 32-lane fragment read is 512 consecutive bytes
-// row_scale != null (MDPT_PACK_LINEAR only): row n is multiplied by row_scale[n] in fp32 BEFORE the bf16 split (a per-output-feature
-// layer scale folded into the weights: diag(gamma) W)
-int mdpt_launch_pack_weight(const void* src, int src_dtype, bf16_t* dst_hi, bf16_t* dst_lo, int kind, int N, int K, int Np, int Kp,
-                            int ksz, hipStream_t stream, int src_ld = 0, int src_col0 = 0, const void* row_scale = nullptr, int scale_dtype = 0);
-// fp32 vector copy with zero padding (biases); `rep` repeats are not needed: plain copy
-int mdpt_launch_pad_copy_f32(const void* src, int src_dtype, float* dst, int n, int np, hipStream_t stream, const void* scale = nullptr,
-                             int scale_dtype = 0);  // dst = float(src) (* float(scale))
-// layout conversions for the stage-level API / debug taps
-int mdpt_launch_nhwc_to_nchw(const float* in_f32, const bf16_t* in_hi, const bf16_t* in_lo, float* out, int B, int H, int W,
-                             int C, int Cp, hipStream_t stream);
-int mdpt_launch_tokens_export(const bf16_t* in_hi, const bf16_t* in_lo, const float* in_f32, float* out, int B, int N,
-                              int npad, int F, int skip_cls, hipStream_t stream);
-int mdpt_launch_tokens_import(const float* in, bf16_t* out_hi, bf16_t* out_lo, int B, int N, int npad, int F,
-                              hipStream_t stream);
-int mdpt_launch_nchw_to_nhwc(const float* in, float* out_f32, bf16_t* out_hi, bf16_t* out_lo, int relu_bf16, int B, int H,
-                             int W, int C, int Cp, hipStream_t stream);
-// stage-level encoder entry: resid[b, 1+t, :] = tokens[b, t, :] + pos[t, :]
-int mdpt_launch_tokens_to_resid(const float* tokens, const float* pos, float* resid, int B, int Np, int npad, int F,
-                                hipStream_t stream);
-// uint8 HWC BGR -> normalised fp32 [3,oh,ow] RGB through PyTorch-compatible antialiased bilinear resize
-int mdpt_launch_prepare_image(const unsigned char* bgr, float* out, int ih, int iw, int oh, int ow, const float mean[3],
-                              const float inv_std[3], int interp, hipStream_t stream);  // interp: 0 bilinear, 1 bicubic (both antialiased)
-// BEiT relative position bias (reference v31_beit/components/relative_positional_encoder.py:117-309): bilinear-resize the
-// learned [(2Gh-1)(2Gw-1)+3, heads] table to the current grid and lay it out per head as an extended LUT so that the bias of
-// (query q, key k) is ext[tq[q] - tk[k]] including the three cls cases; also fills the per-token index terms tq / tk.
-int mdpt_launch_beit_relpos(const float* ref_lut, float* ext_lut, int* tq, int* tk, int heads, int Gh, int Gw, int gh, int gw,
-                            int N, int ntok_pad, hipStream_t stream);
-int mdpt_beit_relpos_elen(int gh, int gw);
 struct BeitRelposBatch {
     const float* ref[32]; float* ext0; size_t ext_stride;  // block l writes ext0 + l * ext_stride (elements)
     int* tq; int* tk;
     int n, heads, Gh, Gw, gh, gw, N, ntok_pad;
 };
-int mdpt_launch_beit_relpos_batch(const BeitRelposBatch& b, hipStream_t stream);
-int mdpt_launch_memset_f32(float* dst, float value, size_t n, hipStream_t stream);
-int mdpt_launch_add_f32(float* dst, const float* src, size_t n, hipStream_t stream);  // dst += src
-// ViT-G SwiGLU gate: fp32 [rows, 2h] -> silu(first half) * second half as bf16 hi (+lo) [rows, hp] (pad columns zero)
-int mdpt_launch_swiglu(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t rows, int h, int hp, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // fused tail of the depth head (head.hip): x(P/8) bilinear upsample -> 3x3 conv (cin -> 32) + ReLU -> 1x1 (32 -> 1) + ReLU | sigmoid
 // ------------------------------------------------------------------------------------------------
 struct HeadTailParams {
-    const bf16_t* src;    // [B, Hi, Wi, cin] bf16 NHWC: output of the head's first conv (pad channels zero)
-    const bf16_t* w_kc;   // MDPT_PACK_CONV3_KC32 image of the 3x3 conv weights
+    const op_t* src;    // [B, Hi, Wi, cin] bf16 NHWC: output of the head's first conv (pad channels zero)
+    const op_t* w_kc;   // MDPT_PACK_CONV3_KC32 image of the 3x3 conv weights
     const float* bias;    // [32]
     const float* head_w;  // [32] 1x1 conv weights
     const float* head_b;  // [1]
@@ -196,39 +137,16 @@ struct HeadTailParams {
     int B, Hi, Wi, Ho, Wo;
     unsigned long long* dbg_times;  // test hook (MDPT_HEAD_DBG=1): per-workgroup s_memtime stamps of the phases of its 2nd tile
 };
-bool mdpt_head_tail_supported(int cin);
-bool mdpt_head_tail_scale_ok(int Hi, int Wi, int Ho, int Wo);
-int mdpt_launch_head_tail(const HeadTailParams& p, int cin, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // SwinV2 helpers (swin.hip)
 // ------------------------------------------------------------------------------------------------
-// out = LN_eps(x) (+ add): fp32 rows -> fp32 (may alias add) and/or bf16 hi (+lo)
-int mdpt_launch_ln_res(const float* x, const float* add, const float* gamma, const float* beta, float eps, float* out_f32,
-                       bf16_t* out_hi, bf16_t* out_lo, int rows, int F, hipStream_t stream, int ld_planes = 0);
-// window -> image token map (with cyclic shift sh, sw), shifted-window region ids [nW][region_ld], window-local tq / tk terms
-// tokmap / vtokmap (optional): the inverse, image token -> w * tok_stride + i resp. w * vtok_stride + i
-int mdpt_launch_swin_window_map(int* rowmap, int* region, int* tq, int* tk, int gh, int gw, int wh, int ww, int sh, int sw,
-                                int region_ld, int ntok_pad, hipStream_t stream, int* tokmap = nullptr, int tok_stride = 0, int* vtokmap = nullptr,
-                                int vtok_stride = 0);
-// continuous position bias LUT [heads][(2wh-1)(2ww-1)] = 16*sigmoid(MLP(log-coords)); pretrained = 0 means "None"
-int mdpt_launch_swin_cpb(const float* w1, const float* b1, const float* w2, float* lut, int heads, int hidden, int wh, int ww,
-                         int pretrained, hipStream_t stream);
 // the same for every block of the encoder in ONE launch (the LUTs depend on weights and window sizes only, not on activations)
 struct SwinCpbBatch {
     const float* w1[32]; const float* b1[32]; const float* w2[32]; float* lut[32];
     int heads[32], wh[32], ww[32], pre[32];
     int n, hidden;
 };
-int mdpt_launch_swin_cpb_batch(const SwinCpbBatch& b, hipStream_t stream);
-// fp32 qkv [B*N, 3F] -> normalised/scaled window operands Q,K [B*nw, heads, npad, 32] and Vt [B*nw, heads, 32, npadv]
-int mdpt_launch_swin_qkv_prep(const float* qkv, const int* rowmap, const float* logit_scale, bf16_t* q_hi, bf16_t* q_lo,
-                              bf16_t* k_hi, bf16_t* k_lo, bf16_t* vt_hi, bf16_t* vt_lo, int B, int N, int nw, int wa, int npad,
-                              int npadv, int heads, hipStream_t stream, bool qk = true);  // qk = false: V only (Q, K came out of the GEMM)
-// fp32 [B,gh,gw,C] -> bf16 rows [B*(gh/2)*(gw/2), 4C] = cat(TL, BL, TR, BR)
-int mdpt_launch_swin_merge_gather(const float* tok, bf16_t* out_hi, bf16_t* out_lo, int B, int gh, int gw, int C,
-                                  hipStream_t stream);
-int mdpt_launch_f32_to_planes(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t rows, int F, int ld, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // depth post-processing (postprocess.hip); scratch2 = 2 uints of device scratch for the min/max reduction
@@ -238,3 +156,12 @@ int mdpt_launch_post_scale(const float* in, float* out, int B, int ih, int iw, i
                            unsigned* scratch2, hipStream_t stream);
 int mdpt_launch_post_normalize(const float* in, const float* minmax, void* out, size_t n, int mode, int lossy,
                                hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// launchers: one set per operand format (op_types.h). A kernel file sees its own set through MDPT_FN; the host side (mdpt_api.cpp)
+// includes mdpt_launchers.inc a second time for the other format and picks per handle (OPL in mdpt_api.cpp). C linkage: the two
+// builds of a file differ in what `op_t*` points at, which must not reach the symbol names.
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+#include "mdpt_launchers.inc"
+}

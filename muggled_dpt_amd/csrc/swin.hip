@@ -14,21 +14,20 @@
 #include <algorithm>
 #include "mdpt_prof.h"
 
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 
-__device__ __forceinline__ void split_store4(bf16_t* hi, bf16_t* lo, size_t off, f32x4 v) {
-    bf16x4 h;
+__device__ __forceinline__ void split_store4(op_t* hi, op_t* lo, size_t off, f32x4 v) {
+    opx4 h;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
-    *(bf16x4*)(hi + off) = h;
+    for (int e = 0; e < 4; ++e) h[e] = to_op(v[e]);
+    *(opx4*)(hi + off) = h;
     if (lo) {
-        bf16x4 l;
+        opx4 l;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) l[e] = (__bf16)(v[e] - (float)h[e]);
-        *(bf16x4*)(lo + off) = l;
+        for (int e = 0; e < 4; ++e) l[e] = to_op(v[e] - (float)h[e]);
+        *(opx4*)(lo + off) = l;
     }
 }
 
@@ -48,8 +47,8 @@ inline int grid_for(size_t total, int block = 256) {
 // ---------------------------------------------------------------------------------------------------
 template <int NV>
 __global__ __launch_bounds__(256) void ln_res_kernel(const float* __restrict__ x, const float* add, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float eps, float* out_f32, bf16_t* out_hi,
-                                                     bf16_t* out_lo, int rows, int F, int ldp) {
+                                                     const float* __restrict__ beta, float eps, float* out_f32, op_t* out_hi,
+                                                     op_t* out_lo, int rows, int F, int ldp) {
     // ldp = row stride of the bf16 planes (>= F; pad columns are zeroed once per forward by the caller, never written here)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -196,8 +195,8 @@ __global__ __launch_bounds__(256) void swin_cpb_batch_kernel(const SwinCpbBatch 
 // QKV GEMM's accumulators when the 8-phase tile runs.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void swin_qk_prep_kernel(const float* __restrict__ qkv, const int* __restrict__ rowmap,
-                                                           const float* __restrict__ logit_scale, bf16_t* q_hi, bf16_t* q_lo, bf16_t* k_hi,
-                                                           bf16_t* k_lo, int B, int N, int nw, int wa, int npad, int heads) {
+                                                           const float* __restrict__ logit_scale, op_t* q_hi, op_t* q_lo, op_t* k_hi,
+                                                           op_t* k_lo, int B, int N, int nw, int wa, int npad, int heads) {
 #pragma clang fp contract(off)
     const int F = heads * 32;
     const size_t per_tok = (size_t)2 * heads * 8;
@@ -232,9 +231,9 @@ __global__ __launch_bounds__(256) void swin_qk_prep_kernel(const float* __restri
 // transposed through an LDS tile [32][npadv + 8] bf16 (hi, and lo in bf16x3 mode) and written out as whole 16-byte runs of the
 // token-contiguous rows. (Round 2 wrote every element with its own 2-byte global store: 74 us per block for Q, K and V at SwinV2-L
 // stage 2 where the bytes moved take ~30 us.)
-__global__ __launch_bounds__(256) void swin_v_prep_kernel(const float* __restrict__ qkv, const int* __restrict__ rowmap, bf16_t* vt_hi,
-                                                          bf16_t* vt_lo, int B, int N, int nw, int wa, int npadv, int heads) {
-    extern __shared__ __attribute__((aligned(16))) bf16_t vtile[];  // [planes][32][pitch]
+__global__ __launch_bounds__(256) void swin_v_prep_kernel(const float* __restrict__ qkv, const int* __restrict__ rowmap, op_t* vt_hi,
+                                                          op_t* vt_lo, int B, int N, int nw, int wa, int npadv, int heads) {
+    extern __shared__ __attribute__((aligned(16))) op_t vtile[];  // [planes][32][pitch]
     const int F = heads * 32, pitch = npadv + 8;
     const size_t ph = blockIdx.x;  // p * heads + h
     const int h = (int)(ph % heads);
@@ -242,18 +241,18 @@ __global__ __launch_bounds__(256) void swin_v_prep_kernel(const float* __restric
     const int w = (int)(p % nw);
     const size_t img = p / nw;
     const int g = threadIdx.x & 7;
-    bf16_t* t_hi = vtile;
-    bf16_t* t_lo = vtile + 32 * pitch;
+    op_t* t_hi = vtile;
+    op_t* t_lo = vtile + 32 * pitch;
     for (int i = threadIdx.x >> 3; i < npadv; i += 32) {
         f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
         if (i < wa) v = *(const f32x4*)(qkv + (img * N + rowmap[(size_t)w * wa + i]) * (size_t)(3 * F) + 2 * F + h * 32 + g * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const __bf16 hi = (__bf16)v[e];
-            t_hi[(g * 4 + e) * pitch + i] = __builtin_bit_cast(bf16_t, hi);
+            const op_t hi = to_op(v[e]);
+            t_hi[(g * 4 + e) * pitch + i] = __builtin_bit_cast(op_t, hi);
             if (vt_lo) {
-                const __bf16 lo = (__bf16)(v[e] - (float)hi);
-                t_lo[(g * 4 + e) * pitch + i] = __builtin_bit_cast(bf16_t, lo);
+                const op_t lo = to_op(v[e] - (float)hi);
+                t_lo[(g * 4 + e) * pitch + i] = __builtin_bit_cast(op_t, lo);
             }
         }
     }
@@ -271,7 +270,7 @@ __global__ __launch_bounds__(256) void swin_v_prep_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------
 // Patch merge gather: tokens fp32 [B, gh, gw, C] -> bf16 rows [B*(gh/2)*(gw/2), 4C] = cat(TL, BL, TR, BR) (patch_merge.py:79-91)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void swin_merge_gather_kernel(const float* __restrict__ tok, bf16_t* out_hi, bf16_t* out_lo, int B, int gh,
+__global__ __launch_bounds__(256) void swin_merge_gather_kernel(const float* __restrict__ tok, op_t* out_hi, op_t* out_lo, int B, int gh,
                                                                 int gw, int C) {
     const int oh = gh / 2, ow = gw / 2, cq = C / 4;
     const size_t total = (size_t)B * oh * ow * 4 * cq;
@@ -288,7 +287,7 @@ __global__ __launch_bounds__(256) void swin_merge_gather_kernel(const float* __r
 }
 
 // fp32 -> bf16 hi (+lo) planes, flat
-__global__ __launch_bounds__(256) void f32_to_planes_kernel(const float* __restrict__ in, bf16_t* out_hi, bf16_t* out_lo, size_t n4, int F4,
+__global__ __launch_bounds__(256) void f32_to_planes_kernel(const float* __restrict__ in, op_t* out_hi, op_t* out_lo, size_t n4, int F4,
                                                             int ld) {
     // rows of F4 float4 each -> planes with row stride ld (elements); ld == 4 * F4: plain contiguous conversion
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * blockDim.x) {
@@ -301,8 +300,8 @@ __global__ __launch_bounds__(256) void f32_to_planes_kernel(const float* __restr
 
 #define LAUNCH_RET() return (int)hipGetLastError()
 
-int mdpt_launch_ln_res(const float* x, const float* add, const float* gamma, const float* beta, float eps, float* out_f32, bf16_t* out_hi,
-                       bf16_t* out_lo, int rows, int F, hipStream_t stream, int ld_planes) {
+int MDPT_FN(mdpt_launch_ln_res)(const float* x, const float* add, const float* gamma, const float* beta, float eps, float* out_f32, op_t* out_hi,
+                       op_t* out_lo, int rows, int F, hipStream_t stream, int ld_planes) {
     if (ld_planes <= 0) ld_planes = F;
     if ((F & 3) || F > 2048 || ld_planes < F || (ld_planes & 3)) return (int)hipErrorInvalidValue;
     if (rows <= 0) return 0;
@@ -318,7 +317,7 @@ int mdpt_launch_ln_res(const float* x, const float* add, const float* gamma, con
     LAUNCH_RET();
 }
 
-int mdpt_launch_swin_window_map(int* rowmap, int* region, int* tq, int* tk, int gh, int gw, int wh, int ww, int sh, int sw, int region_ld,
+int MDPT_FN(mdpt_launch_swin_window_map)(int* rowmap, int* region, int* tq, int* tk, int gh, int gw, int wh, int ww, int sh, int sw, int region_ld,
                                 int ntok_pad, hipStream_t stream, int* tokmap, int tok_stride, int* vtokmap, int vtok_stride) {
     if (wh <= 0 || ww <= 0 || gh % wh || gw % ww || region_ld < wh * ww) return (int)hipErrorInvalidValue;
     const size_t work = (size_t)gh * gw > (size_t)ntok_pad ? (size_t)gh * gw : (size_t)ntok_pad;
@@ -327,7 +326,7 @@ int mdpt_launch_swin_window_map(int* rowmap, int* region, int* tq, int* tk, int 
     LAUNCH_RET();
 }
 
-int mdpt_launch_swin_cpb(const float* w1, const float* b1, const float* w2, float* lut, int heads, int hidden, int wh, int ww, int pretrained,
+int MDPT_FN(mdpt_launch_swin_cpb)(const float* w1, const float* b1, const float* w2, float* lut, int heads, int hidden, int wh, int ww, int pretrained,
                          hipStream_t stream) {
     const int R = (2 * wh - 1) * (2 * ww - 1);
     MdptProfScope prof("swin_cpb_kernel", 0.0, stream);
@@ -336,7 +335,7 @@ int mdpt_launch_swin_cpb(const float* w1, const float* b1, const float* w2, floa
     LAUNCH_RET();
 }
 
-int mdpt_launch_swin_cpb_batch(const SwinCpbBatch& b, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_swin_cpb_batch)(const SwinCpbBatch& b, hipStream_t stream) {
     if (b.n < 1 || b.n > 32) return (int)hipErrorInvalidValue;
     int rmax = 0;
     for (int l = 0; l < b.n; ++l) rmax = std::max(rmax, (2 * b.wh[l] - 1) * (2 * b.ww[l] - 1));
@@ -345,8 +344,8 @@ int mdpt_launch_swin_cpb_batch(const SwinCpbBatch& b, hipStream_t stream) {
     LAUNCH_RET();
 }
 
-int mdpt_launch_swin_qkv_prep(const float* qkv, const int* rowmap, const float* logit_scale, bf16_t* q_hi, bf16_t* q_lo, bf16_t* k_hi,
-                              bf16_t* k_lo, bf16_t* vt_hi, bf16_t* vt_lo, int B, int N, int nw, int wa, int npad, int npadv, int heads,
+int MDPT_FN(mdpt_launch_swin_qkv_prep)(const float* qkv, const int* rowmap, const float* logit_scale, op_t* q_hi, op_t* q_lo, op_t* k_hi,
+                              op_t* k_lo, op_t* vt_hi, op_t* vt_lo, int B, int N, int nw, int wa, int npad, int npadv, int heads,
                               hipStream_t stream, bool qk) {
     if (qk) {
         MdptProfScope prof_qk("swin_qk_prep", 0.0, stream);
@@ -367,7 +366,7 @@ int mdpt_launch_swin_qkv_prep(const float* qkv, const int* rowmap, const float* 
     LAUNCH_RET();
 }
 
-int mdpt_launch_swin_merge_gather(const float* tok, bf16_t* out_hi, bf16_t* out_lo, int B, int gh, int gw, int C, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_swin_merge_gather)(const float* tok, op_t* out_hi, op_t* out_lo, int B, int gh, int gw, int C, hipStream_t stream) {
     if ((gh & 1) || (gw & 1) || (C & 3)) return (int)hipErrorInvalidValue;
     MdptProfScope prof("swin_merge_gather_kernel", 0.0, stream);
     hipLaunchKernelGGL(swin_merge_gather_kernel, dim3(grid_for((size_t)B * gh * gw * (C / 4))), dim3(256), 0, stream, tok, out_hi, out_lo, B, gh,
@@ -375,7 +374,7 @@ int mdpt_launch_swin_merge_gather(const float* tok, bf16_t* out_hi, bf16_t* out_
     LAUNCH_RET();
 }
 
-int mdpt_launch_f32_to_planes(const float* in, bf16_t* out_hi, bf16_t* out_lo, size_t rows, int F, int ld, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_f32_to_planes)(const float* in, op_t* out_hi, op_t* out_lo, size_t rows, int F, int ld, hipStream_t stream) {
     if ((F & 3) || ld < F || (ld & 3)) return (int)hipErrorInvalidValue;
     const size_t n4 = rows * (size_t)(F / 4);
     hipLaunchKernelGGL(f32_to_planes_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, in, out_hi, out_lo, n4, F / 4, ld);

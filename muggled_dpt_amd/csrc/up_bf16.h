@@ -11,18 +11,17 @@ typedef __attribute__((ext_vector_type(4))) unsigned mdpt_u32x4;
 __device__ __forceinline__ mdpt_u32x4 mdpt_up_bf16x8(mdpt_u32x4 v00, mdpt_u32x4 v01, mdpt_u32x4 v10, mdpt_u32x4 v11, float lx, float ly) {
 #pragma clang fp contract(off)
     typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
     const float wx0 = 1.0f - lx, wy0 = 1.0f - ly;
     mdpt_u32x4 out;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         const unsigned d00 = v00[w], d01 = v01[w], d10 = v10[w], d11 = v11[w];  // (scalar copies: bit_cast on a vector ELEMENT expression reads element 0)
-        const f32x2_t a00 = {__builtin_bit_cast(float, d00 << 16), __builtin_bit_cast(float, d00 & 0xFFFF0000u)};
-        const f32x2_t a01 = {__builtin_bit_cast(float, d01 << 16), __builtin_bit_cast(float, d01 & 0xFFFF0000u)};
-        const f32x2_t a10 = {__builtin_bit_cast(float, d10 << 16), __builtin_bit_cast(float, d10 & 0xFFFF0000u)};
-        const f32x2_t a11 = {__builtin_bit_cast(float, d11 << 16), __builtin_bit_cast(float, d11 & 0xFFFF0000u)};
+        const f32x2_t a00 = op2_to_f32(d00);
+        const f32x2_t a01 = op2_to_f32(d01);
+        const f32x2_t a10 = op2_to_f32(d10);
+        const f32x2_t a11 = op2_to_f32(d11);
         const f32x2_t r = wy0 * (wx0 * a00 + lx * a01) + ly * (wx0 * a10 + lx * a11);
-        out[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+        out[w] = __builtin_bit_cast(unsigned, to_op2(r));
     }
     return out;
 }

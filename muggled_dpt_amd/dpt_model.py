@@ -35,7 +35,30 @@ BEIT_RGB_MEAN = (0.5, 0.5, 0.5)   # reference v31_beit/patch_embed.py:39-40
 BEIT_RGB_STD = (0.5, 0.5, 0.5)
 
 
-class _Node(nn.Module):
+# Bumped whenever a Parameter object is (re)assigned anywhere in a model tree of this module: DPTModel caches its parameter list and
+# re-collects it only when this moved (a module-tree walk per forward cost several hundred microseconds at batch 1).
+_TREE_GENERATION = [0]
+
+
+class _ParamWatch:
+    """Mixin: attribute assignment / registration of a Parameter invalidates the cached parameter lists."""
+
+    def __setattr__(self, name, value):
+        if isinstance(value, nn.Parameter) or name in self.__dict__.get("_parameters", ()):
+            _TREE_GENERATION[0] += 1
+        super().__setattr__(name, value)
+
+    def register_parameter(self, name, param):
+        _TREE_GENERATION[0] += 1
+        super().register_parameter(name, param)
+
+    def __delattr__(self, name):
+        if name in self.__dict__.get("_parameters", ()):
+            _TREE_GENERATION[0] += 1
+        super().__delattr__(name)
+
+
+class _Node(_ParamWatch, nn.Module):
     """Anonymous container so dotted reference keys ("stages.0.blocks.1.attn.qkv.weight") become real module paths."""
 
     def forward(self, *args, **kwargs):  # pragma: no cover - containers are not callable
@@ -77,6 +100,15 @@ class _BlockProbe(_Node):
         return block_output_tokens
 
 
+class TransformerBlock(_BlockProbe):
+    """Public name of the encoder blocks of the ViT families (Depth-Anything V1 / V2, BEiT): what the reference's tooling selects with
+    isinstance(module, TransformerBlock) (demo_helpers/model_capture.py:54-59, experiments/block_norm_visualization.py:263-282)."""
+
+
+class SwinTransformerBlock(_BlockProbe):
+    """Public name of the SwinV2 encoder blocks (reference v31_swinv2/image_encoder_model.py:164-225)."""
+
+
 def _register_tree(root: nn.Module, shapes: dict[str, tuple]) -> None:
     for key, shape in shapes.items():
         parts = key.split(".")
@@ -88,7 +120,7 @@ def _register_tree(root: nn.Module, shapes: dict[str, tuple]) -> None:
         mod.register_parameter(parts[-1], nn.Parameter(torch.zeros(tuple(shape)), requires_grad=False))
 
 
-class _Stage(nn.Module):
+class _Stage(_ParamWatch, nn.Module):
     """Base of the five sub-modules: owns its parameters, forwards to the engine of the parent DPTModel."""
 
     def __init__(self, component: str, shapes: dict[str, tuple]):
@@ -330,12 +362,18 @@ class _Engine:
         c.base_patch_grid_h, c.base_patch_grid_w = (int(v) for v in cfg["base_patch_grid_hw"])
         c.fusion_channels, c.patch_size_px = cfg["fusion_channels"], cfg["patch_size_px"]
         c.is_giant, c.is_metric = int(bool(cfg.get("is_giant", False))), int(bool(cfg.get("is_metric", False)))
-        c.precision = native.PREC_BF16X3 if dtype == torch.float32 else native.PREC_BF16
+        # default arithmetic per model dtype: fp32 -> split-bf16 x3 (fp32 class), bf16 -> bf16 operands, fp16 -> fp16 operands (what each
+        # dtype means in the reference: demo_helpers/misc.py:61-77); DPTModel.set_precision overrides it
+        default_prec = {torch.float32: native.PREC_BF16X3, torch.bfloat16: native.PREC_BF16, torch.float16: native.PREC_FP16}
+        override = model.__dict__.get("_precision")
+        c.precision = native.PRECISIONS[override] if override else default_prec.get(dtype, native.PREC_BF16)
         c.family = {"v2": native.FAMILY_DAV2, "v1": native.FAMILY_DAV1, "beit": native.FAMILY_BEIT, "swinv2": native.FAMILY_SWINV2}[model.family]
         self.precision = c.precision
         handle = ctypes.c_void_p()
         native.check(self.lib, self.lib.mdpt_create(ctypes.byref(c), ctypes.byref(handle)))
         self.handle = handle
+        for cls_name, passes in (model.__dict__.get("_class_passes") or {}).items():
+            native.check(self.lib, self.lib.mdpt_set_class_passes(self.handle, native.OP_CLASSES.index(cls_name), int(passes)))
         self._workspaces: dict[tuple, torch.Tensor] = {}
         tile = model.__dict__.get("_gemm_tile", 0)
         if tile:
@@ -493,15 +531,17 @@ class DPTModel(nn.Module):
             bps = max(1, self.config["num_blocks"] // 4)
             block_nodes = [(self.imgencoder.stages[i // bps].blocks[i % bps], i // bps) for i in range(self.config["num_blocks"])]
         for node, _ in block_nodes:
-            node.__class__ = _BlockProbe
+            node.__class__ = SwinTransformerBlock if family == "swinv2" else TransformerBlock
         self.imgencoder.__dict__["_block_probes"] = block_nodes
         self.__dict__["_engine_obj"] = None
+        self.__dict__["_param_cache"] = None
         self.__dict__["_gemm_tile"] = 0
         self.eval()  # inference only (dpt_model.py:57)
 
     # ---- engine lifetime
     def _invalidate(self):
         self.__dict__["_engine_obj"] = None
+        self.__dict__["_param_cache"] = None
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -509,13 +549,18 @@ class DPTModel(nn.Module):
         return out
 
     def _param_versions(self) -> tuple:
-        """(identity, version) of every parameter. Inference tensors (a model built / loaded / moved under torch.inference_mode()) have
-        no version counter - reading it raises - and cannot be modified in place either, so identity + storage address stand in for it.
-        The parameter list itself is re-collected on every call: a Parameter replaced by attribute assignment must force a re-pack."""
-        out = []
-        for p in self.parameters():
-            out.append((id(p), p.data_ptr()) if p.is_inference() else (id(p), p._version))
-        return tuple(out)
+        """Version counter of every parameter, in a fixed order. The parameter LIST is cached (the cache holds the Parameter objects, so
+        an id can not be reused behind its back) and re-collected only when a Parameter was assigned / registered / deleted somewhere in
+        a model tree (_TREE_GENERATION), the model was moved or cast (_apply) or a state dict was loaded. Inference tensors (a model
+        built / loaded / moved under torch.inference_mode()) have no version counter and can not be modified in place either: they
+        contribute a constant."""
+        cache = self.__dict__.get("_param_cache")
+        if cache is None or cache[0] != _TREE_GENERATION[0]:
+            plist = list(self.parameters())
+            versioned = [p for p in plist if not p.is_inference()]
+            cache = (_TREE_GENERATION[0], plist, versioned)
+            self.__dict__["_param_cache"] = cache
+        return (cache[0], len(cache[1]), tuple([p._version for p in cache[2]]))
 
     def _get_engine(self) -> _Engine:
         """The engine holds a PACKED SNAPSHOT of the weights (bf16 hi[/lo] panels, layer scales folded in). It is rebuilt when the model
@@ -532,6 +577,24 @@ class DPTModel(nn.Module):
 
     def refresh_weights(self) -> None:
         """Force a re-pack of the weights on the next call (for edits the version counters cannot see, e.g. writes through raw pointers)."""
+        self._invalidate()
+
+    def set_precision(self, mode: str | None) -> None:
+        """Arithmetic mode of the MFMA operands, independent of the tensor dtype at the boundary: "bf16", "bf16x3", "fp16", "fp16x3",
+        "mixed" (fp16 operands, three passes for the op classes that dominate the error: <= 1e-3 of the fp32 reference at ~3/4 of the
+        single-pass throughput), or None = the default of the model's dtype (fp32 -> bf16x3, bf16 -> bf16, fp16 -> fp16)."""
+        if mode is not None and mode not in native.PRECISIONS:
+            raise ValueError(f"unknown precision mode {mode!r}: one of {sorted(native.PRECISIONS)} or None")
+        self.__dict__["_precision"] = mode
+        self._invalidate()
+
+    def set_class_passes(self, passes: dict[str, int] | None) -> None:
+        """Per op class ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "head") MFMA pass count (1 or 3) on top of the
+        precision mode (mdpt_set_class_passes): the knob the error-budget study turns."""
+        for k, v in (passes or {}).items():
+            if k not in native.OP_CLASSES or int(v) not in (1, 3):
+                raise ValueError(f"bad class pass entry {k!r}: {v!r}")
+        self.__dict__["_class_passes"] = dict(passes) if passes else None
         self._invalidate()
 
     def set_gemm_tile(self, tile: int) -> None:

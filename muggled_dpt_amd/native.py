@@ -17,13 +17,26 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(CSRC, "libmdpt.so")
-SOURCES = ("gemm.hip", "conv3h.hip", "attention.hip", "elementwise.hip", "swin.hip", "postprocess.hip", "head.hip", "mdpt_api.cpp", "mdpt_prof.cpp")
-HEADERS = ("mdpt_kernels.h", "mdpt_prof.h", "mdpt_swin.inc", "ln_row.h", "up_bf16.h", os.path.join(REPO, "include", "mdpt.h"))
+# kernel files that touch MFMA operand planes are compiled twice, once per operand format (csrc/op_types.h): bf16 and, with
+# -DMDPT_OP_F16, fp16; the launcher symbols carry the format as a suffix and mdpt_api.cpp picks per handle
+OPERAND_SOURCES = ("gemm.hip", "conv3h.hip", "attention.hip", "elementwise.hip", "swin.hip", "head.hip")
+PLAIN_SOURCES = ("postprocess.hip", "mdpt_api.cpp", "mdpt_prof.cpp")
+SOURCES = OPERAND_SOURCES + PLAIN_SOURCES
+HEADERS = ("mdpt_kernels.h", "mdpt_launchers.inc", "op_types.h", "mdpt_prof.h", "mdpt_swin.inc", "ln_row.h", "up_bf16.h",
+           os.path.join(REPO, "include", "mdpt.h"))
+# (source, extra flags, object stem)
+UNITS = tuple((s, (), os.path.splitext(s)[0]) for s in SOURCES) + tuple((s, ("-DMDPT_OP_F16",), os.path.splitext(s)[0] + "_f16")
+                                                                        for s in OPERAND_SOURCES)
 
-ABI_VERSION = 3  # MDPT_ABI_VERSION in include/mdpt.h
+ABI_VERSION = 4  # MDPT_ABI_VERSION in include/mdpt.h
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 PREC_BF16 = 0
 PREC_BF16X3 = 1
+PREC_FP16 = 2
+PREC_FP16X3 = 3
+PREC_MIXED = 4
+PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3, "mixed": PREC_MIXED}
+OP_CLASSES = ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "head")  # MDPT_CLASS_* of include/mdpt.h
 FAMILY_DAV2 = 0
 FAMILY_DAV1 = 1
 FAMILY_BEIT = 2
@@ -67,33 +80,55 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(REPO, "include"), "-I", CSRC,
              "-Wno-unused-result"]
-    objs = []
+    _sweep_stale_temporaries()
 
     # objects and the linked library go through pid-unique names and an atomic rename: several processes (one per GPU) may find
     # the library stale at the same time
     tag = f".{os.getpid()}"
+    made = []
 
-    def compile_one(src: str) -> str:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + tag + ".o")
-        cmd = [hipcc, *flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    def compile_one(unit) -> str:
+        src, extra, stem = unit
+        obj = os.path.join(CSRC, stem + tag + ".o")
+        made.append(obj)
+        cmd = [hipcc, *flags, *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+            raise RuntimeError(f"hipcc failed on {src} {' '.join(extra)}:\n{r.stdout}\n{r.stderr}")
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
     tmp = LIB_PATH + tag + ".tmp"
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp, "-ldl"], capture_output=True, text=True)
-    for obj in objs:
-        final = obj[: -len(tag + ".o")] + ".o"
-        os.replace(obj, final)  # keep the objects (incremental relinks by hand, disassembly)
-    if r.returncode != 0:
-        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    os.replace(tmp, LIB_PATH)
+    try:
+        with ThreadPoolExecutor(max_workers=min(len(UNITS), max(2, (os.cpu_count() or 8)))) as ex:
+            objs = list(ex.map(compile_one, UNITS))
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp, "-ldl"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        for obj in objs:
+            os.replace(obj, obj[: -len(tag + ".o")] + ".o")  # keep the objects (incremental relinks by hand, disassembly)
+        os.replace(tmp, LIB_PATH)
+    finally:  # an interrupted / failed build leaves nothing pid-tagged behind (they used to ship to the GPU box with every push)
+        for path in made + [tmp]:
+            if os.path.exists(path):
+                os.remove(path)
     return LIB_PATH
+
+
+def _sweep_stale_temporaries(max_age_s: float = 3600.0) -> None:
+    """Remove pid-tagged objects / libraries of builds that died (older than an hour: not a concurrent build of another rank)."""
+    import re
+    import time
+    now = time.time()
+    for name in os.listdir(CSRC):
+        if re.search(r"\.\d+\.(o|tmp)$", name):
+            path = os.path.join(CSRC, name)
+            try:
+                if now - os.path.getmtime(path) > max_age_s:
+                    os.remove(path)
+            except OSError:
+                pass
 
 
 class MdptConfig(ctypes.Structure):
@@ -159,6 +194,10 @@ SYMBOLS = {
     "mdpt_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "mdpt_profile_report": (ctypes.c_int, [ctypes.c_char_p, _SZ]),
     "mdpt_debug_set_stop": (ctypes.c_int, [_VP, _I, _I]),
+    "mdpt_debug_set_operand_format": (ctypes.c_int, [_I]),
+    "mdpt_set_class_passes": (ctypes.c_int, [_VP, _I, _I]),
+    "mdpt_get_class_passes": (ctypes.c_int, [_VP, _I, ctypes.POINTER(_I)]),
+    "mdpt_default_mixed_passes": (None, [ctypes.POINTER(_I)]),
     "mdpt_debug_read": (ctypes.c_int, [_VP, ctypes.c_char_p, _VP, _SZ, _VP, _SZ, _VP]),
     "mdpt_allgather": (ctypes.c_int, [_VP, _VP, _VP, _SZ, _I, _VP]),
 }

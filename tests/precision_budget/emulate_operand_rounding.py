@@ -1,0 +1,200 @@
+"""CPU emulation of the MFMA operand-rounding modes of libmdpt (TEST INFRASTRUCTURE: imports the oracle).
+
+Every contraction of the path (Linear / conv / transposed conv / q k^T / p v) is computed in fp32 on operands that were first rounded the
+way the GPU kernels round them (bf16, fp16, or the hi + lo split of either), per OP CLASS. That reproduces the error of a precision mode
+against the fp32 oracle without a GPU (the accumulation order differs, which is an fp32-level effect), so the per-class error budget that
+`MDPT_PREC_MIXED` is derived from can be rebuilt anywhere:
+
+    python tests/precision_budget/emulate_operand_rounding.py --model vitl --images 0 7 --study budget
+
+The GPU check of the same table is tests/test_gpu_precision_modes.py (the emulated and the measured errors are compared there).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as TF
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from oracle import dpt_oracle as oracle  # noqa: E402
+
+CLASSES = ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "head")
+F16_MAX = 65504.0
+
+
+def rnd(x: torch.Tensor, mode: str) -> torch.Tensor:
+    if mode == "f32":
+        return x
+    if mode == "bf16":
+        return x.bfloat16().float()
+    if mode == "f16":
+        return x.clamp(-F16_MAX, F16_MAX).half().float()
+    if mode == "bf16x3":
+        hi = x.bfloat16().float()
+        return hi + (x - hi).bfloat16().float()
+    if mode == "f16x3":
+        hi = x.clamp(-F16_MAX, F16_MAX).half().float()
+        return hi + (x - hi).half().float()
+    if mode == "f16x2a":  # activations split (2 planes), weights one fp16 plane: a_hi*w + a_lo*w
+        raise ValueError("asymmetric modes are handled by rnd_a / rnd_w")
+    raise ValueError(mode)
+
+
+def rnd_a(x, mode):
+    if mode == "f16x2a":
+        return rnd(x, "f16x3")
+    if mode == "f16x2w":
+        return rnd(x, "f16")
+    return rnd(x, mode)
+
+
+def rnd_w(x, mode):
+    if mode == "f16x2a":
+        return rnd(x, "f16")
+    if mode == "f16x2w":
+        return rnd(x, "f16x3")
+    return rnd(x, mode)
+
+
+def weight_class(key: str) -> str | None:
+    if key.startswith("patch_embed.proj"):
+        return "patch"
+    if ".attn.qkv." in key:
+        return "qkv"
+    if ".attn.proj." in key:
+        return "proj"
+    if ".mlp.layers.0." in key or "inner_linear_doubled" in key:
+        return "fc1"
+    if ".mlp.layers.2." in key or "outer_linear" in key:
+        return "fc2"
+    if key.startswith("reassemble."):
+        return "reasm"
+    if key.startswith("fusion."):
+        return "fusion"
+    if key.startswith("head.proj_1ch.2"):
+        return None  # the 32 -> 1 projection runs in fp32 registers on the GPU
+    if key.startswith("head."):
+        return "head"
+    return None
+
+
+class _FProxy:
+    """torch.nn.functional with operand rounding in front of the three contraction entry points the oracle uses."""
+
+    def __init__(self, policy: dict, idmap: dict):
+        self.policy, self.idmap = policy, idmap
+
+    def __getattr__(self, name):
+        return getattr(TF, name)
+
+    def _mode(self, weight):
+        cls = self.idmap.get(id(weight))
+        return "f32" if cls is None else self.policy[cls]
+
+    def linear(self, x, weight, bias=None):
+        m = self._mode(weight)
+        return TF.linear(rnd_a(x, m), rnd_w(weight, m), bias)
+
+    def conv2d(self, x, weight, bias=None, **kw):
+        m = self._mode(weight)
+        return TF.conv2d(rnd_a(x, m), rnd_w(weight, m), bias, **kw)
+
+    def conv_transpose2d(self, x, weight, bias=None, **kw):
+        m = self._mode(weight)
+        return TF.conv_transpose2d(rnd_a(x, m), rnd_w(weight, m), bias, **kw)
+
+
+def emulated_forward(w: dict, cfg: dict, x: torch.Tensor, policy: dict, fold_layer_scale: bool = True) -> torch.Tensor:
+    """oracle.forward with the contraction operands of each class rounded per `policy` ({class: mode})."""
+    idmap = {id(t): weight_class(k) for k, t in w.items()}
+    proxy = _FProxy(policy, idmap)
+    am = policy["attn"]
+
+    def attention(wd, pre, t, num_heads, capture=None):
+        b, n, c = t.shape
+        d = c // num_heads
+        qkv = proxy.linear(t, wd[f"{pre}.qkv.weight"], wd[f"{pre}.qkv.bias"]).reshape(b, n, 3, num_heads, d).permute(2, 0, 3, 1, 4)
+        q, k, v = rnd_a(qkv[0] * d**-0.5, am), rnd_w(qkv[1], am), rnd_w(qkv[2], am)
+        s = q @ k.transpose(-2, -1)
+        p = torch.exp(s - s.amax(dim=-1, keepdim=True))  # the kernel rounds the un-normalised probabilities and divides O by the fp32 row sum
+        y = (rnd_a(p, am) @ v) / p.sum(dim=-1, keepdim=True)
+        y = y.transpose(1, 2).reshape(b, n, c)
+        return proxy.linear(y, wd[f"{pre}.proj.weight"], wd[f"{pre}.proj.bias"])
+
+    saved = (oracle.F, oracle.attention)
+    oracle.F, oracle.attention = proxy, attention
+    try:
+        return oracle.forward(w, cfg, x)
+    finally:
+        oracle.F, oracle.attention = saved
+
+
+def rel_err(y, ref):
+    return float((y.double() - ref.double()).abs().max() / ref.double().abs().max())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="vitl")
+    ap.add_argument("--size", type=int, default=504)
+    ap.add_argument("--images", type=int, nargs="+", default=[0])
+    ap.add_argument("--study", default="budget", choices=["budget", "modes", "policy"])
+    ap.add_argument("--policy", default="", help="study=policy: comma list class=mode, others take --base")
+    ap.add_argument("--base", default="f16")
+    ap.add_argument("--out", default="")
+    ap.add_argument("--threads", type=int, default=8)
+    args = ap.parse_args()
+    torch.set_num_threads(args.threads)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from helpers import seeded_input, synthetic_model
+    _, cfg, w = synthetic_model(args.model)
+    xs = seeded_input((32, 3, args.size, args.size), 1)
+    report = {"model": args.model, "size": args.size, "images": args.images, "rows": []}
+
+    def run(label, policy):
+        errs = []
+        for i in args.images:
+            x = xs[i:i + 1]
+            key = ("ref", i)
+            if key not in run.cache:
+                run.cache[key] = oracle.forward(w, cfg, x)
+            t0 = time.time()
+            y = emulated_forward(w, cfg, x, policy)
+            errs.append(rel_err(y, run.cache[key]))
+        report["rows"].append({"label": label, "policy": policy, "rel_err": errs})
+        print(f"{label:34s} " + " ".join(f"{e:.3e}" for e in errs) + f"   ({time.time() - t0:.1f} s)", flush=True)
+
+    run.cache = {}
+    uniform = lambda m: {c: m for c in CLASSES}
+    if args.study == "modes":
+        for m in ("bf16", "f16", "bf16x3", "f16x3"):
+            run(f"all {m}", uniform(m))
+    elif args.study == "budget":
+        for base in ("bf16", "f16"):
+            run(f"all {base}", uniform(base))
+            for c in CLASSES:  # one class alone at 1 pass, everything else exact: that class's own contribution
+                p = uniform("f32")
+                p[c] = base
+                run(f"only {c} = {base}", p)
+            for c in CLASSES:  # one class lifted to 3 passes: what lifting it buys
+                p = uniform(base)
+                p[c] = base + "x3"
+                run(f"all {base}, {c} = {base}x3", p)
+    else:
+        p = uniform(args.base)
+        for item in filter(None, args.policy.split(",")):
+            c, m = item.split("=")
+            p[c] = m
+        run(f"{args.base} + {args.policy}", p)
+    if args.out:
+        with open(args.out, "w") as fh:
+            json.dump(report, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()

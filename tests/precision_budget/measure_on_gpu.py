@@ -1,0 +1,102 @@
+"""Measured error / throughput table of the arithmetic modes on one MI355X (TEST INFRASTRUCTURE: imports the oracle as the checker).
+
+For every policy (a precision mode of include/mdpt.h plus per-class pass counts, mdpt_set_class_passes): the error of images 0 / 7 / 13 /
+31 of the seeded batch-32 input against the CPU fp32 oracle (rel = max|y - ref| / max|ref|, fp32 tensors at the boundary so that only the
+operand arithmetic is measured) and the depth-maps/s of the batch-32 forward (same two-stream split as bench.py's headline).
+
+    python tests/precision_budget/measure_on_gpu.py --out gpurun_out/precision_budget.json
+    python tests/precision_budget/measure_on_gpu.py --render gpurun_out/precision_budget.json > profiles/r04_precision_budget.md
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CLASSES = ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "head")
+
+
+def policies():
+    out = [("bf16", "bf16", {}), ("fp16", "fp16", {}), ("mixed (shipped)", "mixed", {})]
+    for c in CLASSES:
+        out.append((f"fp16 + {c} x3", "fp16", {c: 3}))
+    out += [("fp16 + decoder x3", "fp16", {"reasm": 3, "fusion": 3, "head": 3}),
+            ("fp16 + patch, reasm, fusion x3", "fp16", {"patch": 3, "reasm": 3, "fusion": 3}),
+            ("mixed + proj x3", "mixed", {"proj": 3}),
+            ("mixed + proj, qkv x3", "mixed", {"proj": 3, "qkv": 3}),
+            ("fp16 + encoder GEMMs x3", "fp16", {"patch": 3, "qkv": 3, "proj": 3, "fc1": 3, "fc2": 3}),
+            ("fp16x3", "fp16x3", {}), ("bf16x3", "bf16x3", {})]
+    return out
+
+
+def measure(args):
+    from helpers import seeded_input, synthetic_model
+    from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+    from oracle import dpt_oracle
+    osd, cfg, w = synthetic_model(args.model, 0)
+    x = seeded_input((args.batch, 3, args.size, args.size), 1)
+    idx = [i for i in (0, 7, 13, 31) if i < args.batch]
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    ref = dpt_oracle.forward(w, cfg, x[idx])
+    _, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
+    model = model.to("cuda", torch.float32)
+    xd = x.cuda()
+    rows = []
+    for label, prec, passes in policies():
+        if args.only and not any(s in label for s in args.only):
+            continue
+        model.set_precision(prec)
+        model.set_class_passes(passes)
+        y = model(xd)
+        torch.cuda.synchronize()
+        errs = [float((y[i].cpu().double() - ref[k].double()).abs().max() / ref[k].double().abs().max()) for k, i in enumerate(idx)]
+        for _ in range(2):
+            model(xd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model(xd)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        rows.append({"label": label, "precision": prec, "passes": passes, "rel_err": errs, "ms_per_step": dt * 1e3, "maps_per_s": args.batch / dt})
+        print(f"{label:34s} " + " ".join(f"{e:.2e}" for e in errs) + f"   {dt * 1e3:7.2f} ms  {args.batch / dt:7.1f} maps/s", flush=True)
+    rep = {"model": args.model, "size": args.size, "batch": args.batch, "images": idx, "steps": args.steps, "device": torch.cuda.get_device_name(0), "rows": rows}
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, "w") as fh:
+            json.dump(rep, fh, indent=1)
+
+
+def render(path):
+    rep = json.load(open(path))
+    print(f"# Precision budget, measured: {rep['model']} {rep['size']}x{rep['size']}, batch {rep['batch']}, one {rep['device']}\n")
+    print("rel = max|y - ref| / max|ref| against the CPU fp32 oracle, images " + ", ".join(map(str, rep["images"])) +
+          f" of the seeded batch; fp32 tensors at the boundary; {rep['steps']} timed steps per row (`tests/precision_budget/measure_on_gpu.py`).\n")
+    print("| policy | " + " | ".join(f"image {i}" for i in rep["images"]) + " | worst | ms / step | maps/s |")
+    print("|---|" + "---|" * (len(rep["images"]) + 3))
+    for r in rep["rows"]:
+        print(f"| {r['label']} | " + " | ".join(f"{e:.2e}" for e in r["rel_err"]) + f" | **{max(r['rel_err']):.2e}** | {r['ms_per_step']:.2f} | {r['maps_per_s']:.0f} |")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="vitl")
+    ap.add_argument("--size", type=int, default=504)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--only", nargs="*", default=[])
+    ap.add_argument("--out", default="")
+    ap.add_argument("--render", default="")
+    a = ap.parse_args()
+    if a.render:
+        render(a.render)
+    else:
+        measure(a)

@@ -12,12 +12,12 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "muggled_dpt_amd", "csrc")
 
 
-def _kernel_stats(src, tmp_path):
+def _kernel_stats(src, tmp_path, extra=()):
     hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
     if not hipcc:
         pytest.skip("hipcc not available")
     out = str(tmp_path / (src + ".s"))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(REPO, "include"), "-I", CSRC, "-x", "hip",
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(REPO, "include"), "-I", CSRC, *extra, "-x", "hip",
                         "--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     stats, name = {}, None
@@ -31,10 +31,12 @@ def _kernel_stats(src, tmp_path):
     return stats
 
 
+@pytest.mark.parametrize("operands", ["bf16", "fp16"])  # every kernel file exists once per MFMA operand format (csrc/op_types.h)
 @pytest.mark.parametrize("src,pattern,at_least", [("gemm.hip", "gemm8_kernel", 6), ("attention.hip", "attn_kernel", 6),
                                                   ("head.hip", "head_tail_kernel", 2)])
-def test_hot_kernels_do_not_spill(tmp_path, src, pattern, at_least):
-    stats = {k: v for k, v in _kernel_stats(src, tmp_path).items() if pattern in k}
+def test_hot_kernels_do_not_spill(tmp_path, src, pattern, at_least, operands):
+    extra = ("-DMDPT_OP_F16",) if operands == "fp16" else ()
+    stats = {k: v for k, v in _kernel_stats(src, tmp_path, extra).items() if pattern in k}
     assert len(stats) >= at_least, sorted(stats)
     for name, s in stats.items():
         assert s["ScratchSize"] == 0, f"{name} spills {s['ScratchSize']} bytes of scratch per lane ({s['NumVgprs']} VGPRs)"

@@ -359,14 +359,15 @@ def test_fusion_blocks_are_callable_one_by_one(golden_dir, dtype, tol):
         model.fusion.blocks[1](dev[1])
 
 
-def test_float16_model_dtype_runs_on_the_bf16_path():
-    """run_image.py offers fp16 models (`-f16`, demo_helpers/misc.py:73-77 picks bf16 when supported, else fp16): a float16 model runs the
-    single-pass MFMA path with fp16 tensors at the API boundary."""
+def test_float16_model_dtype_runs_fp16_operands():
+    """run_image.py offers fp16 models (`-f16`, demo_helpers/misc.py:73-77 picks bf16 when supported, else fp16): a float16 model runs
+    fp16 MFMA operands (MDPT_PREC_FP16, round 4; tests/test_gpu_precision_modes.py has the full-size cases) with fp16 tensors at the API
+    boundary. Tolerance: a quarter of the bf16 toy tolerance (measured ~8x below the bf16 model's error)."""
     model, cfg, w = _model("tiny", torch.float16)
     x = seeded_input((2, 3, 56, 84), 23)
     y = model(x.to("cuda", torch.float16))
     assert y.dtype == torch.float16 and tuple(y.shape) == (2, 56, 84)
-    assert rel_err(y.float().cpu(), _oracle().forward(w, cfg, x)) <= REL_TOL_BF16_TOY
+    assert rel_err(y.float().cpu(), _oracle().forward(w, cfg, x)) <= REL_TOL_BF16_TOY / 4
     tok, hw = model.patch_embed(x.to("cuda", torch.float16))
     assert tok.dtype == torch.float16 and tuple(hw) == (4, 6)
 

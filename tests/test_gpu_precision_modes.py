@@ -1,0 +1,252 @@
+"""The fp16-operand and mixed-pass arithmetic modes (MDPT_PREC_FP16 / FP16X3 / MIXED, mdpt_set_class_passes) against the CPU oracle.
+Run with `pytest -m gpu` on an MI355X.
+
+What the reference does with these dtypes: demo_helpers/misc.py:61-77 hands the model float16 whenever bf16 is not preferred, and a
+float16 model there computes with fp16 (11-bit significand) operands. Here a torch.float16 model selects v_mfma_f32_*_f16 (same
+rate as bf16, 8x smaller operand rounding); "mixed" adds three-pass (hi + lo) arithmetic for the op classes that dominate the error
+(tests/precision_budget/: CPU emulation of the budget; profiles/r04_precision_budget.md: the measured table).
+
+Tolerances: rel = max|y - ref| / max|ref|, north-star bar 1e-3.
+  * fp16, ViT-L 504 batch 32: emulated 1.7e-3 ... 2.2e-3 per image  -> asserted at 3e-3 and at <= 1/4 of the bf16 error of the same image
+  * mixed: asserted at the north-star bar itself, 1e-3, on every checked image
+  * fp16x3: asserted at REL_TOL_X3 (1e-4), like bf16x3
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import REL_TOL_BF16_TOY, REL_TOL_X3, record_err, rel_err, seeded_input, synthetic_model
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL_FP16 = 3e-3        # single-pass fp16 operands, full-size models
+REL_TOL_FP16_TOY = 5e-3    # 64-feature toy configurations (bf16: 3e-2; fp16 rounds 8x finer)
+REL_TOL_MIXED = 1e-3       # the north-star bar
+
+
+def _oracle():
+    from oracle import dpt_oracle
+    return dpt_oracle
+
+
+def _model(name, dtype, precision=None, seed=0):
+    from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+    osd, cfg, w = synthetic_model(name, seed)
+    _, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
+    model = model.to("cuda", dtype)
+    if precision:
+        model.set_precision(precision)
+    return model, cfg, w
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu_and_native_lib():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from muggled_dpt_amd import native
+    native.load()
+
+
+def test_float16_model_selects_fp16_operands_and_beats_bf16_by_the_mantissa_ratio(golden_dir):
+    """A float16 model runs MDPT_PREC_FP16: every stage boundary of the toy model against the reference fixture, and the depth error is
+    several times below the bf16 model's on the same input (3 more significand bits = 8x finer rounding)."""
+    g = np.load(os.path.join(golden_dir, "tiny_full.npz"))
+    x = torch.from_numpy(g["input"])
+    errs = {}
+    for dtype in (torch.float16, torch.bfloat16):
+        model, cfg, w = _model("tiny", dtype)
+        y = model(x.to("cuda", dtype))
+        assert y.dtype == dtype and tuple(y.shape) == (2, 56, 56)
+        errs[dtype] = rel_err(y.float().cpu(), torch.from_numpy(g["depth"]))
+        if dtype == torch.float16:
+            from muggled_dpt_amd import native
+            assert model._get_engine().precision == native.PREC_FP16
+            taps = model.debug_taps(2, (56, 56))
+            for i in range(4):
+                assert rel_err(taps["stages"][i].cpu(), torch.from_numpy(g[f"tap{i}"])) <= REL_TOL_FP16_TOY, f"tap{i}"
+                assert rel_err(taps["reasm"][i].cpu(), torch.from_numpy(g[f"reasm{i}"])) <= REL_TOL_FP16_TOY, f"reasm{i}"
+            assert rel_err(taps["fused"].cpu(), torch.from_numpy(g["fused"])) <= REL_TOL_FP16_TOY
+    assert errs[torch.float16] <= REL_TOL_FP16_TOY
+    assert errs[torch.bfloat16] <= REL_TOL_BF16_TOY
+    assert errs[torch.float16] * 3 <= errs[torch.bfloat16], errs
+
+
+@pytest.mark.parametrize("precision,tol", [("fp16", REL_TOL_FP16_TOY), ("fp16x3", REL_TOL_X3), ("mixed", 1.5e-3), ("bf16x3", REL_TOL_X3)])  # toy model, mixed: emulated 5e-4 ... 7e-4
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_precision_override_is_independent_of_the_boundary_dtype(dtype, precision, tol):
+    """set_precision picks the MFMA operand arithmetic; the model dtype only decides what crosses the C ABI (image in, depth out,
+    parameters as bound). A 16-bit boundary adds its own rounding of the input image and of the depth map on top of `tol`."""
+    model, cfg, w = _model("tiny", dtype, precision)
+    x = seeded_input((2, 3, 56, 84), 29)
+    xb = x.to(dtype)
+    ref = _oracle().forward({k: v.to(dtype).float() for k, v in w.items()}, cfg, xb.float())  # the reference's own view of a cast model
+    y = model(xb.cuda())
+    assert y.dtype == dtype
+    boundary = 0.0 if dtype == torch.float32 else (2.0 ** -11 if dtype == torch.float16 else 2.0 ** -8)
+    assert rel_err(y.float().cpu(), ref) <= tol + boundary
+
+
+def test_vits_504_fp16_and_mixed_vs_golden_fixture(golden_dir):
+    """BASELINE configs[1] in the fp16 modes: ViT-S, 518x518 image -> 504x504 tensor, batch 1, against the fixture generated from the
+    reference itself (tests/golden/gen_golden.py)."""
+    g = np.load(os.path.join(golden_dir, "vits504.npz"))
+    x = seeded_input((1, 3, 504, 504), int(g["input_seed"]))
+    for precision, tol in (("fp16", REL_TOL_FP16), ("mixed", REL_TOL_MIXED), ("fp16x3", REL_TOL_X3)):
+        model, cfg, w = _model("vits", torch.float32, precision, seed=int(g["weight_seed"]))
+        y = model(x.cuda()).cpu()
+        err = record_err(float((y[:, ::4, ::4].double() - torch.from_numpy(g["depth_strided"]).double()).abs().max()) / float(g["depth_stats"][1]), precision)
+        assert err <= tol, f"{precision}: {err:.3e}"
+        del model
+        torch.cuda.empty_cache()
+
+
+def test_vitl_batch32_fp16_and_mixed_every_checked_image_vs_oracle():
+    """BASELINE configs[2] at FULL size (ViT-L, 504x504 tensor, batch 32): images 0, 7, 13 and 31 against the CPU oracle in the fp16
+    and the mixed mode, per image; each of them bitwise equal to its batch-of-1 result; the mixed mode meets the north star's 1e-3."""
+    osd, cfg, w = synthetic_model("vitl", 0)
+    x = seeded_input((32, 3, 504, 504), 1)
+    idx = [0, 7, 13, 31]
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    ref = _oracle().forward(w, cfg, x[idx])
+    for dtype, precision, tol in ((torch.float16, None, REL_TOL_FP16), (torch.float32, "mixed", REL_TOL_MIXED), (torch.float16, "mixed", REL_TOL_MIXED + 2.0 ** -11)):
+        model, _, _ = _model("vitl", dtype, precision)
+        xd = x.to("cuda", dtype)
+        y = model(xd)
+        assert tuple(y.shape) == (32, 504, 504) and y.dtype == dtype
+        for k, i in enumerate(idx):
+            err = record_err(float((y[i].float().cpu().double() - ref[k].double()).abs().max() / ref[k].double().abs().max()), f"{dtype} {precision} image {i}")
+            assert err <= tol, f"{dtype} {precision} image {i}: {err:.3e}"
+            assert torch.equal(model(xd[i:i + 1])[0], y[i]), f"{dtype} {precision} image {i}: batch-of-1 result differs from its row in the batch of 32"
+        del model, y, xd
+        torch.cuda.empty_cache()
+
+
+def test_class_passes_all_three_equals_the_x3_mode_bitwise_and_each_class_switches_alone():
+    """mdpt_set_class_passes: every class at 3 passes on top of "fp16" IS "fp16x3" (same bits); one class at a time changes the result
+    and never makes it worse than single-pass fp16 by more than noise."""
+    from muggled_dpt_amd import native
+    x = seeded_input((2, 3, 56, 84), 31)
+    model, cfg, w = _model("tiny", torch.float32, "fp16x3")
+    y_x3 = model(x.cuda())
+    ref = _oracle().forward(w, cfg, x)
+    model.set_precision("fp16")
+    y_1 = model(x.cuda())
+    e1 = rel_err(y_1.cpu(), ref)
+    model.set_class_passes({c: 3 for c in native.OP_CLASSES})
+    assert torch.equal(model(x.cuda()), y_x3)
+    for c in native.OP_CLASSES:
+        model.set_class_passes({c: 3})
+        y_c = model(x.cuda())
+        ec = rel_err(y_c.cpu(), ref)
+        assert ec <= 1.5 * e1 + 1e-5, f"class {c} at 3 passes: {ec:.3e} vs {e1:.3e} single-pass"
+        assert not torch.equal(y_c, y_1), f"class {c}: three passes left every bit unchanged"
+    model.set_class_passes(None)
+    assert torch.equal(model(x.cuda()), y_1)
+    with pytest.raises(ValueError):
+        model.set_class_passes({"nope": 3})
+    with pytest.raises(ValueError):
+        model.set_precision("fp8")
+
+
+def test_raw_c_abi_class_passes_keep_bound_weights_and_reject_bad_arguments():
+    import ctypes
+    from muggled_dpt_amd import native
+    lib = native.load()
+    c = native.MdptConfig()
+    c.features_per_token, c.num_heads, c.num_blocks = 64, 1, 4
+    for i, v in enumerate((16, 32, 64, 64)):
+        c.reassembly_features[i] = v
+    c.base_patch_grid_h = c.base_patch_grid_w = 4
+    c.fusion_channels, c.patch_size_px, c.precision, c.family = 32, 14, native.PREC_MIXED, native.FAMILY_DAV2
+    h = ctypes.c_void_p()
+    native.check(lib, lib.mdpt_create(ctypes.byref(c), ctypes.byref(h)))
+    want = (ctypes.c_int32 * len(native.OP_CLASSES))()
+    lib.mdpt_default_mixed_passes(want)
+    got = ctypes.c_int32()
+    for i in range(len(native.OP_CLASSES)):
+        native.check(lib, lib.mdpt_get_class_passes(h, i, ctypes.byref(got)))
+        assert got.value == want[i] and got.value in (1, 3)
+    n0, b0 = lib.mdpt_num_weights(h), ctypes.c_size_t()
+    native.check(lib, lib.mdpt_packed_bytes(h, ctypes.byref(b0)))
+    t = torch.zeros(64, device="cuda")
+    shape = (ctypes.c_int64 * 1)(64)
+    native.check(lib, lib.mdpt_bind_weight(h, b"patch_embed.proj.bias", t.data_ptr(), native.DTYPE_F32, 1, shape))
+    native.check(lib, lib.mdpt_set_class_passes(h, native.OP_CLASSES.index("fc1"), 3))
+    b1 = ctypes.c_size_t()
+    native.check(lib, lib.mdpt_packed_bytes(h, ctypes.byref(b1)))
+    assert lib.mdpt_num_weights(h) == n0 and b1.value > b0.value  # the fc1 matrices gained lo planes
+    assert lib.mdpt_set_class_passes(h, 99, 3) == -1  # MDPT_E_INVALID
+    assert lib.mdpt_set_class_passes(h, 0, 2) != 0
+    lib.mdpt_destroy(h)
+
+
+def test_fp16_saturates_instead_of_overflowing():
+    """fp32 -> fp16 operand converts clamp at +-65504: an activation far outside the fp16 range gives a finite (saturated) result, not
+    inf / NaN. Driven through the raw GEMM hook with an A operand of 60000 and weights that sum it past the range in the bf16+GELU path's
+    fp16 output plane."""
+    from muggled_dpt_amd import native
+    lib = native.load()
+    M, N, K = 256, 256, 128
+    a = torch.full((M, K), 60000.0, device="cuda", dtype=torch.float16)
+    w = torch.full((N, K), 1.0, device="cuda", dtype=torch.float16)
+    out16 = torch.zeros((M, N), device="cuda", dtype=torch.float16)
+    stream = torch.cuda.current_stream().cuda_stream
+    native.check(lib, lib.mdpt_debug_set_operand_format(1))
+    try:
+        native.check(lib, lib.mdpt_debug_gemm(a.data_ptr(), w.data_ptr(), None, out16.data_ptr(), M, N, K, 5, 1, stream, None))
+        torch.cuda.synchronize()
+    finally:
+        native.check(lib, lib.mdpt_debug_set_operand_format(0))
+    assert bool(torch.isfinite(out16).all()) and float(out16.min()) == 65504.0
+
+
+@pytest.mark.parametrize("tile", [5, 2, 1, 6, 4])
+def test_fp16_gemm_variants_on_ragged_shapes(tile):
+    """The bare GEMM kernels in their fp16 build (mdpt_launch_gemm_f16) for every main-loop variant: fp32 strip output and fp16 direct
+    output against an fp32 matmul of the same fp16-rounded operands (products exact in fp32: only the accumulation order differs)."""
+    from muggled_dpt_amd import native
+    lib = native.load()
+    rng = np.random.default_rng(tile)
+    stream = torch.cuda.current_stream().cuda_stream
+    native.check(lib, lib.mdpt_debug_set_operand_format(1))
+    try:
+        for (M, N, K) in [(1, 256, 128), (257, 1024, 256), (777, 1024, 1024), (1304, 3072, 1024), (1304, 1024, 4096), (4099, 512, 640)]:
+            a = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).cuda().to(torch.float16)
+            w = torch.from_numpy(rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).cuda().to(torch.float16)
+            ref = a.float() @ w.float().t()
+            scale = float(ref.abs().max())
+            out32 = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.float32)
+            native.check(lib, lib.mdpt_debug_gemm(a.data_ptr(), w.data_ptr(), out32.data_ptr(), None, M, N, K, tile, 1, stream, None))
+            out16 = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.float16)
+            native.check(lib, lib.mdpt_debug_gemm(a.data_ptr(), w.data_ptr(), None, out16.data_ptr(), M, N, K, tile | (2 << 8), 1, stream, None))
+            torch.cuda.synchronize()
+            assert float((out32[:M] - ref).abs().max()) <= 2e-5 * scale, f"tile {tile} M={M} N={N} K={K} (fp32 out)"
+            gref = torch.nn.functional.gelu(ref)
+            assert float((out16[:M].float() - gref).abs().max()) <= 8e-4 * float(gref.abs().max()), f"tile {tile} M={M} N={N} K={K} (fp16 + GELU out)"
+            assert torch.all(out32[M:] == 7.0) and torch.all(out16[M:] == 7.0)
+    finally:
+        native.check(lib, lib.mdpt_debug_set_operand_format(0))
+
+
+def test_other_families_in_the_fp16_modes(golden_dir):
+    """BEiT and SwinV2 toy fixtures (generated from the reference) in fp16 / mixed / fp16x3: the relative-position-bias and window
+    attention forms, the readout projection and the patch merge all exist in the fp16 build."""
+    from muggled_dpt_amd import make_beit_dpt_from_midas_v31_state_dict, make_swinv2_dpt_from_midas_v31_state_dict
+    from muggled_dpt_amd.synthetic import make_synthetic_beit_state_dict, make_synthetic_swinv2_state_dict
+    gb = np.load(os.path.join(golden_dir, "beit_tiny.npz"))
+    gs = np.load(os.path.join(golden_dir, "swin2_tiny.npz"))
+    cases = [(make_beit_dpt_from_midas_v31_state_dict, make_synthetic_beit_state_dict("beit_tiny", int(gb["weight_seed"])), gb, "wide_input", "wide_depth")]
+    cases.append((make_swinv2_dpt_from_midas_v31_state_dict, make_synthetic_swinv2_state_dict("swin2_tiny", int(gs["weight_seed"])), gs, "wide_input",
+                  "wide_depth"))
+    for make, osd, g, kin, kout in cases:
+        x = torch.from_numpy(g[kin])
+        ref = torch.from_numpy(g[kout])
+        errs = {}
+        for precision, tol in (("bf16", 6e-2), ("fp16", 1e-2), ("mixed", 5e-3), ("fp16x3", REL_TOL_X3)):
+            _, model = make(osd)
+            model = model.to("cuda", torch.float32)
+            model.set_precision(precision)
+            errs[precision] = rel_err(model(x.cuda()).cpu(), ref)
+            assert errs[precision] <= tol, f"{make.__name__} {precision}: {errs[precision]:.3e}"
+        assert errs["fp16"] * 3 <= errs["bf16"], errs
