@@ -114,6 +114,11 @@ void mdpt_destroy(mdpt_handle* h);
 int mdpt_set_class_passes(mdpt_handle* h, int32_t op_class, int32_t passes);
 int mdpt_get_class_passes(const mdpt_handle* h, int32_t op_class, int32_t* passes);
 void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]);
+/* Token-mean compensation of the weight rounding (ViT families, fp16 operand modes; on by default in MDPT_PREC_FP16 and MDPT_PREC_MIXED): a
+ * single-pass Linear of the encoder (QKV, proj, fc1, fc2) computes A fp16(W)^T; what the weight rounding loses is dominated by the part all
+ * tokens of an image share, mean_t(A) (W - fp16(W))^T, which two small kernels turn into a per-image bias table the GEMM epilogue adds
+ * (transformer_block.py:160,168, misc_helpers.py:111-115 restated with that term). Same call-order rule as mdpt_set_class_passes. */
+int mdpt_set_weight_rounding_compensation(mdpt_handle* h, int32_t on);
 
 /* Parameter inventory, named with the reference's converted ("new format") keys, prefixed by component:
  * "patch_embed.proj.weight", "imgencoder.stages.0.blocks.0.attn.qkv.weight", "reassemble.spatial_upx4.resample.1.weight",

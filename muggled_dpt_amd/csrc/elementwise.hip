@@ -558,6 +558,77 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Token-mean compensation of the weight rounding (fp16 modes; mdpt_api.cpp wrc_bias). A single-pass GEMM computes A_r W_r^T with
+// W_r = fp(W); what it loses, A_r (W - W_r)^T, is dominated by the part every token of an image shares - the image's mean token times
+// the weight residue (measured on the ViT-L budget: 70-99 % of a Linear's weight-rounding error, tests/precision_budget/). That part
+// is a per-image bias:    bias_img[b][n] = bias[n] + sum_k mean_t(A_r[b, t, k]) * W_lo[n][k],   W_lo = fp(W - W_r) (the lo plane).
+// Both kernels sum in a fixed order: one image's table does not depend on the batch it is part of.
+// ---------------------------------------------------------------------------------------------------
+// mean[b][k] = (1 / nreal) * sum over the nreal real rows of image b of A[(b * rows_per_img + t) * lda + k]; one workgroup = one image x 64 columns
+__global__ __launch_bounds__(256) void colmean_kernel(const op_t* __restrict__ A, int lda, int rows_per_img, int nreal, int K, float* __restrict__ mean) {
+    __shared__ float red[32][64];
+    const int b = blockIdx.y, k0 = blockIdx.x * 64;
+    const int rs = threadIdx.x >> 3, cg = threadIdx.x & 7;
+    float sum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const op_t* base = A + (size_t)b * rows_per_img * lda + k0 + cg * 8;
+    for (int t = rs; t < nreal; t += 32) {
+        const opx8 v = *(const opx8*)(base + (size_t)t * lda);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[e] += (float)v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rs][cg * 8 + e] = sum[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) tot += red[r][threadIdx.x];
+        mean[(size_t)b * K + k0 + threadIdx.x] = tot * (1.0f / (float)nreal);
+    }
+}
+
+// out[b][n] = bias[n] + sum_k mean[b][k] * W_lo[n][k]; one workgroup = 16 weight rows x all images (8 at a time), 16 k-slices of 8 columns
+__global__ __launch_bounds__(256) void wrc_bias_kernel(const float* __restrict__ mean, const op_t* __restrict__ w_lo, const float* __restrict__ bias,
+                                                       float* __restrict__ out, int B, int N, int K) {
+#pragma clang fp contract(off)
+    __shared__ float red[16][16][8];
+    const int nl = threadIdx.x >> 4, ks = threadIdx.x & 15;
+    const int n = blockIdx.x * 16 + nl;
+    const op_t* wrow = w_lo + (size_t)(n < N ? n : N - 1) * K;
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = ks * 8; k < K; k += 128) {
+            const opx8 w = *(const opx8*)(wrow + k);
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) {
+                if (b0 + bb < B) {
+                    const float* m = mean + (size_t)(b0 + bb) * K + k;
+                    const f32x4 m0 = *(const f32x4*)m, m1 = *(const f32x4*)(m + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[bb] = __builtin_fmaf((float)w[e], m0[e], acc[bb]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[bb] = __builtin_fmaf((float)w[4 + e], m1[e], acc[bb]);
+                }
+            }
+        }
+        __syncthreads();  // (previous round's readers are done)
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) red[nl][ks][bb] = acc[bb];
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int rn = threadIdx.x >> 3, rb = threadIdx.x & 7;
+            const int on = blockIdx.x * 16 + rn;
+            if (on < N && b0 + rb < B) {
+                float tot = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) tot += red[rn][q][rb];
+                out[(size_t)(b0 + rb) * N + on] = (bias ? bias[on] : 0.0f) + tot;
+            }
+        }
+    }
+}
+
 inline int grid_for(size_t total, int block = 256) {
     size_t g = (total + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -580,6 +651,20 @@ int MDPT_FN(mdpt_launch_layernorm)(const float* x, const float* gamma, const flo
     else if (F <= 1536) LN_CASE(6);
     else LN_CASE(8);
 #undef LN_CASE
+    LAUNCH_RET();
+}
+
+int MDPT_FN(mdpt_launch_colmean)(const op_t* A, int lda, int B, int rows_per_img, int nreal, int K, float* mean, hipStream_t stream) {
+    if (B <= 0 || nreal <= 0 || nreal > rows_per_img || (K & 63) || (lda & 7)) return (int)hipErrorInvalidValue;
+    MdptProfScope prof("colmean_kernel", 0.0, stream);
+    hipLaunchKernelGGL(colmean_kernel, dim3(K / 64, B), dim3(256), 0, stream, A, lda, rows_per_img, nreal, K, mean);
+    LAUNCH_RET();
+}
+
+int MDPT_FN(mdpt_launch_wrc_bias)(const float* mean, const op_t* w_lo, const float* bias, float* out, int B, int N, int K, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || (K & 7)) return (int)hipErrorInvalidValue;
+    MdptProfScope prof("wrc_bias_kernel", 0.0, stream);
+    hipLaunchKernelGGL(wrc_bias_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, mean, w_lo, bias, out, B, N, K);
     LAUNCH_RET();
 }
 

@@ -299,7 +299,7 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const float*
                 const int col = item % WTN, rg = item / WTN;
                 const int m = mbase + rg * 8, n = nbase + col;
                 if (m >= p.M || n >= p.N) continue;
-                const float bz = p.bias[n];
+                const float bz = p.bias_img_stride ? p.bias[(size_t)(m / p.bias_img_rows) * p.bias_img_stride + n] : p.bias[n];  // 8 rows, one image
                 f32x4 v0, v1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -337,7 +337,7 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const float*
                     res[pr][1] = *(const f32x4*)(rp + 4);
                 }
                 if (p.bias && p.bias_img_stride) {
-                    const float* bp = p.bias + nc + (size_t)(mc / p.tok_np) * p.bias_img_stride;
+                    const float* bp = p.bias + nc + (size_t)(mc / p.bias_img_rows) * p.bias_img_stride;
                     bim[pr][0] = *(const f32x4*)bp;
                     bim[pr][1] = *(const f32x4*)(bp + 4);
                 }
@@ -407,8 +407,9 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const float*
 
             if (EKIND == MDPT_E_QKV) {
                 // Q (pre-scaled by 1/sqrt(d), exact power of two) and K, head-major [B,H,npad,64]
-                v[0] += *(const f32x4*)(p.bias + n);
-                v[1] += *(const f32x4*)(p.bias + n + 4);
+                const float* bq = p.bias_img_stride ? p.bias + (size_t)(m / p.bias_img_rows) * p.bias_img_stride : p.bias;
+                v[0] += *(const f32x4*)(bq + n);
+                v[1] += *(const f32x4*)(bq + n + 4);
                 const int which = n >= p.F;
                 const int f = n - which * p.F, h = f >> 6, d = f & 63;
                 const int b = m / p.npad, tk = m - b * p.npad;
@@ -644,6 +645,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
 //   DM_SWQK  : SwinV2 cosine-attention Q / K (heads of 32): L2-normalised, Q times the head's logit scale, scattered to window order
 //              (QKV tiles without V columns when GemmParams::swin_tokmap is set; the V tiles of that GEMM use DM_F32)
 //   DM_SWVT  : SwinV2 V columns written as the transposed window operand (4-token runs, plain operand order like DM_VT)
+// Per-image bias tables in the direct epilogues exist in the fp16 build only (the bf16 build's kernels stay exactly what round 3 tuned);
+// launches that carry one in the bf16 build run the strip-epilogue kernels.
+constexpr bool HAVE_IMGB = MDPT_OP_IS_F16 != 0;
 enum { DM_NONE = 0, DM_BF16 = 1, DM_RESID = 2, DM_QK = 3, DM_VT = 4, DM_F32 = 5, DM_RINIT = 6, DM_SWQK = 7, DM_SWVT = 8 };
 
 // Everything that selects code is a template parameter (MODE, X3 = hi+lo output planes, ACT) and every memory access is a raw
@@ -657,25 +661,44 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, si
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)(bytes < 0xFFFFFFF0ull ? bytes : 0xFFFFFFF0ull), 0x00020000);
 }
 
-template <int MODE, bool X3, int ACT>
+// IMGB: per-image bias table (GemmParams::bias_img_stride, rows of bias_img_rows >= 256 per image - the token-mean compensation of the
+// weight rounding, mdpt_api.cpp wrc_bias): a 256-row tile lies in at most two images, rows from tile-local index `bnd` on take the
+// next image's bias vector. One select per value, then the SAME single add as every other form of the epilogue ((acc + bias) ...).
+template <int MODE, bool X3, int ACT, bool IMGB = false>
 __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc)[2][2][4][2], int m0, int n0, int grp, int wc, int lane) {
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     constexpr unsigned OOB = 0xFFFFFFF0u;
     const int l15 = lane & 15, lh = lane >> 4;
     const int rows_here = p.M - m0 < 256 ? p.M - m0 : 256;  // valid rows of this tile (tail tile: fewer)
+    int bnd = 1 << 30;  // tile-local row where the next image starts (IMGB)
+    const float* bias0 = p.bias;
+    const float* bias1 = p.bias;
+    if (IMGB) {
+        const int img0 = m0 / p.bias_img_rows;
+        bnd = (img0 + 1) * p.bias_img_rows - m0;
+        bias0 = p.bias + (size_t)img0 * p.bias_img_stride;
+        bias1 = bnd < rows_here ? bias0 + p.bias_img_stride : bias0;
+    }
+    auto pick = [&](const f32x4& a, const f32x4& b, bool next) {  // (IMGB only) per-lane select, no arithmetic
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = next ? b[e] : a[e];
+        return r;
+    };
 
     if (MODE == DM_F32) {
         const __amdgpu_buffer_rsrc_t rs = tile_rsrc(p.out_f32 + (size_t)m0 * p.ldc, (size_t)rows_here * p.ldc * 4);
         const unsigned row_b = (unsigned)p.ldc * 4u;
 #pragma unroll
         for (int qn = 0; qn < 2; ++qn) {
-            f32x4 bias[2];
+            f32x4 bias[2], biasn[2];
             unsigned col_off[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int nc = n0 + qn * 128 + wc * 32 + j * 16 + 4 * lh;
-                bias[j] = p.bias ? *(const f32x4*)(p.bias + (nc < p.N ? nc : p.N - 4)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                bias[j] = p.bias ? *(const f32x4*)(bias0 + (nc < p.N ? nc : p.N - 4)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (IMGB) biasn[j] = *(const f32x4*)(bias1 + (nc < p.N ? nc : p.N - 4));
                 col_off[j] = nc < p.N ? (unsigned)nc * 4u : OOB;
             }
 #pragma unroll
@@ -683,9 +706,10 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const unsigned row = (unsigned)(qm * 128 + grp * 64 + i * 16 + l15) * row_b;
+                    const bool next = IMGB && qm * 128 + grp * 64 + i * 16 + l15 >= bnd;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const f32x4 v = acc[qm][qn][i][j] + bias[j];
+                        const f32x4 v = acc[qm][qn][i][j] + (IMGB ? pick(bias[j], biasn[j], next) : bias[j]);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, col_off[j] == OOB ? OOB : row + col_off[j], 0, 0);
                     }
                 }
@@ -778,14 +802,15 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc
     }
     // per-column constants of this lane's 4-column groups, both column halves loaded before the first store (a wait placed
     // after a store would also wait for that store's acknowledgement)
-    f32x4 bias_q[2][2], gam_q[2][2];
+    f32x4 bias_q[2][2], biasn_q[2][2], gam_q[2][2];
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int ncol = n0 + qn * 128 + wc * 32 + j * 16 + 4 * lh;
             const int nc = ncol < p.N ? ncol : p.N - 4;  // clamped: out-of-range columns are never stored
-            bias_q[qn][j] = p.bias ? *(const f32x4*)(p.bias + nc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            bias_q[qn][j] = p.bias ? *(const f32x4*)(bias0 + nc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (IMGB) biasn_q[qn][j] = *(const f32x4*)(bias1 + nc);
             if (MODE == DM_QK && ncol < p.F) gam_q[qn][j] = f32x4{p.qscale, p.qscale, p.qscale, p.qscale};
             else if (MODE == DM_QK) gam_q[qn][j] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
         }
@@ -794,6 +819,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc
         const int nq = n0 + qn * 128 + wc * 32;
         const int n8 = nq + (lh & 1) * 16 + (lh >> 1) * 8;  // first of the 8 columns this lane stores as bf16
         const f32x4(&bias)[2] = bias_q[qn];
+        const f32x4(&biasn)[2] = biasn_q[qn];
         const f32x4(&gam)[2] = gam_q[qn];
         // QKV: this wave's 32 columns lie in one of the Q / K planes (F is a multiple of 64): wave-uniform descriptor
         int qk_h = 0, qk_d = 0;
@@ -817,9 +843,10 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f32x4 v[2];
+                const bool next = IMGB && rfirst + 16 * i >= bnd;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    v[j] = acc[qm][qn][i][j] + bias[j];
+                    v[j] = acc[qm][qn][i][j] + (IMGB ? pick(bias[j], biasn[j], next) : bias[j]);
                     if (MODE == DM_QK) {
                         v[j] *= gam[j];
                     } else if (ACT == MDPT_ACT_GELU) {
@@ -1053,7 +1080,7 @@ __device__ __forceinline__ void epilogue_swin_vt(const GemmParams& p, f32x4 (&ac
 // rows (tokens 4*(lane>>4) .. +3 of a 16-row block) of one column, i.e. 8 bytes of a Vt row; v_permlane16_swap between the two
 // 16-column blocks of the quadrant gives lanes (lane>>4) = 0,1 the 8 tokens 0-7 of a column of block 0 / block 1 and lanes 2,3
 // the tokens 8-15: one 16-byte store per lane and row block, no LDS. Same arithmetic as the strip path (bias add, hi/lo split).
-template <bool X3>
+template <bool X3, bool IMGB = false>
 __device__ __forceinline__ void epilogue_direct_vt(const GemmParams& p, f32x4 (&acc)[2][2][4][2], int m0, int n0, int grp, int wc, int lane) {
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -1062,13 +1089,26 @@ __device__ __forceinline__ void epilogue_direct_vt(const GemmParams& p, f32x4 (&
     const size_t plane = (size_t)(p.M / p.npad) * p.F * p.npadv * 2;  // [B, heads, 64, npadv] bf16; < 4 GiB checked by the caller
     const __amdgpu_buffer_rsrc_t rs_hi = tile_rsrc(p.vt_hi, plane);
     const __amdgpu_buffer_rsrc_t rs_lo = tile_rsrc(X3 ? p.vt_lo : p.vt_hi, X3 ? plane : 0);
-    float bias_q[2][2];
+    // IMGB: per-image bias table, see epilogue_direct. A lane's 4 rows (tokens) start at a multiple of 4 and images at multiples of 8
+    // rows: the four values of a register quad always belong to one image
+    int bnd = 1 << 30;
+    const float* bias0 = p.bias;
+    const float* bias1 = p.bias;
+    if (IMGB) {
+        const int rows_here = p.M - m0 < 256 ? p.M - m0 : 256;
+        const int img0 = m0 / p.bias_img_rows;
+        bnd = (img0 + 1) * p.bias_img_rows - m0;
+        bias0 = p.bias + (size_t)img0 * p.bias_img_stride;
+        bias1 = bnd < rows_here ? bias0 + p.bias_img_stride : bias0;
+    }
+    float bias_q[2][2], biasn_q[2][2];
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + qn * 128 + wc * 32 + j * 16 + l15;
-            bias_q[qn][j] = p.bias[n < p.N ? n : p.N - 1];
+            bias_q[qn][j] = bias0[n < p.N ? n : p.N - 1];
+            if (IMGB) biasn_q[qn][j] = bias1[n < p.N ? n : p.N - 1];
         }
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn) {
@@ -1084,7 +1124,9 @@ __device__ __forceinline__ void epilogue_direct_vt(const GemmParams& p, f32x4 (&
                 unsigned hw_[2][2], lw_[2][2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const f32x4 v = acc[qm][qn][i][j] + bias_q[qn][j];
+                    // plain operand order: this lane's rows of block i are qm*128 + grp*64 + 16 i + 4 lh .. + 3
+                    const bool next = IMGB && qm * 128 + grp * 64 + 16 * i + 4 * lh >= bnd;
+                    const f32x4 v = acc[qm][qn][i][j] + (next ? biasn_q[qn][j] : bias_q[qn][j]);
 #pragma unroll
                     for (int w2 = 0; w2 < 2; ++w2) {
                         const f32x2 pp = {v[2 * w2], v[2 * w2 + 1]};
@@ -1553,8 +1595,19 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
                 epilogue_swin_qk<false>(p, acc, m0, n0, grp, wc, lane);
             }
         } else if (EKIND == MDPT_E_QKV) {
-            if (p.q_lo) epilogue_direct<DM_QK, true, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+            if (HAVE_IMGB && p.bias_img_stride) {
+                if (p.q_lo) epilogue_direct<DM_QK, true, MDPT_ACT_NONE, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);
+                else epilogue_direct<DM_QK, false, MDPT_ACT_NONE, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);
+            } else if (p.q_lo) epilogue_direct<DM_QK, true, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
             else epilogue_direct<DM_QK, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+        } else if (HAVE_IMGB && dmode == DM_BF16 && p.bias_img_stride) {  // the encoder's fc1 with a per-image bias table (single plane or hi + lo)
+            if (p.act == MDPT_ACT_GELU) {
+                if (p.out_lo) epilogue_direct<DM_BF16, true, MDPT_ACT_GELU, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);
+                else epilogue_direct<DM_BF16, false, MDPT_ACT_GELU, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);
+            } else {
+                if (p.out_lo) epilogue_direct<DM_BF16, true, MDPT_ACT_NONE, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);
+                else epilogue_direct<DM_BF16, false, MDPT_ACT_NONE, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);
+            }
         } else if (dmode == DM_BF16) {
             const int sel = (p.out_lo ? 3 : 0) + (p.act == MDPT_ACT_GELU ? 2 : (p.act == MDPT_ACT_RELU || p.relu_bf16) ? 1 : 0);
             switch (sel) {
@@ -1566,7 +1619,8 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
                 default: epilogue_direct<DM_BF16, true, MDPT_ACT_GELU>(p, acc, m0, n0, grp, wc, lane); break;
             }
         } else if (dmode == DM_F32 || dmode == DM_RINIT) {  // DM_RINIT: the residual is already in the accumulators
-            epilogue_direct<DM_F32, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+            if (HAVE_IMGB && p.bias_img_stride) epilogue_direct<DM_F32, false, MDPT_ACT_NONE, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);
+            else epilogue_direct<DM_F32, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
         } else {
             epilogue_direct<DM_RESID, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
         }
@@ -1584,6 +1638,9 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
         if (EKIND == MDPT_E_SWQKV) {
             if (p.vt_lo) epilogue_swin_vt<true>(p, acc, m0, n0, grp, wc, lane);
             else epilogue_swin_vt<false>(p, acc, m0, n0, grp, wc, lane);
+        } else if (HAVE_IMGB && p.bias_img_stride) {
+            if (p.vt_lo) epilogue_direct_vt<true, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);
+            else epilogue_direct_vt<false, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);
         } else if (p.vt_lo) {
             epilogue_direct_vt<true>(p, acc, m0, n0, grp, wc, lane);
         } else {
@@ -1634,11 +1691,13 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
 // register allocation of the 256-VGPR loop predictable); QKV launches decide per tile (tiles that contain V columns are written
 // transposed, token-contiguous, through the strip).
 __host__ __device__ inline int generic_direct_mode(const GemmParams& p) {
-    const bool plain = !p.up_src && !p.bias_img_stride;
+    // a per-image bias table needs the IMGB epilogues (fp16 build, >= 256 rows per image, the forms the encoder uses)
+    const bool imgb_ok = HAVE_IMGB && p.bias_img_rows >= 256 && p.bias && !p.gamma && !p.relu_bf16 && p.act != MDPT_ACT_RELU;
+    const bool plain = !p.up_src && (!p.bias_img_stride || imgb_ok);
     const bool fits = (size_t)256 * p.ldc * 4 < 0xFFFFFFF0ull;  // tile-local byte offsets of the buffer ops are 32-bit
     // relu_bf16 without an fp32 copy is just a ReLU activation (first conv of every residual conv unit)
     if (plain && fits && p.out_hi && !p.out_f32 && !p.gamma && !p.resid && !(p.relu_bf16 && p.act != MDPT_ACT_NONE)) return DM_BF16;
-    if (plain && fits && p.out_f32 && !p.out_hi && p.gamma && p.resid && p.resid == p.out_f32 && p.bias && p.act == MDPT_ACT_NONE && p.ldr == p.ldc)
+    if (plain && fits && !p.bias_img_stride && p.out_f32 && !p.out_hi && p.gamma && p.resid && p.resid == p.out_f32 && p.bias && p.act == MDPT_ACT_NONE && p.ldr == p.ldc)
         return DM_RESID;
     if (plain && fits && p.acc_init && p.out_f32 && !p.out_hi && !p.gamma && p.resid == p.out_f32 && p.ldr == p.ldc && p.act == MDPT_ACT_NONE && !p.relu_bf16)
         return DM_RINIT;
@@ -1784,6 +1843,9 @@ int resolve_tile(const GemmParams& p) {
         if (!big && tiles128 > 330 && p.N <= 64) return -1;
     }
     if (tile == MDPT_TILE_PP256 && (((p.K / 64) * p.npass) & 1)) tile = MDPT_TILE_256x256;  // odd number of K tiles: the 8-phase loop handles pairs
+    // per-image bias table: the direct epilogues of the 8-phase kernel take it in the fp16 build for images of >= 256 rows (two images per
+    // tile at most); everything else goes through the strip epilogues of the lockstep kernels (same arithmetic, same bits)
+    if (tile == MDPT_TILE_PP256 && p.bias_img_stride && p.ekind == MDPT_E_QKV && !(HAVE_IMGB && p.bias_img_rows >= 256)) tile = MDPT_TILE_256x256;
     return tile;
 }
 template <int AMODE, int EKIND>

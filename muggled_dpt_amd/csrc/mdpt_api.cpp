@@ -138,6 +138,7 @@ struct Plan {
     size_t fused[2], h1, h1u[2], scratch;
     size_t scratch_floats;
     size_t tokr[2], cbuf, relpos_lut, relpos_tq, relpos_tk;  // BEiT: readout-projected tokens, per-image cls term, bias LUT
+    size_t wrc_mean, wrc_tab;                                 // fp32 [B, wrc_maxk] operand column means, [B, wrc_maxn] per-image bias table
     size_t swi;                                               // ViT-G: fp32 [rows, 2*hidden] output of the doubled inner linear
     // SwinV2: stage-0 patch grid, per-stage residual streams (fp32, = the taps), shared GEMM fp32 output, token planes,
     // window operands, window maps (plain / shifted) and the position-bias LUT
@@ -160,6 +161,10 @@ struct mdpt_handle {
     bool f16;       // operand format: fp16 (v_mfma_*_f16, *_f16 launchers) instead of bf16
     int np[NCLS];   // MFMA passes per op class: 1 or 3
     bool x3c(int cls) const { return np[cls] == 3; }
+    // token-mean compensation of the weight rounding (fp16 operand modes, single-pass encoder Linears): see wrc_bias() below
+    bool wrc_on;
+    bool wrc(int cls) const { return wrc_on && f16 && !swin && np[cls] == 1 && (cls == CLS_QKV || cls == CLS_PROJ || cls == CLS_FC1 || cls == CLS_FC2); }
+    int wrc_maxn, wrc_maxk;  // widest compensated matrix (table / mean buffers of the plan)
     int gemm_tile;
     std::vector<WeightSpec> specs;
     std::map<std::string, int> spec_index;
@@ -206,7 +211,8 @@ struct mdpt_handle {
         m.off_hi = packed_total;
         packed_total += rup256((size_t)Np * Kp * 2);
         m.off_lo = SIZE_MAX;
-        if (x3c(m.cls)) { m.off_lo = packed_total; packed_total += rup256((size_t)Np * Kp * 2); }
+        if (x3c(m.cls) || wrc(m.cls)) {  // (a compensated single-pass class keeps the lo plane as the weight residue fp(W - fp(W)))
+            if (wrc(m.cls)) { if (Np > wrc_maxn) wrc_maxn = Np; if (Kp > wrc_maxk) wrc_maxk = Kp; } m.off_lo = packed_total; packed_total += rup256((size_t)Np * Kp * 2); }
         m.hi = m.lo = nullptr;
         mat_index[src] = (int)mats.size();
         mats.push_back(m);
@@ -247,6 +253,7 @@ int build_inventory(mdpt_handle* h) {
     const int F = h->F, P = h->P, C = h->C;
     const int G = h->cfg.base_patch_grid_h * h->cfg.base_patch_grid_w;
     h->packed_total = 0;
+    h->wrc_maxn = h->wrc_maxk = 0;
     h->zero_off = 0;
     h->packed_total += 256;
 
@@ -475,9 +482,11 @@ int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
     take_planes(bump, h->x3c(CLS_ATTN), (size_t)B * h->heads * p.npad * 64, p.q);
     take_planes(bump, h->x3c(CLS_ATTN), (size_t)B * h->heads * p.npad * 64, p.k);
     take_planes(bump, h->x3c(CLS_ATTN), (size_t)B * h->heads * 64 * p.npadv, p.vt);
-    take_planes(bump, h->x3c(CLS_PROJ), rows * F, p.att);
+    take_planes(bump, h->x3c(CLS_PROJ) || h->x3c(CLS_ATTN), rows * F, p.att);  // the 3-pass attention kernel always writes its lo plane
     take_planes(bump, h->x3c(CLS_FC2), rows * 4 * F, p.hbuf);
     p.swi = h->gh_hidden ? bump.take(rows * 2 * h->gh_hidden * 4) : SIZE_MAX;
+    p.wrc_mean = h->wrc_maxk ? bump.take((size_t)B * h->wrc_maxk * 4) : SIZE_MAX;
+    p.wrc_tab = h->wrc_maxn ? bump.take((size_t)B * h->wrc_maxn * 4) : SIZE_MAX;
     const bool x3 = h->x3c(CLS_REASM);
     for (int i = 0; i < 4; ++i) take_planes(bump, x3, rows * F, p.tap[i]);
     p.tapf32 = bump.take(rows * F * 4);
@@ -568,6 +577,23 @@ int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype) {
     return 0;
 }
 
+// Token-mean compensation of the weight rounding for one single-pass Linear of the encoder (fp16 operand modes). The GEMM computes
+// A_r W_r^T; the lost part A_r (W - W_r)^T is dominated by what all tokens of an image share, mean_t(A_r) (W - W_r)^T - a per-image bias.
+// Two small launches build the table bias_img[b][n] = bias[n] + sum_k mean_t(A_r[b,t,k]) W_lo[n][k] (W_lo = the lo plane the pack kernel
+// already produces for the 3-pass modes) and the GEMM's epilogue adds row (m / npad) of it instead of the bias vector. Measured on ViT-L
+// (tests/precision_budget/, profiles/r04_precision_budget.md): QKV error -90 %, proj -50 %, fc1 / fc2 -35 ... 40 %, for ~2 % of the step.
+int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias) {
+    const mdpt_handle* h = c.h;
+    if (!h->wrc(w.cls) || !w.lo) return 0;
+    const Plan& p = c.p;
+    float* mean = c.at<float>(p.wrc_mean);
+    float* tab = c.at<float>(p.wrc_tab);
+    CHK(OPLC(mdpt_launch_colmean, g.A_hi, g.lda, p.B, p.npad, p.N, w.Kp, mean, c.s));
+    CHK(OPLC(mdpt_launch_wrc_bias, mean, w.lo, bias, tab, p.B, w.Np, w.Kp, c.s));
+    g.bias = tab; g.bias_img_stride = w.Np; g.bias_img_rows = p.npad;
+    return 0;
+}
+
 // ---- stage: encoder. taps_f32 != null: also emit fp32 copies of the 4 out-normed taps (reference layout)
 int run_encoder(const Ctx& c, void* const taps_f32[4]) {
     const mdpt_handle* h = c.h;
@@ -603,6 +629,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             g.bias = h->V(is_beit(h) ? n + ".attn.qkv.bias@qv" : n + ".attn.qkv.bias");
             g.q_hi = q.hi; g.q_lo = q.lo; g.k_hi = k.hi; g.k_lo = k.lo; g.vt_hi = vt.hi; g.vt_lo = vt.lo;
             g.F = F; g.heads = h->heads; g.npad = p.npad; g.npadv = p.npadv; g.qscale = 0.125f;
+            CHK(wrc_bias(c, g, h->M(n + ".attn.qkv.weight"), g.bias));
             CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         DBG_STOP(1);
@@ -630,6 +657,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             g.bias = h->V(n + ".attn.proj.bias@ls");  // layer scale folded into W and the bias at pack time
             g.acc_init = 1;
             g.resid = resid; g.out_f32 = resid; g.ldr = F; g.ldc = F;
+            CHK(wrc_bias(c, g, h->M(n + ".attn.proj.weight"), g.bias));
             CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         DBG_STOP(3);
@@ -639,6 +667,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             GemmParams g = base_params(c, h->M(n + ".mlp.inner_linear_doubled.weight"), xn, rows, F);
             g.bias = h->V(n + ".mlp.inner_linear_doubled.bias");
             g.out_f32 = c.at<float>(p.swi); g.ldc = 2 * h->gh_hidden;
+            CHK(wrc_bias(c, g, h->M(n + ".mlp.inner_linear_doubled.weight"), g.bias));
             CHK(OPLC(mdpt_launch_gemm, g, c.s));
             CHK(OPLC(mdpt_launch_swiglu, c.at<float>(p.swi), hb.hi, hb.lo, (size_t)rows, h->gh_hidden, h->gh_hidden_p, c.s));
         } else {
@@ -646,6 +675,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             g.bias = h->V(n + ".mlp.layers.0.bias");
             g.act = MDPT_ACT_GELU;
             g.out_hi = hb.hi; g.out_lo = hb.lo; g.ldc = 4 * F;
+            CHK(wrc_bias(c, g, h->M(n + ".mlp.layers.0.weight"), g.bias));
             CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         DBG_STOP(5);
@@ -656,6 +686,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             g.bias = h->V(giant ? n + ".mlp.outer_linear.bias@ls" : n + ".mlp.layers.2.bias@ls");
             g.acc_init = 1;
             g.resid = resid; g.out_f32 = resid; g.ldr = F; g.ldc = F;
+            CHK(wrc_bias(c, g, h->M(giant ? n + ".mlp.outer_linear.weight" : n + ".mlp.layers.2.weight"), g.bias));
             CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         DBG_STOP(6);
@@ -704,7 +735,7 @@ int run_reassemble(const Ctx& c) {
             {
                 GemmParams g = base_params(c, h->M(n + ".readout_proj.1.weight"), tp, p.B * p.Np, F);
                 g.amode = MDPT_A_TOKENS; g.tok_np = p.Np; g.tok_stride = p.npad;
-                g.bias = c.at<float>(p.cbuf); g.bias_img_stride = F;
+                g.bias = c.at<float>(p.cbuf); g.bias_img_stride = F; g.bias_img_rows = p.Np;
                 g.act = MDPT_ACT_GELU;
                 g.out_hi = tr.hi; g.out_lo = tr.lo; g.ldc = F;
                 CHK(OPLC(mdpt_launch_gemm, g, c.s));
@@ -1010,6 +1041,7 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
         const bool all3 = cfg->precision == MDPT_PREC_BF16X3 || cfg->precision == MDPT_PREC_FP16X3;
         for (int i = 0; i < NCLS; ++i) h->np[i] = cfg->precision == MDPT_PREC_MIXED ? mixed[i] : (all3 ? 3 : 1);
     }
+    h->wrc_on = cfg->precision == MDPT_PREC_FP16 || cfg->precision == MDPT_PREC_MIXED;
     h->gemm_tile = MDPT_TILE_AUTO;
     h->finalized = false;
     h->has_last = false;
@@ -1042,12 +1074,18 @@ int mdpt_get_class_passes(const mdpt_handle* h, int32_t op_class, int32_t* passe
     return 0;
 }
 
+static void rebuild_inventory_keeping_bindings(mdpt_handle* h);
+
 int mdpt_set_class_passes(mdpt_handle* h, int32_t op_class, int32_t passes) {
     if (!h || op_class < 0 || op_class >= NCLS) return fail(MDPT_E_INVALID, "bad op class %d", op_class);
     if (passes != 1 && passes != 3) return fail(MDPT_E_INVALID, "passes must be 1 or 3, got %d", passes);
     if (h->np[op_class] == passes) return 0;
     h->np[op_class] = passes;
-    // the packed-weight inventory depends on the pass counts (lo planes): rebuild it, keeping what was bound
+    rebuild_inventory_keeping_bindings(h);  // the packed-weight inventory depends on the pass counts (lo planes)
+    return 0;
+}
+
+static void rebuild_inventory_keeping_bindings(mdpt_handle* h) {
     std::vector<WeightSpec> bound = h->specs;
     h->specs.clear(); h->spec_index.clear(); h->mats.clear(); h->mat_index.clear(); h->vecs.clear(); h->vec_index.clear();
     build_inventory(h);
@@ -1057,6 +1095,14 @@ int mdpt_set_class_passes(mdpt_handle* h, int32_t op_class, int32_t passes) {
     }
     h->finalized = false;
     h->has_last = false;
+}
+
+int mdpt_set_weight_rounding_compensation(mdpt_handle* h, int32_t on) {
+    if (!h) return fail(MDPT_E_INVALID, "null handle");
+    if (on && !h->f16) return fail(MDPT_E_UNSUPPORTED, "the token-mean compensation exists for the fp16 operand modes (MDPT_PREC_FP16 / _MIXED / _FP16X3 with single-pass classes)");
+    if (h->wrc_on == (on != 0)) return 0;
+    h->wrc_on = on != 0;
+    rebuild_inventory_keeping_bindings(h);
     return 0;
 }
 

@@ -34,7 +34,8 @@ struct GemmParams {
     int Hi, Wi, Cin, Ho, Wo, cstride;
     // generic epilogue: v = acc (+bias[n]) -> act -> (*gamma[n]) (+resid[m,n]) (+up2x(up_src)[m,n])
     const float* bias; const float* gamma; const float* resid; int ldr;
-    int bias_img_stride;                      // != 0: bias row (m / tok_np) * stride is used (per-image bias, BEiT readout)
+    int bias_img_stride, bias_img_rows;       // stride != 0: `bias` is a table, row m uses bias + (m / bias_img_rows) * bias_img_stride (per-image
+                                              // bias: BEiT readout cls term; token-mean compensation of the weight rounding in the fp16 modes)
     const float* up_src; int Hu, Wu;          // fp32 NHWC [B,Hu,Wu,N] added through x2 bilinear (align_corners)
     int act;
     float* out_f32; op_t* out_hi; op_t* out_lo; int ldc;

@@ -374,6 +374,9 @@ class _Engine:
         self.handle = handle
         for cls_name, passes in (model.__dict__.get("_class_passes") or {}).items():
             native.check(self.lib, self.lib.mdpt_set_class_passes(self.handle, native.OP_CLASSES.index(cls_name), int(passes)))
+        wrc = model.__dict__.get("_wrc")
+        if wrc is not None:
+            native.check(self.lib, self.lib.mdpt_set_weight_rounding_compensation(self.handle, int(bool(wrc))))
         self._workspaces: dict[tuple, torch.Tensor] = {}
         tile = model.__dict__.get("_gemm_tile", 0)
         if tile:
@@ -595,6 +598,12 @@ class DPTModel(nn.Module):
             if k not in native.OP_CLASSES or int(v) not in (1, 3):
                 raise ValueError(f"bad class pass entry {k!r}: {v!r}")
         self.__dict__["_class_passes"] = dict(passes) if passes else None
+        self._invalidate()
+
+    def set_weight_rounding_compensation(self, on: bool | None) -> None:
+        """Token-mean compensation of the weight rounding in the fp16 operand modes (mdpt_set_weight_rounding_compensation): None = the
+        mode's default (on for "fp16" and "mixed"), True / False force it."""
+        self.__dict__["_wrc"] = None if on is None else bool(on)
         self._invalidate()
 
     def set_gemm_tile(self, tile: int) -> None:

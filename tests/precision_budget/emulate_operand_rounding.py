@@ -61,7 +61,27 @@ def rnd_w(x, mode):
     return rnd(x, mode)
 
 
+FINE = False  # --fine: split the decoder classes by layer (study only; the library switches whole classes)
+FINE_CLASSES = ("reasm_1x1", "reasm_resample", "reasm_fuse3x3", "fusion_rcu_a", "fusion_rcu_b", "fusion_proj1x1", "head_conv1", "head_conv2")
+
+
+def fine_class(key: str) -> str | None:
+    if key.startswith("reassemble."):
+        return "reasm_1x1" if ".resample.0." in key else ("reasm_resample" if ".resample.1." in key else "reasm_fuse3x3")
+    if key.startswith("fusion."):
+        if "conv_reassembly" in key:
+            return "fusion_rcu_a"
+        return "fusion_proj1x1" if key.endswith("_seq.2.weight") or key.endswith("_seq.2.bias") else "fusion_rcu_b"
+    if key.startswith("head.spatial_upsampler"):
+        return "head_conv1"
+    if key.startswith("head.proj_1ch.0"):
+        return "head_conv2"
+    return None
+
+
 def weight_class(key: str) -> str | None:
+    if FINE and fine_class(key):
+        return fine_class(key)
     if key.startswith("patch_embed.proj"):
         return "patch"
     if ".attn.qkv." in key:
@@ -148,7 +168,10 @@ def main():
     ap.add_argument("--base", default="f16")
     ap.add_argument("--out", default="")
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--fine", action="store_true", help="decoder classes split by layer (policy keys: " + ", ".join(FINE_CLASSES) + ")")
     args = ap.parse_args()
+    global FINE
+    FINE = args.fine
     torch.set_num_threads(args.threads)
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from helpers import seeded_input, synthetic_model
@@ -170,7 +193,7 @@ def main():
         print(f"{label:34s} " + " ".join(f"{e:.3e}" for e in errs) + f"   ({time.time() - t0:.1f} s)", flush=True)
 
     run.cache = {}
-    uniform = lambda m: {c: m for c in CLASSES}
+    uniform = lambda m: {c: m for c in CLASSES + (FINE_CLASSES if FINE else ())}
     if args.study == "modes":
         for m in ("bf16", "f16", "bf16x3", "f16x3"):
             run(f"all {m}", uniform(m))

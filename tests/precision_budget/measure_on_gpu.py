@@ -25,7 +25,8 @@ CLASSES = ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "hea
 
 
 def policies():
-    out = [("bf16", "bf16", {}), ("fp16", "fp16", {}), ("mixed (shipped)", "mixed", {})]
+    out = [("bf16", "bf16", {}), ("fp16", "fp16", {}), ("fp16, no compensation", "fp16", {"wrc": False}), ("mixed (shipped)", "mixed", {}),
+           ("mixed, no compensation", "mixed", {"wrc": False})]
     for c in CLASSES:
         out.append((f"fp16 + {c} x3", "fp16", {c: 3}))
     out += [("fp16 + decoder x3", "fp16", {"reasm": 3, "fusion": 3, "head": 3}),
@@ -53,6 +54,8 @@ def measure(args):
     for label, prec, passes in policies():
         if args.only and not any(s in label for s in args.only):
             continue
+        passes = dict(passes)
+        model.set_weight_rounding_compensation(passes.pop("wrc", None))
         model.set_precision(prec)
         model.set_class_passes(passes)
         y = model(xd)

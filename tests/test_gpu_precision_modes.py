@@ -250,3 +250,44 @@ def test_other_families_in_the_fp16_modes(golden_dir):
             errs[precision] = rel_err(model(x.cuda()).cpu(), ref)
             assert errs[precision] <= tol, f"{make.__name__} {precision}: {errs[precision]:.3e}"
         assert errs["fp16"] * 3 <= errs["bf16"], errs
+
+
+@pytest.mark.parametrize("precision", ["fp16", "mixed"])
+def test_every_gemm_tile_variant_is_bitwise_identical_in_the_fp16_modes(precision):
+    """All main-loop variants through every epilogue of the model in the fp16 build, INCLUDING the per-image bias tables of the token-mean
+    compensation: the 8-phase kernel adds them in its direct epilogues (two bias vectors per tile, per-row select), the lockstep kernels in
+    their LDS-strip epilogues (table row per output row) - same single add, same bits. 252x252: 325 tokens -> 328 rows per image (>= 256)."""
+    model, cfg, w = _model("vits", torch.float32, precision)
+    x = seeded_input((3, 3, 252, 252), 11).cuda()
+    y_auto = model(x)
+    ref = _oracle().forward(w, cfg, x.cpu())
+    assert rel_err(y_auto.cpu(), ref) <= (REL_TOL_FP16 if precision == "fp16" else REL_TOL_MIXED)
+    for tile in (1, 2, 4, 5, 6):
+        model.set_gemm_tile(tile)
+        assert torch.equal(model(x), y_auto), f"tile variant {tile} changed the result"
+    model.set_gemm_tile(0)
+    for i in range(3):  # batch invariance with the per-image tables in play
+        assert torch.equal(model(x[i:i + 1])[0], y_auto[i])
+
+
+def test_token_mean_compensation_of_the_weight_rounding_reduces_the_error():
+    """mdpt_set_weight_rounding_compensation: on (the default of "fp16" / "mixed") vs off on ViT-S 504x504 - the compensated run is closer to
+    the fp32 oracle (emulated on ViT-L: the encoder's share of the error halves); toy sizes (24 rows per image: strip epilogues only) too."""
+    for name, shape in (("vits", (2, 3, 504, 504)), ("tiny", (2, 3, 56, 84))):
+        model, cfg, w = _model(name, torch.float32, "fp16")
+        x = seeded_input(shape, 37)
+        ref = _oracle().forward(w, cfg, x)
+        y_on = model(x.cuda()).cpu()
+        model.set_weight_rounding_compensation(False)
+        y_off = model(x.cuda()).cpu()
+        model.set_weight_rounding_compensation(None)
+        assert torch.equal(model(x.cuda()).cpu(), y_on)
+        e_on, e_off = rel_err(y_on, ref), rel_err(y_off, ref)
+        rms = lambda y: float((y.double() - ref.double()).pow(2).mean().sqrt())  # noqa: E731
+        assert not torch.equal(y_on, y_off)
+        assert rms(y_on) <= rms(y_off) * 1.02, f"{name}: rms {rms(y_on):.3e} (on) vs {rms(y_off):.3e} (off); max {e_on:.3e} vs {e_off:.3e}"
+    bf = _model("tiny", torch.bfloat16)[0]
+    bf.set_weight_rounding_compensation(True)
+    from muggled_dpt_amd import native
+    with pytest.raises(native.MdptError):
+        bf(seeded_input((1, 3, 56, 56), 1).to("cuda", torch.bfloat16))
