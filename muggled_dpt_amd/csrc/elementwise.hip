@@ -562,69 +562,85 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ i
 // Token-mean compensation of the weight rounding (fp16 modes; mdpt_api.cpp wrc_bias). A single-pass GEMM computes A_r W_r^T with
 // W_r = fp(W); what it loses, A_r (W - W_r)^T, is dominated by the part every token of an image shares - the image's mean token times
 // the weight residue (measured on the ViT-L budget: 70-99 % of a Linear's weight-rounding error, tests/precision_budget/). That part
-// is a per-image bias:    bias_img[b][n] = bias[n] + sum_k mean_t(A_r[b, t, k]) * W_lo[n][k],   W_lo = fp(W - W_r) (the lo plane).
-// Both kernels sum in a fixed order: one image's table does not depend on the batch it is part of.
+// is a per-image bias:    bias_img[b][n] = bias[n] + sum_k mean_t(A_r[b, t, k]) * W_lo[n][k],   W_lo = fp(W - W_r) (the lo plane):
+// colmean_kernel below (fixed summation order: an image's means do not depend on the batch it is part of) + one small GEMM (gemm.hip).
 // ---------------------------------------------------------------------------------------------------
-// mean[b][k] = (1 / nreal) * sum over the nreal real rows of image b of A[(b * rows_per_img + t) * lda + k]; one workgroup = one image x 64 columns
-__global__ __launch_bounds__(256) void colmean_kernel(const op_t* __restrict__ A, int lda, int rows_per_img, int nreal, int K, float* __restrict__ mean) {
-    __shared__ float red[32][64];
-    const int b = blockIdx.y, k0 = blockIdx.x * 64;
-    const int rs = threadIdx.x >> 3, cg = threadIdx.x & 7;
+// mean[b][k] = operand-format mean over every `step`-th real row t = 0, step, 2 step, ... < nreal of image b of A[(b * rows_per_img + t) * lda + k]
+// (a fixed subsample estimates the shared component as well as all rows do - tests/precision_budget/ - at 1 / step of the traffic).
+// One workgroup = one image x 128 columns: 16 column groups of 8 x 16 row slices (~10 sampled rows per thread at 1297 tokens, loads
+// four deep in flight), slices summed in a fixed order through LDS. The result is the A operand [B, K] of the small GEMM against the
+// weight residue plane.
+__global__ __launch_bounds__(256) void colmean_kernel(const op_t* __restrict__ A, int lda, int rows_per_img, int nreal, int step, int K, op_t* __restrict__ mean) {
+    __shared__ float red[16][128];
+    const int b = blockIdx.y, cg = threadIdx.x & 15, rs = threadIdx.x >> 4;
+    const int k = blockIdx.x * 128 + cg * 8;
+    const int nsamp = (nreal + step - 1) / step;
     float sum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    const op_t* base = A + (size_t)b * rows_per_img * lda + k0 + cg * 8;
-    for (int t = rs; t < nreal; t += 32) {
-        const opx8 v = *(const opx8*)(base + (size_t)t * lda);
+    if (k < K) {
+        const op_t* base = A + (size_t)b * rows_per_img * lda + k;
+        const size_t rstride = (size_t)step * lda;
+        int j = rs;
+        for (; j + 48 < nsamp; j += 64) {  // four independent loads before the first add
+            const opx8 v0 = *(const opx8*)(base + (size_t)j * rstride), v1 = *(const opx8*)(base + (size_t)(j + 16) * rstride);
+            const opx8 v2 = *(const opx8*)(base + (size_t)(j + 32) * rstride), v3 = *(const opx8*)(base + (size_t)(j + 48) * rstride);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sum[e] += (float)v[e];
+            for (int e = 0; e < 8; ++e) sum[e] = (((sum[e] + (float)v0[e]) + (float)v1[e]) + (float)v2[e]) + (float)v3[e];
+        }
+        for (; j < nsamp; j += 16) {
+            const opx8 v = *(const opx8*)(base + (size_t)j * rstride);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum[e] += (float)v[e];
+        }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[rs][cg * 8 + e] = sum[e];
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 128) {
+        const int kk = blockIdx.x * 128 + threadIdx.x;
         float tot = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) tot += red[r][threadIdx.x];
-        mean[(size_t)b * K + k0 + threadIdx.x] = tot * (1.0f / (float)nreal);
+        for (int r = 0; r < 16; ++r) tot += red[r][threadIdx.x];
+        if (kk < K) mean[(size_t)b * K + kk] = to_op(tot * (1.0f / (float)nsamp));
     }
 }
 
-// out[b][n] = bias[n] + sum_k mean[b][k] * W_lo[n][k]; one workgroup = 16 weight rows x all images (8 at a time), 16 k-slices of 8 columns
-__global__ __launch_bounds__(256) void wrc_bias_kernel(const float* __restrict__ mean, const op_t* __restrict__ w_lo, const float* __restrict__ bias,
-                                                       float* __restrict__ out, int B, int N, int K) {
-#pragma clang fp contract(off)
-    __shared__ float red[16][16][8];
-    const int nl = threadIdx.x >> 4, ks = threadIdx.x & 15;
-    const int n = blockIdx.x * 16 + nl;
-    const op_t* wrow = w_lo + (size_t)(n < N ? n : N - 1) * K;
-    for (int b0 = 0; b0 < B; b0 += 8) {
-        float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        for (int k = ks * 8; k < K; k += 128) {
+// out[b][n] = bias[n] + sum_k mean[b][k] * W_lo[n][k]: the [B, K] x [N, K]^T product behind the per-image bias tables. Skinny (B <= 32 rows
+// per pass) and latency-bound, so it gets its own kernel instead of a 64x64 GEMM tile per 64 columns: one workgroup = 16 columns of the
+// table, its four waves take a quarter of K each (v_mfma_f32_16x16x32: both operands are K-contiguous rows, a lane's fragment is one
+// 16-byte global load, no LDS staging), the four partial sums are added in a fixed order. A row of the table depends on its own image only.
+__global__ __launch_bounds__(256) void wrc_table_kernel(const op_t* __restrict__ mean, const op_t* __restrict__ w_lo, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int B, int N, int K) {
+    __shared__ float part[4][2][16][16];  // [wave][image block][image][column]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    const int n = blockIdx.x * 16 + l15;
+    const op_t* wrow = w_lo + (size_t)(n < N ? n : N - 1) * K + kq * 8;
+    const int kw = ((K / 32 + 3) / 4) * 32;  // K range of a wave (multiple of the MFMA's 32)
+    const int k_lo = wave * kw, k_hi = k_lo + kw < K ? k_lo + kw : K;
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        const int r0 = b0 + l15 < B ? b0 + l15 : B - 1, r1 = b0 + 16 + l15 < B ? b0 + 16 + l15 : B - 1;
+        const op_t* a0 = mean + (size_t)r0 * K + kq * 8;
+        const op_t* a1 = mean + (size_t)r1 * K + kq * 8;
+        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+        for (int k = k_lo; k < k_hi; k += 32) {
             const opx8 w = *(const opx8*)(wrow + k);
-#pragma unroll
-            for (int bb = 0; bb < 8; ++bb) {
-                if (b0 + bb < B) {
-                    const float* m = mean + (size_t)(b0 + bb) * K + k;
-                    const f32x4 m0 = *(const f32x4*)m, m1 = *(const f32x4*)(m + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[bb] = __builtin_fmaf((float)w[e], m0[e], acc[bb]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[bb] = __builtin_fmaf((float)w[4 + e], m1[e], acc[bb]);
-                }
-            }
+            const opx8 x0 = *(const opx8*)(a0 + k), x1 = *(const opx8*)(a1 + k);
+            acc0 = MDPT_MFMA_16x16x32(x0, w, acc0, 0, 0, 0);
+            acc1 = MDPT_MFMA_16x16x32(x1, w, acc1, 0, 0, 0);
         }
-        __syncthreads();  // (previous round's readers are done)
+        __syncthreads();  // (the previous pass's readers are done)
 #pragma unroll
-        for (int bb = 0; bb < 8; ++bb) red[nl][ks][bb] = acc[bb];
+        for (int r = 0; r < 4; ++r) {  // acc[r] = C[4 * (lane >> 4) + r][lane & 15]
+            part[wave][0][4 * kq + r][l15] = acc0[r];
+            part[wave][1][4 * kq + r][l15] = acc1[r];
+        }
         __syncthreads();
-        if (threadIdx.x < 128) {
-            const int rn = threadIdx.x >> 3, rb = threadIdx.x & 7;
-            const int on = blockIdx.x * 16 + rn;
-            if (on < N && b0 + rb < B) {
-                float tot = 0.0f;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) tot += red[rn][q][rb];
-                out[(size_t)(b0 + rb) * N + on] = (bias ? bias[on] : 0.0f) + tot;
-            }
+        for (int item = threadIdx.x; item < 512; item += 256) {
+            const int blk = item >> 8, img = (item >> 4) & 15, col = item & 15;
+            const int ob = b0 + blk * 16 + img, on = blockIdx.x * 16 + col;
+            if (ob < B && on < N)
+                out[(size_t)ob * N + on] = (((part[0][blk][img][col] + part[1][blk][img][col]) + part[2][blk][img][col]) + part[3][blk][img][col]) +
+                                           (bias ? bias[on] : 0.0f);
         }
     }
 }
@@ -654,17 +670,17 @@ int MDPT_FN(mdpt_launch_layernorm)(const float* x, const float* gamma, const flo
     LAUNCH_RET();
 }
 
-int MDPT_FN(mdpt_launch_colmean)(const op_t* A, int lda, int B, int rows_per_img, int nreal, int K, float* mean, hipStream_t stream) {
-    if (B <= 0 || nreal <= 0 || nreal > rows_per_img || (K & 63) || (lda & 7)) return (int)hipErrorInvalidValue;
+int MDPT_FN(mdpt_launch_colmean)(const op_t* A, int lda, int B, int rows_per_img, int nreal, int step, int K, op_t* mean, hipStream_t stream) {
+    if (B <= 0 || nreal <= 0 || nreal > rows_per_img || step <= 0 || (K & 7) || (lda & 7)) return (int)hipErrorInvalidValue;
     MdptProfScope prof("colmean_kernel", 0.0, stream);
-    hipLaunchKernelGGL(colmean_kernel, dim3(K / 64, B), dim3(256), 0, stream, A, lda, rows_per_img, nreal, K, mean);
+    hipLaunchKernelGGL(colmean_kernel, dim3((K + 127) / 128, B), dim3(256), 0, stream, A, lda, rows_per_img, nreal, step, K, mean);
     LAUNCH_RET();
 }
 
-int MDPT_FN(mdpt_launch_wrc_bias)(const float* mean, const op_t* w_lo, const float* bias, float* out, int B, int N, int K, hipStream_t stream) {
-    if (B <= 0 || N <= 0 || (K & 7)) return (int)hipErrorInvalidValue;
-    MdptProfScope prof("wrc_bias_kernel", 0.0, stream);
-    hipLaunchKernelGGL(wrc_bias_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, mean, w_lo, bias, out, B, N, K);
+int MDPT_FN(mdpt_launch_wrc_table)(const op_t* mean, const op_t* w_lo, const float* bias, float* out, int B, int N, int K, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || K <= 0 || (K & 31)) return (int)hipErrorInvalidValue;
+    MdptProfScope prof("wrc_table_kernel", 2.0 * B * N * K, stream);
+    hipLaunchKernelGGL(wrc_table_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, mean, w_lo, bias, out, B, N, K);
     LAUNCH_RET();
 }
 

@@ -138,7 +138,7 @@ struct Plan {
     size_t fused[2], h1, h1u[2], scratch;
     size_t scratch_floats;
     size_t tokr[2], cbuf, relpos_lut, relpos_tq, relpos_tk;  // BEiT: readout-projected tokens, per-image cls term, bias LUT
-    size_t wrc_mean, wrc_tab;                                 // fp32 [B, wrc_maxk] operand column means, [B, wrc_maxn] per-image bias table
+    size_t wrc_mean, wrc_tab;                                 // [B, wrc_maxk] operand-format column means, fp32 [B, wrc_maxn] per-image bias table
     size_t swi;                                               // ViT-G: fp32 [rows, 2*hidden] output of the doubled inner linear
     // SwinV2: stage-0 patch grid, per-stage residual streams (fp32, = the taps), shared GEMM fp32 output, token planes,
     // window operands, window maps (plain / shifted) and the position-bias LUT
@@ -485,7 +485,7 @@ int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
     take_planes(bump, h->x3c(CLS_PROJ) || h->x3c(CLS_ATTN), rows * F, p.att);  // the 3-pass attention kernel always writes its lo plane
     take_planes(bump, h->x3c(CLS_FC2), rows * 4 * F, p.hbuf);
     p.swi = h->gh_hidden ? bump.take(rows * 2 * h->gh_hidden * 4) : SIZE_MAX;
-    p.wrc_mean = h->wrc_maxk ? bump.take((size_t)B * h->wrc_maxk * 4) : SIZE_MAX;
+    p.wrc_mean = h->wrc_maxk ? bump.take((size_t)B * h->wrc_maxk * 2) : SIZE_MAX;
     p.wrc_tab = h->wrc_maxn ? bump.take((size_t)B * h->wrc_maxn * 4) : SIZE_MAX;
     const bool x3 = h->x3c(CLS_REASM);
     for (int i = 0; i < 4; ++i) take_planes(bump, x3, rows * F, p.tap[i]);
@@ -579,17 +579,21 @@ int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype) {
 
 // Token-mean compensation of the weight rounding for one single-pass Linear of the encoder (fp16 operand modes). The GEMM computes
 // A_r W_r^T; the lost part A_r (W - W_r)^T is dominated by what all tokens of an image share, mean_t(A_r) (W - W_r)^T - a per-image bias.
-// Two small launches build the table bias_img[b][n] = bias[n] + sum_k mean_t(A_r[b,t,k]) W_lo[n][k] (W_lo = the lo plane the pack kernel
-// already produces for the 3-pass modes) and the GEMM's epilogue adds row (m / npad) of it instead of the bias vector. Measured on ViT-L
+// Two small launches - the column means of every step-th token as a [B, K] operand, and the skinny [B, K] x [N, K]^T product with W_lo (the lo plane
+// the pack kernel already produces for the 3-pass modes) - build the table bias_img[b][n] = bias[n] + sum_k mean_t(A_r[b,t,k]) W_lo[n][k],
+// and the big GEMM's epilogue adds row (m / npad) of it instead of the bias vector. Measured on ViT-L
 // (tests/precision_budget/, profiles/r04_precision_budget.md): QKV error -90 %, proj -50 %, fc1 / fc2 -35 ... 40 %, for ~2 % of the step.
 int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias) {
     const mdpt_handle* h = c.h;
     if (!h->wrc(w.cls) || !w.lo) return 0;
     const Plan& p = c.p;
-    float* mean = c.at<float>(p.wrc_mean);
+    op_t* mean = c.at<op_t>(p.wrc_mean);
     float* tab = c.at<float>(p.wrc_tab);
-    CHK(OPLC(mdpt_launch_colmean, g.A_hi, g.lda, p.B, p.npad, p.N, w.Kp, mean, c.s));
-    CHK(OPLC(mdpt_launch_wrc_bias, mean, w.lo, bias, tab, p.B, w.Np, w.Kp, c.s));
+    // every step-th token estimates the shared component as well as all of them (tests/precision_budget/); the step depends on the token
+    // count only, so an image's table does not depend on the batch it is part of
+    const int step = p.N >= 1024 ? 8 : (p.N >= 256 ? 4 : 1);
+    CHK(OPLC(mdpt_launch_colmean, g.A_hi, g.lda, p.B, p.npad, p.N, step, w.Kp, mean, c.s));
+    CHK(OPLC(mdpt_launch_wrc_table, mean, w.lo, bias, tab, p.B, w.Np, w.Kp, c.s));
     g.bias = tab; g.bias_img_stride = w.Np; g.bias_img_rows = p.npad;
     return 0;
 }

@@ -49,10 +49,21 @@ def measure(args):
     ref = dpt_oracle.forward(w, cfg, x[idx])
     _, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
     model = model.to("cuda", torch.float32)
+    if args.no_split:
+        from muggled_dpt_amd import native
+        _orig = model._get_engine
+
+        def _no_split_engine():
+            eng = _orig()
+            native.check(eng.lib, eng.lib.mdpt_set_batch_split(eng.handle, 0))
+            return eng
+        model._get_engine = _no_split_engine
     xd = x.cuda()
     rows = []
     for label, prec, passes in policies():
         if args.only and not any(s in label for s in args.only):
+            continue
+        if args.labels and label not in args.labels:
             continue
         passes = dict(passes)
         model.set_weight_rounding_compensation(passes.pop("wrc", None))
@@ -95,7 +106,9 @@ if __name__ == "__main__":
     ap.add_argument("--size", type=int, default=504)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--only", nargs="*", default=[])
+    ap.add_argument("--only", nargs="*", default=[], help="rows whose label contains one of these")
+    ap.add_argument("--labels", nargs="*", default=[], help="rows with exactly these labels")
+    ap.add_argument("--no-split", action="store_true", help="batch split off (per-kernel profiles)")
     ap.add_argument("--out", default="")
     ap.add_argument("--render", default="")
     a = ap.parse_args()

@@ -108,8 +108,12 @@ def test_vitl_batch32_fp16_and_mixed_every_checked_image_vs_oracle():
     x = seeded_input((32, 3, 504, 504), 1)
     idx = [0, 7, 13, 31]
     torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
-    ref = _oracle().forward(w, cfg, x[idx])
+    ref32 = _oracle().forward(w, cfg, x[idx])
+    # a float16 MODEL holds fp16-rounded parameters and sees an fp16-rounded image - in the reference too (run_image.py:158 casts the model,
+    # patch_embed.py:133 the image): its cases are checked against the oracle on exactly those rounded tensors
+    ref16 = _oracle().forward({k: v.half().float() for k, v in w.items()}, cfg, x[idx].half().float())
     for dtype, precision, tol in ((torch.float16, None, REL_TOL_FP16), (torch.float32, "mixed", REL_TOL_MIXED), (torch.float16, "mixed", REL_TOL_MIXED + 2.0 ** -11)):
+        ref = ref32 if dtype == torch.float32 else ref16
         model, _, _ = _model("vitl", dtype, precision)
         xd = x.to("cuda", dtype)
         y = model(xd)
@@ -175,7 +179,15 @@ def test_raw_c_abi_class_passes_keep_bound_weights_and_reject_bad_arguments():
     native.check(lib, lib.mdpt_set_class_passes(h, native.OP_CLASSES.index("fc1"), 3))
     b1 = ctypes.c_size_t()
     native.check(lib, lib.mdpt_packed_bytes(h, ctypes.byref(b1)))
-    assert lib.mdpt_num_weights(h) == n0 and b1.value > b0.value  # the fc1 matrices gained lo planes
+    assert lib.mdpt_num_weights(h) == n0 and b1.value == b0.value  # fc1 already carried its weight-residue (lo) planes for the compensation
+    native.check(lib, lib.mdpt_set_weight_rounding_compensation(h, 0))
+    b2 = ctypes.c_size_t()
+    native.check(lib, lib.mdpt_packed_bytes(h, ctypes.byref(b2)))
+    assert b2.value < b1.value  # qkv / proj / fc2 dropped theirs, fc1 keeps its lo planes as a 3-pass class
+    native.check(lib, lib.mdpt_set_class_passes(h, native.OP_CLASSES.index("fc2"), 3))
+    b3 = ctypes.c_size_t()
+    native.check(lib, lib.mdpt_packed_bytes(h, ctypes.byref(b3)))
+    assert b3.value > b2.value
     assert lib.mdpt_set_class_passes(h, 99, 3) == -1  # MDPT_E_INVALID
     assert lib.mdpt_set_class_passes(h, 0, 2) != 0
     lib.mdpt_destroy(h)

@@ -1,0 +1,8 @@
+mkdir -p gpurun_out/r4e
+timeout 900 python -m pytest tests/test_gpu_precision_modes.py -x -q -m gpu > gpurun_out/r4e/prec_tests.log 2>&1
+timeout 300 python tests/precision_budget/measure_on_gpu.py --labels bf16 fp16 "fp16, no compensation" "mixed (shipped)" "mixed, no compensation" --out gpurun_out/r4e/budget_short.json > gpurun_out/r4e/budget.log 2>&1
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r4e/prof -- python tests/precision_budget/measure_on_gpu.py --labels fp16 --no-split --steps 5 > gpurun_out/r4e/prof_run.log 2>&1
+tail -25 gpurun_out/r4e/prec_tests.log
+cat gpurun_out/r4e/budget.log
+find gpurun_out/r4e/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -14 | cut -c1-170
