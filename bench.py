@@ -160,11 +160,12 @@ def roofline(args, pr, how):
          "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic(args, dom["name"]), "kernel": dom["name"],
          "launches": dom["launches"], "avg_us": dom["avg_us"], "gflop_per_launch": round(dom["gflop"] / dom["launches"], 3), "measured": how}
     r["sustained_mfma_tflops"] = SUSTAINED_BF16_TFLOPS  # measured ceiling for random-data bf16 MFMA; frac stays against the nominal peak
-    r["frac_of_sustained"] = round((3 if args.precision == "bf16x3" else 1) * dom["tflops"] / SUSTAINED_BF16_TFLOPS, 4)
-    if args.precision == "bf16x3":
+    x3 = args.precision in ("bf16x3", "fp16x3")  # (mixed: the dominant kernel is a single-pass encoder GEMM)
+    r["frac_of_sustained"] = round((3 if x3 else 1) * dom["tflops"] / SUSTAINED_BF16_TFLOPS, 4)
+    if x3:
         r["executed_mfma_tflops"] = round(3 * dom["tflops"], 2)
         r["executed_mfma_frac"] = round(3 * dom["tflops"] / PEAK_BF16_TFLOPS, 4)
-        r["note"] = "achieved/frac are algorithmic (one product per MAC); the x3 mode executes three bf16 MFMA passes per product"
+        r["note"] = "achieved/frac are algorithmic (one product per MAC); the x3 modes execute three MFMA passes per product"
     return r
 
 
@@ -180,31 +181,52 @@ def profile_pass(lib, fn, steps):
     return prof
 
 
-def fp32_class_leg(args, dev, x_cpu, ref, lib):
-    """The same workload in the bf16x3 mode (hi + lo bf16 operand planes, 3 MFMA passes, fp32 accumulate): the mode that meets the
-    north star's 1e-3 relative tolerance. Reported beside the headline bf16 number, never instead of it; `bench.py --precision bf16x3`
-    is the same measurement as a first-class run (full step count)."""
+PRECISION_DTYPE = {"bf16": "bf16", "bf16x3": "bf16x3 (hi/lo split bf16 MFMA operands, 3 passes, fp32 accumulate)",
+                   "fp16": "fp16 (fp16 MFMA operands, fp32 accumulate, token-mean compensation of the weight rounding)",
+                   "fp16x3": "fp16x3 (hi/lo split fp16 MFMA operands, 3 passes, fp32 accumulate)",
+                   "mixed": "mixed (fp16 MFMA operands; patch embed + decoder convs 3 passes, encoder 1 pass + token-mean compensation; fp32 accumulate)"}
+
+
+def model_for_precision(name: str, precision: str, dev):
+    """bf16 / fp16: a model of that torch dtype (16-bit tensors at the C ABI, the reference's GPU dtypes, demo_helpers/misc.py:61-77);
+    bf16x3 / fp16x3 / mixed: a float32 model (fp32 tensors at the boundary) with the operand arithmetic selected by set_precision."""
+    model, _ = make_model_and_weights(name)
+    if precision in ("bf16", "fp16"):
+        return model.to(dev, torch.bfloat16 if precision == "bf16" else torch.float16)
+    model = model.to(dev, torch.float32)
+    model.set_precision(precision)
+    return model
+
+
+def parity_mode_legs(args, dev, x_cpu, ref, lib):
+    """The same workload in the other arithmetic modes, on ONE float32 model whose operand arithmetic is switched with set_precision
+    (fp32 tensors at the boundary, so `error_vs_cpu_fp32` is the operand arithmetic's error alone):
+      mixed_mode       fp16 operands, 3 passes where the error budget says so: the operating point that meets the north star's 1e-3
+      fp16_mode        single-pass fp16 operands (what a torch.float16 model runs)
+      fp32_class_mode  bf16x3: every product in 3 passes (fp32-class accuracy)
+    Reported beside the headline bf16 number, never instead of it; `bench.py --precision <mode>` is the same measurement as a first-class
+    run (full step count)."""
     model, _ = make_model_and_weights(args.model)
     model = model.to(dev, torch.float32)
     x = x_cpu.to(dev)
     steps = max(2, min(args.steps, 10))
-    with torch.inference_mode():
-        y = model(x)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            y = model(x)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        handle = model._get_engine().handle
-        native.check(lib, lib.mdpt_set_batch_split(handle, 0))
-        model(x)
-        prof = profile_pass(lib, lambda: model(x), 2)
-    sub = argparse.Namespace(**{**vars(args), "precision": "bf16x3"})
-    out = {"value": round(args.batch * steps / dt, 3), "unit": "depth-maps/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-           "dtype": "bf16x3 (hi/lo split bf16 MFMA operands, 3 passes, fp32 accumulate)", "error_vs_cpu_fp32": error_vs(ref, y.float())}
-    if prof and prof["kernels"]:
-        out["roofline"] = roofline(sub, prof, "HIP events, batch split off, 2 steps")
+    out = {}
+    for key, prec in (("mixed_mode", "mixed"), ("fp16_mode", "fp16"), ("fp32_class_mode", "bf16x3")):
+        model.set_precision(prec)
+        dt, y = time_model(model, x, steps)
+        with torch.inference_mode():
+            handle = model._get_engine().handle
+            native.check(lib, lib.mdpt_set_batch_split(handle, 0))
+            model(x)
+            prof = profile_pass(lib, lambda: model(x), 2)
+            native.check(lib, lib.mdpt_set_batch_split(handle, 8))
+        sub = argparse.Namespace(**{**vars(args), "precision": prec})
+        rec = {"value": round(args.batch / dt, 3), "unit": "depth-maps/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+               "dtype": PRECISION_DTYPE[prec], "boundary": "fp32 image in, fp32 depth out", "error_vs_cpu_fp32": error_vs(ref, y.float())}
+        if prof and prof["kernels"]:
+            rec["roofline"] = roofline(sub, prof, "HIP events, batch split off, 2 steps")
+        out[key] = rec
+        del y
     return out
 
 
@@ -295,7 +317,8 @@ def main():
     ap.add_argument("--model", default="vitl", choices=sorted(FAMILY))
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: 32; 8 at --size 1036; 16 for beitl / swinl)")
     ap.add_argument("--size", type=int, default=0, help="model tensor side (default 504 = what a 518x518 image is processed at; 384 for beitl / swinl)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp16", "fp16x3", "mixed"],
+                    help="MFMA operand arithmetic (include/mdpt.h MDPT_PREC_*); bf16 / fp16 run a 16-bit model, the others a float32 model")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event passes behind the timed region (no roofline object)")
@@ -322,9 +345,9 @@ def main():
         dev = torch.device("cpu")
         dtype = torch.float32
 
-        class _Fake(torch.nn.Module):  # [B,3,H,W] -> [B,H,W], per image (like the real path: no cross-sample op)
+        class _Fake(torch.nn.Module):  # [B,3,H,W] -> [B,H,W], per image (like the real path: no cross-sample op, same function on every rank)
             def forward(self, x):
-                return x.mean(dim=1) + float(rank)
+                return x.mean(dim=1)
 
         model = _Fake()
         args.no_profile = args.no_cpu_baseline = args.no_secondary = True
@@ -338,9 +361,8 @@ def main():
             if local_rank == 0:
                 native.load()
             dist.barrier()
-        dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
-        model, _ = make_model_and_weights(args.model)
-        model = model.to(dev, dtype)
+        dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.precision, torch.float32)
+        model = model_for_precision(args.model, args.precision, dev)
         lib = native.load()
         if args.tile:
             model.set_gemm_tile(args.tile)
@@ -372,11 +394,27 @@ def main():
     # max over ranks FIRST: every rank takes part in this collective right behind the timed region; only then does rank 0 go on to its
     # (rank-local, collective-free) profile / baseline legs, so no rank is left parked in a collective while rank 0 is busy elsewhere
     n_ranks_seen = 1
+    per_rank_elapsed = [elapsed]
+    gather_bitwise_ok = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        own = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = torch.empty(world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, own)  # every rank's own clock: a slow rank is visible in the line, the max is `elapsed`
+        per_rank_elapsed = [float(v) for v in every.tolist()]
+        elapsed = max(per_rank_elapsed)
         n_ranks_seen = dist.get_world_size()
+        # Self-check of the gathered tensor ("gathered result == concatenation of single-GPU results bit-for-bit"):
+        # rank 0 recomputes the LAST rank's shard locally (same seed rule, 1 + rank) and compares it bitwise with its slice of what the
+        # all-gather delivered; its own slice must equal its own local forward. Collective-free, after the timed region.
+        if rank == 0:
+            with torch.inference_mode():
+                last = world - 1
+                x_last = torch.randn(args.batch, 3, args.size, args.size, generator=torch.Generator().manual_seed(1 + last)).to(dev).to(dtype)
+                y_last = model(x_last)
+                y_own = model(x)
+                b = args.batch
+                gather_bitwise_ok = bool(torch.equal(y[last * b:(last + 1) * b], y_last)) and bool(torch.equal(y[:b], y_own))
+                del x_last, y_last, y_own
     # Per-kernel measurements are taken AFTER the timed region, in extra passes of the same steps on rank 0 (local forward only, no
     # collective): HIP events around every launch cost host time per launch, which would otherwise be charged to `value` (visibly so for
     # the many-small-kernel models). Pass 1: as timed (two-stream half-batch split: kernels of the two halves overlap, so a launch's
@@ -401,15 +439,31 @@ def main():
             "metric": f"depth-maps/sec @{img}, {FAMILY[args.model]}",
             "value": round(value, 3), "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16x3(fp32-class)", "data": "synthetic",
+            "vs_baseline": None, "dtype": PRECISION_DTYPE[args.precision], "data": "synthetic",
             "config": {"workload": f"{FAMILY[args.model]} ({args.model}), {'518x518 image -> ' if args.size == 504 else ''}{args.size}x{args.size} tensor, batch "
                                    f"{args.batch}/GPU, {args.precision} MFMA operands + fp32 accumulate, mdpt_forward via C ABI"
                                    + (", RCCL all-gather of depth maps" if world > 1 else ""),
                        "global_batch": world * args.batch, "tensor_hw": [args.size, args.size], "parallelism": f"dp{world}",
                        "gemm_tile": args.tile, "batch_split": not args.no_split},
             "n_ranks_seen": n_ranks_seen, "rccl_version": rccl_version() if world > 1 and not args.fake_model else None,
-            "gathered_shape": list(y.shape),
+            "gathered_shape": list(y.shape), "gather_bitwise_ok": gather_bitwise_ok,
+            "per_rank_maps_per_s": {"min": round(args.batch * args.steps / max(per_rank_elapsed), 3),
+                                    "max": round(args.batch * args.steps / min(per_rank_elapsed), 3)},
         }
+        if world == 1 and dev.type == "cuda":
+            # the rate with the H2D copy of each batch inside the loop (SURVEY §8(d) "report both"; the C ABI takes device pointers, only
+            # DPTModel.inference starts from a host image): pinned host batch in the model dtype, one extra pass, never `value`
+            x_host = x_cpu.to(dtype).pin_memory()
+            with torch.inference_mode():
+                for _ in range(2):
+                    model(x_host.to(dev, non_blocking=True))
+                torch.cuda.synchronize()
+                t_h = time.perf_counter()
+                for _ in range(args.steps):
+                    model(x_host.to(dev, non_blocking=True))
+                torch.cuda.synchronize()
+            line["value_incl_h2d"] = round(args.batch * args.steps / (time.perf_counter() - t_h), 3)
+            del x_host
         if gflop:
             line["path_tflops"] = round(value * gflop / 1e3, 2)
             line["path_frac_of_mfma_peak"] = round(value * gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
@@ -426,6 +480,8 @@ def main():
             tot = sum(k["total_ms"] for k in shares["kernels"])
             line["kernel_time_share"] = {k["name"]: round(k["total_ms"] / tot, 4) for k in shares["kernels"][:12]}
             line["kernel_frac_of_mfma_peak"] = {k["name"]: round(k["tflops"] / PEAK_BF16_TFLOPS, 4) for k in shares["kernels"][:12] if k["gflop"] > 0}
+            if gflop:  # the fraction tied to `ms_per_step` (whole path, algorithmic FLOPs per map / timed region), beside the per-kernel one
+                line["roofline"]["path_frac"] = line["path_frac_of_mfma_peak"]
         else:
             line["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
@@ -434,7 +490,7 @@ def main():
             line["error_vs_cpu_fp32"] = err
             if args.precision == "bf16":
                 del y
-                line["fp32_class_mode"] = fp32_class_leg(args, dev, x_cpu, ref, lib)
+                line.update(parity_mode_legs(args, dev, x_cpu, ref, lib))
         else:
             line["cpu_baseline"] = None
         if world == 1 and default_run and not args.no_secondary:

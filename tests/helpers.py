@@ -12,15 +12,45 @@ from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict
 # ---- parity tolerances (rel = max|y - ref| / max|ref|, the north-star metric) ---------------------------
 # float32 model  = MDPT_PREC_BF16X3 (hi/lo split bf16 MFMA operands, fp32 accumulate). North-star bar 1e-3; measured on the
 #                  MI355X 1.5e-5 ... 3.5e-5 on every full-size model (ViT-L 504 / 1036, BEiT-L, SwinV2-L): asserted at 1e-4.
-# bfloat16 model = MDPT_PREC_BF16 (single-pass bf16 MFMA operands, fp32 accumulate). Measured 0.9e-2 ... 1.4e-2 on the full-size
-#                  models (PyTorch's own bf16 CPU path is 1.9e-2 off its fp32 path on the same weights, BASELINE.md §2 - a pure
-#                  bf16 pipeline cannot meet 1e-3): asserted at 2e-2. Where a test needs more, it says so next to the measured figure.
+# bfloat16 model = MDPT_PREC_BF16 (single-pass bf16 MFMA operands, fp32 accumulate, fp32 residual stream). The yardstick is the REFERENCE'S
+#                  OWN bf16 error: tests/golden/gen_reference_lowprec_errors.py runs the imported reference with model and input cast to
+#                  bfloat16 (what its demos do on a GPU, demo_helpers/misc.py:61-77) against its fp32 run on every fixture configuration
+#                  and commits rel errors in tests/golden/reference_lowprec_errors.json. A bf16 result here may be at most 1.25x as far
+#                  from the fp32 reference as the reference's own bf16 path is (it is ~0.6x in practice: fp32 residual stream / LayerNorm /
+#                  softmax statistics). Tolerances below are that rule applied per model family - not numbers fitted to this code.
 REL_TOL_X3 = 1e-4
-REL_TOL_BF16 = 2e-2
-# The 64-feature / 4-block TOY configurations ("tiny", "beit_tiny", "swin2_tiny": no averaging over wide features, a 32-channel toy head)
-# amplify the bf16 rounding noise: measured 0.6e-2 ... 2.5e-2 at the stage boundaries and depth (gpurun_out/parity_report.json of the
-# round-2 run: tiny_v1 2.51e-2, tiny_rect 2.09e-2), up to 3.4e-2 on the depth of beit_tiny's 6x2 grid (tests that need it say so).
-REL_TOL_BF16_TOY = 3e-2
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_lowprec_errors.json")) as _fh:
+    REF_LOWPREC = json.load(_fh)
+
+
+def ref_lowprec_tol(*fixtures: str, dtype: str = "bf16", factor: float = 1.25) -> float:
+    """factor x the largest error the reference's own `dtype` path shows on the named fixture configurations."""
+    return factor * max(REF_LOWPREC[f][dtype] for f in fixtures)
+
+
+REL_TOL_BF16 = ref_lowprec_tol("vits504", "vitl504")               # full-size Depth-Anything models: 1.25 x 2.15e-2 = 2.7e-2 (measured 0.9 ... 1.7e-2)
+REL_TOL_BF16_TOY = ref_lowprec_tol("tiny_full", "tiny_rect")       # 64-feature toy configurations: 1.25 x 2.75e-2 = 3.4e-2 (measured 0.6 ... 2.5e-2)
+REL_TOL_BF16_BEIT = ref_lowprec_tol("beit_large_384")              # 3.9e-2 (measured 1.9e-2)
+REL_TOL_BF16_BEIT_TOY = ref_lowprec_tol("beit_tiny_base", "beit_tiny_wide", "beit_tiny_tall")   # 4.8e-2 (measured up to 3.4e-2 on the 6x2 grid)
+REL_TOL_BF16_SWIN = ref_lowprec_tol("swin2_large_384")             # 2.7e-2 (measured 1.2e-2)
+REL_TOL_BF16_SWIN_TOY = ref_lowprec_tol("swin2_tiny_base", "swin2_tiny_wide", "swin2_tiny_tall")  # 3.1e-2 (measured 1.0 ... 1.5e-2)
+
+
+def emulated_tol(w, cfg, x, mode: str = "bf16", factor: float = 1.5, floor: float = 2e-3) -> float:
+    """For configurations without a reference fixture (randomised fuzz cases): the error the same operand rounding produces in an
+    INDEPENDENT CPU emulation on exactly this input (tests/precision_budget/emulate_operand_rounding.py: every contraction in fp32 on
+    operands rounded to `mode`; within ~10 % of the GPU's error on ViT-L), times `factor`."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "precision_budget"))
+    import emulate_operand_rounding as emu
+    from oracle import dpt_oracle
+    ref = dpt_oracle.forward(w, cfg, x)
+    # a 16-bit MODEL also holds every parameter (biases, norm weights, position embedding, layer scales ...) and sees the image in
+    # that dtype: round those first, as model.to(dtype) / x.to(dtype) do
+    dt = torch.bfloat16 if mode == "bf16" else torch.float16
+    y = emu.emulated_forward({k: v.to(dt).float() for k, v in w.items()}, cfg, x.to(dt).float(), {c: mode for c in emu.CLASSES})
+    return max(floor, factor * emu.rel_err(y, ref))
+
 
 _CACHE = {}
 _RECORDS = []  # (pytest node id, error): every rel_err a test computes, dumped by conftest.py at session end

@@ -6,12 +6,12 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import REL_TOL_BF16, REL_TOL_BF16_TOY, REL_TOL_X3, record_err, rel_err, seeded_input, stats
+from tests.helpers import REL_TOL_BF16_BEIT, REL_TOL_BF16_BEIT_TOY, REL_TOL_X3, record_err, rel_err, seeded_input, stats
 
 pytestmark = pytest.mark.gpu
 
-MODES = [(torch.float32, REL_TOL_X3), (torch.bfloat16, REL_TOL_BF16)]
-MODES_TOY = [(torch.float32, REL_TOL_X3), (torch.bfloat16, REL_TOL_BF16_TOY)]  # toy configs, see tests/helpers.py
+MODES = [(torch.float32, REL_TOL_X3), (torch.bfloat16, REL_TOL_BF16_BEIT)]  # 1.25 x the reference's own bf16 error (tests/helpers.py)
+MODES_TOY = [(torch.float32, REL_TOL_X3), (torch.bfloat16, REL_TOL_BF16_BEIT_TOY)]  # toy configs, see tests/helpers.py
 
 
 def _build(name, seed, dtype):
@@ -46,9 +46,8 @@ def test_beit_tiny_every_stage_boundary_vs_golden(golden_dir, tag, dtype, tol):
         assert rel_err(taps["stages"][i].cpu(), torch.from_numpy(g[f"{tag}_tap{i}"])) <= tol, f"tap{i}"
         assert rel_err(taps["reasm"][i].cpu(), torch.from_numpy(g[f"{tag}_reasm{i}"])) <= tol, f"reasm{i}"
     assert rel_err(taps["fused"].cpu(), torch.from_numpy(g[f"{tag}_fused"])) <= tol
-    # the 32-channel toy head roughly doubles the bf16 noise of the fused map: measured 3.38e-2 on the 6x2 ("tall") grid, 2.0e-2 / 1.8e-2 on
-    # the other two -> 4e-2 for the bf16 depth of this toy model only; the fp32-class mode keeps REL_TOL_X3
-    assert rel_err(y.float().cpu(), torch.from_numpy(g[f"{tag}_depth"])) <= (tol if dtype == torch.float32 else 4e-2)
+    # (measured 3.38e-2 on the 6x2 "tall" grid, where the reference's own bf16 path is 3.84e-2 off; 2.0e-2 / 1.8e-2 on the other two)
+    assert rel_err(y.float().cpu(), torch.from_numpy(g[f"{tag}_depth"])) <= tol
 
 
 @pytest.mark.parametrize("dtype,tol", MODES_TOY)
@@ -85,8 +84,8 @@ def test_beit_odd_grid_raises_and_prepare_image(golden_dir):
     assert rel_err(d.cpu(), dpt_oracle.inference(w, cfg, g["image"], 128, True)) <= REL_TOL_X3
 
 
-# BEiT-L bf16: measured 1.93e-2 (relative-position-bias attention without averaging over a cls-free residual) -> 2.5e-2 for this model
-MODES_BEITL = [(torch.float32, REL_TOL_X3), (torch.bfloat16, 2.5e-2)]
+# BEiT-L bf16: measured 1.93e-2; the reference's own bf16 path is 3.1e-2 off its fp32 path on this fixture
+MODES_BEITL = MODES
 
 
 @pytest.mark.parametrize("dtype,tol", MODES_BEITL)
@@ -132,8 +131,8 @@ def test_beit_latency_mode_split_kv_with_relpos_bias(golden_dir):
     y_default = model(x.to("cuda", torch.bfloat16))
     model.set_latency_mode(True)
     y_fast = model(x.to("cuda", torch.bfloat16))
-    assert rel_err(y_fast.float().cpu(), ref) <= REL_TOL_BF16_TOY  # beit_tiny is a toy config (measured 1.9e-2 ... 2.1e-2)
-    assert rel_err(y_fast.float().cpu(), y_default.float().cpu()) <= REL_TOL_BF16_TOY
+    assert rel_err(y_fast.float().cpu(), ref) <= REL_TOL_BF16_BEIT_TOY  # beit_tiny is a toy config (measured 1.9e-2 ... 2.1e-2)
+    assert rel_err(y_fast.float().cpu(), y_default.float().cpu()) <= REL_TOL_BF16_BEIT_TOY
     model.set_latency_mode(False)
     assert torch.equal(model(x.to("cuda", torch.bfloat16)), y_default)
 

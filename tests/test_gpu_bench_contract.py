@@ -32,3 +32,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert cpu["kind"] == "port" and cpu["unit"] == "depth-maps/s" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
     assert d["error_vs_cpu_fp32"]["rel_to_max"] < 2e-2
     assert d["fp32_class_mode"]["error_vs_cpu_fp32"]["rel_to_max"] < 1e-4 and d["fp32_class_mode"]["value"] > 0
+    # the operating points between bf16 and the 3-pass mode (round 4): mixed meets the north star's 1e-3, single-pass fp16 ~8x below bf16
+    assert d["mixed_mode"]["error_vs_cpu_fp32"]["rel_to_max"] <= 1e-3 and d["mixed_mode"]["value"] > d["fp32_class_mode"]["value"]
+    assert d["fp16_mode"]["error_vs_cpu_fp32"]["rel_to_max"] <= 3e-3 and d["fp16_mode"]["value"] > d["mixed_mode"]["value"]
+    assert abs(roof["path_frac"] - d["path_frac_of_mfma_peak"]) < 1e-9
+    assert 0 < d["value_incl_h2d"] <= d["value"] * 1.02

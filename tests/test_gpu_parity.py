@@ -253,6 +253,22 @@ def test_depth_anything_v1_family(golden_dir, dtype, tol):
     assert rel_err(taps["fused"].cpu(), torch.from_numpy(g["fused"])) <= tol
 
 
+def test_channels_last_model_and_input():
+    """The reference's GPU default: run_image.py:158 moves the model with `.to(device, dtype, memory_format=torch.channels_last)`
+    (demo_helpers/misc.py:76-77) and channels_last images reach forward(). Same bits as the contiguous call; parameters whose strides
+    are permuted by the format (4-D conv weights) are bound through a contiguous view."""
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
+        model, cfg, w = _model("tiny", dtype)
+        x = seeded_input((2, 3, 56, 84), 41).to("cuda", dtype)
+        y = model(x)
+        model_cl = model.to("cuda", dtype, memory_format=torch.channels_last)
+        assert model_cl is model and model.patch_embed.proj.weight.is_contiguous(memory_format=torch.channels_last)
+        x_cl = x.to(memory_format=torch.channels_last)
+        assert not x_cl.is_contiguous() and x_cl.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(model(x_cl), y), f"{dtype}: a channels_last model / image changed the result"
+        assert torch.equal(model(x), y)
+
+
 def test_vit_base_config_matches_oracle():
     """ViT-B sized model (F=768, 12 heads; reference make_depthanythingv2_dpt.py:97-104 standard configs)."""
     model, cfg, w = _model("vitb", torch.float32)

@@ -6,12 +6,12 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import REL_TOL_BF16, REL_TOL_BF16_TOY, REL_TOL_X3, record_err, rel_err, seeded_input, stats
+from tests.helpers import REL_TOL_BF16_SWIN, REL_TOL_BF16_SWIN_TOY, REL_TOL_X3, record_err, rel_err, seeded_input, stats
 
 pytestmark = pytest.mark.gpu
 
-MODES = [(torch.float32, REL_TOL_X3), (torch.bfloat16, REL_TOL_BF16)]
-MODES_TOY = [(torch.float32, REL_TOL_X3), (torch.bfloat16, REL_TOL_BF16_TOY)]  # toy configs, see tests/helpers.py
+MODES = [(torch.float32, REL_TOL_X3), (torch.bfloat16, REL_TOL_BF16_SWIN)]  # 1.25 x the reference's own bf16 error (tests/helpers.py)
+MODES_TOY = [(torch.float32, REL_TOL_X3), (torch.bfloat16, REL_TOL_BF16_SWIN_TOY)]  # toy configs, see tests/helpers.py
 
 
 def _build(name, seed, dtype):

@@ -82,3 +82,8 @@ def test_bench_control_flow_at_world_size_2_on_gloo():
     assert d["cpu_baseline"] is None and d["roofline"] is None and "secondary" not in d
     assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2" and d["gathered_shape"] == [4, 16, 16]
     assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-3
+    # the one-shot 8-GPU line validates itself: the gathered tensor against a local recomputation of the last rank's shard, and every
+    # rank's own clock (value is quoted on the slowest)
+    assert d["gather_bitwise_ok"] is True
+    assert 0 < d["per_rank_maps_per_s"]["min"] <= d["per_rank_maps_per_s"]["max"]
+    assert abs(d["per_rank_maps_per_s"]["min"] * 2 - d["value"]) / d["value"] < 1e-3
