@@ -109,7 +109,6 @@ def test_v1_blocks_are_hookable_and_blocks_carry_the_public_per_family_classes()
     (demo_helpers/model_capture.py:54-59): the same selection works here through the public classes."""
     import muggled_dpt_amd as mda
     from muggled_dpt_amd.dpt_model import SwinTransformerBlock, TransformerBlock
-    from muggled_dpt_amd.state_dict_conversion import convert_state_dict_keys, flatten_components, get_model_config_from_state_dict
     from muggled_dpt_amd.synthetic import STANDARD_CONFIGS, make_synthetic_original_state_dict
     osd = make_synthetic_original_state_dict(dict(STANDARD_CONFIGS["tiny"], num_blocks=8), 3)
     cfg, model = mda.make_depthanythingv1_dpt_from_original_state_dict(osd)
@@ -121,11 +120,9 @@ def test_v1_blocks_are_hookable_and_blocks_carry_the_public_per_family_classes()
         blocks[i].register_forward_hook(lambda mod, args, out, i=i: got.__setitem__(i, out))
     x = seeded_input((2, 3, 56, 84), seed=17)
     model(x.cuda())
-    ocfg = get_model_config_from_state_dict(osd)
-    w = flatten_components(convert_state_dict_keys(ocfg, osd))
-    if "imgencoder.blocks.0.norm1.weight" not in w:  # the v2-layout conversion names stages: rebuild the flat v1 names from the model itself
-        w = {f"{comp}.{k}": v.detach().float().cpu() for comp in ("patch_embed", "imgencoder", "reassemble", "fusion", "head")
-             for k, v in getattr(model, comp).state_dict().items()}
+    # the oracle's flat weight dict straight from the model's own (v1-named: imgencoder.blocks.N...) parameters
+    w = {f"{comp}.{k}": v.detach().float().cpu() for comp in ("patch_embed", "imgencoder", "reassemble", "fusion", "head")
+         for k, v in getattr(model, comp).state_dict().items()}
     orc = _oracle()
     tokens, grid = orc.patch_embed(w, x)
     ref = []

@@ -113,7 +113,8 @@ def test_random_swinv2_configurations_match_the_oracle(cfg, grid, B, seed):
     w = flatten_components(conv.convert_state_dict_keys(c, osd))
     x = torch.randn(B, 3, grid[0] * 4, grid[1] * 4, generator=torch.Generator().manual_seed(300 + seed))
     ref = dpt_oracle.forward(w, c, x)
-    for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, emulated_tol(w, c, x))):  # bf16: 1.5 x an independent CPU emulation of the same rounding on this input
+    for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, emulated_tol(w, c, x, factor=2.0))):  # bf16: 2 x an independent CPU emulation of the same rounding on this input
+        # (cosine attention at logit scale ~10 makes the toy maps chaotic: the emulation itself moves by +-30 % with the host's summation order, and it does not round the attention operands)
         _, model = make_swinv2_dpt_from_midas_v31_state_dict(osd)
         y = model.to("cuda", dtype)(x.to("cuda", dtype))
         e = rel_err(y.float().cpu(), ref)
