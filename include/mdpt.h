@@ -53,9 +53,11 @@ extern "C" {
 #define MDPT_CLASS_FC1 4    /* MLP first linear                          misc_helpers.py:111                       */
 #define MDPT_CLASS_FC2 5    /* MLP second linear                         misc_helpers.py:115                       */
 #define MDPT_CLASS_REASM 6  /* reassembly convs (incl. BEiT readout)     reassembly_model.py:139-149               */
-#define MDPT_CLASS_FUSION 7 /* RefineNet fusion convs                    fusion_model.py:148-154,178-182           */
+#define MDPT_CLASS_FUSION 7 /* RefineNet fusion convs (projection path) fusion_model.py:151-154,178-182           */
 #define MDPT_CLASS_HEAD 8   /* depth head 3x3 convs                      head_model.py:74-85                       */
-#define MDPT_NUM_CLASSES 9
+#define MDPT_CLASS_FUSION_IN 9 /* the fusion blocks' conv_reassembly units (RCU on the reassembly map before the prior is added),
+                                  fusion_model.py:148-150: the least error-sensitive convs of the decoder                  */
+#define MDPT_NUM_CLASSES 10
 
 #define MDPT_FAMILY_DAV2 0
 #define MDPT_FAMILY_DAV1 1

@@ -432,7 +432,11 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     const size_t plane_px = (size_t)p.H * p.W;
     const __amdgpu_buffer_rsrc_t rs_f = plane_rsrc(F32OUT ? p.out_f32 + (size_t)img * plane_px * COUT : nullptr, F32OUT ? plane_px * COUT * 4 : 0);
     const __amdgpu_buffer_rsrc_t rs_b = plane_rsrc(BFOUT ? p.out_bf + (size_t)img * plane_px * COUT : nullptr, BFOUT ? plane_px * COUT * 2 : 0);
-    const __amdgpu_buffer_rsrc_t rs_bl = plane_rsrc(BFOUT && X3 ? p.out_bf_lo + (size_t)img * plane_px * COUT : nullptr, BFOUT && X3 ? plane_px * COUT * 2 : 0);
+    // lo output plane: the 3-pass form writes one unless the consumer runs a single pass (null pointer: zero-size descriptor, the stores are
+    // dropped); the single-pass form of the fp16 build writes one when the consumer runs three passes (mixed-pass mode, wave-uniform test)
+    constexpr bool LO_DYN = MDPT_OP_IS_F16 && !X3 && BFOUT && !UPIN;
+    const bool want_lo = BFOUT && (X3 || LO_DYN) && p.out_bf_lo != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_bl = plane_rsrc(want_lo ? p.out_bf_lo + (size_t)img * plane_px * COUT : nullptr, want_lo ? plane_px * COUT * 2 : 0);
     const bool xok = X0 + l15 < p.W;
 
     // bilinear x2 (align_corners=True) add of the coarser fusion level (fusion_model.py:151,178): stage the <= 10x10 coarse pixels this
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
                     for (int e = 0; e < 4; ++e) v[j][e] = fmaxf(v[j][e], 0.0f);
             }
             if constexpr (BFOUT) {
-                unsigned hw_[2][2], lw_[2][2];
+                unsigned hw_[2][2], lw_[2][2] = {{0u, 0u}, {0u, 0u}};
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -549,18 +553,18 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
                         const f32x2 pp = {v[j][2 * w2], v[j][2 * w2 + 1]};
                         const opx2 hh = to_op2(pp);
                         hw_[j][w2] = __builtin_bit_cast(unsigned, hh);
-                        if constexpr (X3) {
+                        if (X3 || (LO_DYN && want_lo)) {
                             const f32x2 rr = pp - __builtin_convertvector(hh, f32x2);
                             lw_[j][w2] = __builtin_bit_cast(unsigned, to_op2(rr));
                         }
                     }
-                unsigned ph[4], pl[4];
+                unsigned ph[4], pl[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                 for (int w2 = 0; w2 < 2; ++w2) {
                     auto r = __builtin_amdgcn_permlane16_swap(hw_[0][w2], hw_[1][w2], false, false);
                     ph[w2] = r[0];
                     ph[w2 + 2] = r[1];
-                    if constexpr (X3) {
+                    if (X3 || (LO_DYN && want_lo)) {
                         auto rl = __builtin_amdgcn_permlane16_swap(lw_[0][w2], lw_[1][w2], false, false);
                         pl[w2] = rl[0];
                         pl[w2 + 2] = rl[1];
@@ -569,7 +573,8 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
                 // (no branch around the stores: hipcc would wait for every store's acknowledgement)
                 const unsigned boff = ok ? pix * (unsigned)(COUT * 2) + colb : OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{ph[0], ph[1], ph[2], ph[3]}, rs_b, boff, 0, 0);
-                if constexpr (X3) __builtin_amdgcn_raw_buffer_store_b128(u32x4{pl[0], pl[1], pl[2], pl[3]}, rs_bl, boff, 0, 0);
+                // (unconditional where the form can have a lo plane at all: without one the descriptor has zero records and the store is dropped)
+                if constexpr (X3 || LO_DYN) __builtin_amdgcn_raw_buffer_store_b128(u32x4{pl[0], pl[1], pl[2], pl[3]}, rs_bl, boff, 0, 0);
             }
         }
     };
@@ -665,8 +670,8 @@ bool MDPT_FN(mdpt_conv3h_supported)(const Conv3hParams& p) {
     if (p.Cout != 256 && p.Cout != 128) return false;
     if ((size_t)p.H * p.W * p.Cout * 4 >= 0xFFFFFFF0ull || (size_t)p.H * p.W * p.Cin * 2 >= 0xFFFFFFF0ull) return false;  // 32-bit byte offsets inside one image plane
     const bool x3 = p.in_lo != nullptr;
-    if (x3 && (!p.w_lo || (p.out_bf && !p.out_bf_lo))) return false;
-    if (!x3 && (p.w_lo || p.out_bf_lo)) return false;
+    if (x3 && !p.w_lo) return false;  // (a 3-pass conv whose consumer runs one pass writes no lo plane: out_bf_lo may be null)
+    if (!x3 && (p.w_lo || (p.out_bf_lo && (!MDPT_OP_IS_F16 || p.up_in || !p.out_bf)))) return false;  // single pass + lo output: fp16 build only
     const bool skip = p.skip != nullptr, f32 = p.out_f32 != nullptr, relu = p.relu_bf != 0, up = p.up_src != nullptr;
     if (p.Cout == 128) return !skip && !relu && !up && ((p.out_bf != nullptr) != f32);  // bias -> bf16 planes, or bias -> fp32 map
     if (!p.out_bf) return false;

@@ -86,12 +86,13 @@ struct WeightSpec {
 // Op classes: every contraction of the path belongs to one; a class runs 1 MFMA pass (operands rounded to one 16-bit plane) or 3 (hi + lo
 // split planes). The uniform modes set all classes alike; MDPT_PREC_MIXED / mdpt_set_class_passes choose per class (include/mdpt.h).
 enum { CLS_PATCH = MDPT_CLASS_PATCH, CLS_QKV = MDPT_CLASS_QKV, CLS_ATTN = MDPT_CLASS_ATTN, CLS_PROJ = MDPT_CLASS_PROJ, CLS_FC1 = MDPT_CLASS_FC1,
-       CLS_FC2 = MDPT_CLASS_FC2, CLS_REASM = MDPT_CLASS_REASM, CLS_FUSION = MDPT_CLASS_FUSION, CLS_HEAD = MDPT_CLASS_HEAD, NCLS = MDPT_NUM_CLASSES };
+       CLS_FC2 = MDPT_CLASS_FC2, CLS_REASM = MDPT_CLASS_REASM, CLS_FUSION = MDPT_CLASS_FUSION, CLS_HEAD = MDPT_CLASS_HEAD,
+       CLS_FUSION_IN = MDPT_CLASS_FUSION_IN, NCLS = MDPT_NUM_CLASSES };
 
 int mat_class(const std::string& src) {
     if (src.compare(0, 12, "patch_embed.") == 0) return CLS_PATCH;
     if (src.compare(0, 11, "reassemble.") == 0) return CLS_REASM;
-    if (src.compare(0, 7, "fusion.") == 0) return CLS_FUSION;
+    if (src.compare(0, 7, "fusion.") == 0) return src.find(".conv_reassembly.") != std::string::npos ? CLS_FUSION_IN : CLS_FUSION;
     if (src.compare(0, 5, "head.") == 0) return CLS_HEAD;
     if (src.find(".attn.qkv.") != std::string::npos) return CLS_QKV;
     if (src.find(".attn.proj.") != std::string::npos) return CLS_PROJ;
@@ -432,14 +433,16 @@ void take_planes(Bump& bump, bool x3, size_t elems, size_t out[2]) {
 
 // reassembly outputs, fusion and head buffers; p.Np / p.gh / p.gw = the "noscale" level (1/Pv of the image)
 void plan_decoder(Bump& bump, const mdpt_handle* h, Plan& p, size_t min_scratch_floats) {
-    const bool x3 = h->x3c(CLS_FUSION), x3h = h->x3c(CLS_HEAD);  // lo planes exist where the CONSUMING class runs three passes
+    // lo planes exist where the CONSUMING class runs three passes: the reassembly maps of levels 0..2 and a1 feed the conv_reassembly
+    // units (CLS_FUSION_IN), level 3's map and everything else the projection path (CLS_FUSION)
+    const bool x3 = h->x3c(CLS_FUSION), x3i = h->x3c(CLS_FUSION_IN), x3h = h->x3c(CLS_HEAD);
     const int B = p.B;
     const size_t px[4] = {(size_t)16 * p.Np, (size_t)4 * p.Np, (size_t)p.Np, (size_t)p.Np / 4};
     for (int i = 0; i < 4; ++i) {
         const size_t e = (size_t)B * px[i] * h->Cp;
         p.r_f32[i] = bump.take(e * 4);
-        take_planes(bump, x3, e, p.r_bf[i]);
-        take_planes(bump, x3, e, p.a1[i]);
+        take_planes(bump, i == 3 ? x3 : x3i, e, p.r_bf[i]);
+        take_planes(bump, x3i, e, p.a1[i]);
         p.x_f32[i] = bump.take(e * 4);
         take_planes(bump, x3, e, p.x_bf[i]);
         take_planes(bump, x3, e, p.b1[i]);
@@ -801,7 +804,8 @@ int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int 
     if (eligible && h->gemm_tile == MDPT_TILE_AUTO) {
         Conv3hParams q;
         memset(&q, 0, sizeof(q));
-        q.in = in.hi; q.in_lo = in.lo; q.w = w.hi; q.w_lo = w.lo; q.bias = bias; q.skip = skip; q.up_src = up_src; q.Hu = Hu; q.Wu = Wu;
+        const bool three = h->np[w.cls] == 3;  // the weight's class decides (an input buffer may carry a lo plane this conv does not use)
+        q.in = in.hi; q.in_lo = three ? in.lo : nullptr; q.w = w.hi; q.w_lo = three ? w.lo : nullptr; q.bias = bias; q.skip = skip; q.up_src = up_src; q.Hu = Hu; q.Wu = Wu;
         q.out_f32 = out_f32; q.out_bf = out.hi; q.out_bf_lo = out.lo; q.relu_bf = relu_bf16;
         q.B = c.p.B; q.H = sh; q.W = sw; q.Cin = Cin; q.Cout = 256; q.zero_page = h->zero_page;
         const long tiles256 = ((long)c.p.B * sh * sw + 255) / 256;
@@ -1070,6 +1074,7 @@ void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]) {
     passes[CLS_REASM] = 3;
     passes[CLS_FUSION] = 3;
     passes[CLS_HEAD] = 3;
+    passes[CLS_FUSION_IN] = 1;  // 2 % of the decoder's squared error for a quarter of its FLOPs (profiles/r04_precision_budget.md)
 }
 
 int mdpt_get_class_passes(const mdpt_handle* h, int32_t op_class, int32_t* passes) {

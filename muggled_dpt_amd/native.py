@@ -36,7 +36,7 @@ PREC_FP16 = 2
 PREC_FP16X3 = 3
 PREC_MIXED = 4
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3, "mixed": PREC_MIXED}
-OP_CLASSES = ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "head")  # MDPT_CLASS_* of include/mdpt.h
+OP_CLASSES = ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "head", "fusion_in")  # MDPT_CLASS_* of include/mdpt.h
 FAMILY_DAV2 = 0
 FAMILY_DAV1 = 1
 FAMILY_BEIT = 2

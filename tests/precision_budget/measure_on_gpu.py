@@ -21,7 +21,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-CLASSES = ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "head")
+CLASSES = ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "head", "fusion_in")
 
 
 def policies():
@@ -29,7 +29,8 @@ def policies():
            ("mixed, no compensation", "mixed", {"wrc": False})]
     for c in CLASSES:
         out.append((f"fp16 + {c} x3", "fp16", {c: 3}))
-    out += [("fp16 + decoder x3", "fp16", {"reasm": 3, "fusion": 3, "head": 3}),
+    out += [("fp16 + decoder x3", "fp16", {"reasm": 3, "fusion": 3, "fusion_in": 3, "head": 3}),
+            ("mixed + fusion_in x3 (whole decoder)", "mixed", {"fusion_in": 3}),
             ("fp16 + patch, reasm, fusion x3", "fp16", {"patch": 3, "reasm": 3, "fusion": 3}),
             ("mixed + proj x3", "mixed", {"proj": 3}),
             ("mixed + proj, qkv x3", "mixed", {"proj": 3, "qkv": 3}),
