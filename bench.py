@@ -256,7 +256,7 @@ def secondary_legs(args, dev, lib, vitl_model):
     >= 10 timed steps, the roofline of ITS dominant GEMM kernel (HIP events, split off) and the error against the CPU oracle on
     image 0 where that oracle run takes about ten seconds or less. Same JSON fields as `bench.py --model ... --size ...`."""
     out = {}
-    legs = [("vits_504_b1", "vits", 504, 1, True), ("vitl_1036_b8", "vitl", 1036, 8, False),
+    legs = [("vits_504_b1", "vits", 504, 1, True), ("vitl_504_b1", "vitl", 504, 1, False), ("vitl_1036_b8", "vitl", 1036, 8, False),
             ("beitl_384_b16", "beitl", 384, 16, True), ("swinl_384_b16", "swinl", 384, 16, True)]
     for key, name, size, batch, want_err in legs:
         t_leg = time.perf_counter()
@@ -284,6 +284,13 @@ def secondary_legs(args, dev, lib, vitl_model):
                 rec["path_frac_of_mfma_peak"] = round(batch / dt * gflop / 1e3 / PEAK_BF16_TFLOPS, 4)
             if prof and prof["kernels"]:
                 rec["roofline"] = roofline(sub, prof, "HIP events, batch split off, 3 steps")
+                if gflop:
+                    rec["roofline"]["path_frac"] = rec["path_frac_of_mfma_peak"]
+            if batch == 1:  # the opt-in latency mode (mdpt_set_latency_mode: small launches may use forms that are not batch-invariant in the last bit)
+                model.set_latency_mode(True)
+                dt_l, _ = time_model(model, x, steps)
+                model.set_latency_mode(False)
+                rec["latency_mode"] = {"ms_per_step": round(dt_l * 1e3, 3), "value": round(batch / dt_l, 3)}
             if want_err and ow is not None:
                 from oracle import dpt_oracle
                 ref = dpt_oracle.forward(ow[1], ow[0], x_cpu[:1])

@@ -525,7 +525,11 @@ int MDPT_FN(mdpt_launch_attention)(const AttnParams& p, hipStream_t stream) {
     // +1.0 % on BEiT-L; N = 5477 (1036x1036) pads by 3 % and stays wide (+1.4 %), and so does the d = 32 window attention (+4.7 %:
     // profiles/r03_attention_queries_per_wave_ab.txt). Both forms give a query the same bits (per-lane softmax state, same key order).
     const long blocks256 = (long)((p.npad + 255) / 256) * p.heads * p.B;
-    static const int wide_env = getenv("MDPT_ATTN_WIDE") ? atoi(getenv("MDPT_ATTN_WIDE")) : -1;  // A/B switch
+#ifdef MDPT_DEBUG_SWITCHES  // A/B builds only: a stray environment variable must not change which kernel a deployment runs
+    static const int wide_env = getenv("MDPT_ATTN_WIDE") ? atoi(getenv("MDPT_ATTN_WIDE")) : -1;
+#else
+    constexpr int wide_env = -1;
+#endif
     const bool fills = hd == 32 || (long)((p.N + 255) / 256) * 256 * 100 <= (long)p.N * 108;
     const bool wide = !p.x3 && (wide_env >= 0 ? wide_env != 0 : (blocks256 >= 512 && fills));
     const bool bias = p.bias_lut != nullptr;

@@ -22,11 +22,11 @@
 // issued, so that the vmcnt arithmetic is the same in every K tile).
 // Epilogues are the direct register -> global forms (swapped MFMA operands: a lane owns 4 consecutive channels of one pixel):
 //     out = ((conv + bias) [+ x2 bilinear of the coarser level]) [+ skip]  ->  fp32 map and / or bf16 map (optionally ReLU'd)
-// `skip` (fp32) initialises the accumulators (loaded under the first K tiles like gemm8's DM_RINIT form); the coarser level's 10x10 source
-// patch of the bilinear add is staged in the (then free) LDS once per tile.
-// Summation order per output element = K order above, fp32 accumulation in the MFMA pipe, then (skip + sum) + bias (+ up): the generic
-// kernels of gemm.hip walk K in the same order and apply the same epilogue expressions, so a tile-rule change between batch sizes does not
-// change a bit (tests/test_gpu_conv3h.py).
+// `skip` (fp32) is added in the epilogue (its tile is pulled towards the CU by one prefetch DMA per K tile of the main loop); the coarser
+// level's 10x10 source patch of the bilinear add is staged in the (then free) LDS once per tile.
+// Summation order per output element = K order above, fp32 accumulation in the MFMA pipe, then ((sum + bias) + up) + skip: the generic
+// kernels of gemm.hip walk K in the same order and apply the same epilogue expressions in the same order, so a tile-rule change between
+// batch sizes does not change a bit (tests/test_gpu_conv3h.py compares the two paths bit for bit).
 
 #include "mdpt_kernels.h"
 #include "mdpt_prof.h"
@@ -631,10 +631,7 @@ int launch_variant(const Conv3hParams& p, hipStream_t stream) {
         snprintf(prof_name, sizeof(prof_name), "conv3h_kernel<%d, %s, %d, %d, %d, %d>", 128 * NQN, UPIN ? "bf16 up2-in" : (X3 ? "x3" : "bf16"), (int)SKIP, (int)F32OUT, (int)RELU,
                  (int)UP);
     MdptProfScope prof(prof_name, 2.0 * p.B * p.H * p.W * (128.0 * NQN) * 9.0 * p.Cin, stream);  // algorithmic flops (one pass, whatever the mode)
-    static const int dbg_flags = getenv("MDPT_CONV3H_DBG") ? atoi(getenv("MDPT_CONV3H_DBG")) : 0;  // timing experiments (wrong results)
-    Conv3hParams q = p;
-    q.dbg_flags = dbg_flags;
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS_BYTES, stream, q);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS_BYTES, stream, p);
     return (int)hipGetLastError();
 }
 

@@ -353,7 +353,11 @@ int launch_cin(const HeadTailParams& p, hipStream_t stream) {
     static char prof_name[48] = "";
     if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "head_tail_kernel<%d>", CIN);
     MdptProfScope prof(prof_name, 2.0 * p.B * p.Ho * p.Wo * 32.0 * 9.0 * CIN, stream);
+#ifdef MDPT_DEBUG_SWITCHES  // A/B builds only
     static const bool dbg_on = getenv("MDPT_HEAD_DBG") != nullptr;
+#else
+    constexpr bool dbg_on = false;
+#endif
     if (dbg_on) {  // debug hook only (allocates and synchronises): phase stamps of every workgroup's second tile
         static unsigned long long* dbuf = nullptr;
         if (!dbuf) hipMalloc((void**)&dbuf, 256 * 8 * sizeof(unsigned long long));

@@ -790,6 +790,13 @@ int run_reassemble(const Ctx& c) {
 // implicit-GEMM kernels of gemm.hip. Both walk K in the same order and apply the same epilogue expressions (((conv + bias) + up) + skip),
 // so one image's bits do not depend on the batch it is part of. Partial 16x16 tiles may waste at most 25 % of the MFMA work (72x72: 25
 // tiles for 20.25 image-tiles' worth of pixels - the halo-staged loop is ~30 % faster per K tile; 36x36: 9 for 5.06 -> implicit GEMM).
+// From how many 256-row tiles' worth of output pixels the halo-staged kernel replaces the implicit GEMM: measured on the bare kernels at
+// batch 1 / 2 / 4 / 8 (profiles/r04_conv3h_small_batch.txt, tools/probes/gpu_conv3h_small_batch.py) - 144^2 x 1 image (81): 45.2 vs 48.8 us,
+// 72^2 x 4 (81): 46.9 vs 49.4, 72^2 x 2 (41): 43.2 vs 27.5 (one workgroup per tile: few tiles leave the CUs idle). Under the two-stream
+// batch split the other half fills idle CUs, so the faster-per-tile kernel is taken earlier. (The dense GEMMs' tile rule in gemm.hip has its
+// own thresholds, 140 / 70: there the big tile competes with a 64x64 tile that is good at small sizes; here the alternative is slower per K tile.)
+inline long conv3h_min_tiles(const Ctx& c) { return c.split ? 24 : 80; }
+
 bool conv3h_shape_ok(const mdpt_handle* h, int H, int W, int Cin) {
     if (h->Cp != 256 || (Cin & 127) || H < 2 || W < 2) return false;
     const long tile_px = (long)((H + 15) / 16) * ((W + 15) / 16) * 256, px = (long)H * W;
@@ -807,9 +814,9 @@ int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int 
         const bool three = h->np[w.cls] == 3;  // the weight's class decides (an input buffer may carry a lo plane this conv does not use)
         q.in = in.hi; q.in_lo = three ? in.lo : nullptr; q.w = w.hi; q.w_lo = three ? w.lo : nullptr; q.bias = bias; q.skip = skip; q.up_src = up_src; q.Hu = Hu; q.Wu = Wu;
         q.out_f32 = out_f32; q.out_bf = out.hi; q.out_bf_lo = out.lo; q.relu_bf = relu_bf16;
-        q.B = c.p.B; q.H = sh; q.W = sw; q.Cin = Cin; q.Cout = 256; q.zero_page = h->zero_page;
+        q.B = c.p.B; q.H = sh; q.W = sw; q.Cin = Cin; q.Cout = 256;
         const long tiles256 = ((long)c.p.B * sh * sw + 255) / 256;
-        if (tiles256 >= (c.split ? 24 : 140) && mdpt_conv3h_supported(q)) return OPLC(mdpt_launch_conv3h, q, c.s);
+        if (tiles256 >= conv3h_min_tiles(c) && mdpt_conv3h_supported(q)) return OPLC(mdpt_launch_conv3h, q, c.s);
     }
     GemmParams g = base_params(c, w, in, c.p.B * sh * sw, Cin);
     as_conv(g, sh, sw, Cin, sh, sw, 1);
@@ -899,7 +906,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool f
             q.w = h->M("head.spatial_upsampler.0.weight").hi; q.bias = h->V("head.spatial_upsampler.0.bias");
             q.out_bf = h1b; q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
             const long tiles256 = ((long)p.B * fh * fw + 255) / 256;
-            const bool big = tiles256 >= (c.split ? 24 : 140);
+            const bool big = tiles256 >= conv3h_min_tiles(c);
 #ifndef MDPT_NO_UPIN  // (A/B builds: -DMDPT_NO_UPIN keeps the stand-alone upsample in front of the halo-staged conv)
             if (big && !fused_ready) {  // the x2 upsample folded into the conv's halo interpolation
                 q.up_in = c.at<op_t>(p.flo[0]); q.Hs = fh / 2; q.Ws = fw / 2;
@@ -947,7 +954,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool f
             q.in = fu.hi; q.in_lo = fu.lo; q.w = w1.hi; q.w_lo = w1.lo; q.bias = h->V("head.spatial_upsampler.0.bias");
             q.out_f32 = c.at<float>(p.h1); q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
             const long tiles256 = ((long)p.B * fh * fw + 255) / 256;
-            if (tiles256 >= (c.split ? 24 : 140) && mdpt_conv3h_supported(q)) {
+            if (tiles256 >= conv3h_min_tiles(c) && mdpt_conv3h_supported(q)) {
                 CHK(OPLC(mdpt_launch_conv3h, q, c.s));
                 done = true;
             }
@@ -1488,6 +1495,17 @@ int mdpt_fusion(mdpt_handle* h, const void* const maps_in[4], int32_t B, int32_t
         Planes rb = c.pl(p.r_bf[i]);
         CHK(OPLC(mdpt_launch_nchw_to_nhwc, (const float*)maps_in[i], c.at<float>(p.r_f32[i]), rb.hi, rb.lo, 1, B, sh[i], sw[i], h->C, h->Cp, c.s));
     }
+    if (head_upsamples_bf16(h)) {
+        // single-pass head: the fused forward hands the head the 16-bit output of the last projection and upsamples THAT (run_fusion(c, true) +
+        // up_bf16.h arithmetic, inside head conv 1 or stand-alone: same bits). The stage-level call returns exactly that map, so a pipeline
+        // driven sub-module by sub-module (hooks registered, simple_examples/internal_features.py) predicts the same bits as DPTModel.forward
+        CHK(run_fusion(c, true));
+        Planes fu = c.pl(p.fused);
+        CHK(OPLC(mdpt_launch_upsample_bf16, c.at<op_t>(p.flo[0]), fu.hi, B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
+        CHK(OPLC(mdpt_launch_nhwc_to_nchw, nullptr, fu.hi, nullptr, (float*)fused_out, B, 8 * gh, 8 * gw, h->C, h->Cp, c.s));
+        h->has_last = false;
+        return 0;
+    }
     CHK(run_fusion(c));
     float* tmp = c.at<float>(p.scratch);
     CHK(OPLC(mdpt_launch_upsample, c.at<float>(p.flo[0]), nullptr, nullptr, tmp, B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
@@ -1539,13 +1557,22 @@ int mdpt_fusion_block(mdpt_handle* h, int32_t index, const void* reasm_in, const
     Planes b1 = c.pl(p.b1[i]), b2 = c.pl(p.b2[i]);
     CHK(rcu_conv(c, blk + "." + proj_seq(h) + ".0." + rcu_seq(h) + ".1", x_bf, sh, sw, nullptr, nullptr, 0, 0, nullptr, b1, 1));
     CHK(rcu_conv(c, blk + "." + proj_seq(h) + ".0." + rcu_seq(h) + ".3", b1, sh, sw, x_f32, nullptr, 0, 0, nullptr, b2, 0));
+    const bool to_head16 = i == 0 && head_upsamples_bf16(h);  // the last block's output is the head's input: same 16-bit map as the fused path
     {
         GemmParams g = base_params(c, h->M(blk + "." + proj_seq(h) + ".2.weight"), b2, B * sh * sw, h->Cp);
         g.bias = h->V(blk + "." + proj_seq(h) + ".2.bias");
-        g.out_f32 = c.at<float>(p.flo[i]); g.ldc = h->Cp;
+        if (to_head16) g.out_hi = c.at<op_t>(p.flo[0]);
+        else g.out_f32 = c.at<float>(p.flo[i]);
+        g.ldc = h->Cp;
         CHK(OPLC(mdpt_launch_gemm, g, c.s));
     }
     float* tmp = c.at<float>(p.scratch);
+    if (to_head16) {
+        CHK(OPLC(mdpt_launch_upsample_bf16, c.at<op_t>(p.flo[0]), (op_t*)tmp, B, sh, sw, 2 * sh, 2 * sw, h->Cp, c.s));
+        CHK(OPLC(mdpt_launch_nhwc_to_nchw, nullptr, (const op_t*)tmp, nullptr, (float*)out, B, 2 * sh, 2 * sw, h->C, h->Cp, c.s));
+        h->has_last = false;
+        return 0;
+    }
     CHK(OPLC(mdpt_launch_upsample, c.at<float>(p.flo[i]), nullptr, nullptr, tmp, B, sh, sw, 2 * sh, 2 * sw, h->Cp, c.s));
     CHK(OPLC(mdpt_launch_nhwc_to_nchw, tmp, nullptr, nullptr, (float*)out, B, 2 * sh, 2 * sw, h->C, h->Cp, c.s));
     h->has_last = false;
@@ -1776,7 +1803,7 @@ int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void*
         q.in = (const op_t*)in_bf16; q.w = (const op_t*)w_packed_bf16; q.bias = (const float*)bias_f32; q.skip = (const float*)skip_f32;
         q.in_lo = (const op_t*)in_lo_bf16; q.w_lo = (const op_t*)w_lo_bf16; q.out_bf_lo = (op_t*)out_lo_bf16;
         q.up_src = (const float*)up_f32; q.Hu = Hu; q.Wu = Wu; q.out_f32 = (float*)out_f32; q.out_bf = (op_t*)out_bf16; q.relu_bf = relu_bf16;
-        q.B = B; q.H = H; q.W = W; q.Cin = Cin; q.Cout = Cout; q.zero_page = zero_page;
+        q.B = B; q.H = H; q.W = W; q.Cin = Cin; q.Cout = Cout;
         q.dbg_times = (unsigned long long*)dbg_times;
         if (!mdpt_conv3h_supported(q)) return fail(MDPT_E_UNSUPPORTED, "conv3h does not cover this combination");
         for (int i = 0; i < iters; ++i) CHK(OPLG(mdpt_launch_conv3h, q, (hipStream_t)stream));

@@ -84,9 +84,7 @@ struct Conv3hParams {
     int relu_bf;
     int B, H, W, Cin;
     int Cout;                  // 256 (every epilogue form) or 128 (bias-only bf16 output: the head's first conv)
-    const op_t* zero_page;   // unused (out-of-image pixels are staged as zeros by the buffer bounds check)
     unsigned long long* dbg_times;  // test hook: per-workgroup s_memtime stamps [start, first barrier, loop done, stores acknowledged, stores issued, XCC id]
-    int dbg_flags;                  // set by the launcher from MDPT_CONV3H_DBG (timing experiments that skip parts of the loop; results are wrong)
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -80,6 +80,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(REPO, "include"), "-I", CSRC,
              "-Wno-unused-result"]
+    # A/B builds (tools/probes): e.g. MDPT_EXTRA_HIPCC_FLAGS="-DMDPT_DEBUG_SWITCHES" compiles the environment switches of the kernel
+    # launchers in; release builds read no environment variable on the launch path
+    flags += os.environ.get("MDPT_EXTRA_HIPCC_FLAGS", "").split()
     _sweep_stale_temporaries()
 
     # objects and the linked library go through pid-unique names and an atomic rename: several processes (one per GPU) may find

@@ -85,6 +85,11 @@ def test_block_hooks_receive_the_block_output_tokens(family, name, hw, dtype, to
     assert len(got) == n_before
     if dtype == torch.float32:
         assert rel_err(y2.float().cpu(), y.float().cpu()) <= 1e-6
+    elif family == "v2":
+        # 16-bit models: the stage-by-stage pipeline (taken while hooks are attached) hands the head the same 16-bit fused map as the fused
+        # forward, and the 16-bit boundaries between the stages are exact for values that already are 16-bit ... except the encoder taps and
+        # reassembly maps, which cross the Python boundary in the model dtype: bounded, not bitwise
+        assert rel_err(y2.float().cpu(), y.float().cpu()) <= 2e-2
 
 
 def test_stage_level_call_fires_block_hooks_too():

@@ -303,3 +303,28 @@ def test_token_mean_compensation_of_the_weight_rounding_reduces_the_error():
     from muggled_dpt_amd import native
     with pytest.raises(native.MdptError):
         bf(seeded_input((1, 3, 56, 56), 1).to("cuda", torch.bfloat16))
+
+
+def test_beit_large_and_swin_large_fixtures_in_the_fp16_and_mixed_modes(golden_dir):
+    """BASELINE configs[4] models (BEiT-L-384, SwinV2-L-384; fixtures generated from the reference) in the fp16 operand modes. The yardstick
+    for single-pass fp16 is the reference's own float16 CPU path on the same fixture (tests/golden/reference_lowprec_errors.json: 1.4e-2 /
+    9.2e-3 - it rounds the residual stream too); mixed is held to the north-star bar for BEiT (token-mean compensation on) and to 2e-3 for
+    SwinV2, whose window-major encoder runs without the compensation."""
+    from muggled_dpt_amd import make_beit_dpt_from_midas_v31_state_dict, make_swinv2_dpt_from_midas_v31_state_dict
+    from muggled_dpt_amd.synthetic import make_synthetic_beit_state_dict, make_synthetic_swinv2_state_dict
+    from tests.helpers import ref_lowprec_tol
+    for fixture, make, synth, name, mixed_tol in (("beit_large_384", make_beit_dpt_from_midas_v31_state_dict, make_synthetic_beit_state_dict, "beit_large_384", 1e-3),
+                                                  ("swin2_large_384", make_swinv2_dpt_from_midas_v31_state_dict, make_synthetic_swinv2_state_dict, "swin2_large_384", 2e-3)):
+        g = np.load(os.path.join(golden_dir, fixture + ".npz"))
+        osd = synth(name, int(g["weight_seed"]))
+        x = seeded_input((1, 3, 384, 384), int(g["input_seed"]))
+        ref = torch.from_numpy(g["depth_strided"]).double()
+        _, model = make(osd)
+        model = model.to("cuda", torch.float32)
+        for precision, tol in (("fp16", min(ref_lowprec_tol(fixture, dtype="fp16", factor=1.0), 4e-3)), ("mixed", mixed_tol)):
+            model.set_precision(precision)
+            y = model(x.cuda()).cpu()
+            err = record_err(float((y[:, ::4, ::4].double() - ref).abs().max() / ref.abs().max()), f"{fixture} {precision}")
+            assert err <= tol, f"{fixture} {precision}: {err:.3e} > {tol:.3e}"
+        del model
+        torch.cuda.empty_cache()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-phase s_memtime stamps of head_tail_kernel (MDPT_HEAD_DBG=1 debug hook) on the headline shape: ViT-L head, batch 32, 288^2 -> 504^2."""
+"""Per-phase s_memtime stamps of head_tail_kernel (MDPT_HEAD_DBG=1 debug hook; library built with MDPT_EXTRA_HIPCC_FLAGS=-DMDPT_DEBUG_SWITCHES) on the headline shape: ViT-L head, batch 32, 288^2 -> 504^2."""
 import os, sys, time
 os.environ["MDPT_HEAD_DBG"] = "1"
 import torch

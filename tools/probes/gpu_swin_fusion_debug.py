@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fused Q/K epilogue vs swin_qk_prep: max abs difference of the depth maps per (dtype, tile) - run twice, with and without
-MDPT_SWIN_NO_QK_FUSION=1, to separate the fusion from the tile variants."""
+MDPT_SWIN_NO_QK_FUSION=1 (library built with MDPT_EXTRA_HIPCC_FLAGS=-DMDPT_DEBUG_SWITCHES), to separate the fusion from the tile variants."""
 import os, sys
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
