@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ i
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Token-mean compensation of the weight rounding (fp16 modes; mdpt_api.cpp wrc_bias). A single-pass GEMM computes A_r W_r^T with
+// Token-mean compensation of the weight rounding (fp16 modes; mdpt_stages.cpp wrc_bias). A single-pass GEMM computes A_r W_r^T with
 // W_r = fp(W); what it loses, A_r (W - W_r)^T, is dominated by the part every token of an image shares - the image's mean token times
 // the weight residue (measured on the ViT-L budget: 70-99 % of a Linear's weight-rounding error, tests/precision_budget/). That part
 // is a per-image bias:    bias_img[b][n] = bias[n] + sum_k mean_t(A_r[b, t, k]) * W_lo[n][k],   W_lo = fp(W - W_r) (the lo plane):

@@ -662,7 +662,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, si
 }
 
 // IMGB: per-image bias table (GemmParams::bias_img_stride, rows of bias_img_rows >= 256 per image - the token-mean compensation of the
-// weight rounding, mdpt_api.cpp wrc_bias): a 256-row tile lies in at most two images, rows from tile-local index `bnd` on take the
+// weight rounding, mdpt_stages.cpp wrc_bias): a 256-row tile lies in at most two images, rows from tile-local index `bnd` on take the
 // next image's bias vector. One select per value, then the SAME single add as every other form of the epilogue ((acc + bias) ...).
 template <int MODE, bool X3, int ACT, bool IMGB = false>
 __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc)[2][2][4][2], int m0, int n0, int grp, int wc, int lane) {
@@ -1775,7 +1775,7 @@ int launch_pp_mode(const GemmParams& p, hipStream_t stream) {
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     static char prof_name[64] = "";
     if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "gemm8_kernel<%d, %d, %d>", AMODE, EKIND, DMODE);
-    MdptProfScope prof(prof_name, 2.0 * p.M * p.N * p.K, stream);
+    MdptProfScope prof(prof_name, 2.0 * (p.M_alg > 0 ? p.M_alg : p.M) * p.N * p.K, stream);  // algorithmic rows (token pad rows are not work)
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, p);
     return (int)hipGetLastError();
 }
@@ -1814,7 +1814,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
     static char prof_name[112] = "";
     if (!prof_name[0])
         snprintf(prof_name, sizeof(prof_name), "gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, BK, NST, MINW, AMODE, EKIND);
-    MdptProfScope prof(prof_name, 2.0 * p.M * p.N * p.K, stream);  // algorithmic flops (one pass, whatever npass is)
+    MdptProfScope prof(prof_name, 2.0 * (p.M_alg > 0 ? p.M_alg : p.M) * p.N * p.K, stream);  // algorithmic flops (real rows, one pass whatever npass is)
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), LDS, stream, p);
     return (int)hipGetLastError();
 }

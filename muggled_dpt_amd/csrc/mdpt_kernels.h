@@ -1,5 +1,5 @@
 // Internal kernel-launcher interface of libmdpt (gfx950 only). Not part of the public C ABI
-// (that is include/mdpt.h); this header is shared by the .hip kernel files and mdpt_api.cpp.
+// (that is include/mdpt.h); this header is shared by the .hip kernel files and the host-side files (mdpt_internal.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -24,6 +24,7 @@ struct GemmParams {
     const op_t* A_hi; const op_t* A_lo;   // activations, row stride lda (elements)
     const op_t* W_hi; const op_t* W_lo;   // weights [N][K]
     int M, N, K;                              // K % 64 == 0 (conv: K = 9 * Cin)
+    int M_alg;                                // > 0: rows that are algorithmic work (token rows without the per-image pad rows): profiler FLOP accounting only
     int lda;
     int npass;                                // 1 = bf16, 3 = bf16x3 (A_lo*W_hi + A_hi*W_lo + A_hi*W_hi)
     const op_t* zero_page;                  // >= 256 B of zeros (source for padded conv taps)
@@ -157,8 +158,8 @@ int mdpt_launch_post_normalize(const float* in, const float* minmax, void* out, 
                                hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
-// launchers: one set per operand format (op_types.h). A kernel file sees its own set through MDPT_FN; the host side (mdpt_api.cpp)
-// includes mdpt_launchers.inc a second time for the other format and picks per handle (OPL in mdpt_api.cpp). C linkage: the two
+// launchers: one set per operand format (op_types.h). A kernel file sees its own set through MDPT_FN; the host side (mdpt_internal.h)
+// includes mdpt_launchers.inc a second time for the other format and picks per handle (OPL). C linkage: the two
 // builds of a file differ in what `op_t*` points at, which must not reach the symbol names.
 // ------------------------------------------------------------------------------------------------
 extern "C" {

@@ -1,0 +1,464 @@
+// libmdpt: launch sequences of the five stages - patch embed, encoder (4 taps), reassemble, RefineNet fusion, depth head - for all four
+// model families. Stage structure mirrors DPTModel.forward (reference muggled_dpt/dpt_model.py:61-83). Every launch goes on the caller's
+// stream; nothing here allocates or synchronises.
+#include "mdpt_internal.h"
+
+namespace mdpt {
+
+GemmParams base_params(const Ctx& c, const Mat& w, Planes a, int M, int lda) {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.npass = c.h->np[w.cls];  // the class of the weight matrix decides; an A buffer shared with a 3-pass class may carry an unused lo plane
+    g.A_hi = a.hi; g.A_lo = g.npass == 3 ? a.lo : nullptr;
+    g.W_hi = w.hi; g.W_lo = g.npass == 3 ? w.lo : nullptr;
+    g.M = M; g.N = w.Np; g.K = w.Kp; g.lda = lda;
+    g.zero_page = c.h->zero_page;
+    g.amode = MDPT_A_DENSE; g.ekind = MDPT_E_GENERIC; g.tile = c.h->gemm_tile;
+    g.throughput_mode = c.split ? 1 : 0;
+    g.ldc = w.Np; g.ldr = w.Np;
+    return g;
+}
+
+void as_conv(GemmParams& g, int Hi, int Wi, int Cin, int Ho, int Wo, int stride) {
+    g.amode = MDPT_A_CONV3;
+    g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.cstride = stride;
+}
+
+
+// ---- stage: patch embed (fused form: writes the residual stream incl. position embedding)
+int run_pos(const Ctx& c) {
+    const mdpt_handle* h = c.h;
+    return OPLC(mdpt_launch_posembed, h->V("imgencoder.posenc.base_patch_embedding"), c.at<float>(c.p.pos), h->cfg.base_patch_grid_h,
+                                h->cfg.base_patch_grid_w, c.p.gh, c.p.gw, h->F, c.s);
+}
+
+int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype) {
+    const mdpt_handle* h = c.h;
+    const Plan& p = c.p;
+    Planes im = c.pl(p.im2col);
+    CHK(OPLC(mdpt_launch_patchify, image, image_dtype, im.hi, im.lo, p.B, p.H, p.W, h->P, h->Kpatch, c.s));
+    const bool beit = is_beit(h);
+    if (!beit) CHK(run_pos(c));
+    CHK(OPLC(mdpt_launch_init_tokens, c.at<float>(p.resid), h->V("imgencoder.cls_token"), beit ? nullptr : h->V("imgencoder.posenc.cls_embedding"),
+                                p.B, p.N, p.npad, h->F, c.s));
+    GemmParams g = base_params(c, h->M("patch_embed.proj.weight"), im, p.B * p.Np, h->Kpatch);
+    g.ekind = MDPT_E_PATCH;
+    g.bias = h->V("patch_embed.proj.bias");
+    g.pos = beit ? nullptr : c.at<float>(p.pos);
+    g.out_f32 = c.at<float>(p.resid);
+    g.tok_np = p.Np; g.npad = p.npad; g.ldc = h->F;
+    CHK(OPLC(mdpt_launch_gemm, g, c.s));
+    return 0;
+}
+
+// Token-mean compensation of the weight rounding for one single-pass Linear of the encoder (fp16 operand modes). The GEMM computes
+// A_r W_r^T; the lost part A_r (W - W_r)^T is dominated by what all tokens of an image share, mean_t(A_r) (W - W_r)^T - a per-image bias.
+// Two small launches - the column means of every step-th token as a [B, K] operand, and the skinny [B, K] x [N, K]^T product with W_lo (the lo plane
+// the pack kernel already produces for the 3-pass modes) - build the table bias_img[b][n] = bias[n] + sum_k mean_t(A_r[b,t,k]) W_lo[n][k],
+// and the big GEMM's epilogue adds row (m / npad) of it instead of the bias vector. Measured on ViT-L
+// (tests/precision_budget/, profiles/r04_precision_budget.md): QKV error -90 %, proj -50 %, fc1 / fc2 -35 ... 40 %, for ~2 % of the step.
+int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias) {
+    const mdpt_handle* h = c.h;
+    if (!h->wrc(w.cls) || !w.lo) return 0;
+    const Plan& p = c.p;
+    op_t* mean = c.at<op_t>(p.wrc_mean);
+    float* tab = c.at<float>(p.wrc_tab);
+    // every step-th token estimates the shared component as well as all of them (tests/precision_budget/); the step depends on the token
+    // count only, so an image's table does not depend on the batch it is part of
+    const int step = p.N >= 1024 ? 8 : (p.N >= 256 ? 4 : 1);
+    CHK(OPLC(mdpt_launch_colmean, g.A_hi, g.lda, p.B, p.npad, p.N, step, w.Kp, mean, c.s));
+    CHK(OPLC(mdpt_launch_wrc_table, mean, w.lo, bias, tab, p.B, w.Np, w.Kp, c.s));
+    g.bias = tab; g.bias_img_stride = w.Np; g.bias_img_rows = p.npad;
+    return 0;
+}
+
+// ---- stage: encoder. taps_f32 != null: also emit fp32 copies of the 4 out-normed taps (reference layout)
+int run_encoder(const Ctx& c, void* const taps_f32[4]) {
+    const mdpt_handle* h = c.h;
+    const Plan& p = c.p;
+    const int F = h->F, rows = p.B * p.npad;
+    float* resid = c.at<float>(p.resid);
+    Planes xn = c.pl(p.xn), q = c.pl(p.q), k = c.pl(p.k), vt = c.pl(p.vt), att = c.pl(p.att), hb = c.pl(p.hbuf);
+    CHK(OPLC(mdpt_launch_zero_vt_pad, vt.hi, vt.lo, p.B * h->heads * 64, p.N, p.npadv, c.s));
+    // a 3-pass projection behind a 1-pass attention kernel (which writes no lo plane): the plane is zero, i.e. the projection keeps
+    // the rounding of its A operand and loses only that of its weights
+    if (att.lo && !h->x3c(CLS_ATTN)) CHK(hipMemsetAsync(att.lo, 0, (size_t)rows * F * 2, c.s));
+    const Planes xn_qkv = {xn.hi, h->x3c(CLS_QKV) ? xn.lo : nullptr}, xn_fc1 = {xn.hi, h->x3c(CLS_FC1) ? xn.lo : nullptr};
+#define DBG_STOP(step) if (h->dbg_block == b && h->dbg_step == (step)) return 0
+    const size_t relpos_stride = is_beit(h) ? (size_t)h->heads * mdpt_beit_relpos_elen(p.gh, p.gw) : 0;
+    const bool relpos_batched = is_beit(h) && h->nblocks <= 32;
+    if (relpos_batched) {  // every block's relative-position table, resized to the current grid: one launch per forward
+        BeitRelposBatch rb;
+        memset(&rb, 0, sizeof(rb));
+        for (int b = 0; b < h->nblocks; ++b) rb.ref[b] = h->V(blk_name(h, b) + ".attn.relpos_enc.ref_bias_lut");
+        rb.ext0 = c.at<float>(p.relpos_lut); rb.ext_stride = relpos_stride;
+        rb.tq = c.at<int>(p.relpos_tq); rb.tk = c.at<int>(p.relpos_tk);
+        rb.n = h->nblocks; rb.heads = h->heads; rb.Gh = h->cfg.base_patch_grid_h; rb.Gw = h->cfg.base_patch_grid_w;
+        rb.gh = p.gh; rb.gw = p.gw; rb.N = p.N; rb.ntok_pad = p.npadv;
+        CHK(OPLC(mdpt_launch_beit_relpos_batch, rb, c.s));
+    }
+    for (int b = 0; b < h->nblocks; ++b) {
+        const std::string n = blk_name(h, b);
+        CHK(OPLC(mdpt_launch_layernorm, resid, h->V(n + ".norm1.weight"), h->V(n + ".norm1.bias"), xn_qkv.hi, xn_qkv.lo, nullptr, rows, F, c.s));
+        DBG_STOP(0);
+        {
+            GemmParams g = base_params(c, h->M(n + ".attn.qkv.weight"), xn, rows, F);
+            g.M_alg = p.B * p.N;
+            g.ekind = MDPT_E_QKV;
+            g.bias = h->V(is_beit(h) ? n + ".attn.qkv.bias@qv" : n + ".attn.qkv.bias");
+            g.q_hi = q.hi; g.q_lo = q.lo; g.k_hi = k.hi; g.k_lo = k.lo; g.vt_hi = vt.hi; g.vt_lo = vt.lo;
+            g.F = F; g.heads = h->heads; g.npad = p.npad; g.npadv = p.npadv; g.qscale = 0.125f;
+            CHK(wrc_bias(c, g, h->M(n + ".attn.qkv.weight"), g.bias));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
+        }
+        DBG_STOP(1);
+        {
+            AttnParams a;
+            memset(&a, 0, sizeof(a));
+            a.q_hi = q.hi; a.q_lo = q.lo; a.k_hi = k.hi; a.k_lo = k.lo; a.vt_hi = vt.hi; a.vt_lo = vt.lo;
+            a.out_hi = att.hi; a.out_lo = att.lo;
+            a.B = p.B; a.heads = h->heads; a.N = p.N; a.npad = p.npad; a.npadv = p.npadv; a.F = F; a.x3 = h->x3c(CLS_ATTN);
+            a.allow_split_kv = h->latency_mode;
+            if (is_beit(h)) {
+                float* lut_b = c.at<float>(p.relpos_lut) + (relpos_batched ? (size_t)b * relpos_stride : 0);
+                if (!relpos_batched)  // more than 32 blocks: this layer's table on its own (tiny kernel)
+                    CHK(OPLC(mdpt_launch_beit_relpos, h->V(n + ".attn.relpos_enc.ref_bias_lut"), lut_b, c.at<int>(p.relpos_tq), c.at<int>(p.relpos_tk),
+                                                h->heads, h->cfg.base_patch_grid_h, h->cfg.base_patch_grid_w, p.gh, p.gw, p.N, p.npadv, c.s));
+                a.bias_lut = lut_b; a.bias_elen = mdpt_beit_relpos_elen(p.gh, p.gw);
+                a.tq = c.at<int>(p.relpos_tq); a.tk = c.at<int>(p.relpos_tk);
+            }
+            if (c.attn_dump && c.attn_dump[b]) CHK(OPLC(mdpt_launch_attn_weights, a, (float*)c.attn_dump[b], c.s));
+            CHK(OPLC(mdpt_launch_attention, a, c.s));
+        }
+        DBG_STOP(2);
+        {
+            GemmParams g = base_params(c, h->M(n + ".attn.proj.weight"), att, rows, F);
+            g.M_alg = p.B * p.N;
+            g.bias = h->V(n + ".attn.proj.bias@ls");  // layer scale folded into W and the bias at pack time
+            g.acc_init = 1;
+            g.resid = resid; g.out_f32 = resid; g.ldr = F; g.ldc = F;
+            CHK(wrc_bias(c, g, h->M(n + ".attn.proj.weight"), g.bias));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
+        }
+        DBG_STOP(3);
+        CHK(OPLC(mdpt_launch_layernorm, resid, h->V(n + ".norm2.weight"), h->V(n + ".norm2.bias"), xn_fc1.hi, xn_fc1.lo, nullptr, rows, F, c.s));
+        DBG_STOP(4);
+        if (h->gh_hidden) {  // ViT-G: (a | b) = x W12^T + b12 ; hidden = silu(a) * b
+            GemmParams g = base_params(c, h->M(n + ".mlp.inner_linear_doubled.weight"), xn, rows, F);
+            g.M_alg = p.B * p.N;
+            g.bias = h->V(n + ".mlp.inner_linear_doubled.bias");
+            g.out_f32 = c.at<float>(p.swi); g.ldc = 2 * h->gh_hidden;
+            CHK(wrc_bias(c, g, h->M(n + ".mlp.inner_linear_doubled.weight"), g.bias));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
+            CHK(OPLC(mdpt_launch_swiglu, c.at<float>(p.swi), hb.hi, hb.lo, (size_t)rows, h->gh_hidden, h->gh_hidden_p, c.s));
+        } else {
+            GemmParams g = base_params(c, h->M(n + ".mlp.layers.0.weight"), xn, rows, F);
+            g.M_alg = p.B * p.N;
+            g.bias = h->V(n + ".mlp.layers.0.bias");
+            g.act = MDPT_ACT_GELU;
+            g.out_hi = hb.hi; g.out_lo = hb.lo; g.ldc = 4 * F;
+            CHK(wrc_bias(c, g, h->M(n + ".mlp.layers.0.weight"), g.bias));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
+        }
+        DBG_STOP(5);
+        {
+            const bool giant = h->gh_hidden != 0;
+            GemmParams g = base_params(c, h->M(giant ? n + ".mlp.outer_linear.weight" : n + ".mlp.layers.2.weight"), hb, rows,
+                                       giant ? h->gh_hidden_p : 4 * F);
+            g.M_alg = p.B * p.N;
+            g.bias = h->V(giant ? n + ".mlp.outer_linear.bias@ls" : n + ".mlp.layers.2.bias@ls");
+            g.acc_init = 1;
+            g.resid = resid; g.out_f32 = resid; g.ldr = F; g.ldc = F;
+            CHK(wrc_bias(c, g, h->M(giant ? n + ".mlp.outer_linear.weight" : n + ".mlp.layers.2.weight"), g.bias));
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
+        }
+        DBG_STOP(6);
+        if (c.block_dump && c.block_dump[b])  // TransformerBlock output (transformer_block.py:61-62), pad rows dropped
+            CHK(OPLC(mdpt_launch_tokens_export, nullptr, nullptr, resid, (float*)c.block_dump[b], p.B, p.N, p.npad, F, 0, c.s));
+        const bool v1 = h->cfg.family == MDPT_FAMILY_DAV1;
+        if (v1 ? b >= h->nblocks - 4 : (b + 1) % h->bps == 0) {
+            const int st = v1 ? b - (h->nblocks - 4) : b / h->bps;
+            Planes tp = c.pl(p.tap[st]);
+            float* f32 = taps_f32 ? c.at<float>(p.tapf32) : nullptr;
+            if (is_beit(h)) {  // BEiT taps the raw residual stream (no out-norm, v31_beit/image_encoder_model.py:84-91)
+                CHK(OPLC(mdpt_launch_tokens_import, resid, tp.hi, tp.lo, p.B, p.npad, p.npad, F, c.s));
+                if (taps_f32) CHK(OPLC(mdpt_launch_tokens_export, nullptr, nullptr, resid, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
+            } else {
+                CHK(OPLC(mdpt_launch_layernorm, resid, h->V("imgencoder.outnorm.weight"), h->V("imgencoder.outnorm.bias"), tp.hi, tp.lo, f32, rows, F, c.s));
+                if (taps_f32)
+                    CHK(OPLC(mdpt_launch_tokens_export, nullptr, nullptr, f32, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
+            }
+        }
+    }
+    return 0;
+}
+
+int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int sw, const float* bias, const float* skip, const float* up_src,
+                    int Hu, int Wu, float* out_f32, Planes out, int relu_bf16);
+
+// ---- stage: reassemble
+int run_reassemble(const Ctx& c) {
+    const mdpt_handle* h = c.h;
+    const Plan& p = c.p;
+    const int F = h->F, gh = p.gh, gw = p.gw;
+    for (int i = 0; i < 4; ++i) {
+        const std::string n = std::string("reassemble.") + kStageNames[i];
+        const int hp = h->hidp[i];
+        Planes tp = c.pl(p.tap[i]), t = c.pl(p.t[i]);
+        bool tokens_mode = true;
+        if (is_beit(h)) {
+            // readout projection: GELU(W [tok ; cls] + b) = GELU(W_tok tok + (W_cls cls + b)); the cls term is one row per image
+            {
+                GemmParams g = base_params(c, h->M(n + ".readout_proj.1.weight@cls"), tp, p.B, p.npad * F);  // row b = cls token of image b
+                g.bias = h->V(n + ".readout_proj.1.bias");
+                g.out_f32 = c.at<float>(p.cbuf); g.ldc = F;
+                CHK(OPLC(mdpt_launch_gemm, g, c.s));
+            }
+            Planes tr = c.pl(p.tokr);
+            {
+                GemmParams g = base_params(c, h->M(n + ".readout_proj.1.weight"), tp, p.B * p.Np, F);
+                g.amode = MDPT_A_TOKENS; g.tok_np = p.Np; g.tok_stride = p.npad;
+                g.bias = c.at<float>(p.cbuf); g.bias_img_stride = F; g.bias_img_rows = p.Np;
+                g.act = MDPT_ACT_GELU;
+                g.out_hi = tr.hi; g.out_lo = tr.lo; g.ldc = F;
+                CHK(OPLC(mdpt_launch_gemm, g, c.s));
+            }
+            tp = tr;
+            tokens_mode = false;
+        }
+        {   // 1x1 conv on the patch tokens (cls row skipped by the A-row generator)
+            GemmParams g = base_params(c, h->M(n + ".resample.0.weight"), tp, p.B * p.Np, F);
+            if (tokens_mode) { g.amode = MDPT_A_TOKENS; g.tok_np = p.Np; g.tok_stride = p.npad; }
+            g.bias = h->V(n + ".resample.0.bias");
+            g.out_hi = t.hi; g.out_lo = t.lo; g.ldc = hp;
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
+        }
+        Planes src = t;
+        int sh = gh, sw = gw;
+        if (i == 0 || i == 1) {  // ConvTranspose2d k == s: GEMM + depth-to-space
+            const int kk = i == 0 ? 4 : 2;
+            Planes u = c.pl(i == 0 ? p.u0 : p.u1);
+            GemmParams g = base_params(c, h->M(n + ".resample.1.weight"), t, p.B * p.Np, hp);
+            g.ekind = MDPT_E_D2S;
+            g.bias = h->V(n + ".resample.1.bias");
+            g.Ho = gh; g.Wo = gw; g.d2s_k = kk; g.d2s_cout = hp;
+            g.out_hi = u.hi; g.out_lo = u.lo;
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
+            src = u; sh = gh * kk; sw = gw * kk;
+        } else if (i == 3) {  // 3x3 stride-2
+            Planes d = c.pl(p.d3);
+            GemmParams g = base_params(c, h->M(n + ".resample.1.weight"), t, p.B * (gh / 2) * (gw / 2), hp);
+            as_conv(g, gh, gw, hp, gh / 2, gw / 2, 2);
+            g.bias = h->V(n + ".resample.1.bias");
+            g.out_hi = d.hi; g.out_lo = d.lo; g.ldc = hp;
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
+            src = d; sh = gh / 2; sw = gw / 2;
+        }
+        {   // 3x3 projection to the fusion width (no bias): fp32 copy (skip path) + ReLU'd bf16 (next conv input)
+            CHK(conv3_to_fusion(c, h->M(n + ".fuse_proj.weight"), src, hp, sh, sw, nullptr, nullptr, nullptr, 0, 0, c.at<float>(p.r_f32[i]),
+                                c.pl(p.r_bf[i]), 1));
+        }
+    }
+    return 0;
+}
+
+// Halo-staged conv kernel (conv3h.hip) for a 3x3 stride-1 conv to the 256-wide fusion width, used for big launches; small ones run the
+// implicit-GEMM kernels of gemm.hip. Both walk K in the same order and apply the same epilogue expressions (((conv + bias) + up) + skip),
+// so one image's bits do not depend on the batch it is part of. Partial 16x16 tiles may waste at most 25 % of the MFMA work (72x72: 25
+// tiles for 20.25 image-tiles' worth of pixels - the halo-staged loop is ~30 % faster per K tile; 36x36: 9 for 5.06 -> implicit GEMM).
+// From how many 256-row tiles' worth of output pixels the halo-staged kernel replaces the implicit GEMM: measured on the bare kernels at
+// batch 1 / 2 / 4 / 8 (profiles/r04_conv3h_small_batch.txt, tools/probes/gpu_conv3h_small_batch.py) - 144^2 x 1 image (81): 45.2 vs 48.8 us,
+// 72^2 x 4 (81): 46.9 vs 49.4, 72^2 x 2 (41): 43.2 vs 27.5 (one workgroup per tile: few tiles leave the CUs idle). Under the two-stream
+// batch split the other half fills idle CUs, so the faster-per-tile kernel is taken earlier. (The dense GEMMs' tile rule in gemm.hip has its
+// own thresholds, 140 / 70: there the big tile competes with a 64x64 tile that is good at small sizes; here the alternative is slower per K tile.)
+inline long conv3h_min_tiles(const Ctx& c) { return c.split ? 24 : 80; }
+
+bool conv3h_shape_ok(const mdpt_handle* h, int H, int W, int Cin) {
+    if (h->Cp != 256 || (Cin & 127) || H < 2 || W < 2) return false;
+    const long tile_px = (long)((H + 15) / 16) * ((W + 15) / 16) * 256, px = (long)H * W;
+    return tile_px * 4 <= px * 5;
+}
+
+// one 3x3 stride-1 conv Cin -> Cp: out = [skip +] conv(in) [+ bias] [+ up2(up_src)] -> fp32 map and / or bf16 planes (ReLU'd if relu_bf16)
+int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int sw, const float* bias, const float* skip, const float* up_src,
+                    int Hu, int Wu, float* out_f32, Planes out, int relu_bf16) {
+    const mdpt_handle* h = c.h;
+    const bool eligible = conv3h_shape_ok(h, sh, sw, Cin);
+    if (eligible && h->gemm_tile == MDPT_TILE_AUTO) {
+        Conv3hParams q;
+        memset(&q, 0, sizeof(q));
+        const bool three = h->np[w.cls] == 3;  // the weight's class decides (an input buffer may carry a lo plane this conv does not use)
+        q.in = in.hi; q.in_lo = three ? in.lo : nullptr; q.w = w.hi; q.w_lo = three ? w.lo : nullptr; q.bias = bias; q.skip = skip; q.up_src = up_src; q.Hu = Hu; q.Wu = Wu;
+        q.out_f32 = out_f32; q.out_bf = out.hi; q.out_bf_lo = out.lo; q.relu_bf = relu_bf16;
+        q.B = c.p.B; q.H = sh; q.W = sw; q.Cin = Cin; q.Cout = 256;
+        const long tiles256 = ((long)c.p.B * sh * sw + 255) / 256;
+        if (tiles256 >= conv3h_min_tiles(c) && mdpt_conv3h_supported(q)) return OPLC(mdpt_launch_conv3h, q, c.s);
+    }
+    GemmParams g = base_params(c, w, in, c.p.B * sh * sw, Cin);
+    as_conv(g, sh, sw, Cin, sh, sw, 1);
+    g.bias = bias;
+    g.resid = skip; g.ldr = h->Cp;
+    g.up_src = up_src; g.Hu = Hu; g.Wu = Wu;
+    g.out_f32 = out_f32; g.out_hi = out.hi; g.out_lo = out.lo; g.relu_bf16 = relu_bf16; g.ldc = h->Cp;
+    return OPLC(mdpt_launch_gemm, g, c.s);
+}
+
+// one 3x3 conv C->C of a residual conv unit at level `lv` (spatial sh x sw)
+int rcu_conv(const Ctx& c, const std::string& wname, Planes in, int sh, int sw, const float* skip, const float* up_src, int Hu, int Wu,
+             float* out_f32, Planes out, int relu_bf16) {
+    const mdpt_handle* h = c.h;
+    return conv3_to_fusion(c, h->M(wname + ".weight"), in, h->Cp, sh, sw, h->V(wname + ".bias"), skip, up_src, Hu, Wu, out_f32, out, relu_bf16);
+}
+
+// ---- stage: fusion. Level index i: 3 = coarsest (gh/2), 0 = finest (4gh). Output: flo[0] (fp32, 4gh x 4gw, before the
+//      final x2 upsample) and `fused` planes (8gh x 8gw).
+// bf16 mode, forward path (for_head): the last projection (level 0) writes its output as bf16 and the x2 upsample in front of the head is
+// left to run_head, which either interpolates it inside the head's first conv (halo-staged kernel, big launches) or runs the stand-alone
+// bf16 upsample - same arithmetic, same bits (up_bf16.h). The stage-level API and the bf16x3 mode keep the fp32 map + fp32 upsample.
+bool head_upsamples_bf16(const mdpt_handle* h) { return !h->x3c(CLS_HEAD) && (h->Cp & 7) == 0; }
+
+int run_fusion(const Ctx& c, bool for_head) {
+    const mdpt_handle* h = c.h;
+    const Plan& p = c.p;
+    const int sh[4] = {4 * p.gh, 2 * p.gh, p.gh, p.gh / 2}, sw[4] = {4 * p.gw, 2 * p.gw, p.gw, p.gw / 2};
+    for (int i = 3; i >= 0; --i) {
+        char pb[64];
+        snprintf(pb, sizeof(pb), "fusion.blocks.%d", i);
+        const std::string blk = pb;
+        const float* x_f32;
+        Planes x_bf;
+        if (i == 3) {  // top-most block: no reassembly RCU, no prior (fusion_model.py:89-114)
+            x_f32 = c.at<float>(p.r_f32[3]);
+            x_bf = c.pl(p.r_bf[3]);
+        } else {
+            // x = RCU_a(r_i) + up2(prev)   (fusion_model.py:148-154)
+            Planes a1 = c.pl(p.a1[i]);
+            CHK(rcu_conv(c, blk + ".conv_reassembly." + rcu_seq(h) + ".1", c.pl(p.r_bf[i]), sh[i], sw[i], nullptr, nullptr, 0, 0, nullptr, a1, 1));
+            x_bf = c.pl(p.x_bf[i]);
+            CHK(rcu_conv(c, blk + ".conv_reassembly." + rcu_seq(h) + ".3", a1, sh[i], sw[i], c.at<float>(p.r_f32[i]), c.at<float>(p.flo[i + 1]),
+                         sh[i + 1], sw[i + 1], c.at<float>(p.x_f32[i]), x_bf, 1));
+            x_f32 = c.at<float>(p.x_f32[i]);
+        }
+        Planes b1 = c.pl(p.b1[i]), b2 = c.pl(p.b2[i]);
+        CHK(rcu_conv(c, blk + "." + proj_seq(h) + ".0." + rcu_seq(h) + ".1", x_bf, sh[i], sw[i], nullptr, nullptr, 0, 0, nullptr, b1, 1));
+        CHK(rcu_conv(c, blk + "." + proj_seq(h) + ".0." + rcu_seq(h) + ".3", b1, sh[i], sw[i], x_f32, nullptr, 0, 0, nullptr, b2, 0));
+        {   // 1x1 projection at LOW resolution; the x2 bilinear upsample commutes with it exactly (both linear, weights
+            // sum to 1) and is applied by the consumer (next level's epilogue / final upsample kernel)
+            GemmParams g = base_params(c, h->M(blk + "." + proj_seq(h) + ".2.weight"), b2, p.B * sh[i] * sw[i], h->Cp);
+            g.bias = h->V(blk + "." + proj_seq(h) + ".2.bias");
+            if (i == 0 && for_head && head_upsamples_bf16(h)) g.out_hi = c.at<op_t>(p.flo[0]);  // bf16 map in the fp32 map's buffer
+            else g.out_f32 = c.at<float>(p.flo[i]);
+            g.ldc = h->Cp;
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
+        }
+    }
+    if (for_head && head_upsamples_bf16(h)) return 0;
+    Planes fu = c.pl(p.fused);
+    CHK(OPLC(mdpt_launch_upsample, c.at<float>(p.flo[0]), fu.hi, fu.lo, nullptr, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
+    return 0;
+}
+
+// ---- stage: head
+// from_flo0b: the head's input is still the bf16 output of the last fusion projection at half resolution (run_fusion(c, true))
+int run_head(const Ctx& c, void* depth, int depth_dtype, bool from_flo0b) {
+    const mdpt_handle* h = c.h;
+    const Plan& p = c.p;
+    const int fh = 8 * p.gh, fw = 8 * p.gw;
+    bool fused_ready = !from_flo0b;
+    auto materialise_fused = [&]() -> int {  // stand-alone bf16 upsample (small launches / shapes the fused kernel does not cover)
+        if (!fused_ready) CHK(OPLC(mdpt_launch_upsample_bf16, c.at<op_t>(p.flo[0]), c.pl(p.fused).hi, p.B, fh / 2, fw / 2, fh, fw, h->Cp, c.s));
+        fused_ready = true;
+        return 0;
+    };
+    if (!h->x3c(CLS_HEAD) && mdpt_head_tail_supported(h->C2p) && mdpt_head_tail_scale_ok(fh, fw, p.H, p.W)) {
+        // bf16 mode: the first conv writes bf16 (the buffer of the fp32 map is reused), everything behind it is ONE kernel that keeps the
+        // upsampled map in LDS tiles: upsample + 3x3 conv + ReLU + 1x1 conv + ReLU | sigmoid (head.hip). The bf16x3 mode keeps the
+        // unfused form below (its hi + lo operand planes do not fit the LDS tile next to the weights).
+        op_t* h1b = c.at<op_t>(p.h1);
+        bool done = false;
+        if (h->C2p == 128 && conv3h_shape_ok(h, fh, fw, h->Cp) && h->gemm_tile == MDPT_TILE_AUTO) {  // halo-staged form, 128 output channels
+            Conv3hParams q;
+            memset(&q, 0, sizeof(q));
+            q.w = h->M("head.spatial_upsampler.0.weight").hi; q.bias = h->V("head.spatial_upsampler.0.bias");
+            q.out_bf = h1b; q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
+            const long tiles256 = ((long)p.B * fh * fw + 255) / 256;
+            const bool big = tiles256 >= conv3h_min_tiles(c);
+#ifndef MDPT_NO_UPIN  // (A/B builds: -DMDPT_NO_UPIN keeps the stand-alone upsample in front of the halo-staged conv)
+            if (big && !fused_ready) {  // the x2 upsample folded into the conv's halo interpolation
+                q.up_in = c.at<op_t>(p.flo[0]); q.Hs = fh / 2; q.Ws = fw / 2;
+                if (mdpt_conv3h_supported(q)) {
+                    CHK(OPLC(mdpt_launch_conv3h, q, c.s));
+                    done = true;
+                }
+                q.up_in = nullptr;
+            }
+#endif
+            if (big && !done) {
+                CHK(materialise_fused());
+                q.in = c.pl(p.fused).hi;
+                if (mdpt_conv3h_supported(q)) {
+                    CHK(OPLC(mdpt_launch_conv3h, q, c.s));
+                    done = true;
+                }
+            }
+        }
+        if (!done) {
+            CHK(materialise_fused());
+            GemmParams g = base_params(c, h->M("head.spatial_upsampler.0.weight"), c.pl(p.fused), p.B * fh * fw, h->Cp);
+            as_conv(g, fh, fw, h->Cp, fh, fw, 1);
+            g.bias = h->V("head.spatial_upsampler.0.bias");
+            g.out_hi = h1b; g.ldc = h->C2p;
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
+        }
+        HeadTailParams t;
+        memset(&t, 0, sizeof(t));
+        t.src = h1b; t.w_kc = h->M("head.proj_1ch.0.weight@kc32").hi;
+        t.bias = h->V("head.proj_1ch.0.bias"); t.head_w = h->V("head.proj_1ch.2.weight"); t.head_b = h->V("head.proj_1ch.2.bias");
+        t.out = depth; t.out_dtype = depth_dtype; t.sigmoid = h->cfg.is_metric;
+        t.B = p.B; t.Hi = fh; t.Wi = fw; t.Ho = p.H; t.Wo = p.W;
+        CHK(OPLC(mdpt_launch_head_tail, t, h->C2p, c.s));
+        return 0;
+    }
+    CHK(materialise_fused());
+    {
+        bool done = false;
+        if (h->C2p == 128 && conv3h_shape_ok(h, fh, fw, h->Cp) && h->gemm_tile == MDPT_TILE_AUTO) {  // halo-staged form, fp32 map out
+            const Mat& w1 = h->M("head.spatial_upsampler.0.weight");
+            Planes fu = c.pl(p.fused);
+            Conv3hParams q;
+            memset(&q, 0, sizeof(q));
+            q.in = fu.hi; q.in_lo = fu.lo; q.w = w1.hi; q.w_lo = w1.lo; q.bias = h->V("head.spatial_upsampler.0.bias");
+            q.out_f32 = c.at<float>(p.h1); q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
+            const long tiles256 = ((long)p.B * fh * fw + 255) / 256;
+            if (tiles256 >= conv3h_min_tiles(c) && mdpt_conv3h_supported(q)) {
+                CHK(OPLC(mdpt_launch_conv3h, q, c.s));
+                done = true;
+            }
+        }
+        if (!done) {
+            GemmParams g = base_params(c, h->M("head.spatial_upsampler.0.weight"), c.pl(p.fused), p.B * fh * fw, h->Cp);
+            as_conv(g, fh, fw, h->Cp, fh, fw, 1);
+            g.bias = h->V("head.spatial_upsampler.0.bias");
+            g.out_f32 = c.at<float>(p.h1); g.ldc = h->C2p;
+            CHK(OPLC(mdpt_launch_gemm, g, c.s));
+        }
+    }
+    Planes hu = c.pl(p.h1u);
+    CHK(OPLC(mdpt_launch_upsample, c.at<float>(p.h1), hu.hi, hu.lo, nullptr, p.B, fh, fw, p.H, p.W, h->C2p, c.s));
+    {
+        GemmParams g = base_params(c, h->M("head.proj_1ch.0.weight"), hu, p.B * p.H * p.W, h->C2p);
+        as_conv(g, p.H, p.W, h->C2p, p.H, p.W, 1);
+        g.ekind = MDPT_E_HEAD;
+        g.bias = h->V("head.proj_1ch.0.bias");
+        g.head_w = h->V("head.proj_1ch.2.weight");
+        g.head_b = h->V("head.proj_1ch.2.bias");
+        g.head_sigmoid = h->cfg.is_metric;
+        g.head_out = depth; g.head_out_dtype = depth_dtype;
+        CHK(OPLC(mdpt_launch_gemm, g, c.s));
+    }
+    return 0;
+}
+
+#include "mdpt_swin_stages.inc"
+
+}  // namespace mdpt

@@ -18,11 +18,12 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(CSRC, "libmdpt.so")
 # kernel files that touch MFMA operand planes are compiled twice, once per operand format (csrc/op_types.h): bf16 and, with
-# -DMDPT_OP_F16, fp16; the launcher symbols carry the format as a suffix and mdpt_api.cpp picks per handle
+# -DMDPT_OP_F16, fp16; the launcher symbols carry the format as a suffix and the host side (mdpt_internal.h: OPL) picks per handle
 OPERAND_SOURCES = ("gemm.hip", "conv3h.hip", "attention.hip", "elementwise.hip", "swin.hip", "head.hip")
-PLAIN_SOURCES = ("postprocess.hip", "mdpt_api.cpp", "mdpt_prof.cpp")
+PLAIN_SOURCES = ("postprocess.hip", "mdpt_api.cpp", "mdpt_inventory.cpp", "mdpt_stages.cpp", "mdpt_debug.cpp", "mdpt_prof.cpp")
 SOURCES = OPERAND_SOURCES + PLAIN_SOURCES
-HEADERS = ("mdpt_kernels.h", "mdpt_launchers.inc", "op_types.h", "mdpt_prof.h", "mdpt_swin.inc", "ln_row.h", "up_bf16.h",
+HEADERS = ("mdpt_kernels.h", "mdpt_launchers.inc", "op_types.h", "mdpt_prof.h", "mdpt_internal.h", "mdpt_swin_plan.inc", "mdpt_swin_stages.inc", "ln_row.h",
+           "up_bf16.h",
            os.path.join(REPO, "include", "mdpt.h"))
 # (source, extra flags, object stem)
 UNITS = tuple((s, (), os.path.splitext(s)[0]) for s in SOURCES) + tuple((s, ("-DMDPT_OP_F16",), os.path.splitext(s)[0] + "_f16")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does the halo-staged conv kernel start to beat the implicit-GEMM path at SMALL batches (the conv3h dispatch threshold in
-mdpt_api.cpp conv3_to_fusion / run_head)? 256 -> 256 at 144^2 / 72^2 and the head's 256 -> 128 at 288^2, batch 1 / 2 / 4 / 8, bf16 + ReLU form."""
+mdpt_stages.cpp conv3_to_fusion / run_head)? 256 -> 256 at 144^2 / 72^2 and the head's 256 -> 128 at 288^2, batch 1 / 2 / 4 / 8, bf16 + ReLU form."""
 import os, sys
 import numpy as np
 import torch
