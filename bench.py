@@ -297,6 +297,14 @@ def secondary_legs(args, dev, lib, vitl_model):
                 rec["error_vs_cpu_fp32"] = error_vs(ref, y.float())
             else:
                 rec["error_vs_cpu_fp32"] = None
+            if name in SYNTH_NAME and want_err and ow is not None:
+                # BASELINE configs[4] in the mixed-pass mode too (fp32 tensors at the boundary; SwinV2's window-major encoder runs it
+                # without the token-mean compensation)
+                m32 = model.to(dev, torch.float32)
+                m32.set_precision("mixed")
+                dt_m, y_m = time_model(m32, x_cpu.to(dev), steps)
+                rec["mixed_mode"] = {"value": round(batch / dt_m, 3), "ms_per_step": round(dt_m * 1e3, 3), "error_vs_cpu_fp32": error_vs(ref, y_m.float())}
+                del y_m
             rec["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
             out[key] = rec
             if name != "vitl":

@@ -59,8 +59,13 @@ __device__ __forceinline__ opx8 cat44(opx4 a, opx4 b) {
 // SPLIT (latency form for small launches, e.g. batch 1): the four waves of a workgroup share ONE block of 32*QB queries and each
 // takes every fourth key tile (private K/V ring per wave, no barrier in the loop); the partial (m, l, O) states are merged through
 // LDS at the end. A launch that cannot fill the GPU anyway finishes in a quarter of the key-loop time.
-template <bool X3, int QB, int MODE, int HD, bool SPLIT = false>
+// RUN4 (MODE 2, window width % 4 == 0): four consecutive keys of a lane's accumulator quad sit in one row of the window, so their LUT
+// indices tq - tk, tq - tk - 1, ... are consecutive: the table is staged REVERSED and one index + two ds_read2_b32 fetch the four
+// biases (before: four index subtractions and four single gathers) - the window attention spent more issue slots on the bias
+// gather than on the softmax.
+template <bool X3, int QB, int MODE, int HD, bool SPLIT = false, bool RUN4 = false>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
+    static_assert(!RUN4 || MODE == 2, "the 4-key bias runs exist for the window attention");
     constexpr bool BIAS = MODE != 0;
     constexpr int NPL = X3 ? 2 : 1;           // planes per operand
     constexpr int TILE = 64 * HD * 2;         // one [64 keys][HD] (or [HD][64 keys]) bf16 tile
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const bool masked = MODE == 2 && p.region != nullptr;
     if (BIAS) {
         const float* lut = p.bias_lut + (size_t)h * p.bias_elen;
-        for (int i = tid; i < p.bias_elen; i += 256) lds_lut[i] = lut[i];
+        for (int i = tid; i < p.bias_elen; i += 256) lds_lut[i] = lut[RUN4 ? p.bias_elen - 1 - i : i];
         const int nk = ((p.N + 63) >> 6) << 6;
         for (int i = tid; i < nk; i += 256) lds_tk[i] = p.tk[i < p.npad ? i : p.npad - 1];
         if (MODE == 2)
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         for (int qb = 0; qb < QB; ++qb) {
             const int q = q0 + qb * 32 + l31;
             tqv[qb] = p.tq[q < p.npad ? q : p.npad - 1];
+            if (RUN4) tqv[qb] = p.bias_elen - 1 - tqv[qb];  // index into the reversed table: lut[tq - tk - e] = rev[(elen - 1 - tq) + tk + e]
             rqv[qb] = masked ? p.region[(size_t)win * p.region_ld + (q < p.N ? q : p.N - 1)] : 0;
         }
     }
@@ -233,11 +239,22 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const i32x4 tk4 = *(const i32x4*)(lds_tk + t * 64 + blk * 32 + 8 * g + 4 * half);
+                    if constexpr (RUN4) {
+                        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                        const int tk0 = lds_tk[t * 64 + blk * 32 + 8 * g + 4 * half];
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb)
+                        for (int qb = 0; qb < QB; ++qb) {
+                            const f32x4u b4 = *(const f32x4u*)(lds_lut + tqv[qb] + tk0);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) s[qb][blk][4 * g + e] += lds_lut[tqv[qb] - tk4[e]];
+                            for (int e = 0; e < 4; ++e) s[qb][blk][4 * g + e] += b4[e];
+                        }
+                    } else {
+                        const i32x4 tk4 = *(const i32x4*)(lds_tk + t * 64 + blk * 32 + 8 * g + 4 * half);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s[qb][blk][4 * g + e] += lds_lut[tqv[qb] - tk4[e]];
+                    }
                     if (MODE == 2 && masked) {
                         const i32x4 rk4 = *(const i32x4*)(lds_reg + t * 64 + blk * 32 + 8 * g + 4 * half);
 #pragma unroll
@@ -578,9 +595,10 @@ int MDPT_FN(mdpt_launch_attention)(const AttnParams& p, hipStream_t stream) {
     AttnParams pq = p;
     pq.tail_last = 1;  // -4 % per launch when the kernel runs alone (N = 1297); neutral under the two-stream batch split
     const dim3 grid128(((p.npad + 127) / 128) * p.heads * p.B), grid256((unsigned)blocks256), block(256);
-#define ATTN_LAUNCH(X3_, QB_, MODE_, HD_, GRID_)                                                                        \
+#define ATTN_LAUNCH(X3_, QB_, MODE_, HD_, GRID_) ATTN_LAUNCH_R(X3_, QB_, MODE_, HD_, GRID_, false)
+#define ATTN_LAUNCH_R(X3_, QB_, MODE_, HD_, GRID_, RUN4_)                                                               \
     do {                                                                                                                \
-        auto kern = attn_kernel<X3_, QB_, MODE_, HD_>;                                                                  \
+        auto kern = attn_kernel<X3_, QB_, MODE_, HD_, false, RUN4_>;                                                    \
         static bool attr_done = false;                                                                                  \
         if (!attr_done) {                                                                                               \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -589,7 +607,12 @@ int MDPT_FN(mdpt_launch_attention)(const AttnParams& p, hipStream_t stream) {
         }                                                                                                               \
         hipLaunchKernelGGL(kern, GRID_, block, lds, stream, pq);                                                        \
     } while (0)
-    if (p.x3) {
+    // window attention with 4-key bias runs (AttnParams::bias_run4: the caller guarantees window width and token count are multiples of 4)
+    if (mode == 2 && p.bias_run4) {
+        if (p.x3) ATTN_LAUNCH_R(true, 1, 2, 32, grid128, true);
+        else if (wide) ATTN_LAUNCH_R(false, 2, 2, 32, grid256, true);
+        else ATTN_LAUNCH_R(false, 1, 2, 32, grid128, true);
+    } else if (p.x3) {
         if (mode == 2) ATTN_LAUNCH(true, 1, 2, 32, grid128);
         else if (mode == 1) ATTN_LAUNCH(true, 1, 1, 64, grid128);
         else ATTN_LAUNCH(true, 1, 0, 64, grid128);
@@ -603,6 +626,7 @@ int MDPT_FN(mdpt_launch_attention)(const AttnParams& p, hipStream_t stream) {
         else ATTN_LAUNCH(false, 1, 0, 64, grid128);
     }
 #undef ATTN_LAUNCH
+#undef ATTN_LAUNCH_R
     return (int)hipGetLastError();
 }
 

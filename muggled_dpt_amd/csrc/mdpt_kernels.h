@@ -103,6 +103,7 @@ struct AttnParams {
     // rowmap[win_nw*N] = image token of every window token, region[win_nw][region_ld] = shifted-window region ids (null: no mask)
     int head_dim;  // 0 = 64
     int win_nw; const int* rowmap; const int* region; int region_ld;
+    int bias_run4;       // window width and tokens per window are multiples of 4: four consecutive keys have consecutive bias-table indices
     int out_ld;          // row stride of out_hi / out_lo in elements (0 = F); pad columns are the caller's
     int allow_split_kv;  // latency mode: small launches may split the key loop over the waves (not batch-invariant in the last bit)
     int tail_last;  // set by the launcher: dispatch nearly empty last q-tiles after all full ones
