@@ -139,7 +139,7 @@ def hbm_traffic(args, kernel_name: str):
     if args.model != "vitl" or args.batch != 32 or args.size != 504 or args.precision != "bf16":
         return None
     sha = native.source_hash()
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         path = os.path.join(REPO, "profiles", f"{tag}_hbm_traffic.json")
         if not os.path.exists(path):
             continue
@@ -300,6 +300,9 @@ def secondary_legs(args, dev, lib, vitl_model):
             if name in SYNTH_NAME and want_err and ow is not None:
                 # BASELINE configs[4] in the mixed-pass mode too (fp32 tensors at the boundary; SwinV2's window-major encoder runs it
                 # without the token-mean compensation)
+                del model  # (a float32 model built afresh: casting the bf16 model back would keep its bf16-rounded parameters)
+                torch.cuda.empty_cache()
+                model, _ = make_model_and_weights(name)
                 m32 = model.to(dev, torch.float32)
                 m32.set_precision("mixed")
                 dt_m, y_m = time_model(m32, x_cpu.to(dev), steps)

@@ -124,7 +124,7 @@ int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void*
             q.up_in = (const op_t*)in_bf16; q.Hs = Hu; q.Ws = Wu; q.w = (const op_t*)w_packed_bf16; q.bias = (const float*)bias_f32;
             q.out_bf = (op_t*)out_bf16; q.B = B; q.H = H; q.W = W; q.Cin = Cin; q.Cout = 128;
             q.dbg_times = (unsigned long long*)dbg_times;
-            if (!mdpt_conv3h_supported(q)) return fail(MDPT_E_UNSUPPORTED, "conv3h does not cover this combination");
+            if (!OPLG(mdpt_conv3h_supported, q)) return fail(MDPT_E_UNSUPPORTED, "conv3h does not cover this combination");
             for (int i = 0; i < iters; ++i) CHK(OPLG(mdpt_launch_conv3h, q, (hipStream_t)stream));
             return 0;
         }
@@ -150,7 +150,7 @@ int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void*
         q.up_src = (const float*)up_f32; q.Hu = Hu; q.Wu = Wu; q.out_f32 = (float*)out_f32; q.out_bf = (op_t*)out_bf16; q.relu_bf = relu_bf16;
         q.B = B; q.H = H; q.W = W; q.Cin = Cin; q.Cout = Cout;
         q.dbg_times = (unsigned long long*)dbg_times;
-        if (!mdpt_conv3h_supported(q)) return fail(MDPT_E_UNSUPPORTED, "conv3h does not cover this combination");
+        if (!OPLG(mdpt_conv3h_supported, q)) return fail(MDPT_E_UNSUPPORTED, "conv3h does not cover this combination");
         for (int i = 0; i < iters; ++i) CHK(OPLG(mdpt_launch_conv3h, q, (hipStream_t)stream));
         return 0;
     }

@@ -43,12 +43,11 @@ extern "C" {
 #define OPLC(fn, ...) OPL_(c.h->f16, fn, __VA_ARGS__)   // inside a stage driver (a Ctx named c)
 #define OPLH(fn, ...) OPL_(h->f16, fn, __VA_ARGS__)     // with only the handle in scope
 #define OPLG(fn, ...) OPL_(g_debug_f16, fn, __VA_ARGS__)  // handle-less test hooks (mdpt_debug_set_operand_format)
-// host-only predicates of the kernel files: the same answer in both builds
+// host-only predicates of the kernel files with the same answer in both builds (mdpt_conv3h_supported is NOT one of them: the fp16 build
+// covers more output-plane combinations - call it through OPLC / OPLG)
 #define mdpt_head_tail_supported mdpt_head_tail_supported_bf16
 #define mdpt_head_tail_scale_ok mdpt_head_tail_scale_ok_bf16
 #define mdpt_beit_relpos_elen mdpt_beit_relpos_elen_bf16
-#define mdpt_gemm_resolves_to_pp256 mdpt_gemm_resolves_to_pp256_bf16
-#define mdpt_conv3h_supported mdpt_conv3h_supported_bf16
 
 namespace mdpt {
 

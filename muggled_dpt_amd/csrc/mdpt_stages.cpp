@@ -292,7 +292,7 @@ int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int 
         q.out_f32 = out_f32; q.out_bf = out.hi; q.out_bf_lo = out.lo; q.relu_bf = relu_bf16;
         q.B = c.p.B; q.H = sh; q.W = sw; q.Cin = Cin; q.Cout = 256;
         const long tiles256 = ((long)c.p.B * sh * sw + 255) / 256;
-        if (tiles256 >= conv3h_min_tiles(c) && mdpt_conv3h_supported(q)) return OPLC(mdpt_launch_conv3h, q, c.s);
+        if (tiles256 >= conv3h_min_tiles(c) && OPLC(mdpt_conv3h_supported, q)) return OPLC(mdpt_launch_conv3h, q, c.s);
     }
     GemmParams g = base_params(c, w, in, c.p.B * sh * sw, Cin);
     as_conv(g, sh, sw, Cin, sh, sw, 1);
@@ -386,7 +386,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype, bool from_flo0b) {
 #ifndef MDPT_NO_UPIN  // (A/B builds: -DMDPT_NO_UPIN keeps the stand-alone upsample in front of the halo-staged conv)
             if (big && !fused_ready) {  // the x2 upsample folded into the conv's halo interpolation
                 q.up_in = c.at<op_t>(p.flo[0]); q.Hs = fh / 2; q.Ws = fw / 2;
-                if (mdpt_conv3h_supported(q)) {
+                if (OPLC(mdpt_conv3h_supported, q)) {
                     CHK(OPLC(mdpt_launch_conv3h, q, c.s));
                     done = true;
                 }
@@ -396,7 +396,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype, bool from_flo0b) {
             if (big && !done) {
                 CHK(materialise_fused());
                 q.in = c.pl(p.fused).hi;
-                if (mdpt_conv3h_supported(q)) {
+                if (OPLC(mdpt_conv3h_supported, q)) {
                     CHK(OPLC(mdpt_launch_conv3h, q, c.s));
                     done = true;
                 }
@@ -430,7 +430,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype, bool from_flo0b) {
             q.in = fu.hi; q.in_lo = fu.lo; q.w = w1.hi; q.w_lo = w1.lo; q.bias = h->V("head.spatial_upsampler.0.bias");
             q.out_f32 = c.at<float>(p.h1); q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
             const long tiles256 = ((long)p.B * fh * fw + 255) / 256;
-            if (tiles256 >= conv3h_min_tiles(c) && mdpt_conv3h_supported(q)) {
+            if (tiles256 >= conv3h_min_tiles(c) && OPLC(mdpt_conv3h_supported, q)) {
                 CHK(OPLC(mdpt_launch_conv3h, q, c.s));
                 done = true;
             }

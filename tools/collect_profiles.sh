@@ -7,7 +7,7 @@
 #   3. the driver-runnable secondary configurations (1036x1036, BEiT-L, SwinV2-L) as plain bench lines
 # Output: gpurun_out/profiles_<tag>/ ; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
@@ -15,6 +15,8 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/split" -- python "$R/bench.py" --steps 10 --warmup 3 --no-secondary > "$OUT/bench_under_rocprof.json" 2> "$OUT/split.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/nosplit" -- python "$R/bench.py" --no-split --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_nosplit_under_rocprof.json" 2> "$OUT/nosplit.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/x3" -- python "$R/bench.py" --precision bf16x3 --no-split --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_x3_nosplit_under_rocprof.json" 2> "$OUT/x3.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/fp16" -- python "$R/bench.py" --precision fp16 --no-split --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_fp16_nosplit_under_rocprof.json" 2> "$OUT/fp16.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/mixed" -- python "$R/bench.py" --precision mixed --no-split --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_mixed_nosplit_under_rocprof.json" 2> "$OUT/mixed.log"
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/timeline" -- python "$R/bench.py" --no-split --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> "$OUT/timeline.log"
 python "$R/tools/forward_timeline.py" "$OUT/timeline" "$OUT/forward_timeline.md" > /dev/null 2>> "$OUT/timeline.log"
 for C in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
@@ -24,16 +26,24 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
   --kernel-trace --output-format csv -d "$OUT/pmc_SQ" -- python "$R/bench.py" --no-split --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> "$OUT/pmc_SQ.log"
 python "$R/tools/summarize_sq.py" "$OUT/pmc_SQ" "$OUT/sq_counters.md" > "$OUT/sq_counters.log" 2>&1
 python "$R/tools/summarize_clock.py" "$OUT/pmc_GRBM_GUI_ACTIVE" "$OUT/effective_clock.md" > "$OUT/effective_clock.log" 2>&1
-for d in split nosplit x3; do
+for d in split nosplit x3 fp16 mixed; do
   f=$(find "$OUT/$d" -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${d}_kernel_stats.csv"
 done
 python "$R/tools/summarize_pmc.py" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/hbm_traffic" > "$OUT/hbm_traffic.log" 2>&1
 # the raw per-dispatch traces are large; keep the summaries only
-rm -rf "$OUT/split" "$OUT/nosplit" "$OUT/x3" "$OUT/timeline" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ" "$OUT/pmc_GRBM_GUI_ACTIVE"
+rm -rf "$OUT/split" "$OUT/nosplit" "$OUT/x3" "$OUT/fp16" "$OUT/mixed" "$OUT/timeline" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ" "$OUT/pmc_GRBM_GUI_ACTIVE"
 cd "$R"
 python bench.py --steps 20 --warmup 3 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 python bench.py --precision bf16x3 --steps 20 --warmup 3 > "$OUT/bench_x3.json" 2> "$OUT/bench_x3.err"
+python bench.py --precision mixed --steps 20 --warmup 3 > "$OUT/bench_mixed.json" 2> "$OUT/bench_mixed.err"
+python bench.py --precision fp16 --steps 20 --warmup 3 > "$OUT/bench_fp16.json" 2> "$OUT/bench_fp16.err"
+# round 4: measured error / throughput table of the arithmetic modes, batch-1 tile sweep, small-batch conv dispatch sweep, batch-1 kernel shares
+python tests/precision_budget/measure_on_gpu.py --out "$OUT/precision_budget.json" > "$OUT/precision_budget.log" 2>&1
+python tests/precision_budget/measure_on_gpu.py --render "$OUT/precision_budget.json" > "$OUT/precision_budget.md" 2>> "$OUT/precision_budget.log"
+python tools/probes/gpu_b1_tile_sweep.py 2>&1 | grep -v amdgpu.ids > "$OUT/b1_tile_sweep.txt"
+python tools/probes/gpu_conv3h_small_batch.py 2>&1 | grep -v amdgpu.ids > "$OUT/conv3h_small_batch.txt"
+{ python tools/probes/gpu_kernel_share_any.py vitl 504 1; python tools/probes/gpu_kernel_share_any.py vits 504 1; } 2>&1 | grep -v amdgpu.ids > "$OUT/kernel_share_b1.txt"
 python bench.py --size 1036 --steps 10 --warmup 2 > "$OUT/bench_1036.json" 2> "$OUT/bench_1036.err"
 python bench.py --model beitl --steps 10 --warmup 2 > "$OUT/bench_beitl.json" 2> "$OUT/bench_beitl.err"
 python bench.py --model swinl --steps 10 --warmup 2 > "$OUT/bench_swinl.json" 2> "$OUT/bench_swinl.err"
