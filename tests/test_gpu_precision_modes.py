@@ -328,3 +328,38 @@ def test_beit_large_and_swin_large_fixtures_in_the_fp16_and_mixed_modes(golden_d
             assert err <= tol, f"{fixture} {precision}: {err:.3e} > {tol:.3e}"
         del model
         torch.cuda.empty_cache()
+
+
+def test_massive_activation_channels_in_the_residual_stream():
+    """Real DINOv2 checkpoints carry "massive activation" channels - a few features of the residual stream sit tens of sigma away from the rest in
+    every token (the synthetic weights have none: VERDICT r03, missing item 4). Emulated here by adding +100 / -60 to two channels of the position
+    embedding (the same offset in every token): LayerNorm then sees rows dominated by two features, its output has a large shared component - the
+    regime the token-mean compensation is built for - and every arithmetic mode has to stay inside its tolerance against the fp32 oracle."""
+    from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+    from muggled_dpt_amd.state_dict_conversion import convert_state_dict_keys, flatten_components, get_model_config_from_state_dict
+    from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict
+    from tests.helpers import emulated_tol
+    osd = make_synthetic_original_state_dict("vits", 0)
+    key = [k for k in osd if k.endswith("pos_embed")][0]
+    osd[key] = osd[key].clone()
+    osd[key][:, 1:, 7] += 100.0   # patch positions (index 0 is the cls entry)
+    osd[key][:, 1:, 201] -= 60.0
+    cfg = get_model_config_from_state_dict(osd)
+    w = flatten_components(convert_state_dict_keys(cfg, osd))
+    x = seeded_input((2, 3, 252, 252), 5)
+    ref = _oracle().forward(w, cfg, x)
+    assert float(ref.max()) > 0.1
+    _, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
+    model = model.to("cuda", torch.float32)
+    errs = {}
+    for precision, tol in (("bf16x3", REL_TOL_X3), ("fp16x3", REL_TOL_X3), ("mixed", REL_TOL_MIXED), ("fp16", REL_TOL_FP16),
+                           ("bf16", emulated_tol(w, cfg, x, "bf16"))):
+        model.set_precision(precision)
+        y = model(x.cuda())
+        assert bool(torch.isfinite(y).all())
+        errs[precision] = rel_err(y.cpu(), ref)
+        assert errs[precision] <= tol, f"{precision}: {errs[precision]:.3e} > {tol:.3e}"
+    model.set_precision("fp16")
+    model.set_weight_rounding_compensation(False)
+    e_off = rel_err(model(x.cuda()).cpu(), ref)
+    assert errs["fp16"] <= e_off * 1.1, f"compensation on {errs['fp16']:.3e} vs off {e_off:.3e}"

@@ -17,7 +17,7 @@ for (M, N, K, tag) in shapes:
     out16 = torch.zeros(max(M * N, 4 * N), device="cuda", dtype=torch.bfloat16)
     out32 = torch.zeros(M, N, device="cuda", dtype=torch.float32)
     res = {}
-    for tile in (6, 1, 2, 4, 5):
+    for tile in (6, 1, 2, 4, 5):  # (6 = 64x64: a 3-deep ring from 32 K tiles on, 2-deep below)
         flags = tile | ((1 << 11) if rinit else 0)
         args = (a.data_ptr(), w.data_ptr(), out32.data_ptr() if rinit else None, out16.data_ptr(), M, N, K, flags)
         native.check(lib, lib.mdpt_debug_gemm(*args, 3, stream, None))
