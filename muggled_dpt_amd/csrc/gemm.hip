@@ -1863,7 +1863,7 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
         // long K on the small tile (fc2 at batch 1: 64 K tiles per workgroup, a serial chain): a 3-deep ring hides more of the L2 latency
         // per step - same K order, same bits. Measured on the bare kernels (profiles/r04_b1_tile_sweep.txt, column t7): K = 4096 32.6 -> 28.5 us
         // (ViT-L, M = 1304), 30.7 -> 22.4 us (BEiT-L, M = 584); K <= 1536 is 2-8 % slower with the deeper ring and keeps the 2-deep one.
-        if constexpr (AMODE == MDPT_A_DENSE && EKIND == MDPT_E_GENERIC) {
+        if constexpr ((AMODE == MDPT_A_DENSE || AMODE == MDPT_A_CONV3) && EKIND == MDPT_E_GENERIC) {
             if ((p.K / 64) * p.npass >= 32) return launch_cfg<64, 64, 2, 2, 64, 3, 1, AMODE, EKIND>(p, stream);
         }
         return launch_cfg<64, 64, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);
