@@ -1842,7 +1842,10 @@ int resolve_tile(const GemmParams& p) {
         // MFMAs on padding columns. 128x64, four waves stacked in M: ViT-S B=32 +8.4 %
         if (!big && tiles128 > 330 && p.N <= 64) return -1;
     }
-    if (tile == MDPT_TILE_PP256 && (((p.K / 64) * p.npass) & 1)) tile = MDPT_TILE_256x256;  // odd number of K tiles: the 8-phase loop handles pairs
+    // odd number of K tiles: the 8-phase loop handles pairs. Three K tiles or fewer (SwinV2's 192-wide first stage) are all prologue and
+    // epilogue on a big tile: the 64x64 tile wins there (M = 147456, K = 192: N = 576 93.8 vs 116.4 us, N = 192 33.0 vs 47.3 us, N = 768 a tie;
+    // tools/probes/gpu_swin_tile_sweep.py, profiles/r04_swin_tile_sweep.txt), the lockstep 256x256 tile from five K tiles on
+    if (tile == MDPT_TILE_PP256 && (((p.K / 64) * p.npass) & 1)) tile = (p.K / 64) * p.npass <= 3 && p.tile == MDPT_TILE_AUTO ? MDPT_TILE_64x64 : MDPT_TILE_256x256;
     // per-image bias table: the direct epilogues of the 8-phase kernel take it in the fp16 build for images of >= 256 rows (two images per
     // tile at most); everything else goes through the strip epilogues of the lockstep kernels (same arithmetic, same bits)
     if (tile == MDPT_TILE_PP256 && p.bias_img_stride && p.ekind == MDPT_E_QKV && !(HAVE_IMGB && p.bias_img_rows >= 256)) tile = MDPT_TILE_256x256;
