@@ -912,7 +912,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4 (&acc
 // swin_qk_prep_kernel (swin.hip) uses on the fp32 QKV rows - (a^2 + b^2) + (c^2 + d^2) per group, group c with group c+4, then the neighbour
 // group pair, then the other half - with unfused multiplies, so the fused and the unfused form of a block give the same bits whichever tile
 // rule picks which. Rows scatter through the token map: image token t -> swin_tokmap[t] = w*heads*npad + i, + img*swin_img_rows + h*npad.
-template <bool X3>
+template <bool X3, bool IMGB = false>
 __device__ __forceinline__ void epilogue_swin_qk(const GemmParams& p, f32x4 (&acc)[2][2][4][2], int m0, int n0, int grp, int wc, int lane) {
 #pragma clang fp contract(off)
     typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -920,8 +920,19 @@ __device__ __forceinline__ void epilogue_swin_qk(const GemmParams& p, f32x4 (&ac
     constexpr unsigned OOB = 0xFFFFFFF0u;
     const int l15 = lane & 15, lh = lane >> 4;
     const size_t plane = (size_t)(p.M / p.swin_N) * p.swin_img_rows * 64;  // bytes of a Q / K plane (< 4 GiB: checked by the caller)
+    // IMGB: per-image bias table (token-mean compensation, see epilogue_direct): >= 256 token rows per image, two bias vectors per tile
+    int bnd = 1 << 30;
+    const float* bias0 = p.bias;
+    const float* bias1 = p.bias;
+    if (IMGB) {
+        const int rows_here = p.M - m0 < 256 ? p.M - m0 : 256;
+        const int img0 = m0 / p.bias_img_rows;
+        bnd = (img0 + 1) * p.bias_img_rows - m0;
+        bias0 = p.bias + (size_t)img0 * p.bias_img_stride;
+        bias1 = bnd < rows_here ? bias0 + p.bias_img_stride : bias0;
+    }
     // everything that is loaded comes before the first store (a wait after a store also waits for the store)
-    f32x4 bias_q[2][2];
+    f32x4 bias_q[2][2], biasn_q[2][2];
     float scale_q[2];
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn) {
@@ -930,7 +941,10 @@ __device__ __forceinline__ void epilogue_swin_qk(const GemmParams& p, f32x4 (&ac
         const float ls = p.swin_logit_scale[(nq - which * p.F) >> 5];
         scale_q[qn] = which ? 1.0f : ls;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bias_q[qn][j] = p.bias ? *(const f32x4*)(p.bias + nq + j * 16 + 4 * lh) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < 2; ++j) {
+            bias_q[qn][j] = p.bias ? *(const f32x4*)(bias0 + nq + j * 16 + 4 * lh) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (IMGB) biasn_q[qn][j] = *(const f32x4*)(bias1 + nq + j * 16 + 4 * lh);
+        }
     }
     int dst[2][4];
 #pragma unroll
@@ -959,9 +973,15 @@ __device__ __forceinline__ void epilogue_swin_qk(const GemmParams& p, f32x4 (&ac
             for (int i = 0; i < 4; ++i) {
                 f32x4 v[2];
                 float sg[2];
+                const bool next = IMGB && qm * 128 + grp * 64 + 16 * i + l15 >= bnd;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    v[j] = acc[qm][qn][i][j] + bias_q[qn][j];
+                    f32x4 bj = bias_q[qn][j];
+                    if (IMGB) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bj[e] = next ? biasn_q[qn][j][e] : bj[e];
+                    }
+                    v[j] = acc[qm][qn][i][j] + bj;
                     sg[j] = (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
                 }
                 float ss = sg[0] + sg[1];
@@ -1019,7 +1039,7 @@ __device__ __forceinline__ void epilogue_swin_qk(const GemmParams& p, f32x4 (&ac
 // rows = image tokens t .. t+3 (t % 4 == 0) of one column; the caller guarantees grid width, window width and shift are multiples of 4,
 // so the four tokens are consecutive positions of one window: one 8-byte store per lane, row block and column. Pad positions [wa, npadv)
 // are zeroed by the caller once per stage.
-template <bool X3>
+template <bool X3, bool IMGB = false>
 __device__ __forceinline__ void epilogue_swin_vt(const GemmParams& p, f32x4 (&acc)[2][2][4][2], int m0, int n0, int grp, int wc, int lane) {
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -1028,14 +1048,25 @@ __device__ __forceinline__ void epilogue_swin_vt(const GemmParams& p, f32x4 (&ac
     const size_t plane = (size_t)(p.M / p.swin_N) * p.swin_img_velems * 2;  // bytes; < 4 GiB checked by the caller
     const __amdgpu_buffer_rsrc_t rs_hi = tile_rsrc(p.vt_hi, plane);
     const __amdgpu_buffer_rsrc_t rs_lo = tile_rsrc(X3 ? p.vt_lo : p.vt_hi, X3 ? plane : 0);
-    float bias_q[2][2];
+    int bnd = 1 << 30;  // IMGB: per-image bias table, see epilogue_direct_vt (a lane's 4 rows never straddle two images: token counts are multiples of 4)
+    const float* bias0 = p.bias;
+    const float* bias1 = p.bias;
+    if (IMGB) {
+        const int rows_here = p.M - m0 < 256 ? p.M - m0 : 256;
+        const int img0 = m0 / p.bias_img_rows;
+        bnd = (img0 + 1) * p.bias_img_rows - m0;
+        bias0 = p.bias + (size_t)img0 * p.bias_img_stride;
+        bias1 = bnd < rows_here ? bias0 + p.bias_img_stride : bias0;
+    }
+    float bias_q[2][2], biasn_q[2][2];
     int col_q[2][2];
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + qn * 128 + wc * 32 + j * 16 + l15;
-            bias_q[qn][j] = p.bias ? p.bias[n < p.N ? n : p.N - 1] : 0.0f;
+            bias_q[qn][j] = p.bias ? bias0[n < p.N ? n : p.N - 1] : 0.0f;
+            if (IMGB) biasn_q[qn][j] = bias1[n < p.N ? n : p.N - 1];
             col_q[qn][j] = n < p.N ? (n - 2 * p.F) * p.npadv : -1;  // (h*32 + d) * npadv
         }
     int dst[2][4];
@@ -1058,7 +1089,8 @@ __device__ __forceinline__ void epilogue_swin_vt(const GemmParams& p, f32x4 (&ac
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const f32x4 v = acc[qm][qn][i][j] + bias_q[qn][j];
+                    const bool next = IMGB && qm * 128 + grp * 64 + 16 * i + 4 * lh >= bnd;
+                    const f32x4 v = acc[qm][qn][i][j] + (next ? biasn_q[qn][j] : bias_q[qn][j]);
                     unsigned hw_[2], lw_[2];
 #pragma unroll
                     for (int w2 = 0; w2 < 2; ++w2) {
@@ -1588,7 +1620,11 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
     if constexpr (SW) {
         if (EKIND == MDPT_E_SWQKV) {
             if (dmode == DM_F32) {  // V columns as fp32 rows (swin_v_prep follows)
-                epilogue_direct<DM_F32, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+                if (HAVE_IMGB && p.bias_img_stride) epilogue_direct<DM_F32, false, MDPT_ACT_NONE, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);
+                else epilogue_direct<DM_F32, false, MDPT_ACT_NONE>(p, acc, m0, n0, grp, wc, lane);
+            } else if (HAVE_IMGB && p.bias_img_stride) {
+                if (p.q_lo) epilogue_swin_qk<true, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);
+                else epilogue_swin_qk<false, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);
             } else if (p.q_lo) {
                 epilogue_swin_qk<true>(p, acc, m0, n0, grp, wc, lane);
             } else {
@@ -1636,7 +1672,10 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
     }
     if ((EKIND == MDPT_E_QKV && dmode == DM_VT) || (EKIND == MDPT_E_SWQKV && dmode == DM_SWVT)) {
         if (EKIND == MDPT_E_SWQKV) {
-            if (p.vt_lo) epilogue_swin_vt<true>(p, acc, m0, n0, grp, wc, lane);
+            if (HAVE_IMGB && p.bias_img_stride) {
+                if (p.vt_lo) epilogue_swin_vt<true, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);
+                else epilogue_swin_vt<false, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);
+            } else if (p.vt_lo) epilogue_swin_vt<true>(p, acc, m0, n0, grp, wc, lane);
             else epilogue_swin_vt<false>(p, acc, m0, n0, grp, wc, lane);
         } else if (HAVE_IMGB && p.bias_img_stride) {
             if (p.vt_lo) epilogue_direct_vt<true, HAVE_IMGB>(p, acc, m0, n0, grp, wc, lane);

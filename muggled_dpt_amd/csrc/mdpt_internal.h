@@ -155,7 +155,7 @@ struct mdpt_handle {
     bool x3c(int cls) const { return np[cls] == 3; }
     // token-mean compensation of the weight rounding (fp16 operand modes, single-pass encoder Linears): see wrc_bias() below
     bool wrc_on;
-    bool wrc(int cls) const { return wrc_on && f16 && !swin && np[cls] == 1 && (cls == CLS_QKV || cls == CLS_PROJ || cls == CLS_FC1 || cls == CLS_FC2); }
+    bool wrc(int cls) const { return wrc_on && f16 && np[cls] == 1 && (cls == CLS_QKV || cls == CLS_PROJ || cls == CLS_FC1 || cls == CLS_FC2); }
     int wrc_maxn, wrc_maxk;  // widest compensated matrix (table / mean buffers of the plan)
     int gemm_tile;
     std::vector<WeightSpec> specs;
@@ -273,6 +273,7 @@ GemmParams base_params(const Ctx& c, const Mat& w, Planes a, int M, int lda);
 void as_conv(GemmParams& g, int Hi, int Wi, int Cin, int Ho, int Wo, int stride);
 int run_pos(const Ctx& c);
 int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype);
+int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias, int rows_per_img = 0, int nreal = 0);
 int run_encoder(const Ctx& c, void* const taps_f32[4]);
 int run_reassemble(const Ctx& c);
 int rcu_conv(const Ctx& c, const std::string& wname, Planes in, int sh, int sw, const float* skip, const float* up_src, int Hu, int Wu,

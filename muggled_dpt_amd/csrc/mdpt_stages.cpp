@@ -57,18 +57,19 @@ int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype) {
 // the pack kernel already produces for the 3-pass modes) - build the table bias_img[b][n] = bias[n] + sum_k mean_t(A_r[b,t,k]) W_lo[n][k],
 // and the big GEMM's epilogue adds row (m / npad) of it instead of the bias vector. Measured on ViT-L
 // (tests/precision_budget/, profiles/r04_precision_budget.md): QKV error -90 %, proj -50 %, fc1 / fc2 -35 ... 40 %, for ~2 % of the step.
-int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias) {
+int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias, int rows_per_img, int nreal) {  // (0, 0: the ViT families' padded token rows)
     const mdpt_handle* h = c.h;
     if (!h->wrc(w.cls) || !w.lo) return 0;
     const Plan& p = c.p;
+    if (rows_per_img <= 0) { rows_per_img = p.npad; nreal = p.N; }
     op_t* mean = c.at<op_t>(p.wrc_mean);
     float* tab = c.at<float>(p.wrc_tab);
     // every step-th token estimates the shared component as well as all of them (tests/precision_budget/); the step depends on the token
     // count only, so an image's table does not depend on the batch it is part of
-    const int step = p.N >= 1024 ? 8 : (p.N >= 256 ? 4 : 1);
-    CHK(OPLC(mdpt_launch_colmean, g.A_hi, g.lda, p.B, p.npad, p.N, step, w.Kp, mean, c.s));
+    const int step = nreal >= 1024 ? 8 : (nreal >= 256 ? 4 : 1);
+    CHK(OPLC(mdpt_launch_colmean, g.A_hi, g.lda, p.B, rows_per_img, nreal, step, w.Kp, mean, c.s));
     CHK(OPLC(mdpt_launch_wrc_table, mean, w.lo, bias, tab, p.B, w.Np, w.Kp, c.s));
-    g.bias = tab; g.bias_img_stride = w.Np; g.bias_img_rows = p.npad;
+    g.bias = tab; g.bias_img_stride = w.Np; g.bias_img_rows = rows_per_img;
     return 0;
 }
 

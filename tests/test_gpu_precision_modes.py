@@ -367,3 +367,33 @@ def test_massive_activation_channels_in_the_residual_stream():
     model.set_weight_rounding_compensation(False)
     r_off = rms(model(x.cuda()).cpu())
     assert r_on <= r_off * 1.05, f"compensation on: rms {r_on:.3e}, off: {r_off:.3e}"
+
+
+def test_swinv2_token_mean_compensation_tile_variants_and_batch_invariance(golden_dir):
+    """SwinV2 with the per-image bias tables (round 4: the fused Q / K / V epilogues of its QKV GEMM take them too, for stages of >= 256 tokens per
+    image; smaller stages go through the strip epilogues): every GEMM tile variant gives the same bits, an image's result does not depend on its
+    batch, and the compensated run is at least as close to the reference fixture as the uncompensated one (rms)."""
+    from muggled_dpt_amd import make_swinv2_dpt_from_midas_v31_state_dict
+    from muggled_dpt_amd.synthetic import make_synthetic_swinv2_state_dict
+    g = np.load(os.path.join(golden_dir, "swin2_tiny.npz"))
+    osd = make_synthetic_swinv2_state_dict("swin2_tiny", int(g["weight_seed"]))
+    x = torch.from_numpy(g["wide_input"])  # 64 x 96 image: 384 tokens in stage 0, 96 / 24 / 6 in the later stages
+    x3 = torch.cat((x, x.flip(0), x[:1] * 0.5), dim=0)
+    ref = torch.from_numpy(g["wide_depth"]).double()
+    _, model = make_swinv2_dpt_from_midas_v31_state_dict(osd)
+    model = model.to("cuda", torch.float32)
+    for precision in ("fp16", "mixed"):
+        model.set_precision(precision)
+        y = model(x3.cuda())
+        for tile in (1, 2, 4, 5, 6):
+            model.set_gemm_tile(tile)
+            assert torch.equal(model(x3.cuda()), y), f"{precision}: tile variant {tile} changed the result"
+        model.set_gemm_tile(0)
+        for i in range(x3.shape[0]):
+            assert torch.equal(model(x3[i:i + 1].cuda())[0], y[i]), f"{precision}: image {i} depends on its batch"
+        rms = lambda t: float((t.cpu().double() - ref).pow(2).mean().sqrt())  # noqa: E731
+        r_on = rms(y[:x.shape[0]])
+        model.set_weight_rounding_compensation(False)
+        r_off = rms(model(x.cuda()))
+        model.set_weight_rounding_compensation(None)
+        assert r_on <= r_off * 1.05, f"{precision}: rms {r_on:.3e} with the compensation, {r_off:.3e} without"
