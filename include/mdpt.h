@@ -206,7 +206,10 @@ int mdpt_set_batch_split(mdpt_handle* h, int32_t min_batch);
  * not depend on the batch size in any way that changes the arithmetic). On: launches that are too small to fill the GPU (batch 1 of
  * the small models) may use forms that change the summation order - today the attention kernel splits the key loop over the four
  * waves of a workgroup and merges the partial softmax states (ViT-S, batch 1: +13 %) - so results can differ in the last bit from
- * the batch-invariant form. Accuracy against the fp32 oracle is unchanged. */
+ * the batch-invariant form. Accuracy against the fp32 oracle is unchanged. Round 4: fc2 of a small batch (long K on the small GEMM tile:
+ * one serial chain of 64 K tiles per workgroup at ViT-L) splits K into two fixed halves, twice the workgroups in flight; the second half's
+ * partial sums are folded in by the LayerNorm that follows (no reduction launch). The split is fixed, so within latency mode these bits do
+ * not depend on the batch either. */
 int mdpt_set_latency_mode(mdpt_handle* h, int32_t on);
 
 /* PatchEmbed.prepare_image (v2_depthanything/patch_embed.py:103-145): uint8 [in_h,in_w,3] BGR on the device ->
@@ -247,6 +250,9 @@ int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspac
  * read an internal activation buffer ("resid","xn","q","k","vt","att","hbuf","im2col","pos","t0".."t3","u0","u1","d3",
  * "xf0".."xf3","a10".."a13","b20".."b23","flo0".."flo3","fused","h1","h1u") of the last forward as flat fp32 in its internal layout. */
 int mdpt_debug_set_stop(mdpt_handle* h, int32_t block, int32_t step);
+/* Test hook: latency mode's K split of the residual GEMMs applies from `min_k_tiles` 64-wide K tiles on (two ranges, 64x64 tile) and from
+ * `big_tile_k_tiles` on as four ranges on the 128x128 tile (toy models have 4 K tiles). */
+int mdpt_debug_set_ksplit_min(mdpt_handle* h, int32_t min_k_tiles, int32_t big_tile_k_tiles);
 int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_floats, void* workspace, size_t workspace_bytes,
                     void* stream);
 

@@ -46,6 +46,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     ln_row<NV>(x + (size_t)row * F, gamma, beta, out_hi, out_lo, out_f32, (size_t)row * F, F, lane);  // ln_row.h: shared with gemm.hip
 }
 
+// The same behind a K-split GEMM (GemmParams::ksplit, latency mode): the row is x + part[0] + part[1] + ... (the partial sums of the K
+// ranges 1 .. npart, added in that order), written back to x and normalised - the reduction of the split costs no launch of its own.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_addp_kernel(float* __restrict__ x, const float* __restrict__ part, size_t part_stride, int npart,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, op_t* out_hi,
+                                                             op_t* out_lo, float* out_f32, int rows, int F) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* xr = x + (size_t)row * F;
+    const float* pr = part + (size_t)row * F;
+    ln_row_from<NV>([&](int c) {
+        ln_f32x4 v = *(const ln_f32x4*)(xr + c);
+        for (int z = 0; z < npart; ++z) v += *(const ln_f32x4*)(pr + z * part_stride + c);
+        *(ln_f32x4*)(xr + c) = v;
+        return v;
+    }, gamma, beta, out_hi, out_lo, out_f32, (size_t)row * F, F, lane);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // patchify: NCHW fp32 -> rows [B*Np][Kp] with k = c*P*P + ky*P + kx (the conv weight's own flatten
 // order, patch_embed.py:56-62,92), zero padded to Kp. One thread = 4 consecutive k.
@@ -661,6 +680,22 @@ int MDPT_FN(mdpt_launch_layernorm)(const float* x, const float* gamma, const flo
     MdptProfScope prof("layernorm_kernel", 0.0, stream);
     const dim3 grid((rows + 3) / 4), block(256);
 #define LN_CASE(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, stream, x, gamma, beta, out_hi, out_lo, out_f32, rows, F)
+    if (F <= 256) LN_CASE(1);
+    else if (F <= 512) LN_CASE(2);
+    else if (F <= 1024) LN_CASE(4);
+    else if (F <= 1536) LN_CASE(6);
+    else LN_CASE(8);
+#undef LN_CASE
+    LAUNCH_RET();
+}
+
+int MDPT_FN(mdpt_launch_layernorm_addp)(float* x, const float* part, size_t part_stride, int npart, const float* gamma, const float* beta,
+                                       op_t* out_hi, op_t* out_lo, float* out_f32, int rows, int F, hipStream_t stream) {
+    if ((F & 3) || F > 64 * 4 * LN_MAXV || !part || npart < 1) return (int)hipErrorInvalidValue;
+    if (rows <= 0) return 0;
+    MdptProfScope prof("layernorm_addp_kernel", 0.0, stream);
+    const dim3 grid((rows + 3) / 4), block(256);
+#define LN_CASE(NV) hipLaunchKernelGGL(layernorm_addp_kernel<NV>, grid, block, 0, stream, x, part, part_stride, npart, gamma, beta, out_hi, out_lo, out_f32, rows, F)
     if (F <= 256) LN_CASE(1);
     else if (F <= 512) LN_CASE(2);
     else if (F <= 1024) LN_CASE(4);

@@ -149,8 +149,10 @@ struct Stager {
     ptrdiff_t a_hi_minus_lo, w_lo_minus_hi;
     const op_t* conv_plane;
     int st_pass, st_k0, st_tap, st_ci, st_sub;  // conv K order: 64-channel block (st_ci) outer, tap, then the BK-wide part of the block (st_sub)
+    int kspan;                                  // K extent this workgroup walks per pass (p.K, or p.K / ksplit from kofs on: GemmParams::ksplit)
 
-    __device__ __forceinline__ void init(const GemmParams& p, int m0, int n0, int wave, int lane) {
+    __device__ __forceinline__ void init(const GemmParams& p, int m0, int n0, int wave, int lane, int kofs = 0, int kspan_ = 0) {
+        kspan = kspan_ > 0 ? kspan_ : p.K;
         const int lrow = lane / CPR, slot = lane % CPR;
         const op_t* A0 = p.npass == 3 ? p.A_lo : p.A_hi;  // operand plane of pass 0
 #pragma unroll
@@ -163,7 +165,7 @@ struct Stager {
             a_ko[i] = koff;
             a_ptr[i] = nullptr;
             if (AMODE == MDPT_A_DENSE) {
-                a_ptr[i] = A0 + (size_t)m * p.lda + koff;
+                a_ptr[i] = A0 + (size_t)m * p.lda + koff + kofs;
             } else if (AMODE == MDPT_A_TOKENS) {
                 const int b = m / p.tok_np, t = m - b * p.tok_np;
                 a_ptr[i] = A0 + ((size_t)b * p.tok_stride + 1 + t) * p.lda + koff;
@@ -182,7 +184,7 @@ struct Stager {
             const int koff = (slot ^ ((r / RPB) & (CPR - 1))) * 8;
             int n = n0 + r;
             n = n < p.N ? n : p.N - 1;
-            b_ptr[i] = p.W_hi + (size_t)n * p.K + koff;
+            b_ptr[i] = p.W_hi + (size_t)n * p.K + koff + kofs;
         }
         // plane switches at pass roll-over (bf16x3 passes: A_lo*W_hi, A_hi*W_lo, A_hi*W_hi); all wave-uniform
         a_hi_minus_lo = p.npass == 3 ? p.A_hi - p.A_lo : 0;
@@ -222,10 +224,10 @@ struct Stager {
                 if (++st_tap == 9) { st_tap = 0; st_ci += 64; }
             }
         }
-        if (st_k0 == p.K) {  // next pass: rewind K and switch operand planes
+        if (st_k0 == kspan) {  // next pass: rewind K and switch operand planes
             st_k0 = 0; st_tap = 0; st_ci = 0; st_sub = 0;
-            const ptrdiff_t da = (st_pass == 0 ? a_hi_minus_lo : 0) - p.K;
-            const ptrdiff_t dw = (st_pass == 0 ? w_lo_minus_hi : -w_lo_minus_hi) - p.K;
+            const ptrdiff_t da = (st_pass == 0 ? a_hi_minus_lo : 0) - kspan;
+            const ptrdiff_t dw = (st_pass == 0 ? w_lo_minus_hi : -w_lo_minus_hi) - kspan;
             if (st_pass == 0) conv_plane = p.A_hi;
 #pragma unroll
             for (int i = 0; i < CA; ++i)
@@ -468,6 +470,34 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const float*
     }
 }
 
+// K-split partial sums (GemmParams::ksplit, ranges z >= 1): the bare accumulators as fp32 rows of `out` (row stride ldc), through the same
+// wave-private strip; no bias, no activation - the consumer adds the partials to range 0's output in a fixed order.
+template <int WTN, int TM, int TN>
+__device__ __forceinline__ void run_epilogue_partial(const GemmParams& p, f32x16 (&acc)[TM][TN], char* smem, int wave, int lane, int mwave0,
+                                                     int nbase, float* out) {
+    constexpr int LPR = WTN / 8, RPP = 64 / LPR;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int erow = lane / LPR, ecol = (lane % LPR) * 8;
+    float* strip = (float*)smem + wave * (32 * WTN);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                strip[((r & 3) + 8 * (r >> 2) + 4 * half) * WTN + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+        for (int pr = 0; pr < 32 / RPP; ++pr) {
+            const int row = pr * RPP + erow;
+            const int m = mwave0 + i * 32 + row, n = nbase + ecol;
+            if (m >= p.M || n >= p.N) continue;
+            float* o = out + (size_t)m * p.ldc + n;
+            *(f32x4*)o = *(const f32x4*)(strip + row * WTN + ecol);
+            *(f32x4*)(o + 4) = *(const f32x4*)(strip + row * WTN + ecol + 4);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Variant A ("lockstep"): all waves run  wait-DMA -> barrier -> issue next DMA -> LDS reads -> MFMAs  together.
 // Used for small tiles (128x128, 2 workgroups per CU) and the 32-wide head tile.
@@ -493,8 +523,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
 
     int m0, n0;
     tile_coords((p.N + BN - 1) / BN, BM, BN, m0, n0);
+    // K split (GemmParams::ksplit; the launcher sets grid.y for the 64x64 and 128x128 dense / generic instantiations only): range z of the K axis
+    constexpr bool KSPLIT = AMODE == MDPT_A_DENSE && EKIND == MDPT_E_GENERIC && BM == BN && (BM == 64 || BM == 128);
+    const int kz = KSPLIT ? (int)blockIdx.y : 0;
+    const int kspan = KSPLIT && p.ksplit > 1 ? p.K / p.ksplit : p.K;
     St st;
-    st.init(p, m0, n0, wave, lane);
+    st.init(p, m0, n0, wave, lane, kz * kspan, kspan);
 
     // ---- fragment read offsets: row = 32*blk + (lane&31), chunk = 2*kk + (lane>>5), swizzled with key(row)
     const int l31 = lane & 31, half = lane >> 5;
@@ -511,7 +545,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    if (EKIND == MDPT_E_GENERIC && p.acc_init) {
+    if (EKIND == MDPT_E_GENERIC && p.acc_init && kz == 0) {
         // residual GEMMs (out = resid + A W^T + bias, in place): the accumulators START at the residual, the epilogue adds the bias and
         // stores - the same order of operations in every tile variant (see gemm8_body's RI form, where this hides the residual read
         // under the main loop). acc[i][j][r] = C[32 i + (r&3) + 8 (r>>2) + 4 half][32 j + (lane&31)]; out-of-range elements read 0.
@@ -537,7 +571,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
     //      3-deep ring the DMA of slab t+1 stays in flight across the barrier), barrier (everybody's part of slab t
     //      has landed AND everybody finished reading slab t-1), refill the slot of slab t-1 with slab t+NST-1, compute.
     //      LDS-DMA completion is only tracked by vmcnt: the waits are explicit (hipcc does not reliably insert them).
-    const int total = (p.K / BK) * p.npass;
+    const int total = (kspan / BK) * p.npass;
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
         if (s < total) st.issue(p, smem + s * STAGE, wave);
@@ -597,7 +631,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
     }
     if (p.dbg_times) t_loop = memtime_now();
     __syncthreads();  // every wave is done reading the ring: reuse it as epilogue staging
-    run_epilogue<WTN, TM, TN, EKIND>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+    if (KSPLIT && kz > 0) run_epilogue_partial<WTN, TM, TN>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN, p.ks_part + (size_t)(kz - 1) * p.M * p.ldc);
+    else run_epilogue<WTN, TM, TN, EKIND>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
     if (p.dbg_times && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long* d = p.dbg_times + (size_t)blockIdx.x * 6;
@@ -1854,13 +1889,15 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
     if (!prof_name[0])
         snprintf(prof_name, sizeof(prof_name), "gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, BK, NST, MINW, AMODE, EKIND);
     MdptProfScope prof(prof_name, 2.0 * (p.M_alg > 0 ? p.M_alg : p.M) * p.N * p.K, stream);  // algorithmic flops (real rows, one pass whatever npass is)
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), LDS, stream, p);
+    const int ks = (AMODE == MDPT_A_DENSE && EKIND == MDPT_E_GENERIC && BM == BN && (BM == 64 || BM == 128) && p.ksplit > 1) ? p.ksplit : 1;
+    hipLaunchKernelGGL(kern, dim3(tiles, ks), dim3(64 * WM * WN), LDS, stream, p);
     return (int)hipGetLastError();
 }
 
 // the tile mdpt_launch_gemm runs for p (MDPT_TILE_AUTO resolved); -1: the 128x64 form of narrow outputs
 int resolve_tile(const GemmParams& p) {
     int tile = p.tile;
+    if (p.ksplit > 1) return tile == MDPT_TILE_128x128 ? MDPT_TILE_128x128 : MDPT_TILE_64x64;  // the K split exists on the two small lockstep tiles (mdpt_launch_gemm validates the rest)
     if (tile == MDPT_TILE_AUTO) {
         // measured on MI355X, kernel alone on the GPU (tests/gpu_gemm_tile_sweep.py): the 8-phase 256x256 tile wins from ~140
         // tiles (0.55 rounds; one tile takes ~25 us at K = 1024 whatever the count), 64x64 tiles win the latency race while
@@ -1876,10 +1913,12 @@ int resolve_tile(const GemmParams& p) {
         // of each half - SwinV2-L stage 2 proj / fc2 at batch 16 - fills 42 % of the CUs with big tiles and 84 % with 128x128 ones:
         // SwinV2-L +1.1 ... 1.6 %, ViT-S batch 32 +0.3 %, ViT-L / BEiT-L (76 tiles) unchanged, profiles/r03_gemm_tile_threshold_ab.txt)
         const bool big = cols_ok && tiles256 >= (p.throughput_mode ? 70 : 140);
-        tile = big ? MDPT_TILE_PP256 : (tiles128 <= 330 ? MDPT_TILE_64x64 : MDPT_TILE_128x128);
+        // (round 4: 352, was 330 - fc1 of ViT-L at batch 1, M = 1304, N = 4096, is exactly 352 tiles: 22.5 us on the 64x64 tile against 24.4 us,
+        // profiles/r04_b1_tile_sweep.txt; same bits on every tile)
+        tile = big ? MDPT_TILE_PP256 : (tiles128 <= 352 ? MDPT_TILE_64x64 : MDPT_TILE_128x128);
         // narrow outputs with many rows (64-channel decoder convs of the small models): a 128-wide tile would spend half of its
         // MFMAs on padding columns. 128x64, four waves stacked in M: ViT-S B=32 +8.4 %
-        if (!big && tiles128 > 330 && p.N <= 64) return -1;
+        if (!big && tiles128 > 352 && p.N <= 64) return -1;
     }
     // odd number of K tiles: the 8-phase loop handles pairs. Three K tiles or fewer (SwinV2's 192-wide first stage) are all prologue and
     // epilogue on a big tile: the 64x64 tile wins there (M = 147456, K = 192: N = 576 93.8 vs 116.4 us, N = 192 33.0 vs 47.3 us, N = 768 a tie;
@@ -1906,7 +1945,7 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
         // per step - same K order, same bits. Measured on the bare kernels (profiles/r04_b1_tile_sweep.txt, column t7): K = 4096 32.6 -> 28.5 us
         // (ViT-L, M = 1304), 30.7 -> 22.4 us (BEiT-L, M = 584); K <= 1536 is 2-8 % slower with the deeper ring and keeps the 2-deep one.
         if constexpr ((AMODE == MDPT_A_DENSE || AMODE == MDPT_A_CONV3) && EKIND == MDPT_E_GENERIC) {
-            if ((p.K / 64) * p.npass >= 32) return launch_cfg<64, 64, 2, 2, 64, 3, 1, AMODE, EKIND>(p, stream);
+            if ((p.K / 64 / (p.ksplit > 1 ? p.ksplit : 1)) * p.npass >= 32) return launch_cfg<64, 64, 2, 2, 64, 3, 1, AMODE, EKIND>(p, stream);
         }
         return launch_cfg<64, 64, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);
     }
@@ -1924,6 +1963,9 @@ int MDPT_FN(mdpt_launch_gemm)(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0) return 0;
     if (p.K <= 0 || (p.K & 63) || (p.N & 7)) return (int)hipErrorInvalidValue;
     if (p.npass != 1 && p.npass != 3) return (int)hipErrorInvalidValue;
+    if (p.ksplit > 1 && (p.ekind != MDPT_E_GENERIC || p.amode != MDPT_A_DENSE || !p.ks_part || !p.out_f32 || p.out_hi || p.up_src || p.gamma ||
+                         p.act != MDPT_ACT_NONE || (p.K / 64) % p.ksplit))
+        return (int)hipErrorInvalidValue;  // the split is for fp32 outputs whose consumer adds the partial sums
     switch (p.ekind) {
         case MDPT_E_GENERIC:
             if (p.amode == MDPT_A_DENSE) return launch_tile<MDPT_A_DENSE, MDPT_E_GENERIC>(p, stream);

@@ -15,9 +15,10 @@ __device__ __forceinline__ float ln_wave_sum(float v) {
     return v;
 }
 
-template <int NV>
-__device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       op_t* out_hi, op_t* out_lo, float* out_f32, size_t out_off, int F, int lane) {
+// `load(c)` returns the four row values at columns c .. c+3 (a plain row read, or the row plus pending partial sums: layernorm_addp_kernel)
+template <int NV, class Load>
+__device__ __forceinline__ void ln_row_from(Load load, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                            op_t* out_hi, op_t* out_lo, float* out_f32, size_t out_off, int F, int lane) {
 #pragma clang fp contract(off)
     ln_f32x4 v[NV];
     float s = 0.0f;
@@ -25,7 +26,7 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < F) {
-            v[i] = *(const ln_f32x4*)(xr + c);
+            v[i] = load(c);
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -66,4 +67,10 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
             if (out_f32) *(ln_f32x4*)(out_f32 + out_off + c) = y;
         }
     }
+}
+
+template <int NV>
+__device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       op_t* out_hi, op_t* out_lo, float* out_f32, size_t out_off, int F, int lane) {
+    ln_row_from<NV>([&](int c) { return *(const ln_f32x4*)(xr + c); }, gamma, beta, out_hi, out_lo, out_f32, out_off, F, lane);
 }

@@ -69,6 +69,7 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     h->has_last = false;
     h->zero_page = nullptr;
     h->dbg_block = h->dbg_step = -1;
+    h->ks_min_ktiles = 16; h->ks_big_ktiles = 1 << 30;
     h->split_min = 8;
     h->side_stream = nullptr;
     h->ev_fork = h->ev_join = nullptr;

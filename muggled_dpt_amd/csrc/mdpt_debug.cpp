@@ -10,6 +10,13 @@ int mdpt_debug_set_stop(mdpt_handle* h, int32_t block, int32_t step) {
     return 0;
 }
 
+int mdpt_debug_set_ksplit_min(mdpt_handle* h, int32_t min_k_tiles, int32_t big_tile_k_tiles) {
+    if (!h || min_k_tiles < 2 || big_tile_k_tiles < 4) return fail(MDPT_E_INVALID, "null handle or thresholds below 2 / 4 K tiles");
+    h->ks_min_ktiles = min_k_tiles;
+    h->ks_big_ktiles = big_tile_k_tiles;
+    return 0;
+}
+
 int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_floats, void* workspace, size_t workspace_bytes,
                     void* stream) {
     if (!h || !name || !out_f32) return fail(MDPT_E_INVALID, "null argument");

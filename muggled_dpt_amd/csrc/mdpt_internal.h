@@ -130,6 +130,7 @@ struct Plan {
     size_t tokr[2], cbuf, relpos_lut, relpos_tq, relpos_tk;  // BEiT: readout-projected tokens, per-image cls term, bias LUT
     size_t wrc_mean, wrc_tab;                                 // [B, wrc_maxk] operand-format column means, fp32 [B, wrc_maxn] per-image bias table
     size_t swi;                                               // ViT-G: fp32 [rows, 2*hidden] output of the doubled inner linear
+    size_t kspart;                                            // small batches: 3 x fp32 [rows, F] partial sums of the K-split proj / fc2 (latency mode), else absent
     // SwinV2: stage-0 patch grid, per-stage residual streams (fp32, = the taps), shared GEMM fp32 output, token planes,
     // window operands, window maps (plain / shifted) and the position-bias LUT
     struct {
@@ -176,6 +177,7 @@ struct mdpt_handle {
     // events, no host sync) so that one half's kernels fill the tile-quantisation tails and epilogue phases of the other's
     int split_min;
     int latency_mode;  // mdpt_set_latency_mode: small launches may use summation orders that are not batch-invariant
+    int ks_min_ktiles, ks_big_ktiles;  // ... proj / fc2 split K in two on the 64x64 tile from ks_min K tiles on, in four on the 128x128 tile from ks_big on (mdpt_debug_set_ksplit_min)
     hipStream_t side_stream;
     hipEvent_t ev_fork, ev_join;
     ~mdpt_handle() {
@@ -274,6 +276,7 @@ void as_conv(GemmParams& g, int Hi, int Wi, int Cin, int Ho, int Wo, int stride)
 int run_pos(const Ctx& c);
 int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype);
 int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias, int rows_per_img = 0, int nreal = 0);
+bool fc2_ksplit_fits(int rows, int F);  // batch small enough for the K-split form of fc2 (the 64x64 tile's range): the plan then holds kspart
 int run_encoder(const Ctx& c, void* const taps_f32[4]);
 int run_reassemble(const Ctx& c);
 int rcu_conv(const Ctx& c, const std::string& wname, Planes in, int sh, int sw, const float* skip, const float* up_src, int Hu, int Wu,

@@ -273,6 +273,7 @@ int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
     take_planes(bump, h->x3c(CLS_PROJ) || h->x3c(CLS_ATTN), rows * F, p.att);  // the 3-pass attention kernel always writes its lo plane
     take_planes(bump, h->x3c(CLS_FC2), rows * 4 * F, p.hbuf);
     p.swi = h->gh_hidden ? bump.take(rows * 2 * h->gh_hidden * 4) : SIZE_MAX;
+    p.kspart = fc2_ksplit_fits((int)rows, F) ? bump.take(rows * F * 4 * 3) : SIZE_MAX;  // three partial-sum planes (a split in four); reserved whatever the latency switch says: it may flip later
     p.wrc_mean = h->wrc_maxk ? bump.take((size_t)B * h->wrc_maxk * 2) : SIZE_MAX;
     p.wrc_tab = h->wrc_maxn ? bump.take((size_t)B * h->wrc_maxn * 4) : SIZE_MAX;
     const bool x3 = h->x3c(CLS_REASM);

@@ -60,6 +60,12 @@ struct GemmParams {
     const float* head_w; const float* head_b; int head_sigmoid; void* head_out; int head_out_dtype;  // MDPT_DT_*
     // test hook: per-workgroup phase timestamps (s_memtime): [start, first barrier passed, main loop done, epilogue done]
     int throughput_mode;  // 1: another stream runs the other half batch concurrently -> pick tiles by CU-time efficiency, not latency
+    // latency mode, long-K residual GEMMs of a small batch (fc2 at batch 1: one 64-K-tile serial chain per workgroup): ksplit > 1 splits K into
+    // ksplit equal ranges, one workgroup each (grid.y). Range 0 runs the normal epilogue (accumulators from resid, + bias, in place); range z >= 1
+    // stores its bare fp32 partial sums to ks_part + (z - 1) * M * ldc, and the CONSUMER adds them in the order z = 1, 2, ... (the LayerNorm
+    // that follows: mdpt_launch_layernorm_addp). Dense A, generic epilogue, the 64x64 tile or (tile = MDPT_TILE_128x128) the 128x128 one; a fixed
+    // split, so bits do not depend on the batch.
+    int ksplit; float* ks_part;
     unsigned long long* dbg_times;
 };
 

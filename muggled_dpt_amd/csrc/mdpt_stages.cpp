@@ -73,6 +73,13 @@ int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias, int r
     return 0;
 }
 
+// Latency mode (mdpt_set_latency_mode), fc2 of a small batch: on the 64x64 tile every workgroup walks all of K (ViT-L: 64 K tiles) as one serial
+// chain of L2 round trips while most of the MFMA pipes idle. Splitting K in two fixed halves doubles the workgroups in flight and halves
+// the chain; half 1's partial sums are added by the LayerNorm that follows anyway (mdpt_launch_layernorm_addp) - no reduction launch. The
+// summation order differs from the default path's (hence latency mode) but not with the batch: the split is fixed.
+bool fc2_ksplit_fits(int rows, int F) { return (long)((rows + 127) / 128) * ((F + 127) / 128) <= 330; }  // = resolve_tile()'s 64x64 range (gemm.hip)
+constexpr int KS_MAX_PARTS = 3;  // partial-sum planes the plan reserves (a split in four)
+
 // ---- stage: encoder. taps_f32 != null: also emit fp32 copies of the 4 out-normed taps (reference layout)
 int run_encoder(const Ctx& c, void* const taps_f32[4]) {
     const mdpt_handle* h = c.h;
@@ -98,9 +105,30 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
         rb.gh = p.gh; rb.gw = p.gw; rb.N = p.N; rb.ntok_pad = p.npadv;
         CHK(OPLC(mdpt_launch_beit_relpos_batch, rb, c.s));
     }
+    // K-split fc2: `pending` = partial sums the residual stream still lacks; the next LayerNorm over it folds them in
+    const float* pending = nullptr;
+    int npending = 0;
+    auto layernorm = [&](const float* gamma, const float* beta, op_t* ohi, op_t* olo, float* of32) -> int {
+        if (!pending) return OPLC(mdpt_launch_layernorm, resid, gamma, beta, ohi, olo, of32, rows, F, c.s);
+        const float* part = pending;
+        pending = nullptr;
+        return OPLC(mdpt_launch_layernorm_addp, resid, part, (size_t)rows * F, npending, gamma, beta, ohi, olo, of32, rows, F, c.s);
+    };
+    // latency mode, small batch, enough K tiles; never in a debug-stop run. From ks_big_ktiles K tiles on: four ranges on the 128x128 tile (fc2 of
+    // ViT-L at batch 1: 88 tiles x 4 = 352 workgroups of 16 K tiles, half the L2 -> LDS operand traffic of 336 x 2 64x64 workgroups)
+    auto ksplit_setup = [&](GemmParams& g) -> bool {
+        const int ktiles = g.K / 64;
+        if (!(h->latency_mode && p.kspart != SIZE_MAX && h->gemm_tile == MDPT_TILE_AUTO && (ktiles >= h->ks_min_ktiles || ktiles >= h->ks_big_ktiles) && h->dbg_block < 0)) return false;
+        const bool big = ktiles >= h->ks_big_ktiles;
+        g.ksplit = big ? 4 : 2;
+        if (ktiles % g.ksplit) { g.ksplit = 0; return false; }
+        if (big) g.tile = MDPT_TILE_128x128;
+        g.ks_part = c.at<float>(p.kspart);
+        return true;
+    };
     for (int b = 0; b < h->nblocks; ++b) {
         const std::string n = blk_name(h, b);
-        CHK(OPLC(mdpt_launch_layernorm, resid, h->V(n + ".norm1.weight"), h->V(n + ".norm1.bias"), xn_qkv.hi, xn_qkv.lo, nullptr, rows, F, c.s));
+        CHK(layernorm(h->V(n + ".norm1.weight"), h->V(n + ".norm1.bias"), xn_qkv.hi, xn_qkv.lo, nullptr));
         DBG_STOP(0);
         {
             GemmParams g = base_params(c, h->M(n + ".attn.qkv.weight"), xn, rows, F);
@@ -139,10 +167,11 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             g.acc_init = 1;
             g.resid = resid; g.out_f32 = resid; g.ldr = F; g.ldc = F;
             CHK(wrc_bias(c, g, h->M(n + ".attn.proj.weight"), g.bias));
+            if (ksplit_setup(g)) { pending = g.ks_part; npending = g.ksplit - 1; }  // LN2 is the next reader of the residual stream
             CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         DBG_STOP(3);
-        CHK(OPLC(mdpt_launch_layernorm, resid, h->V(n + ".norm2.weight"), h->V(n + ".norm2.bias"), xn_fc1.hi, xn_fc1.lo, nullptr, rows, F, c.s));
+        CHK(layernorm(h->V(n + ".norm2.weight"), h->V(n + ".norm2.bias"), xn_fc1.hi, xn_fc1.lo, nullptr));
         DBG_STOP(4);
         if (h->gh_hidden) {  // ViT-G: (a | b) = x W12^T + b12 ; hidden = silu(a) * b
             GemmParams g = base_params(c, h->M(n + ".mlp.inner_linear_doubled.weight"), xn, rows, F);
@@ -162,6 +191,8 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         DBG_STOP(5);
+        const bool v1 = h->cfg.family == MDPT_FAMILY_DAV1;
+        const bool is_tap = v1 ? b >= h->nblocks - 4 : (b + 1) % h->bps == 0;
         {
             const bool giant = h->gh_hidden != 0;
             GemmParams g = base_params(c, h->M(giant ? n + ".mlp.outer_linear.weight" : n + ".mlp.layers.2.weight"), hb, rows,
@@ -171,13 +202,17 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             g.acc_init = 1;
             g.resid = resid; g.out_f32 = resid; g.ldr = F; g.ldc = F;
             CHK(wrc_bias(c, g, h->M(giant ? n + ".mlp.outer_linear.weight" : n + ".mlp.layers.2.weight"), g.bias));
+            // a LayerNorm must be the next reader of the residual stream: not when this block's raw output is exported (block hooks, BEiT's
+            // un-normed taps, a debug stop) or nothing follows (BEiT's last block is a tap)
+            if (!(c.block_dump && c.block_dump[b]) && !(is_beit(h) && is_tap) && (b + 1 < h->nblocks || is_tap) && ksplit_setup(g)) {
+                pending = g.ks_part; npending = g.ksplit - 1;
+            }
             CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         DBG_STOP(6);
         if (c.block_dump && c.block_dump[b])  // TransformerBlock output (transformer_block.py:61-62), pad rows dropped
             CHK(OPLC(mdpt_launch_tokens_export, nullptr, nullptr, resid, (float*)c.block_dump[b], p.B, p.N, p.npad, F, 0, c.s));
-        const bool v1 = h->cfg.family == MDPT_FAMILY_DAV1;
-        if (v1 ? b >= h->nblocks - 4 : (b + 1) % h->bps == 0) {
+        if (is_tap) {
             const int st = v1 ? b - (h->nblocks - 4) : b / h->bps;
             Planes tp = c.pl(p.tap[st]);
             float* f32 = taps_f32 ? c.at<float>(p.tapf32) : nullptr;
@@ -185,7 +220,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
                 CHK(OPLC(mdpt_launch_tokens_import, resid, tp.hi, tp.lo, p.B, p.npad, p.npad, F, c.s));
                 if (taps_f32) CHK(OPLC(mdpt_launch_tokens_export, nullptr, nullptr, resid, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
             } else {
-                CHK(OPLC(mdpt_launch_layernorm, resid, h->V("imgencoder.outnorm.weight"), h->V("imgencoder.outnorm.bias"), tp.hi, tp.lo, f32, rows, F, c.s));
+                CHK(layernorm(h->V("imgencoder.outnorm.weight"), h->V("imgencoder.outnorm.bias"), tp.hi, tp.lo, f32));
                 if (taps_f32)
                     CHK(OPLC(mdpt_launch_tokens_export, nullptr, nullptr, f32, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
             }
