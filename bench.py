@@ -182,7 +182,7 @@ def profile_pass(lib, fn, steps):
 
 
 PRECISION_DTYPE = {"bf16": "bf16", "bf16x3": "bf16x3 (hi/lo split bf16 MFMA operands, 3 passes, fp32 accumulate)",
-                   "fp16": "fp16 (fp16 MFMA operands, fp32 accumulate, token-mean compensation of the weight rounding)",
+                   "fp16": "fp16 (fp16 MFMA operands, single pass, fp32 accumulate)",
                    "fp16x3": "fp16x3 (hi/lo split fp16 MFMA operands, 3 passes, fp32 accumulate)",
                    "mixed": "mixed (fp16 MFMA operands; patch embed + decoder convs 3 passes, encoder 1 pass + token-mean compensation; fp32 accumulate)"}
 

@@ -116,7 +116,7 @@ void mdpt_destroy(mdpt_handle* h);
 int mdpt_set_class_passes(mdpt_handle* h, int32_t op_class, int32_t passes);
 int mdpt_get_class_passes(const mdpt_handle* h, int32_t op_class, int32_t* passes);
 void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]);
-/* Token-mean compensation of the weight rounding (ViT families, fp16 operand modes; on by default in MDPT_PREC_FP16 and MDPT_PREC_MIXED): a
+/* Token-mean compensation of the weight rounding (fp16 operand modes; on by default in MDPT_PREC_MIXED, available in MDPT_PREC_FP16): a
  * single-pass Linear of the encoder (QKV, proj, fc1, fc2) computes A fp16(W)^T; what the weight rounding loses is dominated by the part all
  * tokens of an image share, mean_t(A) (W - fp16(W))^T, which two small kernels turn into a per-image bias table the GEMM epilogue adds
  * (transformer_block.py:160,168, misc_helpers.py:111-115 restated with that term). Same call-order rule as mdpt_set_class_passes. */
@@ -250,9 +250,9 @@ int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspac
  * read an internal activation buffer ("resid","xn","q","k","vt","att","hbuf","im2col","pos","t0".."t3","u0","u1","d3",
  * "xf0".."xf3","a10".."a13","b20".."b23","flo0".."flo3","fused","h1","h1u") of the last forward as flat fp32 in its internal layout. */
 int mdpt_debug_set_stop(mdpt_handle* h, int32_t block, int32_t step);
-/* Test hook: latency mode's K split of the residual GEMMs applies from `min_k_tiles` 64-wide K tiles on (two ranges, 64x64 tile) and from
- * `big_tile_k_tiles` on as four ranges on the 128x128 tile (toy models have 4 K tiles). */
-int mdpt_debug_set_ksplit_min(mdpt_handle* h, int32_t min_k_tiles, int32_t big_tile_k_tiles);
+/* Test hook: latency mode's K split of the residual GEMMs applies from `min_k_tiles` 64-wide K tiles on (two ranges) and from
+ * `four_k_tiles` on as four ranges (toy models have 4 K tiles). */
+int mdpt_debug_set_ksplit_min(mdpt_handle* h, int32_t min_k_tiles, int32_t four_k_tiles);
 int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_floats, void* workspace, size_t workspace_bytes,
                     void* stream);
 

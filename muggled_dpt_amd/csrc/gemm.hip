@@ -523,8 +523,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
 
     int m0, n0;
     tile_coords((p.N + BN - 1) / BN, BM, BN, m0, n0);
-    // K split (GemmParams::ksplit; the launcher sets grid.y for the 64x64 and 128x128 dense / generic instantiations only): range z of the K axis
-    constexpr bool KSPLIT = AMODE == MDPT_A_DENSE && EKIND == MDPT_E_GENERIC && BM == BN && (BM == 64 || BM == 128);
+    // K split (GemmParams::ksplit; the launcher sets grid.y for the 64x64 dense / generic instantiations only): range z of the K axis
+    constexpr bool KSPLIT = AMODE == MDPT_A_DENSE && EKIND == MDPT_E_GENERIC && BM == 64 && BN == 64;
     const int kz = KSPLIT ? (int)blockIdx.y : 0;
     const int kspan = KSPLIT && p.ksplit > 1 ? p.K / p.ksplit : p.K;
     St st;
@@ -1889,7 +1889,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
     if (!prof_name[0])
         snprintf(prof_name, sizeof(prof_name), "gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, BK, NST, MINW, AMODE, EKIND);
     MdptProfScope prof(prof_name, 2.0 * (p.M_alg > 0 ? p.M_alg : p.M) * p.N * p.K, stream);  // algorithmic flops (real rows, one pass whatever npass is)
-    const int ks = (AMODE == MDPT_A_DENSE && EKIND == MDPT_E_GENERIC && BM == BN && (BM == 64 || BM == 128) && p.ksplit > 1) ? p.ksplit : 1;
+    const int ks = (AMODE == MDPT_A_DENSE && EKIND == MDPT_E_GENERIC && BM == 64 && BN == 64 && p.ksplit > 1) ? p.ksplit : 1;
     hipLaunchKernelGGL(kern, dim3(tiles, ks), dim3(64 * WM * WN), LDS, stream, p);
     return (int)hipGetLastError();
 }
@@ -1897,7 +1897,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 // the tile mdpt_launch_gemm runs for p (MDPT_TILE_AUTO resolved); -1: the 128x64 form of narrow outputs
 int resolve_tile(const GemmParams& p) {
     int tile = p.tile;
-    if (p.ksplit > 1) return tile == MDPT_TILE_128x128 ? MDPT_TILE_128x128 : MDPT_TILE_64x64;  // the K split exists on the two small lockstep tiles (mdpt_launch_gemm validates the rest)
+    if (p.ksplit > 1) return MDPT_TILE_64x64;  // the K split exists on the small tile only (mdpt_launch_gemm validates the rest)
     if (tile == MDPT_TILE_AUTO) {
         // measured on MI355X, kernel alone on the GPU (tests/gpu_gemm_tile_sweep.py): the 8-phase 256x256 tile wins from ~140
         // tiles (0.55 rounds; one tile takes ~25 us at K = 1024 whatever the count), 64x64 tiles win the latency race while
@@ -1950,6 +1950,7 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
         return launch_cfg<64, 64, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);
     }
     if (tile == MDPT_TILE_PP256) return launch_pp<AMODE, EKIND>(p, stream);
+    if (tile == MDPT_TILE_192x128) return launch_cfg<192, 128, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);
     if (tile == MDPT_TILE_256x128) return launch_cfg<256, 128, 2, 2, 32, 3, 2, AMODE, EKIND>(p, stream);
     if (tile == MDPT_TILE_256x256) return launch_cfg<256, 256, 2, 4, 64, 2, 1, AMODE, EKIND>(p, stream);
     return launch_cfg<128, 128, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);

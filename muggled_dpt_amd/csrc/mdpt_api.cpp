@@ -63,7 +63,10 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
         const bool all3 = cfg->precision == MDPT_PREC_BF16X3 || cfg->precision == MDPT_PREC_FP16X3;
         for (int i = 0; i < NCLS; ++i) h->np[i] = cfg->precision == MDPT_PREC_MIXED ? mixed[i] : (all3 ? 3 : 1);
     }
-    h->wrc_on = cfg->precision == MDPT_PREC_FP16 || cfg->precision == MDPT_PREC_MIXED;
+    // token-mean compensation: on where the encoder's single-pass Linears are what is left of the error (mixed). With a single-pass decoder behind
+    // them (MDPT_PREC_FP16) the map does not get better - encoder taps -25 %, map rms +10 ... +37 % on BEiT-L / SwinV2-L, -15 % on ViT-L,
+    // profiles/r04_wrc_by_family.txt - for 3.5 % of the step: off there unless asked for
+    h->wrc_on = cfg->precision == MDPT_PREC_MIXED;
     h->gemm_tile = MDPT_TILE_AUTO;
     h->finalized = false;
     h->has_last = false;
@@ -257,7 +260,7 @@ int mdpt_set_latency_mode(mdpt_handle* h, int32_t on) {
 }
 
 int mdpt_set_gemm_tile(mdpt_handle* h, int32_t tile) {
-    if (!h || tile < 0 || tile > 6 || tile == 3) return fail(MDPT_E_INVALID, "tile must be 0 (auto), 1 (128x128x64), 2 (256x256x64 lockstep), 4 (256x128x32) or 5 (256x256x32 ping-pong)");
+    if (!h || tile < 0 || tile > 7 || tile == 3) return fail(MDPT_E_INVALID, "tile must be 0 (auto), 1 (128x128), 2 (256x256 lockstep), 4 (256x128x32), 5 (8-phase 256x256), 6 (64x64) or 7 (192x128)");
     h->gemm_tile = tile;
     return 0;
 }

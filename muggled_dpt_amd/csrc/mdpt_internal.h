@@ -177,7 +177,7 @@ struct mdpt_handle {
     // events, no host sync) so that one half's kernels fill the tile-quantisation tails and epilogue phases of the other's
     int split_min;
     int latency_mode;  // mdpt_set_latency_mode: small launches may use summation orders that are not batch-invariant
-    int ks_min_ktiles, ks_big_ktiles;  // ... proj / fc2 split K in two on the 64x64 tile from ks_min K tiles on, in four on the 128x128 tile from ks_big on (mdpt_debug_set_ksplit_min)
+    int ks_min_ktiles, ks_big_ktiles;  // ... proj / fc2 split K in two (64x64 tile) from ks_min K tiles on, in four from ks_big on (mdpt_debug_set_ksplit_min)
     hipStream_t side_stream;
     hipEvent_t ev_fork, ev_join;
     ~mdpt_handle() {

@@ -17,7 +17,7 @@ enum { MDPT_DT_F32 = 0, MDPT_DT_BF16 = 1, MDPT_DT_F16 = 2 };
 enum { MDPT_A_DENSE = 0, MDPT_A_TOKENS = 1, MDPT_A_CONV3 = 2 };
 enum { MDPT_E_GENERIC = 0, MDPT_E_QKV = 1, MDPT_E_PATCH = 2, MDPT_E_D2S = 3, MDPT_E_HEAD = 4, MDPT_E_SWQKV = 5 };
 enum { MDPT_ACT_NONE = 0, MDPT_ACT_RELU = 1, MDPT_ACT_GELU = 2 };
-enum { MDPT_TILE_AUTO = 0, MDPT_TILE_128x128 = 1, MDPT_TILE_256x256 = 2, MDPT_TILE_128x32 = 3, MDPT_TILE_256x128 = 4, MDPT_TILE_PP256 = 5, MDPT_TILE_64x64 = 6 };
+enum { MDPT_TILE_AUTO = 0, MDPT_TILE_128x128 = 1, MDPT_TILE_256x256 = 2, MDPT_TILE_128x32 = 3, MDPT_TILE_256x128 = 4, MDPT_TILE_PP256 = 5, MDPT_TILE_64x64 = 6, MDPT_TILE_192x128 = 7 };
 
 struct GemmParams {
     // operands
@@ -63,8 +63,8 @@ struct GemmParams {
     // latency mode, long-K residual GEMMs of a small batch (fc2 at batch 1: one 64-K-tile serial chain per workgroup): ksplit > 1 splits K into
     // ksplit equal ranges, one workgroup each (grid.y). Range 0 runs the normal epilogue (accumulators from resid, + bias, in place); range z >= 1
     // stores its bare fp32 partial sums to ks_part + (z - 1) * M * ldc, and the CONSUMER adds them in the order z = 1, 2, ... (the LayerNorm
-    // that follows: mdpt_launch_layernorm_addp). Dense A, generic epilogue, the 64x64 tile or (tile = MDPT_TILE_128x128) the 128x128 one; a fixed
-    // split, so bits do not depend on the batch.
+    // that follows: mdpt_launch_layernorm_addp). Dense A, generic epilogue, 64x64 tile only (four ranges on the 128x128 tile - half the operand
+    // traffic per flop - measured 7 % slower: profiles/r04_b1_ksplit_sweep.txt); a fixed split, so bits do not depend on the batch.
     int ksplit; float* ks_part;
     unsigned long long* dbg_times;
 };

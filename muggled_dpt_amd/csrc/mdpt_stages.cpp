@@ -114,15 +114,12 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
         pending = nullptr;
         return OPLC(mdpt_launch_layernorm_addp, resid, part, (size_t)rows * F, npending, gamma, beta, ohi, olo, of32, rows, F, c.s);
     };
-    // latency mode, small batch, enough K tiles; never in a debug-stop run. From ks_big_ktiles K tiles on: four ranges on the 128x128 tile (fc2 of
-    // ViT-L at batch 1: 88 tiles x 4 = 352 workgroups of 16 K tiles, half the L2 -> LDS operand traffic of 336 x 2 64x64 workgroups)
+    // latency mode, small batch, enough K tiles; never in a debug-stop run. Two ranges from ks_min_ktiles K tiles on, four from ks_big_ktiles on
     auto ksplit_setup = [&](GemmParams& g) -> bool {
         const int ktiles = g.K / 64;
         if (!(h->latency_mode && p.kspart != SIZE_MAX && h->gemm_tile == MDPT_TILE_AUTO && (ktiles >= h->ks_min_ktiles || ktiles >= h->ks_big_ktiles) && h->dbg_block < 0)) return false;
-        const bool big = ktiles >= h->ks_big_ktiles;
-        g.ksplit = big ? 4 : 2;
+        g.ksplit = ktiles >= h->ks_big_ktiles ? 4 : 2;
         if (ktiles % g.ksplit) { g.ksplit = 0; return false; }
-        if (big) g.tile = MDPT_TILE_128x128;
         g.ks_part = c.at<float>(p.kspart);
         return true;
     };

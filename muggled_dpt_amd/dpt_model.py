@@ -602,7 +602,8 @@ class DPTModel(nn.Module):
 
     def set_weight_rounding_compensation(self, on: bool | None) -> None:
         """Token-mean compensation of the weight rounding in the fp16 operand modes (mdpt_set_weight_rounding_compensation): None = the
-        mode's default (on for "fp16" and "mixed"), True / False force it."""
+        mode's default (on for "mixed"; off for single-pass "fp16", where the decoder's own rounding dominates and the map does not improve),
+        True / False force it."""
         self.__dict__["_wrc"] = None if on is None else bool(on)
         self._invalidate()
 

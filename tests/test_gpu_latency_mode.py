@@ -25,7 +25,7 @@ def _require_gpu_and_native_lib():
 
 def _split_from(model, k_tiles: int, big_k_tiles: int = 1 << 30):
     """Toy models have 4 K tiles in fc2 and 1 in proj (the production thresholds are far above): lower them through the test hook on the model's
-    engine. big_k_tiles: from this many K tiles on the split is in four on the 128x128 tile."""
+    engine. big_k_tiles: from this many K tiles on the split is in four."""
     from muggled_dpt_amd import native
     eng = model._get_engine()
     native.check(eng.lib, eng.lib.mdpt_debug_set_ksplit_min(eng.handle, k_tiles, big_k_tiles))
@@ -108,10 +108,9 @@ def test_every_consumer_of_the_residual_stream_behind_a_split_fc2(family, big):
         ref = orc.forward(w, cfg, x)
     y_default = model(x.cuda())
     model.set_latency_mode(True)
-    _split_from(model, 2, 4 if big else 1 << 30)  # big: fc2 (4 K tiles) in four ranges of one K tile on the 128x128 tile
+    _split_from(model, 2, 4 if big else 1 << 30)  # big: fc2 (4 K tiles) in four ranges of one K tile, three partial-sum planes
     names = _profile_names(lambda: model(x.cuda()))
     assert "layernorm_addp_kernel" in names, sorted(names)
-    assert any(k.startswith("gemm_kernel<128, 128") for k in names) == big or family == "beit", sorted(names)
     y = model(x.cuda())
     assert rel_err(y.float().cpu(), ref) <= REL_TOL_X3
     assert rel_err(y.float().cpu(), y_default.float().cpu()) <= REL_TOL_X3

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Batch-1 step time (bf16, 200 steps, three interleaved rounds): default path, latency mode without the K split (threshold out of reach),
-and latency mode with the K split of the residual GEMMs from 24 (fc2 only at ViT-L / BEiT-L; fc2 of ViT-S), 16 (proj at F = 1024 too) and 8 K
-tiles on. mdpt_debug_set_ksplit_min is the test hook that moves the threshold."""
+and latency mode with the K split of the residual GEMMs (two / four ranges on the 64x64 tile) from several K-tile thresholds. mdpt_debug_set_ksplit_min is the test hook that moves the threshold."""
 import os, sys, torch
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
@@ -20,9 +19,9 @@ for name, size in (("vitl", 504), ("vits", 504), ("beitl", 384)):
         rows.setdefault("default", []).append(bench.time_model(model, x, 200)[0] * 1e3)
         model.set_latency_mode(True)
         OFF = 1 << 30
-        for thr, big in ((OFF, OFF), (24, OFF), (16, OFF), (16, 64), (16, 24), (16, 16), (OFF - 1, 64)):
+        for thr, big in ((OFF, OFF), (16, OFF), (16, 64), (16, 24), (16, 16), (8, 16)):
             native.check(eng.lib, eng.lib.mdpt_debug_set_ksplit_min(eng.handle, thr, big))
-            label = "latency, no K split" if thr == OFF else f"latency, x2 (64x64) from {thr if thr < OFF - 1 else 'never'}, x4 (128x128) from {big if big < OFF else 'never'}"
+            label = "latency, no K split" if thr == OFF else f"latency, x2 from {thr} K tiles, x4 from {big if big < OFF else 'never'}"
             rows.setdefault(label, []).append(bench.time_model(model, x, 200)[0] * 1e3)
     for k, v in rows.items():
         print(f"{name:6s} {k:62s} " + " ".join(f"{t:.3f}" for t in v) + f"   min {min(v):.3f} ms", flush=True)
