@@ -1950,7 +1950,6 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
         return launch_cfg<64, 64, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);
     }
     if (tile == MDPT_TILE_PP256) return launch_pp<AMODE, EKIND>(p, stream);
-    if (tile == MDPT_TILE_192x128) return launch_cfg<192, 128, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);
     if (tile == MDPT_TILE_256x128) return launch_cfg<256, 128, 2, 2, 32, 3, 2, AMODE, EKIND>(p, stream);
     if (tile == MDPT_TILE_256x256) return launch_cfg<256, 256, 2, 4, 64, 2, 1, AMODE, EKIND>(p, stream);
     return launch_cfg<128, 128, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);

@@ -260,7 +260,7 @@ int mdpt_set_latency_mode(mdpt_handle* h, int32_t on) {
 }
 
 int mdpt_set_gemm_tile(mdpt_handle* h, int32_t tile) {
-    if (!h || tile < 0 || tile > 7 || tile == 3) return fail(MDPT_E_INVALID, "tile must be 0 (auto), 1 (128x128), 2 (256x256 lockstep), 4 (256x128x32), 5 (8-phase 256x256), 6 (64x64) or 7 (192x128)");
+    if (!h || tile < 0 || tile > 6 || tile == 3) return fail(MDPT_E_INVALID, "tile must be 0 (auto), 1 (128x128), 2 (256x256 lockstep), 4 (256x128x32), 5 (8-phase 256x256) or 6 (64x64)");
     h->gemm_tile = tile;
     return 0;
 }

@@ -17,7 +17,7 @@ enum { MDPT_DT_F32 = 0, MDPT_DT_BF16 = 1, MDPT_DT_F16 = 2 };
 enum { MDPT_A_DENSE = 0, MDPT_A_TOKENS = 1, MDPT_A_CONV3 = 2 };
 enum { MDPT_E_GENERIC = 0, MDPT_E_QKV = 1, MDPT_E_PATCH = 2, MDPT_E_D2S = 3, MDPT_E_HEAD = 4, MDPT_E_SWQKV = 5 };
 enum { MDPT_ACT_NONE = 0, MDPT_ACT_RELU = 1, MDPT_ACT_GELU = 2 };
-enum { MDPT_TILE_AUTO = 0, MDPT_TILE_128x128 = 1, MDPT_TILE_256x256 = 2, MDPT_TILE_128x32 = 3, MDPT_TILE_256x128 = 4, MDPT_TILE_PP256 = 5, MDPT_TILE_64x64 = 6, MDPT_TILE_192x128 = 7 };
+enum { MDPT_TILE_AUTO = 0, MDPT_TILE_128x128 = 1, MDPT_TILE_256x256 = 2, MDPT_TILE_128x32 = 3, MDPT_TILE_256x128 = 4, MDPT_TILE_PP256 = 5, MDPT_TILE_64x64 = 6 };
 
 struct GemmParams {
     // operands
