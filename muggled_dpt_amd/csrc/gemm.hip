@@ -184,7 +184,7 @@ struct Stager {
             const int koff = (slot ^ ((r / RPB) & (CPR - 1))) * 8;
             int n = n0 + r;
             n = n < p.N ? n : p.N - 1;
-            b_ptr[i] = p.W_hi + (size_t)n * p.K + koff + kofs;
+            b_ptr[i] = p.W_hi + (size_t)n * p.ldw + koff + kofs;
         }
         // plane switches at pass roll-over (bf16x3 passes: A_lo*W_hi, A_hi*W_lo, A_hi*W_hi); all wave-uniform
         a_hi_minus_lo = p.npass == 3 ? p.A_hi - p.A_lo : 0;
@@ -1276,8 +1276,8 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
             const size_t row0 = src_row(m0), row_last = src_row(m0 + rows_here - 1);
             a_base_hi = p.A_hi + row0 * p.lda; a_base_lo = p.npass == 3 ? p.A_lo + row0 * p.lda : a_base_hi;
             a_bytes = (row_last - row0 + 1) * p.lda * 2;
-            w_base_hi = p.W_hi + (size_t)n0 * p.K; w_base_lo = p.npass == 3 ? p.W_lo + (size_t)n0 * p.K : w_base_hi;
-            w_bytes = (size_t)cols_here * p.K * 2;
+            w_base_hi = p.W_hi + (size_t)n0 * p.ldw; w_base_lo = p.npass == 3 ? p.W_lo + (size_t)n0 * p.ldw : w_base_hi;
+            w_bytes = ((size_t)(cols_here - 1) * p.ldw + p.K) * 2;
             rs_a = rsrc(p.npass == 3 ? a_base_lo : a_base_hi, a_bytes);  // pass 0 of bf16x3: A_lo * W_hi
             rs_w = rsrc(w_base_hi, w_bytes);
 #pragma unroll
@@ -1288,10 +1288,10 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
             }
             {
                 const int r = wave * 8 + lrow;  // rows of DMA instruction i: r + 64 i, same swizzle key
-                b_voff = (unsigned)(((size_t)r * p.K + ((slot ^ ((r >> 1) & 7)) * 8)) * 2);
+                b_voff = (unsigned)(((size_t)r * p.ldw + ((slot ^ ((r >> 1) & 7)) * 8)) * 2);
             }
             a_soff = b_soff = 0;
-            b_row_step = 64 * p.K * 2;
+            b_row_step = 64 * p.ldw * 2;
             a_row_step = 0;
             a_hi_minus_lo = w_lo_minus_hi = 0;
             conv_plane = nullptr;
@@ -1321,7 +1321,7 @@ struct HalfStager {  // BM = BN = 256, 8 waves, BK = 64: chunk c = wave + 8 i co
             }
             int n = n0 + r;
             n = n < p.N ? n : p.N - 1;
-            b_ptr[i] = p.W_hi + (size_t)n * p.K + koff;
+            b_ptr[i] = p.W_hi + (size_t)n * p.ldw + koff;
         }
         a_hi_minus_lo = p.npass == 3 ? p.A_hi - p.A_lo : 0;
         w_lo_minus_hi = p.npass == 3 ? p.W_lo - p.W_hi : 0;
@@ -1438,13 +1438,13 @@ __device__ __forceinline__ void gemm8_body(const GemmParams& p, char* smem, cons
     if constexpr (FAST) {
         const int rows_here = p.M - m0 < 256 ? p.M - m0 : 256, cols_here = p.N - n0 < 256 ? p.N - n0 : 256;
         rs_a = tile_rsrc(p.A_hi + (size_t)m0 * p.lda, (size_t)rows_here * p.lda * 2);
-        rs_w = tile_rsrc(p.W_hi + (size_t)n0 * p.K, (size_t)cols_here * p.K * 2);
+        rs_w = tile_rsrc(p.W_hi + (size_t)n0 * p.ldw, ((size_t)(cols_here - 1) * p.ldw + p.K) * 2);
         const int r = wave * 8 + (lane >> 3);  // DMA instruction i of this wave stages rows r + 64 i (same swizzle key for all four)
         const int koff = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
         fa_voff = (unsigned)(r * p.lda + koff) * 2u;
-        fb_voff = (unsigned)(r * p.K + koff) * 2u;
+        fb_voff = (unsigned)(r * p.ldw + koff) * 2u;
         fa_step = 64 * p.lda * 2;
-        fb_step = 64 * p.K * 2;
+        fb_step = 64 * p.ldw * 2;
     }
     // half-tile H of the K tile at byte offset KB_ (FAST) / of the stager's next K tile (state machine) -> ring buffer BUF_
 #define ISSUE_A(H_, BUF_, KB_)                                                                                          \
@@ -1823,6 +1823,19 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmParams p) {
         } else {
             gemm8_body<AMODE, EKIND, false>(p, smem, DM_NONE, m0, n0, t_start);
         }
+    } else if constexpr (AMODE == MDPT_A_DENSE && DMODE == DM_F32) {
+        // plain fp32 outputs; with GemmParams::ksplit > 1 (grid.y = range) this workgroup walks K range z of rows that are ldw wide: range 0 is the
+        // normal kernel on a shorter K, ranges z >= 1 store bare partial sums (no bias) to the partial planes
+        GemmParams q = p;
+        if (p.ksplit > 1) {
+            const int z = (int)blockIdx.y, ks = p.K / p.ksplit;
+            q.K = ks;
+            q.A_hi = p.A_hi + z * ks; q.W_hi = p.W_hi + z * ks;
+            if (p.npass == 3) { q.A_lo = p.A_lo + z * ks; q.W_lo = p.W_lo + z * ks; }
+            if (z > 0) { q.bias = nullptr; q.bias_img_stride = 0; q.out_f32 = p.ks_part + (size_t)(z - 1) * p.M * p.ldc; }
+        }
+        if (q.npass == 1) gemm8_body<AMODE, EKIND, true, false, true>(q, smem, DMODE, m0, n0, t_start);
+        else gemm8_body<AMODE, EKIND, true, false, false>(q, smem, DMODE, m0, n0, t_start);
     } else if constexpr (AMODE == MDPT_A_DENSE && DMODE != DM_NONE) {
         // the encoder's hot forms: stateless staging when there is one pass (bf16 mode), the state-machine stager for bf16x3
 #ifdef MDPT_GEMM8_NO_FAST  // A/B builds only
@@ -1850,7 +1863,8 @@ int launch_pp_mode(const GemmParams& p, hipStream_t stream) {
     static char prof_name[64] = "";
     if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "gemm8_kernel<%d, %d, %d>", AMODE, EKIND, DMODE);
     MdptProfScope prof(prof_name, 2.0 * (p.M_alg > 0 ? p.M_alg : p.M) * p.N * p.K, stream);  // algorithmic rows (token pad rows are not work)
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, p);
+    const int ks = (AMODE == MDPT_A_DENSE && EKIND == MDPT_E_GENERIC && DMODE == DM_F32 && p.ksplit > 1) ? p.ksplit : 1;
+    hipLaunchKernelGGL(kern, dim3(tiles, ks), dim3(512), LDS, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -1897,7 +1911,14 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 // the tile mdpt_launch_gemm runs for p (MDPT_TILE_AUTO resolved); -1: the 128x64 form of narrow outputs
 int resolve_tile(const GemmParams& p) {
     int tile = p.tile;
-    if (p.ksplit > 1) return MDPT_TILE_64x64;  // the K split exists on the small tile only (mdpt_launch_gemm validates the rest)
+    if (p.ksplit > 1) {
+        // the K split exists on the 64x64 tile and in the DM_F32 form of the 8-phase kernel (>= 4 K tiles per range, in pairs; same sums, same bits):
+        // the big tile when all ranges together make enough workgroups (the rule of the unsplit launches, counted over the ranges)
+        const long wgs = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.ksplit;
+        const int kt = (p.K / 64 / p.ksplit) * p.npass;
+        const bool pp = p.tile == MDPT_TILE_PP256 || (p.tile == MDPT_TILE_AUTO && wgs >= (p.throughput_mode ? 70 : 140));
+        return (pp && p.amode == MDPT_A_DENSE && generic_direct_mode(p) == DM_F32 && kt >= 4 && !(kt & 1) && (p.N & 255) == 0) ? MDPT_TILE_PP256 : MDPT_TILE_64x64;
+    }
     if (tile == MDPT_TILE_AUTO) {
         // measured on MI355X, kernel alone on the GPU (tests/gpu_gemm_tile_sweep.py): the 8-phase 256x256 tile wins from ~140
         // tiles (0.55 rounds; one tile takes ~25 us at K = 1024 whatever the count), 64x64 tiles win the latency race while
@@ -1959,12 +1980,14 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
 
 bool MDPT_FN(mdpt_gemm_resolves_to_pp256)(const GemmParams& p) { return p.M > 0 && p.N > 0 && p.K > 0 && !(p.K & 63) && resolve_tile(p) == MDPT_TILE_PP256; }
 
-int MDPT_FN(mdpt_launch_gemm)(const GemmParams& p, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_gemm)(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    if (p.ldw <= 0) p.ldw = p.K;  // packed panels: rows are K wide
     if (p.M <= 0 || p.N <= 0) return 0;
     if (p.K <= 0 || (p.K & 63) || (p.N & 7)) return (int)hipErrorInvalidValue;
     if (p.npass != 1 && p.npass != 3) return (int)hipErrorInvalidValue;
     if (p.ksplit > 1 && (p.ekind != MDPT_E_GENERIC || p.amode != MDPT_A_DENSE || !p.ks_part || !p.out_f32 || p.out_hi || p.up_src || p.gamma ||
-                         p.act != MDPT_ACT_NONE || (p.K / 64) % p.ksplit))
+                         p.act != MDPT_ACT_NONE || (p.K / 64) % p.ksplit || p.ldw != p.K))
         return (int)hipErrorInvalidValue;  // the split is for fp32 outputs whose consumer adds the partial sums
     switch (p.ekind) {
         case MDPT_E_GENERIC:

@@ -24,6 +24,7 @@ struct GemmParams {
     const op_t* A_hi; const op_t* A_lo;   // activations, row stride lda (elements)
     const op_t* W_hi; const op_t* W_lo;   // weights [N][K]
     int M, N, K;                              // K % 64 == 0 (conv: K = 9 * Cin)
+    int ldw;                                  // row stride of W in elements (0 = K: the packed panels; > K: a K range of wider rows, see ksplit)
     int M_alg;                                // > 0: rows that are algorithmic work (token rows without the per-image pad rows): profiler FLOP accounting only
     int lda;
     int npass;                                // 1 = bf16, 3 = bf16x3 (A_lo*W_hi + A_hi*W_lo + A_hi*W_hi)
@@ -60,11 +61,13 @@ struct GemmParams {
     const float* head_w; const float* head_b; int head_sigmoid; void* head_out; int head_out_dtype;  // MDPT_DT_*
     // test hook: per-workgroup phase timestamps (s_memtime): [start, first barrier passed, main loop done, epilogue done]
     int throughput_mode;  // 1: another stream runs the other half batch concurrently -> pick tiles by CU-time efficiency, not latency
-    // latency mode, long-K residual GEMMs of a small batch (fc2 at batch 1: one 64-K-tile serial chain per workgroup): ksplit > 1 splits K into
-    // ksplit equal ranges, one workgroup each (grid.y). Range 0 runs the normal epilogue (accumulators from resid, + bias, in place); range z >= 1
-    // stores its bare fp32 partial sums to ks_part + (z - 1) * M * ldc, and the CONSUMER adds them in the order z = 1, 2, ... (the LayerNorm
-    // that follows: mdpt_launch_layernorm_addp). Dense A, generic epilogue, 64x64 tile only (four ranges on the 128x128 tile - half the operand
-    // traffic per flop - measured 7 % slower: profiles/r04_b1_ksplit_sweep.txt); a fixed split, so bits do not depend on the batch.
+    // K split: ksplit > 1 splits K into ksplit equal ranges, one workgroup each (grid.y). Range 0 runs the normal epilogue; range z >= 1 stores its
+    // bare fp32 partial sums to ks_part + (z - 1) * M * ldc, and the CONSUMER adds them in the order z = 1, 2, ... - the LayerNorm that follows
+    // (mdpt_launch_layernorm_addp, mdpt_launch_ln_res). A fixed split: bits do not depend on the batch. Two users:
+    //  * latency mode, proj / fc2 of a small batch (one 16 ... 64-K-tile serial chain per 64x64 workgroup): dense A, generic epilogue, 64x64 tile
+    //    (four ranges on the 128x128 tile - half the operand traffic per flop - measured 7 % slower: profiles/r04_b1_ksplit_sweep.txt);
+    //  * SwinV2 fc2 with K >= 3072 at EVERY batch size (stages of few, long-K tiles: 108 8-phase tiles at batch 16): fp32 output without
+    //    residual (DM_F32 form of the 8-phase kernel from 140 workgroups on, the 64x64 tile below - same sums, same bits).
     int ksplit; float* ks_part;
     unsigned long long* dbg_times;
 };

@@ -48,7 +48,8 @@ inline int grid_for(size_t total, int block = 256) {
 template <int NV>
 __global__ __launch_bounds__(256) void ln_res_kernel(const float* __restrict__ x, const float* add, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, float* out_f32, op_t* out_hi,
-                                                     op_t* out_lo, int rows, int F, int ldp) {
+                                                     op_t* out_lo, int rows, int F, int ldp, const float* __restrict__ part) {
+    // part: partial sums of the second K range of a K-split GEMM (GemmParams::ksplit): the row normalised is x + part
     // ldp = row stride of the bf16 planes (>= F; pad columns are zeroed once per forward by the caller, never written here)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256) void ln_res_kernel(const float* __restrict__ x
         if (c < F) {
             v[i] = *(const f32x4*)(xr + c);
             if (add) av[i] = *(const f32x4*)(add + (size_t)row * F + c);
+            if (part) v[i] += *(const f32x4*)(part + (size_t)row * F + c);
         }
     }
     float s = 0.0f;
@@ -307,13 +309,13 @@ __global__ __launch_bounds__(256) void f32_to_planes_kernel(const float* __restr
 #define LAUNCH_RET() return (int)hipGetLastError()
 
 int MDPT_FN(mdpt_launch_ln_res)(const float* x, const float* add, const float* gamma, const float* beta, float eps, float* out_f32, op_t* out_hi,
-                       op_t* out_lo, int rows, int F, hipStream_t stream, int ld_planes) {
+                       op_t* out_lo, int rows, int F, hipStream_t stream, int ld_planes, const float* part) {
     if (ld_planes <= 0) ld_planes = F;
     if ((F & 3) || F > 2048 || ld_planes < F || (ld_planes & 3)) return (int)hipErrorInvalidValue;
     if (rows <= 0) return 0;
     MdptProfScope prof("ln_res_kernel", 0.0, stream);
     const dim3 grid((rows + 3) / 4), block(256);
-#define LN_CASE(NV) hipLaunchKernelGGL(ln_res_kernel<NV>, grid, block, 0, stream, x, add, gamma, beta, eps, out_f32, out_hi, out_lo, rows, F, ld_planes)
+#define LN_CASE(NV) hipLaunchKernelGGL(ln_res_kernel<NV>, grid, block, 0, stream, x, add, gamma, beta, eps, out_f32, out_hi, out_lo, rows, F, ld_planes, part)
     if (F <= 256) LN_CASE(1);
     else if (F <= 512) LN_CASE(2);
     else if (F <= 1024) LN_CASE(4);
