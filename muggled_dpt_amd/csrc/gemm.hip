@@ -150,6 +150,7 @@ struct Stager {
     const op_t* conv_plane;
     int st_pass, st_k0, st_tap, st_ci, st_sub;  // conv K order: 64-channel block (st_ci) outer, tap, then the BK-wide part of the block (st_sub)
     int kspan;                                  // K extent this workgroup walks per pass (p.K, or p.K / ksplit from kofs on: GemmParams::ksplit)
+    int st_tap0, st_ci0;                        // conv state at the start of the range
 
     __device__ __forceinline__ void init(const GemmParams& p, int m0, int n0, int wave, int lane, int kofs = 0, int kspan_ = 0) {
         kspan = kspan_ > 0 ? kspan_ : p.K;
@@ -168,7 +169,7 @@ struct Stager {
                 a_ptr[i] = A0 + (size_t)m * p.lda + koff + kofs;
             } else if (AMODE == MDPT_A_TOKENS) {
                 const int b = m / p.tok_np, t = m - b * p.tok_np;
-                a_ptr[i] = A0 + ((size_t)b * p.tok_stride + 1 + t) * p.lda + koff;
+                a_ptr[i] = A0 + ((size_t)b * p.tok_stride + 1 + t) * p.lda + koff + kofs;
             } else {
                 const int hw = p.Ho * p.Wo;
                 const int b = m / hw, rem = m - b * hw;
@@ -190,7 +191,11 @@ struct Stager {
         a_hi_minus_lo = p.npass == 3 ? p.A_hi - p.A_lo : 0;
         w_lo_minus_hi = p.npass == 3 ? p.W_lo - p.W_hi : 0;
         conv_plane = A0;
-        st_pass = st_k0 = st_tap = st_ci = st_sub = 0;
+        st_pass = st_k0 = st_sub = 0;
+        // a K range that starts at kofs (a multiple of 64): conv K order k = (cb * 9 + tap) * 64 + c
+        st_tap0 = AMODE == MDPT_A_CONV3 ? (kofs >> 6) % 9 : 0;
+        st_ci0 = AMODE == MDPT_A_CONV3 ? ((kofs >> 6) / 9) * 64 : 0;
+        st_tap = st_tap0; st_ci = st_ci0;
     }
 
     // issue this wave's NLOAD LDS-DMA instructions for the next slab into the ring slot at `slab_base`, then advance
@@ -225,7 +230,7 @@ struct Stager {
             }
         }
         if (st_k0 == kspan) {  // next pass: rewind K and switch operand planes
-            st_k0 = 0; st_tap = 0; st_ci = 0; st_sub = 0;
+            st_k0 = 0; st_tap = st_tap0; st_ci = st_ci0; st_sub = 0;
             const ptrdiff_t da = (st_pass == 0 ? a_hi_minus_lo : 0) - kspan;
             const ptrdiff_t dw = (st_pass == 0 ? w_lo_minus_hi : -w_lo_minus_hi) - kspan;
             if (st_pass == 0) conv_plane = p.A_hi;
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
     int m0, n0;
     tile_coords((p.N + BN - 1) / BN, BM, BN, m0, n0);
     // K split (GemmParams::ksplit; the launcher sets grid.y for the 64x64 dense / generic instantiations only): range z of the K axis
-    constexpr bool KSPLIT = AMODE == MDPT_A_DENSE && EKIND == MDPT_E_GENERIC && BM == 64 && BN == 64;
+    constexpr bool KSPLIT = EKIND == MDPT_E_GENERIC && BM == 64 && BN == 64 && BK == 64;
     const int kz = KSPLIT ? (int)blockIdx.y : 0;
     const int kspan = KSPLIT && p.ksplit > 1 ? p.K / p.ksplit : p.K;
     St st;
@@ -631,6 +636,55 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const GemmPara
     }
     if (p.dbg_times) t_loop = memtime_now();
     __syncthreads();  // every wave is done reading the ring: reuse it as epilogue staging
+    if constexpr (KSPLIT) {
+        if (p.ksplit > 1 && p.ks_ctr) {
+            // In-kernel reduction of the K ranges (GemmParams::ks_ctr): raw accumulators -> partial plane of (range, tile), device-scope
+            // release, one ticket per workgroup; the last one to arrive (any of them) adds the planes in the order z = 0, 1, ... - its own
+            // included, read back like the others - so the sum does not depend on who that is. No workgroup waits for another.
+            static_assert(TM == 1 && TN == 1, "one accumulator block per wave");
+            const int ks = p.ksplit;
+            float* const plane0 = p.ks_part + (size_t)blockIdx.x * (BM * BN);
+            const size_t zstride = (size_t)gridDim.x * (BM * BN);
+            float* mine = plane0 + (size_t)kz * zstride;
+            // Partial planes and tickets are DEVICE-SCOPE atomics (sc1: coherent across the per-XCD L2s by themselves). A device-scope
+            // release / acquire FENCE would write back / invalidate the whole L2 of the XCD (measured: the split then costs more than it
+            // saves); here the stores only have to be complete (vmcnt(0), workgroup-scope fence) before the ticket is taken.
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __hip_atomic_store(mine + r * 256 + tid, acc[0][0][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            unsigned* const flag = (unsigned*)smem;
+            if (tid == 0) {
+                const unsigned ticket = __hip_atomic_fetch_add(p.ks_ctr + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ticket == (unsigned)(ks - 1)) __hip_atomic_store(p.ks_ctr + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+                *flag = ticket;
+            }
+            __syncthreads();
+            const unsigned ticket = *flag;
+            __syncthreads();  // (the strip epilogue reuses smem)
+            if (ticket != (unsigned)(ks - 1)) return;
+            // ranges in the order z = 0, 1, ...; four planes (64 loads per lane) in flight at a time
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] = __hip_atomic_load(plane0 + r * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int z0 = 1; z0 < ks; z0 += 4) {
+                float t[4][16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int z = z0 + u < ks ? z0 + u : 0;  // (past the end: re-read plane 0, not added)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t[u][r] = __hip_atomic_load(plane0 + (size_t)z * zstride + r * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (z0 + u < ks) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[0][0][r] += t[u][r];
+                    }
+            }
+            run_epilogue<WTN, TM, TN, EKIND>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+            return;
+        }
+    }
     if (KSPLIT && kz > 0) run_epilogue_partial<WTN, TM, TN>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN, p.ks_part + (size_t)(kz - 1) * p.M * p.ldc);
     else run_epilogue<WTN, TM, TN, EKIND>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
     if (p.dbg_times && tid == 0) {
@@ -1903,7 +1957,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
     if (!prof_name[0])
         snprintf(prof_name, sizeof(prof_name), "gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, BK, NST, MINW, AMODE, EKIND);
     MdptProfScope prof(prof_name, 2.0 * (p.M_alg > 0 ? p.M_alg : p.M) * p.N * p.K, stream);  // algorithmic flops (real rows, one pass whatever npass is)
-    const int ks = (AMODE == MDPT_A_DENSE && EKIND == MDPT_E_GENERIC && BM == 64 && BN == 64 && p.ksplit > 1) ? p.ksplit : 1;
+    const int ks = (EKIND == MDPT_E_GENERIC && BM == 64 && BN == 64 && BK == 64 && p.ksplit > 1) ? p.ksplit : 1;
     hipLaunchKernelGGL(kern, dim3(tiles, ks), dim3(64 * WM * WN), LDS, stream, p);
     return (int)hipGetLastError();
 }
@@ -1911,6 +1965,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 // the tile mdpt_launch_gemm runs for p (MDPT_TILE_AUTO resolved); -1: the 128x64 form of narrow outputs
 int resolve_tile(const GemmParams& p) {
     int tile = p.tile;
+    if (p.ksplit > 1 && p.ks_ctr) return MDPT_TILE_64x64;  // in-kernel reduction: the small tile only
     if (p.ksplit > 1) {
         // the K split exists on the 64x64 tile and in the DM_F32 form of the 8-phase kernel (>= 4 K tiles per range, in pairs; same sums, same bits):
         // the big tile when all ranges together make enough workgroups (the rule of the unsplit launches, counted over the ranges)
@@ -1986,7 +2041,26 @@ int MDPT_FN(mdpt_launch_gemm)(const GemmParams& p_in, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0) return 0;
     if (p.K <= 0 || (p.K & 63) || (p.N & 7)) return (int)hipErrorInvalidValue;
     if (p.npass != 1 && p.npass != 3) return (int)hipErrorInvalidValue;
-    if (p.ksplit > 1 && (p.ekind != MDPT_E_GENERIC || p.amode != MDPT_A_DENSE || !p.ks_part || !p.out_f32 || p.out_hi || p.up_src || p.gamma ||
+    if (p.ksplit <= 1 && p.ks_auto && p.ks_ctr && p.ks_part && p.ekind == MDPT_E_GENERIC && p.tile == MDPT_TILE_AUTO && resolve_tile(p) == MDPT_TILE_64x64) {
+        // latency mode: few workgroups, each walking a long K (the small decoder convs of a batch of one: 24 ... 96 workgroups x 36 ... 144 K
+        // tiles). Smallest divisor of the K-tile count that brings the launch to >= 256 workgroups while a range keeps >= 6 K tiles.
+        const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+        const int kt = p.K / 64;
+        constexpr int lim = 400, tgt = 256, minr = 6;  // (swept on the GPU: 192 / 192 ... 700 / 512 workgroups, 4 ... 9 K tiles per range - flat within 0.6 %)
+        if (tiles < lim && kt >= 2 * minr) {
+            int best = 1;
+            for (int d = 2; d <= 8 && kt / d >= minr; ++d)
+                if (kt % d == 0) { best = d; if (tiles * d >= tgt) break; }
+            if (best > 1 && tiles <= p.ks_ctr_n && (size_t)best * tiles * 64 * 64 * 4 <= p.ks_cap) p.ksplit = best;
+        }
+        if (p.ksplit <= 1) p.ks_ctr = nullptr;
+    }
+    if (p.ksplit > 1 && p.ks_ctr) {
+        const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+        if (p.ekind != MDPT_E_GENERIC || !p.ks_part || (p.K / 64) % p.ksplit || p.ldw != p.K || tiles > p.ks_ctr_n ||
+            (size_t)p.ksplit * tiles * 64 * 64 * 4 > p.ks_cap)
+            return (int)hipErrorInvalidValue;
+    } else if (p.ksplit > 1 && (p.ekind != MDPT_E_GENERIC || p.amode != MDPT_A_DENSE || !p.ks_part || !p.out_f32 || p.out_hi || p.up_src || p.gamma ||
                          p.act != MDPT_ACT_NONE || (p.K / 64) % p.ksplit || p.ldw != p.K))
         return (int)hipErrorInvalidValue;  // the split is for fp32 outputs whose consumer adds the partial sums
     switch (p.ekind) {

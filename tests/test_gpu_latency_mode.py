@@ -148,3 +148,27 @@ def test_block_hooks_and_stage_calls_in_latency_mode():
     for t, r in zip(taps, ref_taps):
         assert rel_err(t.float().cpu(), r) <= 1e-4
     del y_plain
+
+
+def test_in_kernel_k_split_reduction_is_deterministic_and_exact():
+    """Latency mode, decoder convs of a batch of one (few workgroups walking 36 ... 144 K tiles): K ranges reduced inside the kernel by the last
+    workgroup to arrive, always in the order z = 0, 1, ... (GemmParams::ks_ctr). Whichever workgroup that is, the bits are the same: 25 forwards
+    of ViT-S at batch 1 (54-K-tile convs on 6 ... 36 tiles: nine ranges each) are bitwise equal; fp32-class arithmetic stays at 1e-4 of the
+    oracle; the ticket counters re-arm themselves (every forward after the first would go wrong otherwise)."""
+    from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+    osd, cfg, w = synthetic_model("vits", 0)
+    x = seeded_input((1, 3, 504, 504), 33)
+    ref = _oracle().forward(w, cfg, x)
+    for dtype, tol in ((torch.float32, REL_TOL_X3), (torch.bfloat16, REL_TOL_BF16)):
+        _, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
+        model = model.to("cuda", dtype)
+        model.set_latency_mode(True)
+        xd = x.to("cuda", dtype)
+        y0 = model(xd)
+        assert rel_err(y0.float().cpu(), ref) <= tol
+        for _ in range(25):
+            assert torch.equal(model(xd), y0)
+        # another shape in between (other tile counts on the same counters), then back
+        x2 = seeded_input((1, 3, 252, 364), 34).to("cuda", dtype)
+        y2 = model(x2)
+        assert torch.equal(model(xd), y0) and torch.equal(model(x2), y2)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel table (in-library HIP-event profile, batch split off) of any bench.py model: python tools/probes/gpu_kernel_share_any.py swinl 384 16"""
+"""Per-kernel table (in-library HIP-event profile, batch split off) of any bench.py model: python tools/probes/gpu_kernel_share_any.py swinl 384 16 [latency]"""
 import ctypes, json, os, sys, torch
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
@@ -10,6 +10,8 @@ lib = native.load()
 model, _ = bench.make_model_and_weights(name)
 model = model.to("cuda", torch.bfloat16)
 x = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(1)).to("cuda", torch.bfloat16)
+if len(sys.argv) > 4 and sys.argv[4] == "latency":
+    model.set_latency_mode(True)
 native.check(lib, lib.mdpt_set_batch_split(model._get_engine().handle, 0))
 with torch.inference_mode():
     for _ in range(2): model(x)
