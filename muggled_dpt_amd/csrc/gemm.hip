@@ -30,6 +30,10 @@
 // The epilogue stages each wave's accumulators through its private LDS strip so that global stores are
 // row-major 16-byte (fp32) / 8-byte (bf16) vectors.
 //
+// K split (GemmParams::ksplit): K in equal ranges over grid.y. Three forms - (i) the consumer adds the partial planes (the LayerNorm behind a
+// residual GEMM: 64x64 tile, and the DM_F32 form of the 8-phase kernel for SwinV2's fc2), (ii) the kernel reduces itself, last workgroup to
+// arrive, fixed order (GemmParams::ks_ctr: 64x64 tile, any generic epilogue; latency mode), (iii) none. A split is fixed per shape.
+//
 // Workgroup -> tile mapping is XCD-aware: the dispatcher places block b on XCD b%8 (8 private L2s), so
 // each XCD is given a contiguous run of tiles (same A rows, all N tiles) to keep operand panels L2-resident.
 
