@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(CSRC, "libmdpt.so")
 OPERAND_SOURCES = ("gemm.hip", "conv3h.hip", "attention.hip", "elementwise.hip", "swin.hip", "head.hip")
 PLAIN_SOURCES = ("postprocess.hip", "mdpt_api.cpp", "mdpt_inventory.cpp", "mdpt_stages.cpp", "mdpt_debug.cpp", "mdpt_prof.cpp")
 SOURCES = OPERAND_SOURCES + PLAIN_SOURCES
-HEADERS = ("mdpt_kernels.h", "mdpt_launchers.inc", "op_types.h", "mdpt_prof.h", "mdpt_internal.h", "mdpt_swin_plan.inc", "mdpt_swin_stages.inc", "ln_row.h",
+HEADERS = ("gemm_common.inc", "gemm_epilogue_strip.inc", "gemm_lockstep.inc", "gemm8_epilogues.inc", "gemm8.inc", "mdpt_kernels.h", "mdpt_launchers.inc", "op_types.h", "mdpt_prof.h", "mdpt_internal.h", "mdpt_swin_plan.inc", "mdpt_swin_stages.inc", "ln_row.h",
            "up_bf16.h",
            os.path.join(REPO, "include", "mdpt.h"))
 # (source, extra flags, object stem)
