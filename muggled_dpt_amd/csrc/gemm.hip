@@ -34,9 +34,10 @@
 // The epilogue stages each wave's accumulators through its private LDS strip so that global stores are
 // row-major 16-byte (fp32) / 8-byte (bf16) vectors.
 //
-// K split (GemmParams::ksplit): K in equal ranges over grid.y. Three forms - (i) the consumer adds the partial planes (the LayerNorm behind a
-// residual GEMM: 64x64 tile, and the DM_F32 form of the 8-phase kernel for SwinV2's fc2), (ii) the kernel reduces itself, last workgroup to
-// arrive, fixed order (GemmParams::ks_ctr: 64x64 tile, any generic epilogue; latency mode), (iii) none. A split is fixed per shape.
+// K split (GemmParams::ksplit): K in equal ranges over grid.y, the CONSUMER adds the partial planes (the LayerNorm behind a residual GEMM):
+// the 64x64 tile (latency mode: proj / fc2 of a small batch) and the DM_F32 form of the 8-phase kernel (SwinV2's fc2, every batch size). A
+// split is fixed per shape. (A form that reduces inside the kernel - last workgroup to arrive, fixed order - was built and removed: between
+// XCDs it needs a device-scope release that costs what the split saves)
 //
 // Workgroup -> tile mapping is XCD-aware: the dispatcher places block b on XCD b%8 (8 private L2s), so
 // each XCD is given a contiguous run of tiles (same A rows, all N tiles) to keep operand panels L2-resident.
@@ -117,7 +118,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
     if (!prof_name[0])
         snprintf(prof_name, sizeof(prof_name), "gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, BK, NST, MINW, AMODE, EKIND);
     MdptProfScope prof(prof_name, 2.0 * (p.M_alg > 0 ? p.M_alg : p.M) * p.N * p.K, stream);  // algorithmic flops (real rows, one pass whatever npass is)
-    const int ks = (EKIND == MDPT_E_GENERIC && BM == 64 && BN == 64 && BK == 64 && p.ksplit > 1) ? p.ksplit : 1;
+    const int ks = (AMODE == MDPT_A_DENSE && EKIND == MDPT_E_GENERIC && BM == 64 && BN == 64 && p.ksplit > 1) ? p.ksplit : 1;
     hipLaunchKernelGGL(kern, dim3(tiles, ks), dim3(64 * WM * WN), LDS, stream, p);
     return (int)hipGetLastError();
 }
@@ -125,7 +126,6 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 // the tile mdpt_launch_gemm runs for p (MDPT_TILE_AUTO resolved); -1: the 128x64 form of narrow outputs
 int resolve_tile(const GemmParams& p) {
     int tile = p.tile;
-    if (p.ksplit > 1 && p.ks_ctr) return MDPT_TILE_64x64;  // in-kernel reduction: the small tile only
     if (p.ksplit > 1) {
         // the K split exists on the 64x64 tile and in the DM_F32 form of the 8-phase kernel (>= 4 K tiles per range, in pairs; same sums, same bits):
         // the big tile when all ranges together make enough workgroups (the rule of the unsplit launches, counted over the ranges)
@@ -201,26 +201,7 @@ int MDPT_FN(mdpt_launch_gemm)(const GemmParams& p_in, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0) return 0;
     if (p.K <= 0 || (p.K & 63) || (p.N & 7)) return (int)hipErrorInvalidValue;
     if (p.npass != 1 && p.npass != 3) return (int)hipErrorInvalidValue;
-    if (p.ksplit <= 1 && p.ks_auto && p.ks_ctr && p.ks_part && p.ekind == MDPT_E_GENERIC && p.tile == MDPT_TILE_AUTO && resolve_tile(p) == MDPT_TILE_64x64) {
-        // latency mode: few workgroups, each walking a long K (the small decoder convs of a batch of one: 24 ... 96 workgroups x 36 ... 144 K
-        // tiles). Smallest divisor of the K-tile count that brings the launch to >= 256 workgroups while a range keeps >= 6 K tiles.
-        const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
-        const int kt = p.K / 64;
-        constexpr int lim = 400, tgt = 256, minr = 6;  // (swept on the GPU: 192 / 192 ... 700 / 512 workgroups, 4 ... 9 K tiles per range - flat within 0.6 %)
-        if (tiles < lim && kt >= 2 * minr) {
-            int best = 1;
-            for (int d = 2; d <= 8 && kt / d >= minr; ++d)
-                if (kt % d == 0) { best = d; if (tiles * d >= tgt) break; }
-            if (best > 1 && tiles <= p.ks_ctr_n && (size_t)best * tiles * 64 * 64 * 4 <= p.ks_cap) p.ksplit = best;
-        }
-        if (p.ksplit <= 1) p.ks_ctr = nullptr;
-    }
-    if (p.ksplit > 1 && p.ks_ctr) {
-        const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
-        if (p.ekind != MDPT_E_GENERIC || !p.ks_part || (p.K / 64) % p.ksplit || p.ldw != p.K || tiles > p.ks_ctr_n ||
-            (size_t)p.ksplit * tiles * 64 * 64 * 4 > p.ks_cap)
-            return (int)hipErrorInvalidValue;
-    } else if (p.ksplit > 1 && (p.ekind != MDPT_E_GENERIC || p.amode != MDPT_A_DENSE || !p.ks_part || !p.out_f32 || p.out_hi || p.up_src || p.gamma ||
+    if (p.ksplit > 1 && (p.ekind != MDPT_E_GENERIC || p.amode != MDPT_A_DENSE || !p.ks_part || !p.out_f32 || p.out_hi || p.up_src || p.gamma ||
                          p.act != MDPT_ACT_NONE || (p.K / 64) % p.ksplit || p.ldw != p.K))
         return (int)hipErrorInvalidValue;  // the split is for fp32 outputs whose consumer adds the partial sums
     switch (p.ekind) {

@@ -71,7 +71,6 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     h->finalized = false;
     h->has_last = false;
     h->zero_page = nullptr;
-    h->ks_ctr = nullptr;
     h->dbg_block = h->dbg_step = -1;
     h->ks_min_ktiles = 16; h->ks_big_ktiles = 1 << 30;
     h->split_min = 8;
@@ -187,9 +186,8 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
         if (!s.ptr) return fail(MDPT_E_MISSING, "missing parameter \"%s\" (strict load)", s.name.c_str());
     hipStream_t st = (hipStream_t)stream;
     char* base = (char*)packed_dev;
-    CHK(hipMemsetAsync(base + h->zero_off, 0, 256 + KS_CTR_BYTES, st));
+    CHK(hipMemsetAsync(base + h->zero_off, 0, 256, st));
     h->zero_page = (op_t*)(base + h->zero_off);
-    h->ks_ctr = (unsigned*)(base + h->zero_off + 256);
     for (Mat& m : h->mats) {
         m.hi = (op_t*)(base + m.off_hi);
         m.lo = m.off_lo == SIZE_MAX ? nullptr : (op_t*)(base + m.off_lo);

@@ -107,8 +107,6 @@ struct Vec {  // packed fp32 vector (zero padded)
     float* ptr;
 };
 
-constexpr size_t KS_CTR_BYTES = 4096;
-
 struct Planes {
     op_t* hi = nullptr;
     op_t* lo = nullptr;
@@ -132,7 +130,6 @@ struct Plan {
     size_t tokr[2], cbuf, relpos_lut, relpos_tq, relpos_tk;  // BEiT: readout-projected tokens, per-image cls term, bias LUT
     size_t wrc_mean, wrc_tab;                                 // [B, wrc_maxk] operand-format column means, fp32 [B, wrc_maxn] per-image bias table
     size_t swi;                                               // ViT-G: fp32 [rows, 2*hidden] output of the doubled inner linear
-    size_t kspart_bytes;
     size_t kspart;                                            // small batches: 3 x fp32 [rows, F] partial sums of the K-split proj / fc2 (latency mode), else absent
     // SwinV2: stage-0 patch grid, per-stage residual streams (fp32, = the taps), shared GEMM fp32 output, token planes,
     // window operands, window maps (plain / shifted) and the position-bias LUT
@@ -171,7 +168,6 @@ struct mdpt_handle {
     size_t packed_total;
     size_t zero_off;
     op_t* zero_page;
-    unsigned* ks_ctr;  // KS_CTR_BYTES / 4 ticket counters behind the zero page (GemmParams::ks_ctr)
     bool finalized;
     // last forward (for export taps)
     Plan last_plan;

@@ -50,7 +50,7 @@ int build_inventory(mdpt_handle* h) {
     h->packed_total = 0;
     h->wrc_maxn = h->wrc_maxk = 0;
     h->zero_off = 0;
-    h->packed_total += 256 + KS_CTR_BYTES;  // zero page, then the ticket counters of the in-kernel K-split reduction (zeroed at finalize, self-resetting)
+    h->packed_total += 256;
 
     h->add_spec("patch_embed.proj.weight", {F, 3, P, P});
     h->add_spec("patch_embed.proj.bias", {F});
@@ -273,8 +273,7 @@ int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
     take_planes(bump, h->x3c(CLS_PROJ) || h->x3c(CLS_ATTN), rows * F, p.att);  // the 3-pass attention kernel always writes its lo plane
     take_planes(bump, h->x3c(CLS_FC2), rows * 4 * F, p.hbuf);
     p.swi = h->gh_hidden ? bump.take(rows * 2 * h->gh_hidden * 4) : SIZE_MAX;
-    p.kspart_bytes = std::max<size_t>(rows * F * 4 * 3, (size_t)8 << 20);  // also the scratch of the in-kernel K-split reduction (<= ~400 planes of 16 KB)
-    p.kspart = fc2_ksplit_fits((int)rows, F) ? bump.take(p.kspart_bytes) : SIZE_MAX;  // three partial-sum planes (a split in four); reserved whatever the latency switch says: it may flip later
+    p.kspart = fc2_ksplit_fits((int)rows, F) ? bump.take(rows * F * 4 * 3) : SIZE_MAX;  // three partial-sum planes (a split in four); reserved whatever the latency switch says: it may flip later
     p.wrc_mean = h->wrc_maxk ? bump.take((size_t)B * h->wrc_maxk * 2) : SIZE_MAX;
     p.wrc_tab = h->wrc_maxn ? bump.take((size_t)B * h->wrc_maxn * 4) : SIZE_MAX;
     const bool x3 = h->x3c(CLS_REASM);

@@ -69,13 +69,6 @@ struct GemmParams {
     //  * SwinV2 fc2 with K >= 3072 at EVERY batch size (stages of few, long-K tiles: 108 8-phase tiles at batch 16): fp32 output without
     //    residual (DM_F32 form of the 8-phase kernel from 140 workgroups on, the 64x64 tile below - same sums, same bits).
     int ksplit; float* ks_part;
-    // ... or, ks_ctr != nullptr, the kernel reduces itself (64x64 tile, dense / token / 3x3-conv rows, any generic epilogue): every range
-    // stores its raw accumulators to ks_part[(z * tiles + tile) * 4096 floats], takes a ticket from ks_ctr[tile], and the LAST workgroup to
-    // arrive sums the ks partials in the order z = 0, 1, ... (whichever workgroup that is: same bits) and runs the epilogue; it resets the
-    // ticket counter, so ks_ctr (>= ks_ctr_n zeroed counters) needs zeroing once. With ksplit == 0 and ks_auto set the launcher picks the
-    // split from the tile and K-tile counts (few workgroups walking long K: the small decoder convs of a batch of one). Latency mode only -
-    // the summation order differs from the unsplit launch.
-    unsigned* ks_ctr; int ks_ctr_n; size_t ks_cap; int ks_auto;
     unsigned long long* dbg_times;
 };
 

@@ -16,12 +16,6 @@ GemmParams base_params(const Ctx& c, const Mat& w, Planes a, int M, int lda) {
     g.amode = MDPT_A_DENSE; g.ekind = MDPT_E_GENERIC; g.tile = c.h->gemm_tile;
     g.throughput_mode = c.split ? 1 : 0;
     g.ldc = w.Np; g.ldr = w.Np;
-    // latency mode, small batch: launches of few workgroups with a long K may split K and reduce in the kernel (GemmParams::ks_auto; the
-    // launcher decides from the tile / K-tile counts). Scratch = the partial planes of the plan, tickets = the handle's counters.
-    if (c.h->latency_mode && !c.split && c.p.kspart != SIZE_MAX && c.h->ks_ctr && c.h->dbg_block < 0) {
-        g.ks_auto = 1; g.ks_part = c.at<float>(c.p.kspart); g.ks_cap = c.p.kspart_bytes;
-        g.ks_ctr = c.h->ks_ctr; g.ks_ctr_n = (int)(KS_CTR_BYTES / 4);
-    }
     return g;
 }
 
@@ -127,7 +121,6 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
         g.ksplit = ktiles >= h->ks_big_ktiles ? 4 : 2;
         if (ktiles % g.ksplit) { g.ksplit = 0; return false; }
         g.ks_part = c.at<float>(p.kspart);
-        g.ks_ctr = nullptr; g.ks_auto = 0;  // (the consumer folds the partial sums in: not the in-kernel reduction)
         return true;
     };
     for (int b = 0; b < h->nblocks; ++b) {

@@ -150,11 +150,11 @@ def test_block_hooks_and_stage_calls_in_latency_mode():
     del y_plain
 
 
-def test_in_kernel_k_split_reduction_is_deterministic_and_exact():
-    """Latency mode, decoder convs of a batch of one (few workgroups walking 36 ... 144 K tiles): K ranges reduced inside the kernel by the last
-    workgroup to arrive, always in the order z = 0, 1, ... (GemmParams::ks_ctr). Whichever workgroup that is, the bits are the same: 25 forwards
-    of ViT-S at batch 1 (54-K-tile convs on 6 ... 36 tiles: nine ranges each) are bitwise equal; fp32-class arithmetic stays at 1e-4 of the
-    oracle; the ticket counters re-arm themselves (every forward after the first would go wrong otherwise)."""
+def test_latency_mode_is_deterministic_run_to_run():
+    """The K split of latency mode is a fixed split whose partial sums are added by the NEXT kernel (the LayerNorm) in a fixed order: 25 forwards of
+    ViT-S at batch 1 are bitwise equal, also with another shape in between. (A form that reduced the K ranges of the small decoder convs INSIDE the
+    kernel - last workgroup to arrive - failed exactly this check in 1-10 % of the forwards until it carried device-scope fences that cost what it
+    saved, and was removed: DESIGN.md section 3, tools/probes/gpu_ksplit_determinism.py.)"""
     from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
     osd, cfg, w = synthetic_model("vits", 0)
     x = seeded_input((1, 3, 504, 504), 33)
@@ -168,7 +168,6 @@ def test_in_kernel_k_split_reduction_is_deterministic_and_exact():
         assert rel_err(y0.float().cpu(), ref) <= tol
         for _ in range(25):
             assert torch.equal(model(xd), y0)
-        # another shape in between (other tile counts on the same counters), then back
         x2 = seeded_input((1, 3, 252, 364), 34).to("cuda", dtype)
         y2 = model(x2)
         assert torch.equal(model(xd), y0) and torch.equal(model(x2), y2)
