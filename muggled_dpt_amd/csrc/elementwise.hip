@@ -65,6 +65,29 @@ __global__ __launch_bounds__(256) void layernorm_addp_kernel(float* __restrict__
     }, gamma, beta, out_hi, out_lo, out_f32, (size_t)row * F, F, lane);
 }
 
+// Behind a K-split GEMM whose ranges ALL stored bare partial sums (GemmParams::ks_all): v = ((part[0] + part[1]) + ...) [+ bias] -> fp32 rows and / or
+// operand planes (ReLU'd if relu_planes) - the plain generic epilogue, with the launch boundary as the fence between the ranges and their sum.
+__global__ __launch_bounds__(256) void ksplit_finish_kernel(const float* __restrict__ part, size_t part_stride, int nparts, const float* __restrict__ bias,
+                                                            float* out_f32, op_t* out_hi, op_t* out_lo, int relu_planes, int M, int N, int ldc) {
+    const size_t n4 = (size_t)M * (N / 4);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = idx / (N / 4);
+        const int n = (int)(idx - m * (N / 4)) * 4;
+        const size_t o = m * ldc + n;
+        f32x4 v = *(const f32x4*)(part + o);
+        for (int z = 1; z < nparts; ++z) v += *(const f32x4*)(part + z * part_stride + o);
+        if (bias) v += *(const f32x4*)(bias + n);
+        if (out_f32) *(f32x4*)(out_f32 + o) = v;
+        if (out_hi) {
+            if (relu_planes) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+            }
+            split_store4(out_hi, out_lo, o, v);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // patchify: NCHW fp32 -> rows [B*Np][Kp] with k = c*P*P + ky*P + kx (the conv weight's own flatten
 // order, patch_embed.py:56-62,92), zero padded to Kp. One thread = 4 consecutive k.
@@ -702,6 +725,15 @@ int MDPT_FN(mdpt_launch_layernorm_addp)(float* x, const float* part, size_t part
     else if (F <= 1536) LN_CASE(6);
     else LN_CASE(8);
 #undef LN_CASE
+    LAUNCH_RET();
+}
+
+int MDPT_FN(mdpt_launch_ksplit_finish)(const float* part, size_t part_stride, int nparts, const float* bias, float* out_f32, op_t* out_hi, op_t* out_lo,
+                                      int relu_planes, int M, int N, int ldc, hipStream_t stream) {
+    if (!part || nparts < 1 || (N & 3) || (ldc & 3) || M <= 0) return (int)hipErrorInvalidValue;
+    MdptProfScope prof("ksplit_finish_kernel", 0.0, stream);
+    const size_t n4 = (size_t)M * (N / 4);
+    hipLaunchKernelGGL(ksplit_finish_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, part, part_stride, nparts, bias, out_f32, out_hi, out_lo, relu_planes, M, N, ldc);
     LAUNCH_RET();
 }
 

@@ -118,7 +118,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
     if (!prof_name[0])
         snprintf(prof_name, sizeof(prof_name), "gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, BK, NST, MINW, AMODE, EKIND);
     MdptProfScope prof(prof_name, 2.0 * (p.M_alg > 0 ? p.M_alg : p.M) * p.N * p.K, stream);  // algorithmic flops (real rows, one pass whatever npass is)
-    const int ks = (AMODE == MDPT_A_DENSE && EKIND == MDPT_E_GENERIC && BM == 64 && BN == 64 && p.ksplit > 1) ? p.ksplit : 1;
+    const int ks = ((AMODE == MDPT_A_DENSE || AMODE == MDPT_A_CONV3) && EKIND == MDPT_E_GENERIC && BM == 64 && BN == 64 && BK == 64 && p.ksplit > 1) ? p.ksplit : 1;
     hipLaunchKernelGGL(kern, dim3(tiles, ks), dim3(64 * WM * WN), LDS, stream, p);
     return (int)hipGetLastError();
 }
@@ -126,6 +126,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 // the tile mdpt_launch_gemm runs for p (MDPT_TILE_AUTO resolved); -1: the 128x64 form of narrow outputs
 int resolve_tile(const GemmParams& p) {
     int tile = p.tile;
+    if (p.ksplit > 1 && p.ks_all) return MDPT_TILE_64x64;  // all-partial form (a finishing kernel follows): the small tile only
     if (p.ksplit > 1) {
         // the K split exists on the 64x64 tile and in the DM_F32 form of the 8-phase kernel (>= 4 K tiles per range, in pairs; same sums, same bits):
         // the big tile when all ranges together make enough workgroups (the rule of the unsplit launches, counted over the ranges)
@@ -201,7 +202,10 @@ int MDPT_FN(mdpt_launch_gemm)(const GemmParams& p_in, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0) return 0;
     if (p.K <= 0 || (p.K & 63) || (p.N & 7)) return (int)hipErrorInvalidValue;
     if (p.npass != 1 && p.npass != 3) return (int)hipErrorInvalidValue;
-    if (p.ksplit > 1 && (p.ekind != MDPT_E_GENERIC || p.amode != MDPT_A_DENSE || !p.ks_part || !p.out_f32 || p.out_hi || p.up_src || p.gamma ||
+    if (p.ksplit > 1 && p.ks_all) {
+        if (p.ekind != MDPT_E_GENERIC || (p.amode != MDPT_A_DENSE && p.amode != MDPT_A_CONV3) || !p.ks_part || (p.K / 64) % p.ksplit || p.ldw != p.K || p.acc_init)
+            return (int)hipErrorInvalidValue;
+    } else if (p.ksplit > 1 && (p.ekind != MDPT_E_GENERIC || p.amode != MDPT_A_DENSE || !p.ks_part || !p.out_f32 || p.out_hi || p.up_src || p.gamma ||
                          p.act != MDPT_ACT_NONE || (p.K / 64) % p.ksplit || p.ldw != p.K))
         return (int)hipErrorInvalidValue;  // the split is for fp32 outputs whose consumer adds the partial sums
     switch (p.ekind) {

@@ -69,6 +69,9 @@ struct GemmParams {
     //  * SwinV2 fc2 with K >= 3072 at EVERY batch size (stages of few, long-K tiles: 108 8-phase tiles at batch 16): fp32 output without
     //    residual (DM_F32 form of the 8-phase kernel from 140 workgroups on, the 64x64 tile below - same sums, same bits).
     int ksplit; float* ks_part;
+    int ks_all;  // 1: EVERY range (z = 0 too) stores its bare partial sums, plane z at ks_part + z * M * ldc, and nothing else is written: a finishing
+                 // kernel (mdpt_launch_ksplit_finish) adds the planes in the order z = 0, 1, ... and applies bias / ReLU / the output planes.
+                 // Dense rows or 3x3-conv rows, 64x64 tile. Latency mode: the long-K convs of the 18^2 / 36^2 levels at batch 1.
     unsigned long long* dbg_times;
 };
 

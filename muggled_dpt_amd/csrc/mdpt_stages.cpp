@@ -229,6 +229,35 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
 int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int sw, const float* bias, const float* skip, const float* up_src,
                     int Hu, int Wu, float* out_f32, Planes out, int relu_bf16);
 
+// Latency mode, small batch: a generic-epilogue conv / GEMM of FEW 64x64 workgroups that each walk a LONG K (the 3x3 convs of the 18^2 / 36^2 levels at
+// batch 1: 24 ... 96 workgroups x 72 ... 144 K tiles, 33 ... 65 us each) runs as K ranges over grid.y that all store bare partial planes, and a small
+// finishing kernel adds them in the order z = 0, 1, ... and applies bias / ReLU / the output planes - the launch boundary is the fence between the
+// ranges and their sum (an in-kernel reduction needs a device-scope release per workgroup that costs what the split saves: DESIGN.md section 3).
+// Plain epilogues only (no skip, no upsample-add, no activation other than the planes' ReLU). *done = false: the caller launches the GEMM itself.
+int try_ksplit_conv(const Ctx& c, const GemmParams& g, bool* done) {
+    *done = false;
+    const mdpt_handle* h = c.h;
+    const Plan& p = c.p;
+    if (!h->latency_mode || c.split || p.kspart == SIZE_MAX || h->gemm_tile != MDPT_TILE_AUTO || h->dbg_block >= 0) return 0;
+    if (g.ekind != MDPT_E_GENERIC || g.resid || g.up_src || g.gamma || g.acc_init || g.act != MDPT_ACT_NONE || g.bias_img_stride) return 0;
+    const long tiles = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+    const int kt = g.K / 64;
+    if (tiles >= 256 || kt < 64) return 0;
+    int ks = 1;
+    for (int d = 2; d <= 8 && kt / d >= 8; ++d)
+        if (kt % d == 0) { ks = d; if (tiles * d >= 256) break; }
+    const size_t plane = (size_t)g.M * g.ldc;
+    if (ks < 2 || plane * ks * 4 > (size_t)p.B * p.npad * h->F * 4 * 3) return 0;  // (the three partial planes of the plan: kspart)
+    float* part = c.at<float>(p.kspart);
+    GemmParams q = g;
+    q.ksplit = ks; q.ks_all = 1; q.ks_part = part;
+    q.bias = nullptr; q.out_f32 = nullptr; q.out_hi = nullptr; q.out_lo = nullptr;
+    CHK(OPLC(mdpt_launch_gemm, q, c.s));
+    CHK(OPLC(mdpt_launch_ksplit_finish, part, plane, ks, g.bias, g.out_f32, g.out_hi, g.out_lo, g.relu_bf16, g.M, g.N, g.ldc, c.s));
+    *done = true;
+    return 0;
+}
+
 // ---- stage: reassemble
 int run_reassemble(const Ctx& c) {
     const mdpt_handle* h = c.h;
@@ -284,7 +313,9 @@ int run_reassemble(const Ctx& c) {
             as_conv(g, gh, gw, hp, gh / 2, gw / 2, 2);
             g.bias = h->V(n + ".resample.1.bias");
             g.out_hi = d.hi; g.out_lo = d.lo; g.ldc = hp;
-            CHK(OPLC(mdpt_launch_gemm, g, c.s));
+            bool split_done = false;
+            CHK(try_ksplit_conv(c, g, &split_done));
+            if (!split_done) CHK(OPLC(mdpt_launch_gemm, g, c.s));
             src = d; sh = gh / 2; sw = gw / 2;
         }
         {   // 3x3 projection to the fusion width (no bias): fp32 copy (skip path) + ReLU'd bf16 (next conv input)
@@ -333,6 +364,9 @@ int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int 
     g.resid = skip; g.ldr = h->Cp;
     g.up_src = up_src; g.Hu = Hu; g.Wu = Wu;
     g.out_f32 = out_f32; g.out_hi = out.hi; g.out_lo = out.lo; g.relu_bf16 = relu_bf16; g.ldc = h->Cp;
+    bool split_done = false;
+    CHK(try_ksplit_conv(c, g, &split_done));
+    if (split_done) return 0;
     return OPLC(mdpt_launch_gemm, g, c.s);
 }
 

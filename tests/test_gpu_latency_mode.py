@@ -171,3 +171,28 @@ def test_latency_mode_is_deterministic_run_to_run():
         x2 = seeded_input((1, 3, 252, 364), 34).to("cuda", dtype)
         y2 = model(x2)
         assert torch.equal(model(xd), y0) and torch.equal(model(x2), y2)
+
+
+def test_long_k_decoder_convs_split_with_a_finishing_kernel():
+    """Latency mode, batch 1 of the 1024-wide models: the 3x3 convs of the 18^2 / 36^2 levels (144 K tiles on 24 ... 96 workgroups) run as K ranges that
+    store partial planes + ksplit_finish_kernel (mdpt_stages.cpp try_ksplit_conv). ViT-B-sized decoder here (hidden 768 at the coarse levels: 108 K
+    tiles) at 252x252: fp32-class result against the oracle at 1e-4, bf16 inside its tolerance, run-to-run bitwise equal."""
+    from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+    osd, cfg, w = synthetic_model("vitb", 0)
+    x = seeded_input((1, 3, 252, 252), 35)
+    ref = _oracle().forward(w, cfg, x)
+    for dtype, tol in ((torch.float32, REL_TOL_X3), (torch.bfloat16, REL_TOL_BF16)):
+        _, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
+        model = model.to("cuda", dtype)
+        xd = x.to("cuda", dtype)
+        y_default = model(xd)
+        model.set_latency_mode(True)
+        names = _profile_names(lambda: model(xd))
+        assert "ksplit_finish_kernel" in names, sorted(names)
+        y = model(xd)
+        assert rel_err(y.float().cpu(), ref) <= tol
+        for _ in range(10):
+            assert torch.equal(model(xd), y)
+        model.set_latency_mode(False)
+        assert torch.equal(model(xd), y_default)
+        assert "ksplit_finish_kernel" not in _profile_names(lambda: model(xd))
