@@ -47,5 +47,8 @@ python tools/probes/gpu_conv3h_small_batch.py 2>&1 | grep -v amdgpu.ids > "$OUT/
 python bench.py --size 1036 --steps 10 --warmup 2 > "$OUT/bench_1036.json" 2> "$OUT/bench_1036.err"
 python bench.py --model beitl --steps 10 --warmup 2 > "$OUT/bench_beitl.json" 2> "$OUT/bench_beitl.err"
 python bench.py --model swinl --steps 10 --warmup 2 > "$OUT/bench_swinl.json" 2> "$OUT/bench_swinl.err"
+# later in round 4: SwinV2-L / BEiT-L kernel stats, SwinV2-L kernel shares, determinism screens (default path and latency mode)
+bash tools/probes/gpu_r4_final_evidence.sh > "$OUT/final_evidence.log" 2>&1
+cp -r "$R/gpurun_out/final_evidence" "$OUT/" 2>/dev/null
 [ -x tools/probes/_bin/exp_throughput ] && tools/probes/_bin/exp_throughput > "$OUT/exp_throughput.txt" 2>&1
 ls -la "$OUT"
