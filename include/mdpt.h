@@ -208,8 +208,8 @@ int mdpt_set_batch_split(mdpt_handle* h, int32_t min_batch);
  * waves of a workgroup and merges the partial softmax states (ViT-S, batch 1: +13 %) - so results can differ in the last bit from
  * the batch-invariant form. Accuracy against the fp32 oracle is unchanged. Round 4: fc2 of a small batch (long K on the small GEMM tile:
  * one serial chain of 64 K tiles per workgroup at ViT-L) splits K into two fixed halves, twice the workgroups in flight; the second half's
- * partial sums are folded in by the LayerNorm that follows (no reduction launch). The split is fixed, so within latency mode these bits do
- * not depend on the batch either. */
+ * partial sums are folded in by the LayerNorm that follows (no reduction launch); the long-K 3x3 convs of the coarse decoder levels run as K
+ * ranges that store partial planes plus a small finishing kernel. The splits are fixed per shape: results are reproducible run to run. */
 int mdpt_set_latency_mode(mdpt_handle* h, int32_t on);
 
 /* PatchEmbed.prepare_image (v2_depthanything/patch_embed.py:103-145): uint8 [in_h,in_w,3] BGR on the device ->

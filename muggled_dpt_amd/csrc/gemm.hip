@@ -36,8 +36,10 @@
 //
 // K split (GemmParams::ksplit): K in equal ranges over grid.y, the CONSUMER adds the partial planes (the LayerNorm behind a residual GEMM):
 // the 64x64 tile (latency mode: proj / fc2 of a small batch) and the DM_F32 form of the 8-phase kernel (SwinV2's fc2, every batch size). A
-// split is fixed per shape. (A form that reduces inside the kernel - last workgroup to arrive, fixed order - was built and removed: between
-// XCDs it needs a device-scope release that costs what the split saves)
+// split is fixed per shape. With GemmParams::ks_all EVERY range stores a bare partial plane and a finishing kernel (elementwise.hip) adds them
+// and applies the epilogue - the long-K decoder convs of a batch of one (latency mode). (A form that reduces inside the kernel - last
+// workgroup to arrive, fixed order - was built and removed: between XCDs it needs a device-scope release that costs what the split saves,
+// DESIGN.md section 3.)
 //
 // Workgroup -> tile mapping is XCD-aware: the dispatcher places block b on XCD b%8 (8 private L2s), so
 // each XCD is given a contiguous run of tiles (same A rows, all N tiles) to keep operand panels L2-resident.
