@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDPT_ABI_VERSION 4
+#define MDPT_ABI_VERSION 5
 
 /* arithmetic modes (all accumulate in fp32; residual stream, LayerNorm and softmax statistics are fp32) */
 #define MDPT_PREC_BF16 0   /* bf16 MFMA operands - the reference's GPU default dtype (demo_helpers/misc.py:73-77) */
@@ -41,9 +41,9 @@ extern "C" {
                               +-65504) - what the reference's device policy hands the model when bf16 is not preferred
                               (demo_helpers/misc.py:61-77: float16)                                                  */
 #define MDPT_PREC_FP16X3 3 /* split-fp16 (hi+lo) operands, 3 passes                                                 */
-#define MDPT_PREC_MIXED 4  /* fp16 operands; the op classes listed in mdpt_default_mixed_passes() run 3 passes, the others 1:
+#define MDPT_PREC_MIXED 4  /* fp16 operands; the op classes listed in mdpt_default_mixed_passes() run 3 or 2 passes, the others 1:
                               the cheapest per-class assignment that keeps the depth map within 1e-3 of the fp32 reference
-                              (profiles/r04_precision_budget.md)                                                     */
+                              (profiles/r05_precision_budget.md)                                                     */
 
 /* op classes of the path (what mdpt_set_class_passes / MDPT_PREC_MIXED address) */
 #define MDPT_CLASS_PATCH 0  /* patch-embed projection                    patch_embed.py:92                         */
@@ -53,11 +53,13 @@ extern "C" {
 #define MDPT_CLASS_FC1 4    /* MLP first linear                          misc_helpers.py:111                       */
 #define MDPT_CLASS_FC2 5    /* MLP second linear                         misc_helpers.py:115                       */
 #define MDPT_CLASS_REASM 6  /* reassembly convs (incl. BEiT readout)     reassembly_model.py:139-149               */
-#define MDPT_CLASS_FUSION 7 /* RefineNet fusion convs (projection path) fusion_model.py:151-154,178-182           */
-#define MDPT_CLASS_HEAD 8   /* depth head 3x3 convs                      head_model.py:74-85                       */
+#define MDPT_CLASS_FUSION 7 /* RefineNet fusion: the 3x3 convs of the projection path's residual conv unit  fusion_model.py:151-154,210-220 */
+#define MDPT_CLASS_HEAD 8   /* depth head, first 3x3 conv (C -> C/2)     head_model.py:74-76                       */
 #define MDPT_CLASS_FUSION_IN 9 /* the fusion blocks' conv_reassembly units (RCU on the reassembly map before the prior is added),
                                   fusion_model.py:148-150: the least error-sensitive convs of the decoder                  */
-#define MDPT_NUM_CLASSES 10
+#define MDPT_CLASS_HEAD_TAIL 10   /* depth head behind its upsample: 3x3 conv C/2 -> 32 (the 32 -> 1 projection runs in fp32)  head_model.py:78-85 */
+#define MDPT_CLASS_FUSION_PROJ 11 /* the 1x1 output projection of every fusion block                                            fusion_model.py:178-182 */
+#define MDPT_NUM_CLASSES 12
 
 #define MDPT_FAMILY_DAV2 0
 #define MDPT_FAMILY_DAV1 1
@@ -110,7 +112,10 @@ const char* mdpt_last_error(void);
 int mdpt_create(const mdpt_config* cfg, mdpt_handle** out);
 void mdpt_destroy(mdpt_handle* h);
 
-/* Per-class MFMA pass count (1 or 3) on top of whatever mdpt_config.precision chose. Changes the packed-weight layout and the workspace
+/* Per-class MFMA pass count on top of whatever mdpt_config.precision chose: 1 = one rounded 16-bit plane per operand; 3 = hi + lo planes
+ * for both operands (A_lo W_hi + A_hi W_lo + A_hi W_hi, fp32-class); 2 = ACTIVATIONS split, weights one plane (A_lo W_hi + A_hi W_hi) -
+ * for the decoder classes whose error is the rounding of their activations, two thirds of the cost of 3 (not for MDPT_CLASS_ATTN, whose
+ * operands are both activations). Changes the packed-weight layout and the workspace
  * plan: call it after mdpt_create and BEFORE mdpt_packed_bytes / mdpt_finalize / mdpt_workspace_bytes (bound pointers are kept).
  * mdpt_get_class_passes reads the current assignment; mdpt_default_mixed_passes fills the table MDPT_PREC_MIXED uses. */
 int mdpt_set_class_passes(mdpt_handle* h, int32_t op_class, int32_t passes);

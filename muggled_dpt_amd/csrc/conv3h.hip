@@ -65,16 +65,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* base, s
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)(bytes < 0xFFFFFFF0ull ? bytes : 0xFFFFFFF0ull), 0x00020000);
 }
 
-// X3: bf16x3 split precision (x = hi + lo planes for the input and the weights, hi / lo output planes): the K loop runs three times,
+// NP = 3: split precision (x = hi + lo planes for the input and the weights, hi / lo output planes): the K loop runs three times,
 // A_lo * W_hi, A_hi * W_lo, A_hi * W_hi, into the same fp32 accumulators - the pass order of the implicit-GEMM kernels. A pass is just
 // ncb more channel blocks whose halo patches / weight tiles come from the other operand planes ("virtual" channel block vcb = pass * ncb + cb).
+// NP = 2: the activation-split form, A_lo * W_hi then A_hi * W_hi (input hi + lo planes, ONE weight plane; GemmParams::npass == 2).
 // BFOUT: bf16 output planes (false: fp32 map only - the bf16x3 head keeps the fp32 map for its bilinear upsample).
 // UPIN (128-channel bf16 form only): the conv's input is the x2 bilinear upsample (align_corners=True) of a bf16 map `up_in` that never
 // exists in memory - the 18x18 halo patch of a channel block is INTERPOLATED in LDS from the <= 11x11 source pixels it touches (arithmetic
 // of up_bf16.h, rounded to bf16 like the stand-alone upsample kernel): SpatialUpsampleLayer + head conv 1, fusion_model.py:182 ->
 // head_model.py:74-76 fused.
-template <int NQN, bool X3, bool SKIP, bool F32OUT, bool RELU, bool UP, bool BFOUT, bool UPIN = false>
+template <int NQN, int NP, bool SKIP, bool F32OUT, bool RELU, bool UP, bool BFOUT, bool UPIN = false>
 __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
+    static_assert(NP >= 1 && NP <= 3, "passes");
+    constexpr bool X3 = NP >= 2;   // the input has a lo plane (pass 0 reads it) and the output planes are split
+    constexpr bool W3 = NP == 3;   // the weights have a lo plane (pass 1 of 3)
     static_assert(!UPIN || (NQN == 1 && !X3 && BFOUT && !F32OUT), "the upsampled-input form exists for the bf16 head conv");
     constexpr int COUT = 128 * NQN;  // output channels: 256 (two 128-column halves per wave) or 128
     static_assert(NQN == 2 || (!SKIP && !UP && !RELU), "the 128-channel form has the bias-only epilogues");
@@ -111,19 +115,19 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const int Kw = p.Cin * 9;
     const __amdgpu_buffer_rsrc_t rs_w_hi = plane_rsrc(p.w, (size_t)COUT * Kw * 2);
-    const __amdgpu_buffer_rsrc_t rs_w_lo = plane_rsrc(X3 ? p.w_lo : p.w, (size_t)COUT * Kw * 2);
+    const __amdgpu_buffer_rsrc_t rs_w_lo = plane_rsrc(W3 ? p.w_lo : p.w, (size_t)COUT * Kw * 2);
     const __amdgpu_buffer_rsrc_t rs_in_hi = plane_rsrc(in_img, UPIN ? (size_t)p.Hs * p.Ws * p.Cin * 2 : (size_t)p.H * p.W * p.Cin * 2);
     const __amdgpu_buffer_rsrc_t rs_in_lo = plane_rsrc(X3 ? p.in_lo + (size_t)img * p.H * p.W * p.Cin : in_img, (size_t)p.H * p.W * p.Cin * 2);
-    const int nvcb = X3 ? 3 * ncb : ncb;  // channel blocks of all passes
+    const int nvcb = NP * ncb;  // channel blocks of all passes
     const int T = 9 * ncb;                // K tiles per pass; ncb is even (the launcher checks Cin % 128 == 0)
     // K tile kt of the whole loop -> (operand plane of the weights, byte offset of its K tile inside the plane)
-    auto w_pass = [&](int kt) -> int { return X3 ? (kt >= 2 * T ? 2 : (kt >= T ? 1 : 0)) : 0; };
+    auto w_pass = [&](int kt) -> int { return NP == 3 ? (kt >= 2 * T ? 2 : (kt >= T ? 1 : 0)) : (NP == 2 ? (kt >= T ? 1 : 0) : 0); };
     // B (weights): DMA instruction i of a wave stages rows r = 8 * (wave + 8 i) + lane / 8 = r0 + 64 i; 16-byte slot lane % 8 holds k-chunk
     // slot ^ ((r >> 1) & 7) (the key is the same for all four i). One lane constant; (K tile kt, i) enter through the scalar offset.
     const unsigned b_voff = (unsigned)((wave * 8 + (lane >> 3)) * Kw + (((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)) << 3)) * 2u;
     auto issue_b = [&](int half, int buf, int kt) {  // half-tile `half` (128 weight rows) of K tile kt -> B buffer `buf`
         const int ps = w_pass(kt);
-        const __amdgpu_buffer_rsrc_t rs = ps == 1 ? rs_w_lo : rs_w_hi;
+        const __amdgpu_buffer_rsrc_t rs = (W3 && ps == 1) ? rs_w_lo : rs_w_hi;
         const int soff = (kt - ps * T) * 128;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     };
     auto issue_b128 = [&](int buf4, int kt) {  // COUT = 128: the whole 16 KB K tile kt -> slot buf4 of a FOUR-deep ring (two instructions per wave)
         const int ps = w_pass(kt);
-        const __amdgpu_buffer_rsrc_t rs = ps == 1 ? rs_w_lo : rs_w_hi;
+        const __amdgpu_buffer_rsrc_t rs = (W3 && ps == 1) ? rs_w_lo : rs_w_hi;
         const int soff = (kt - ps * T) * 128;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
         const bool real = c < HALO_INSTR && !dummy;
         const unsigned voff = dummy ? OOB : h_voff[j];
         const bool lo_plane = X3 && vcbn < ncb;  // pass 0 reads the lo plane of the input
-        const int cbn = X3 ? (vcbn >= 2 * ncb ? vcbn - 2 * ncb : (vcbn >= ncb ? vcbn - ncb : vcbn)) : vcbn;
+        const int cbn = X3 ? (vcbn >= 2 * ncb ? vcbn - 2 * ncb : (vcbn >= ncb ? vcbn - ncb : vcbn)) : vcbn;  // (NP == 2: vcbn < 2 ncb)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(lo_plane ? rs_in_lo : rs_in_hi, (lds_ptr_t)(smem + (real ? OFF_H + hbn * HALO_BYTES + c * 1024 : OFF_SCR)), 16, voff,
                                                  cbn * 128, 0, 0);
     };
@@ -616,9 +620,9 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 #undef WAIT_LGKM
 #undef WAIT_VM_IMM
 
-template <int NQN, bool X3, bool SKIP, bool F32OUT, bool RELU, bool UP, bool BFOUT = true, bool UPIN = false>
+template <int NQN, int NP, bool SKIP, bool F32OUT, bool RELU, bool UP, bool BFOUT = true, bool UPIN = false>
 int launch_variant(const Conv3hParams& p, hipStream_t stream) {
-    auto kern = conv3h_kernel<NQN, X3, SKIP, F32OUT, RELU, UP, BFOUT, UPIN>;
+    auto kern = conv3h_kernel<NQN, NP, SKIP, F32OUT, RELU, UP, BFOUT, UPIN>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -628,7 +632,7 @@ int launch_variant(const Conv3hParams& p, hipStream_t stream) {
     const int tiles = p.B * ((p.H + 15) / 16) * ((p.W + 15) / 16);
     static char prof_name[80] = "";
     if (!prof_name[0])
-        snprintf(prof_name, sizeof(prof_name), "conv3h_kernel<%d, %s, %d, %d, %d, %d>", 128 * NQN, UPIN ? "bf16 up2-in" : (X3 ? "x3" : "bf16"), (int)SKIP, (int)F32OUT, (int)RELU,
+        snprintf(prof_name, sizeof(prof_name), "conv3h_kernel<%d, %s, %d, %d, %d, %d>", 128 * NQN, UPIN ? "bf16 up2-in" : (NP == 3 ? "x3" : (NP == 2 ? "x2a" : "bf16")), (int)SKIP, (int)F32OUT, (int)RELU,
                  (int)UP);
     MdptProfScope prof(prof_name, 2.0 * p.B * p.H * p.W * (128.0 * NQN) * 9.0 * p.Cin, stream);  // algorithmic flops (one pass, whatever the mode)
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS_BYTES, stream, p);
@@ -636,12 +640,13 @@ int launch_variant(const Conv3hParams& p, hipStream_t stream) {
 }
 
 // the epilogue combinations the decoder uses
-template <bool X3>
+template <int NP>
 int launch_mode(const Conv3hParams& p, hipStream_t stream) {
+    constexpr int X3 = NP;  // (pass count of every variant below)
     const bool skip = p.skip != nullptr, f32 = p.out_f32 != nullptr, up = p.up_src != nullptr;
     if (p.Cout == 128) {
-        if constexpr (!X3) {
-            if (p.up_in) return launch_variant<1, false, false, false, false, false, true, true>(p, stream);
+        if constexpr (NP == 1) {
+            if (p.up_in) return launch_variant<1, 1, false, false, false, false, true, true>(p, stream);
         }
         if (p.out_bf) return launch_variant<1, X3, false, false, false, false>(p, stream);
         return launch_variant<1, X3, false, true, false, false, false>(p, stream);
@@ -666,8 +671,8 @@ bool MDPT_FN(mdpt_conv3h_supported)(const Conv3hParams& p) {
     }
     if (p.Cout != 256 && p.Cout != 128) return false;
     if ((size_t)p.H * p.W * p.Cout * 4 >= 0xFFFFFFF0ull || (size_t)p.H * p.W * p.Cin * 2 >= 0xFFFFFFF0ull) return false;  // 32-bit byte offsets inside one image plane
-    const bool x3 = p.in_lo != nullptr;
-    if (x3 && !p.w_lo) return false;  // (a 3-pass conv whose consumer runs one pass writes no lo plane: out_bf_lo may be null)
+    const bool x3 = p.in_lo != nullptr;  // multi-pass: three passes with a lo plane of the weights, two (activation-split) without
+    // (a multi-pass conv whose consumer runs one pass writes no lo plane: out_bf_lo may be null)
     if (!x3 && (p.w_lo || (p.out_bf_lo && (!MDPT_OP_IS_F16 || p.up_in || !p.out_bf)))) return false;  // single pass + lo output: fp16 build only
     const bool skip = p.skip != nullptr, f32 = p.out_f32 != nullptr, relu = p.relu_bf != 0, up = p.up_src != nullptr;
     if (p.Cout == 128) return !skip && !relu && !up && ((p.out_bf != nullptr) != f32);  // bias -> bf16 planes, or bias -> fp32 map
@@ -685,5 +690,5 @@ bool MDPT_FN(mdpt_conv3h_supported)(const Conv3hParams& p) {
 
 int MDPT_FN(mdpt_launch_conv3h)(const Conv3hParams& p, hipStream_t stream) {
     if (!MDPT_FN(mdpt_conv3h_supported)(p)) return (int)hipErrorInvalidValue;
-    return p.in_lo ? launch_mode<true>(p, stream) : launch_mode<false>(p, stream);
+    return p.in_lo ? (p.w_lo ? launch_mode<3>(p, stream) : launch_mode<2>(p, stream)) : launch_mode<1>(p, stream);
 }

@@ -30,7 +30,9 @@
 // applied to the per-lane *source* address and again on the ds_read_b128 side (conflict-free for the
 // 32x32x16 fragment pattern: 16 rows x 16 B land on 16 distinct 16-B slots of the 256-B bank row).
 // bf16x3 mode (npass == 3) runs the K loop three times (A_lo*W_hi, A_hi*W_lo, A_hi*W_hi) into the same
-// fp32 accumulators: fp32-class accuracy from bf16 MFMAs.
+// fp32 accumulators: fp32-class accuracy from bf16 MFMAs. npass == 2 is the activation-split form (A_lo*W_hi, A_hi*W_hi): the
+// activations keep their hi + lo planes, the weights one rounded plane - for the decoder classes whose error is the rounding of their
+// activations (profiles/r05_precision_budget.md).
 // The epilogue stages each wave's accumulators through its private LDS strip so that global stores are
 // row-major 16-byte (fp32) / 8-byte (bf16) vectors.
 //
@@ -203,7 +205,7 @@ int MDPT_FN(mdpt_launch_gemm)(const GemmParams& p_in, hipStream_t stream) {
     if (p.ldw <= 0) p.ldw = p.K;  // packed panels: rows are K wide
     if (p.M <= 0 || p.N <= 0) return 0;
     if (p.K <= 0 || (p.K & 63) || (p.N & 7)) return (int)hipErrorInvalidValue;
-    if (p.npass != 1 && p.npass != 3) return (int)hipErrorInvalidValue;
+    if (p.npass < 1 || p.npass > 3 || (p.npass >= 2 && !p.A_lo) || (p.npass == 3 && !p.W_lo)) return (int)hipErrorInvalidValue;
     if (p.ksplit > 1 && p.ks_all) {
         if (p.ekind != MDPT_E_GENERIC || (p.amode != MDPT_A_DENSE && p.amode != MDPT_A_CONV3) || !p.ks_part || (p.K / 64) % p.ksplit || p.ldw != p.K || p.acc_init)
             return (int)hipErrorInvalidValue;

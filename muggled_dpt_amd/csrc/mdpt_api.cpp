@@ -83,15 +83,20 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
 
 void mdpt_destroy(mdpt_handle* h) { delete h; }
 
-// MDPT_PREC_MIXED: which classes pay for three passes. From the per-class error budget (profiles/r04_precision_budget.md; the CPU
+// MDPT_PREC_MIXED: which classes pay for more than one pass. From the per-class error budget (profiles/r05_precision_budget.md; the CPU
 // emulation tests/precision_budget/emulate_operand_rounding.py reproduces it): the decoder's convs feed the depth map directly - no
-// LayerNorm or residual stream between them and the output averages their operand rounding away - and carry ~85 % of the squared error.
+// LayerNorm or residual stream between them and the output averages their operand rounding away. Round 5 split the rounding of every
+// decoder layer group by OPERAND: in the fusion blocks' 3x3 convs and in both head convs it is the ACTIVATIONS' rounding that reaches the map
+// (weights rounded once cost 3e-5 rms each on top of 7.4e-5), so they run the two-pass activation-split form; the reassembly convs and the
+// 1x1 fusion projections need their weights split too (three passes).
 void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]) {
     for (int i = 0; i < NCLS; ++i) passes[i] = 1;
     passes[CLS_PATCH] = 3;  // 0.13 % of the FLOPs
     passes[CLS_REASM] = 3;
-    passes[CLS_FUSION] = 3;
-    passes[CLS_HEAD] = 3;
+    passes[CLS_FUSION] = 2;
+    passes[CLS_FUSION_PROJ] = 3;
+    passes[CLS_HEAD] = 2;
+    passes[CLS_HEAD_TAIL] = 2;
     passes[CLS_FUSION_IN] = 1;  // 2 % of the decoder's squared error for a quarter of its FLOPs (profiles/r04_precision_budget.md)
 }
 
@@ -105,7 +110,8 @@ static void rebuild_inventory_keeping_bindings(mdpt_handle* h);
 
 int mdpt_set_class_passes(mdpt_handle* h, int32_t op_class, int32_t passes) {
     if (!h || op_class < 0 || op_class >= NCLS) return fail(MDPT_E_INVALID, "bad op class %d", op_class);
-    if (passes != 1 && passes != 3) return fail(MDPT_E_INVALID, "passes must be 1 or 3, got %d", passes);
+    if (passes < 1 || passes > 3) return fail(MDPT_E_INVALID, "passes must be 1, 2 (activations split) or 3, got %d", passes);
+    if (passes == 2 && op_class == CLS_ATTN) return fail(MDPT_E_INVALID, "the attention kernel's operands are both activations: 1 or 3 passes");
     if (h->np[op_class] == passes) return 0;
     h->np[op_class] = passes;
     rebuild_inventory_keeping_bindings(h);  // the packed-weight inventory depends on the pass counts (lo planes)

@@ -31,7 +31,7 @@ int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_
     const size_t* planes = nullptr;
     size_t f32_off = SIZE_MAX, elems = 0;
     size_t bf16_only[2] = {SIZE_MAX, SIZE_MAX};  // a bf16 map without a lo plane
-    const bool bf16_head = !h->x3c(CLS_HEAD) && mdpt_head_tail_supported(h->C2p) && mdpt_head_tail_scale_ok(8 * p.gh, 8 * p.gw, p.H, p.W);
+    const bool bf16_head = head_tail_fused(h) && mdpt_head_tail_scale_ok(8 * p.gh, 8 * p.gw, p.H, p.W);
     const size_t px[4] = {(size_t)16 * p.Np, (size_t)4 * p.Np, (size_t)p.Np, (size_t)p.Np / 4};
     if (n == "im2col") { planes = p.im2col; elems = (size_t)p.B * p.Np * h->Kpatch; }
     else if (n == "pos") { f32_off = p.pos; elems = (size_t)p.Np * h->F; }
@@ -114,7 +114,7 @@ int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void*
                      int32_t path, int32_t tile, int32_t iters, void* stream, void* dbg_times, const void* in_lo_bf16, const void* w_lo_bf16,
                      void* out_lo_bf16) {
     if (Cout != 256 && Cout != 128) return fail(MDPT_E_INVALID, "Cout must be 256 or 128");
-    if ((in_lo_bf16 != nullptr) != (w_lo_bf16 != nullptr)) return fail(MDPT_E_INVALID, "bf16x3 needs the lo planes of input and weights");
+    if (w_lo_bf16 && !in_lo_bf16) return fail(MDPT_E_INVALID, "a lo plane of the weights needs one of the input (three passes); the input alone = two passes");
     if (!in_bf16 || !w_packed_bf16 || (!out_bf16 && !out_f32)) return fail(MDPT_E_INVALID, "null argument");
     static op_t* zero_page = nullptr;  // test hook only: allocated once, never freed
     if (!zero_page) {
@@ -164,7 +164,7 @@ int mdpt_debug_conv3(const void* in_bf16, const void* w_packed_bf16, const void*
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.A_hi = (const op_t*)in_bf16; g.W_hi = (const op_t*)w_packed_bf16; g.A_lo = (const op_t*)in_lo_bf16; g.W_lo = (const op_t*)w_lo_bf16;
-    g.M = B * H * W; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.npass = in_lo_bf16 ? 3 : 1;
+    g.M = B * H * W; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.npass = in_lo_bf16 ? (w_lo_bf16 ? 3 : 2) : 1;  // (input lo plane without a weight lo plane: the two-pass form)
     g.zero_page = zero_page;
     g.amode = MDPT_A_CONV3; g.ekind = MDPT_E_GENERIC; g.tile = tile;
     g.Hi = H; g.Wi = W; g.Cin = Cin; g.Ho = H; g.Wo = W; g.cstride = 1;

@@ -81,11 +81,12 @@ struct WeightSpec {
     }
 };
 
-// Op classes: every contraction of the path belongs to one; a class runs 1 MFMA pass (operands rounded to one 16-bit plane) or 3 (hi + lo
-// split planes). The uniform modes set all classes alike; MDPT_PREC_MIXED / mdpt_set_class_passes choose per class (include/mdpt.h).
+// Op classes: every contraction of the path belongs to one; a class runs 1 MFMA pass (operands rounded to one 16-bit plane), 3 (hi + lo
+// split planes of both operands) or 2 (activations split, weights one plane). The uniform modes set all classes alike; MDPT_PREC_MIXED /
+// mdpt_set_class_passes choose per class (include/mdpt.h).
 enum { CLS_PATCH = MDPT_CLASS_PATCH, CLS_QKV = MDPT_CLASS_QKV, CLS_ATTN = MDPT_CLASS_ATTN, CLS_PROJ = MDPT_CLASS_PROJ, CLS_FC1 = MDPT_CLASS_FC1,
        CLS_FC2 = MDPT_CLASS_FC2, CLS_REASM = MDPT_CLASS_REASM, CLS_FUSION = MDPT_CLASS_FUSION, CLS_HEAD = MDPT_CLASS_HEAD,
-       CLS_FUSION_IN = MDPT_CLASS_FUSION_IN, NCLS = MDPT_NUM_CLASSES };
+       CLS_FUSION_IN = MDPT_CLASS_FUSION_IN, CLS_HEAD_TAIL = MDPT_CLASS_HEAD_TAIL, CLS_FUSION_PROJ = MDPT_CLASS_FUSION_PROJ, NCLS = MDPT_NUM_CLASSES };
 
 int mat_class(const std::string& src);
 
@@ -152,8 +153,9 @@ struct mdpt_handle {
     int gh_hidden, gh_hidden_p;  // ViT-G SwiGLU hidden width (and padded to 64), 0 otherwise
     int sH[4], sL[4], swh, sww, spre[4];  // SwinV2: heads / layers per stage, target window, pretrained window sizes (0 = None)
     bool f16;       // operand format: fp16 (v_mfma_*_f16, *_f16 launchers) instead of bf16
-    int np[NCLS];   // MFMA passes per op class: 1 or 3
-    bool x3c(int cls) const { return np[cls] == 3; }
+    int np[NCLS];   // MFMA passes per op class: 1, 2 (activations split) or 3
+    bool x3c(int cls) const { return np[cls] == 3; }   // the class's WEIGHTS have a lo plane
+    bool alo(int cls) const { return np[cls] >= 2; }   // the class reads a lo plane of its ACTIVATIONS (its producers write one)
     // token-mean compensation of the weight rounding (fp16 operand modes, single-pass encoder Linears): see wrc_bias() below
     bool wrc_on;
     bool wrc(int cls) const { return wrc_on && f16 && np[cls] == 1 && (cls == CLS_QKV || cls == CLS_PROJ || cls == CLS_FC1 || cls == CLS_FC2); }
@@ -282,6 +284,7 @@ int run_reassemble(const Ctx& c);
 int rcu_conv(const Ctx& c, const std::string& wname, Planes in, int sh, int sw, const float* skip, const float* up_src, int Hu, int Wu,
              float* out_f32, Planes out, int relu_bf16);
 bool head_upsamples_bf16(const mdpt_handle* h);
+bool head_tail_fused(const mdpt_handle* h);
 int run_fusion(const Ctx& c, bool for_head = false);
 int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool from_flo0b = false);
 int swin_zero_pad_planes(const Ctx& c, int rows0);

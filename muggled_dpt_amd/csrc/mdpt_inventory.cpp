@@ -22,8 +22,11 @@ const char* const kSwinStageNames[4] = {"spatial_noscale", "spatial_downx2", "sp
 int mat_class(const std::string& src) {
     if (src.compare(0, 12, "patch_embed.") == 0) return CLS_PATCH;
     if (src.compare(0, 11, "reassemble.") == 0) return CLS_REASM;
-    if (src.compare(0, 7, "fusion.") == 0) return src.find(".conv_reassembly.") != std::string::npos ? CLS_FUSION_IN : CLS_FUSION;
-    if (src.compare(0, 5, "head.") == 0) return CLS_HEAD;
+    if (src.compare(0, 7, "fusion.") == 0) {
+        if (src.find(".conv_reassembly.") != std::string::npos) return CLS_FUSION_IN;
+        return src.find("proj_seq.2.") != std::string::npos ? CLS_FUSION_PROJ : CLS_FUSION;  // the 1x1 output projection | the RCU's 3x3 convs
+    }
+    if (src.compare(0, 5, "head.") == 0) return src.compare(0, 14, "head.proj_1ch.") == 0 ? CLS_HEAD_TAIL : CLS_HEAD;
     if (src.find(".attn.qkv.") != std::string::npos) return CLS_QKV;
     if (src.find(".attn.proj.") != std::string::npos) return CLS_PROJ;
     if (src.find(".mlp.layers.0.") != std::string::npos || src.find("inner_linear_doubled") != std::string::npos) return CLS_FC1;
@@ -200,7 +203,7 @@ int build_inventory_decoder(mdpt_handle* h) {
     h->add_mat("head.spatial_upsampler.0.weight", MDPT_PACK_CONV3, h->C2, C, h->C2p, 9 * h->Cp, 3);
     h->add_vec("head.spatial_upsampler.0.bias", h->C2, h->C2p);
     h->add_mat("head.proj_1ch.0.weight", MDPT_PACK_CONV3, 32, h->C2, 32, 9 * h->C2p, 3);
-    if (!h->x3c(CLS_HEAD) && mdpt_head_tail_supported(h->C2p))  // LDS image of the same weights for the fused head tail (head.hip)
+    if (head_tail_fused(h))  // LDS image of the same weights for the fused head tail (head.hip)
         h->add_mat("head.proj_1ch.0.weight@kc32", MDPT_PACK_CONV3_KC32, 32, h->C2, 32, 9 * h->C2p, 3);
     h->add_vec("head.proj_1ch.0.bias", 32, 32);
     h->add_vec("head.proj_1ch.2.weight", 32, 32);
@@ -218,9 +221,9 @@ void take_planes(Bump& bump, bool x3, size_t elems, size_t out[2]) {
 
 // reassembly outputs, fusion and head buffers; p.Np / p.gh / p.gw = the "noscale" level (1/Pv of the image)
 void plan_decoder(Bump& bump, const mdpt_handle* h, Plan& p, size_t min_scratch_floats) {
-    // lo planes exist where the CONSUMING class runs three passes: the reassembly maps of levels 0..2 and a1 feed the conv_reassembly
-    // units (CLS_FUSION_IN), level 3's map and everything else the projection path (CLS_FUSION)
-    const bool x3 = h->x3c(CLS_FUSION), x3i = h->x3c(CLS_FUSION_IN), x3h = h->x3c(CLS_HEAD);
+    // lo planes exist where the CONSUMING class reads one (2 or 3 passes): the reassembly maps of levels 0..2 and a1 feed the conv_reassembly
+    // units (CLS_FUSION_IN), level 3's map, x and b1 the projection path's 3x3 convs (CLS_FUSION), b2 the 1x1 projection (CLS_FUSION_PROJ)
+    const bool x3 = h->alo(CLS_FUSION), x3i = h->alo(CLS_FUSION_IN), x3p = h->alo(CLS_FUSION_PROJ), x3h = h->alo(CLS_HEAD);
     const int B = p.B;
     const size_t px[4] = {(size_t)16 * p.Np, (size_t)4 * p.Np, (size_t)p.Np, (size_t)p.Np / 4};
     for (int i = 0; i < 4; ++i) {
@@ -231,17 +234,17 @@ void plan_decoder(Bump& bump, const mdpt_handle* h, Plan& p, size_t min_scratch_
         p.x_f32[i] = bump.take(e * 4);
         take_planes(bump, x3, e, p.x_bf[i]);
         take_planes(bump, x3, e, p.b1[i]);
-        take_planes(bump, x3, e, p.b2[i]);
+        take_planes(bump, x3p, e, p.b2[i]);
         p.flo[i] = bump.take(e * 4);
     }
     const size_t fpx = (size_t)64 * p.Np;  // (8gh)*(8gw)
     take_planes(bump, x3h, (size_t)B * fpx * h->Cp, p.fused);
     // bf16 mode with the fused head tail (run_head): conv 1 writes a bf16 map and the full-resolution upsampled map never exists (ViT-L,
     // 504x504, batch 32: 2.1 GB + 0.7 GB of workspace that used to be reserved and never touched)
-    const bool bf16_head = !x3h && mdpt_head_tail_supported(h->C2p) && mdpt_head_tail_scale_ok(8 * p.gh, 8 * p.gw, p.H, p.W);
+    const bool bf16_head = head_tail_fused(h) && mdpt_head_tail_scale_ok(8 * p.gh, 8 * p.gw, p.H, p.W);
     p.h1 = bump.take((size_t)B * fpx * h->C2p * (bf16_head ? 2 : 4));
     if (bf16_head) p.h1u[0] = p.h1u[1] = SIZE_MAX;
-    else take_planes(bump, x3h, (size_t)B * p.H * p.W * h->C2p, p.h1u);
+    else take_planes(bump, h->alo(CLS_HEAD_TAIL), (size_t)B * p.H * p.W * h->C2p, p.h1u);
     p.scratch_floats = (size_t)B * fpx * h->Cp;
     if (min_scratch_floats > p.scratch_floats) p.scratch_floats = min_scratch_floats;
     p.scratch = bump.take(p.scratch_floats * 4);
@@ -263,20 +266,20 @@ int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
     p.Np = gh * gw; p.N = p.Np + 1; p.npad = rup(p.N, 8); p.npadv = rup(p.N, 64);
     Bump bump;
     const size_t rows = (size_t)B * p.npad;
-    take_planes(bump, h->x3c(CLS_PATCH), (size_t)B * p.Np * h->Kpatch, p.im2col);
+    take_planes(bump, h->alo(CLS_PATCH), (size_t)B * p.Np * h->Kpatch, p.im2col);
     p.pos = bump.take((size_t)p.Np * F * 4);
     p.resid = bump.take(rows * F * 4);
-    take_planes(bump, h->x3c(CLS_QKV) || h->x3c(CLS_FC1), rows * F, p.xn);
+    take_planes(bump, h->alo(CLS_QKV) || h->alo(CLS_FC1), rows * F, p.xn);
     take_planes(bump, h->x3c(CLS_ATTN), (size_t)B * h->heads * p.npad * 64, p.q);
     take_planes(bump, h->x3c(CLS_ATTN), (size_t)B * h->heads * p.npad * 64, p.k);
     take_planes(bump, h->x3c(CLS_ATTN), (size_t)B * h->heads * 64 * p.npadv, p.vt);
-    take_planes(bump, h->x3c(CLS_PROJ) || h->x3c(CLS_ATTN), rows * F, p.att);  // the 3-pass attention kernel always writes its lo plane
-    take_planes(bump, h->x3c(CLS_FC2), rows * 4 * F, p.hbuf);
+    take_planes(bump, h->alo(CLS_PROJ) || h->x3c(CLS_ATTN), rows * F, p.att);  // the 3-pass attention kernel always writes its lo plane
+    take_planes(bump, h->alo(CLS_FC2), rows * 4 * F, p.hbuf);
     p.swi = h->gh_hidden ? bump.take(rows * 2 * h->gh_hidden * 4) : SIZE_MAX;
     p.kspart = fc2_ksplit_fits((int)rows, F) ? bump.take(rows * F * 4 * 3) : SIZE_MAX;  // three partial-sum planes (a split in four); reserved whatever the latency switch says: it may flip later
     p.wrc_mean = h->wrc_maxk ? bump.take((size_t)B * h->wrc_maxk * 2) : SIZE_MAX;
     p.wrc_tab = h->wrc_maxn ? bump.take((size_t)B * h->wrc_maxn * 4) : SIZE_MAX;
-    const bool x3 = h->x3c(CLS_REASM);
+    const bool x3 = h->alo(CLS_REASM);
     for (int i = 0; i < 4; ++i) take_planes(bump, x3, rows * F, p.tap[i]);
     p.tapf32 = bump.take(rows * F * 4);
     const size_t px[4] = {(size_t)16 * p.Np, (size_t)4 * p.Np, (size_t)p.Np, (size_t)p.Np / 4};

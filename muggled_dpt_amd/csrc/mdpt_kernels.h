@@ -27,7 +27,8 @@ struct GemmParams {
     int ldw;                                  // row stride of W in elements (0 = K: the packed panels; > K: a K range of wider rows, see ksplit)
     int M_alg;                                // > 0: rows that are algorithmic work (token rows without the per-image pad rows): profiler FLOP accounting only
     int lda;
-    int npass;                                // 1 = bf16, 3 = bf16x3 (A_lo*W_hi + A_hi*W_lo + A_hi*W_hi)
+    int npass;                                // 1 = one rounded plane per operand, 3 = split planes (A_lo*W_hi + A_hi*W_lo + A_hi*W_hi),
+                                              // 2 = activations split, weights one plane (A_lo*W_hi + A_hi*W_hi)
     const op_t* zero_page;                  // >= 256 B of zeros (source for padded conv taps)
     int amode, ekind, tile;
     // A_TOKENS: logical row m = (b, p) reads source row b*tok_stride + 1 + p (skips the cls row)

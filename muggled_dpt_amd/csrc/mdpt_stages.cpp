@@ -9,7 +9,7 @@ GemmParams base_params(const Ctx& c, const Mat& w, Planes a, int M, int lda) {
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.npass = c.h->np[w.cls];  // the class of the weight matrix decides; an A buffer shared with a 3-pass class may carry an unused lo plane
-    g.A_hi = a.hi; g.A_lo = g.npass == 3 ? a.lo : nullptr;
+    g.A_hi = a.hi; g.A_lo = g.npass >= 2 ? a.lo : nullptr;
     g.W_hi = w.hi; g.W_lo = g.npass == 3 ? w.lo : nullptr;
     g.M = M; g.N = w.Np; g.K = w.Kp; g.lda = lda;
     g.zero_page = c.h->zero_page;
@@ -91,7 +91,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
     // a 3-pass projection behind a 1-pass attention kernel (which writes no lo plane): the plane is zero, i.e. the projection keeps
     // the rounding of its A operand and loses only that of its weights
     if (att.lo && !h->x3c(CLS_ATTN)) CHK(hipMemsetAsync(att.lo, 0, (size_t)rows * F * 2, c.s));
-    const Planes xn_qkv = {xn.hi, h->x3c(CLS_QKV) ? xn.lo : nullptr}, xn_fc1 = {xn.hi, h->x3c(CLS_FC1) ? xn.lo : nullptr};
+    const Planes xn_qkv = {xn.hi, h->alo(CLS_QKV) ? xn.lo : nullptr}, xn_fc1 = {xn.hi, h->alo(CLS_FC1) ? xn.lo : nullptr};
 #define DBG_STOP(step) if (h->dbg_block == b && h->dbg_step == (step)) return 0
     const size_t relpos_stride = is_beit(h) ? (size_t)h->heads * mdpt_beit_relpos_elen(p.gh, p.gw) : 0;
     const bool relpos_batched = is_beit(h) && h->nblocks <= 32;
@@ -351,8 +351,8 @@ int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int 
     if (eligible && h->gemm_tile == MDPT_TILE_AUTO) {
         Conv3hParams q;
         memset(&q, 0, sizeof(q));
-        const bool three = h->np[w.cls] == 3;  // the weight's class decides (an input buffer may carry a lo plane this conv does not use)
-        q.in = in.hi; q.in_lo = three ? in.lo : nullptr; q.w = w.hi; q.w_lo = three ? w.lo : nullptr; q.bias = bias; q.skip = skip; q.up_src = up_src; q.Hu = Hu; q.Wu = Wu;
+        const int np = h->np[w.cls];  // the weight's class decides (an input buffer may carry a lo plane this conv does not use)
+        q.in = in.hi; q.in_lo = np >= 2 ? in.lo : nullptr; q.w = w.hi; q.w_lo = np == 3 ? w.lo : nullptr; q.bias = bias; q.skip = skip; q.up_src = up_src; q.Hu = Hu; q.Wu = Wu;
         q.out_f32 = out_f32; q.out_bf = out.hi; q.out_bf_lo = out.lo; q.relu_bf = relu_bf16;
         q.B = c.p.B; q.H = sh; q.W = sw; q.Cin = Cin; q.Cout = 256;
         const long tiles256 = ((long)c.p.B * sh * sw + 255) / 256;
@@ -382,7 +382,10 @@ int rcu_conv(const Ctx& c, const std::string& wname, Planes in, int sh, int sw, 
 // bf16 mode, forward path (for_head): the last projection (level 0) writes its output as bf16 and the x2 upsample in front of the head is
 // left to run_head, which either interpolates it inside the head's first conv (halo-staged kernel, big launches) or runs the stand-alone
 // bf16 upsample - same arithmetic, same bits (up_bf16.h). The stage-level API and the bf16x3 mode keep the fp32 map + fp32 upsample.
-bool head_upsamples_bf16(const mdpt_handle* h) { return !h->x3c(CLS_HEAD) && (h->Cp & 7) == 0; }
+bool head_upsamples_bf16(const mdpt_handle* h) { return h->np[CLS_HEAD] == 1 && (h->Cp & 7) == 0; }
+// everything behind the head's first conv as ONE kernel (head.hip: upsample + 3x3 conv + ReLU + 1x1 + ReLU | sigmoid out of LDS tiles): the
+// single-pass form of the tail class; conv 1 then writes a 16-bit map whatever its own pass count
+bool head_tail_fused(const mdpt_handle* h) { return h->np[CLS_HEAD_TAIL] == 1 && mdpt_head_tail_supported(h->C2p); }
 
 int run_fusion(const Ctx& c, bool for_head) {
     const mdpt_handle* h = c.h;
@@ -426,57 +429,65 @@ int run_fusion(const Ctx& c, bool for_head) {
 }
 
 // ---- stage: head
-// from_flo0b: the head's input is still the bf16 output of the last fusion projection at half resolution (run_fusion(c, true))
+// from_flo0b: the head's input is still the 16-bit output of the last fusion projection at half resolution (run_fusion(c, true))
+// Two op classes: conv 1 (CLS_HEAD: 3x3, C -> C/2 at 8gh x 8gw) and the tail (CLS_HEAD_TAIL: x(P/8) upsample, 3x3 conv C/2 -> 32 + ReLU, 1x1 + ReLU |
+// sigmoid). A single-pass tail is ONE kernel fed by a 16-bit map conv 1 writes whatever its own pass count; a multi-pass tail runs
+// upsample kernel + implicit-GEMM conv with the fused 32 -> 1 epilogue on hi + lo planes of the upsampled fp32 map.
 int run_head(const Ctx& c, void* depth, int depth_dtype, bool from_flo0b) {
     const mdpt_handle* h = c.h;
     const Plan& p = c.p;
     const int fh = 8 * p.gh, fw = 8 * p.gw;
+    const int np1 = h->np[CLS_HEAD];
+    const Mat& w1 = h->M("head.spatial_upsampler.0.weight");
+    const float* b1 = h->V("head.spatial_upsampler.0.bias");
+    const bool tail_fused = head_tail_fused(h) && mdpt_head_tail_scale_ok(fh, fw, p.H, p.W);
+    const bool halo_ok = h->C2p == 128 && conv3h_shape_ok(h, fh, fw, h->Cp) && h->gemm_tile == MDPT_TILE_AUTO;
+    const bool big = ((long)p.B * fh * fw + 255) / 256 >= conv3h_min_tiles(c);
     bool fused_ready = !from_flo0b;
     auto materialise_fused = [&]() -> int {  // stand-alone bf16 upsample (small launches / shapes the fused kernel does not cover)
         if (!fused_ready) CHK(OPLC(mdpt_launch_upsample_bf16, c.at<op_t>(p.flo[0]), c.pl(p.fused).hi, p.B, fh / 2, fw / 2, fh, fw, h->Cp, c.s));
         fused_ready = true;
         return 0;
     };
-    if (!h->x3c(CLS_HEAD) && mdpt_head_tail_supported(h->C2p) && mdpt_head_tail_scale_ok(fh, fw, p.H, p.W)) {
-        // bf16 mode: the first conv writes bf16 (the buffer of the fp32 map is reused), everything behind it is ONE kernel that keeps the
-        // upsampled map in LDS tiles: upsample + 3x3 conv + ReLU + 1x1 conv + ReLU | sigmoid (head.hip). The bf16x3 mode keeps the
-        // unfused form below (its hi + lo operand planes do not fit the LDS tile next to the weights).
-        op_t* h1b = c.at<op_t>(p.h1);
-        bool done = false;
-        if (h->C2p == 128 && conv3h_shape_ok(h, fh, fw, h->Cp) && h->gemm_tile == MDPT_TILE_AUTO) {  // halo-staged form, 128 output channels
-            Conv3hParams q;
-            memset(&q, 0, sizeof(q));
-            q.w = h->M("head.spatial_upsampler.0.weight").hi; q.bias = h->V("head.spatial_upsampler.0.bias");
-            q.out_bf = h1b; q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
-            const long tiles256 = ((long)p.B * fh * fw + 255) / 256;
-            const bool big = tiles256 >= conv3h_min_tiles(c);
+    // ---- conv 1 -> a 16-bit map (fused tail; the buffer of the fp32 map is reused) or the fp32 map (the tail's own upsample reads it)
+    op_t* h1b = tail_fused ? c.at<op_t>(p.h1) : nullptr;
+    float* h1f = tail_fused ? nullptr : c.at<float>(p.h1);
+    bool done = false;
+    if (halo_ok && big) {  // halo-staged form, 128 output channels
+        Conv3hParams q;
+        memset(&q, 0, sizeof(q));
+        q.w = w1.hi; q.w_lo = np1 == 3 ? w1.lo : nullptr; q.bias = b1;
+        q.out_bf = h1b; q.out_f32 = h1f; q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
 #ifndef MDPT_NO_UPIN  // (A/B builds: -DMDPT_NO_UPIN keeps the stand-alone upsample in front of the halo-staged conv)
-            if (big && !fused_ready) {  // the x2 upsample folded into the conv's halo interpolation
-                q.up_in = c.at<op_t>(p.flo[0]); q.Hs = fh / 2; q.Ws = fw / 2;
-                if (OPLC(mdpt_conv3h_supported, q)) {
-                    CHK(OPLC(mdpt_launch_conv3h, q, c.s));
-                    done = true;
-                }
-                q.up_in = nullptr;
+        if (!fused_ready && np1 == 1 && h1b) {  // single pass: the x2 upsample folded into the conv's halo interpolation
+            q.up_in = c.at<op_t>(p.flo[0]); q.Hs = fh / 2; q.Ws = fw / 2;
+            if (OPLC(mdpt_conv3h_supported, q)) {
+                CHK(OPLC(mdpt_launch_conv3h, q, c.s));
+                done = true;
             }
-#endif
-            if (big && !done) {
-                CHK(materialise_fused());
-                q.in = c.pl(p.fused).hi;
-                if (OPLC(mdpt_conv3h_supported, q)) {
-                    CHK(OPLC(mdpt_launch_conv3h, q, c.s));
-                    done = true;
-                }
-            }
+            q.up_in = nullptr;
         }
+#endif
         if (!done) {
             CHK(materialise_fused());
-            GemmParams g = base_params(c, h->M("head.spatial_upsampler.0.weight"), c.pl(p.fused), p.B * fh * fw, h->Cp);
-            as_conv(g, fh, fw, h->Cp, fh, fw, 1);
-            g.bias = h->V("head.spatial_upsampler.0.bias");
-            g.out_hi = h1b; g.ldc = h->C2p;
-            CHK(OPLC(mdpt_launch_gemm, g, c.s));
+            Planes fu = c.pl(p.fused);
+            q.in = fu.hi; q.in_lo = np1 >= 2 ? fu.lo : nullptr;
+            if (OPLC(mdpt_conv3h_supported, q)) {
+                CHK(OPLC(mdpt_launch_conv3h, q, c.s));
+                done = true;
+            }
         }
+    }
+    if (!done) {
+        CHK(materialise_fused());
+        GemmParams g = base_params(c, w1, c.pl(p.fused), p.B * fh * fw, h->Cp);
+        as_conv(g, fh, fw, h->Cp, fh, fw, 1);
+        g.bias = b1;
+        g.out_hi = h1b; g.out_f32 = h1f; g.ldc = h->C2p;
+        CHK(OPLC(mdpt_launch_gemm, g, c.s));
+    }
+    // ---- tail
+    if (tail_fused) {
         HeadTailParams t;
         memset(&t, 0, sizeof(t));
         t.src = h1b; t.w_kc = h->M("head.proj_1ch.0.weight@kc32").hi;
@@ -486,32 +497,8 @@ int run_head(const Ctx& c, void* depth, int depth_dtype, bool from_flo0b) {
         CHK(OPLC(mdpt_launch_head_tail, t, h->C2p, c.s));
         return 0;
     }
-    CHK(materialise_fused());
-    {
-        bool done = false;
-        if (h->C2p == 128 && conv3h_shape_ok(h, fh, fw, h->Cp) && h->gemm_tile == MDPT_TILE_AUTO) {  // halo-staged form, fp32 map out
-            const Mat& w1 = h->M("head.spatial_upsampler.0.weight");
-            Planes fu = c.pl(p.fused);
-            Conv3hParams q;
-            memset(&q, 0, sizeof(q));
-            q.in = fu.hi; q.in_lo = fu.lo; q.w = w1.hi; q.w_lo = w1.lo; q.bias = h->V("head.spatial_upsampler.0.bias");
-            q.out_f32 = c.at<float>(p.h1); q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
-            const long tiles256 = ((long)p.B * fh * fw + 255) / 256;
-            if (tiles256 >= conv3h_min_tiles(c) && OPLC(mdpt_conv3h_supported, q)) {
-                CHK(OPLC(mdpt_launch_conv3h, q, c.s));
-                done = true;
-            }
-        }
-        if (!done) {
-            GemmParams g = base_params(c, h->M("head.spatial_upsampler.0.weight"), c.pl(p.fused), p.B * fh * fw, h->Cp);
-            as_conv(g, fh, fw, h->Cp, fh, fw, 1);
-            g.bias = h->V("head.spatial_upsampler.0.bias");
-            g.out_f32 = c.at<float>(p.h1); g.ldc = h->C2p;
-            CHK(OPLC(mdpt_launch_gemm, g, c.s));
-        }
-    }
     Planes hu = c.pl(p.h1u);
-    CHK(OPLC(mdpt_launch_upsample, c.at<float>(p.h1), hu.hi, hu.lo, nullptr, p.B, fh, fw, p.H, p.W, h->C2p, c.s));
+    CHK(OPLC(mdpt_launch_upsample, h1f, hu.hi, hu.lo, nullptr, p.B, fh, fw, p.H, p.W, h->C2p, c.s));
     {
         GemmParams g = base_params(c, h->M("head.proj_1ch.0.weight"), hu, p.B * p.H * p.W, h->C2p);
         as_conv(g, p.H, p.W, h->C2p, p.H, p.W, 1);

@@ -36,8 +36,11 @@ BEIT_RGB_STD = (0.5, 0.5, 0.5)
 
 
 # Bumped whenever a Parameter object is (re)assigned anywhere in a model tree of this module: DPTModel caches its parameter list and
-# re-collects it only when this moved (a module-tree walk per forward cost several hundred microseconds at batch 1).
+# re-collects it only when this moved (a module-tree walk per forward cost several hundred microseconds at batch 1). The counter is process-wide
+# on purpose (a node does not know its DPTModel), so it only ever says "walk your tree again": what decides whether an ENGINE is stale is the
+# identity of the Parameter objects found and their version counters - building a second model never re-packs the first one's weights.
 _TREE_GENERATION = [0]
+_RECHECK_EVERY = 256  # forwards between two unconditional re-walks of the tree (writes to module._parameters[...] that bypass the hooks below)
 
 
 class _ParamWatch:
@@ -56,6 +59,13 @@ class _ParamWatch:
         if name in self.__dict__.get("_parameters", ()):
             _TREE_GENERATION[0] += 1
         super().__delattr__(name)
+
+    def _apply(self, fn, *args, **kwargs):
+        # sub_module.to(...) / .half() / .to_empty() may replace Parameter objects by writing module._parameters[...] directly
+        # (torch.__future__.set_overwrite_module_params_on_conversion, swap_tensors): no __setattr__ is seen
+        out = super()._apply(fn, *args, **kwargs)
+        _TREE_GENERATION[0] += 1
+        return out
 
 
 class _Node(_ParamWatch, nn.Module):
@@ -552,18 +562,22 @@ class DPTModel(nn.Module):
         return out
 
     def _param_versions(self) -> tuple:
-        """Version counter of every parameter, in a fixed order. The parameter LIST is cached (the cache holds the Parameter objects, so
-        an id can not be reused behind its back) and re-collected only when a Parameter was assigned / registered / deleted somewhere in
-        a model tree (_TREE_GENERATION), the model was moved or cast (_apply) or a state dict was loaded. Inference tensors (a model
-        built / loaded / moved under torch.inference_mode()) have no version counter and can not be modified in place either: they
-        contribute a constant."""
+        """(identity of every Parameter object, version counter of every parameter), in a fixed order: what an engine's packed snapshot is
+        compared against. The parameter LIST is cached (the cache holds the Parameter objects, so an id can not be reused behind its back)
+        and re-collected when a Parameter was assigned / registered / deleted / converted somewhere in ANY model tree (_TREE_GENERATION -
+        process-wide, so it only triggers the walk; it is not part of the key), the model was moved or cast (_apply), a state dict was
+        loaded, and unconditionally every _RECHECK_EVERY calls (raw writes to module._parameters[...] by third-party utilities bypass
+        every hook: DPTModel.refresh_weights() is the documented way to pick those up at once). Inference tensors (a model built / loaded /
+        moved under torch.inference_mode()) have no version counter and can not be modified in place either: they contribute a constant."""
         cache = self.__dict__.get("_param_cache")
-        if cache is None or cache[0] != _TREE_GENERATION[0]:
+        calls = self.__dict__.get("_param_calls", 0) + 1
+        self.__dict__["_param_calls"] = calls
+        if cache is None or cache[0] != _TREE_GENERATION[0] or calls % _RECHECK_EVERY == 0:
             plist = list(self.parameters())
             versioned = [p for p in plist if not p.is_inference()]
-            cache = (_TREE_GENERATION[0], plist, versioned)
+            cache = (_TREE_GENERATION[0], plist, versioned, tuple([id(p) for p in plist]))
             self.__dict__["_param_cache"] = cache
-        return (cache[0], len(cache[1]), tuple([p._version for p in cache[2]]))
+        return (cache[3], tuple([p._version for p in cache[2]]))
 
     def _get_engine(self) -> _Engine:
         """The engine holds a PACKED SNAPSHOT of the weights (bf16 hi[/lo] panels, layer scales folded in). It is rebuilt when the model
@@ -592,10 +606,11 @@ class DPTModel(nn.Module):
         self._invalidate()
 
     def set_class_passes(self, passes: dict[str, int] | None) -> None:
-        """Per op class ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "head") MFMA pass count (1 or 3) on top of the
-        precision mode (mdpt_set_class_passes): the knob the error-budget study turns."""
+        """Per op class (native.OP_CLASSES: "patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "fusion_in", "fusion_proj", "head",
+        "head_tail") MFMA pass count on top of the precision mode (mdpt_set_class_passes): 1, 3 (both operands split) or 2 (activations split,
+        weights one plane; not for "attn"): the knob the error-budget study turns."""
         for k, v in (passes or {}).items():
-            if k not in native.OP_CLASSES or int(v) not in (1, 3):
+            if k not in native.OP_CLASSES or int(v) not in (1, 2, 3) or (k == "attn" and int(v) == 2):
                 raise ValueError(f"bad class pass entry {k!r}: {v!r}")
         self.__dict__["_class_passes"] = dict(passes) if passes else None
         self._invalidate()

@@ -29,7 +29,7 @@ HEADERS = ("gemm_common.inc", "gemm_epilogue_strip.inc", "gemm_lockstep.inc", "g
 UNITS = tuple((s, (), os.path.splitext(s)[0]) for s in SOURCES) + tuple((s, ("-DMDPT_OP_F16",), os.path.splitext(s)[0] + "_f16")
                                                                         for s in OPERAND_SOURCES)
 
-ABI_VERSION = 4  # MDPT_ABI_VERSION in include/mdpt.h
+ABI_VERSION = 5  # MDPT_ABI_VERSION in include/mdpt.h
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 PREC_BF16 = 0
 PREC_BF16X3 = 1
@@ -37,7 +37,7 @@ PREC_FP16 = 2
 PREC_FP16X3 = 3
 PREC_MIXED = 4
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3, "mixed": PREC_MIXED}
-OP_CLASSES = ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "head", "fusion_in")  # MDPT_CLASS_* of include/mdpt.h
+OP_CLASSES = ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "head", "fusion_in", "head_tail", "fusion_proj")  # MDPT_CLASS_* of include/mdpt.h
 FAMILY_DAV2 = 0
 FAMILY_DAV1 = 1
 FAMILY_BEIT = 2

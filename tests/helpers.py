@@ -28,12 +28,19 @@ def ref_lowprec_tol(*fixtures: str, dtype: str = "bf16", factor: float = 1.25) -
     return factor * max(REF_LOWPREC[f][dtype] for f in fixtures)
 
 
-REL_TOL_BF16 = ref_lowprec_tol("vits504", "vitl504")               # full-size Depth-Anything models: 1.25 x 2.15e-2 = 2.7e-2 (measured 0.9 ... 1.7e-2)
-REL_TOL_BF16_TOY = ref_lowprec_tol("tiny_full", "tiny_rect")       # 64-feature toy configurations: 1.25 x 2.75e-2 = 3.4e-2 (measured 0.6 ... 2.5e-2)
-REL_TOL_BF16_BEIT = ref_lowprec_tol("beit_large_384")              # 3.9e-2 (measured 1.9e-2)
-REL_TOL_BF16_BEIT_TOY = ref_lowprec_tol("beit_tiny_base", "beit_tiny_wide", "beit_tiny_tall")   # 4.8e-2 (measured up to 3.4e-2 on the 6x2 grid)
-REL_TOL_BF16_SWIN = ref_lowprec_tol("swin2_large_384")             # 2.7e-2 (measured 1.2e-2)
-REL_TOL_BF16_SWIN_TOY = ref_lowprec_tol("swin2_tiny_base", "swin2_tiny_wide", "swin2_tiny_tall")  # 3.1e-2 (measured 1.0 ... 1.5e-2)
+def _gated(ref_bound: float, measured_worst: float) -> float:
+    """The tolerance a bf16 test asserts: the reference-derived bound stays the UPPER sanity bound, and a regression gate at 1.3 x the worst error
+    this code has measured on that family (profiles/r04_parity_report.json, deterministic per source version) sits below it - an error that
+    doubles fails even though the reference's own bf16 path would still be further away."""
+    return min(ref_bound, 1.3 * measured_worst)
+
+
+REL_TOL_BF16 = _gated(ref_lowprec_tol("vits504", "vitl504"), 1.73e-2)               # full-size Depth-Anything models: min(1.25 x 2.15e-2 = 2.7e-2, 2.25e-2)
+REL_TOL_BF16_TOY = _gated(ref_lowprec_tol("tiny_full", "tiny_rect"), 2.19e-2)       # 64-feature toy configurations: min(3.4e-2, 2.85e-2)
+REL_TOL_BF16_BEIT = _gated(ref_lowprec_tol("beit_large_384"), 2.04e-2)              # min(3.9e-2, 2.65e-2)
+REL_TOL_BF16_BEIT_TOY = _gated(ref_lowprec_tol("beit_tiny_base", "beit_tiny_wide", "beit_tiny_tall"), 2.30e-2)   # min(4.8e-2, 3.0e-2)
+REL_TOL_BF16_SWIN = _gated(ref_lowprec_tol("swin2_large_384"), 1.34e-2)             # min(2.7e-2, 1.75e-2)
+REL_TOL_BF16_SWIN_TOY = _gated(ref_lowprec_tol("swin2_tiny_base", "swin2_tiny_wide", "swin2_tiny_tall"), 1.64e-2)  # min(3.1e-2, 2.13e-2)
 
 
 def emulated_tol(w, cfg, x, mode: str = "bf16", factor: float = 1.5, floor: float = 2e-3) -> float:

@@ -118,6 +118,13 @@ class _FProxy:
 
     def linear(self, x, weight, bias=None):
         m = self._mode(weight)
+        if m == "f16c":  # single fp16 pass + the token-mean compensation of the weight rounding (mdpt_stages.cpp wrc_bias)
+            xr, wr = rnd(x, "f16"), rnd(weight, "f16")
+            wlo = rnd(weight - wr, "f16")
+            n = xr.shape[-2]
+            step = 8 if n >= 1024 else (4 if n >= 256 else 1)
+            mean = rnd(xr[..., ::step, :].mean(dim=-2, keepdim=True), "f16")
+            return TF.linear(xr, wr, bias) + TF.linear(mean, wlo)
         return TF.linear(rnd_a(x, m), rnd_w(weight, m), bias)
 
     def conv2d(self, x, weight, bias=None, **kw):
@@ -163,7 +170,7 @@ def main():
     ap.add_argument("--model", default="vitl")
     ap.add_argument("--size", type=int, default=504)
     ap.add_argument("--images", type=int, nargs="+", default=[0])
-    ap.add_argument("--study", default="budget", choices=["budget", "modes", "policy"])
+    ap.add_argument("--study", default="budget", choices=["budget", "modes", "policy", "twopass"])
     ap.add_argument("--policy", default="", help="study=policy: comma list class=mode, others take --base")
     ap.add_argument("--base", default="f16")
     ap.add_argument("--out", default="")
@@ -208,6 +215,28 @@ def main():
                 p = uniform(base)
                 p[c] = base + "x3"
                 run(f"all {base}, {c} = {base}x3", p)
+    elif args.study == "twopass":
+        # the shipped mixed assignment (encoder: one fp16 pass + compensation; decoder at 3 passes except the fusion blocks' conv_reassembly
+        # units), then every decoder layer group alone at 2 passes: weights split (x2w = A_hi W_hi + A_hi W_lo) or activations split (x2a)
+        assert FINE, "--study twopass needs --fine"
+        def mixed():
+            p = uniform("f16x3")
+            for c in ("qkv", "proj", "fc1", "fc2"):
+                p[c] = "f16c"
+            p["attn"] = "f16"
+            p["fusion_rcu_a"] = "f16"
+            return p
+        run("mixed (shipped)", mixed())
+        dec = ("reasm_1x1", "reasm_resample", "reasm_fuse3x3", "fusion_rcu_b", "fusion_proj1x1", "head_conv1", "head_conv2")
+        for two in ("f16x2w", "f16x2a", "f16"):
+            for c in dec:
+                p = mixed()
+                p[c] = two
+                run(f"mixed, {c} = {two}", p)
+            p = mixed()
+            for c in dec:
+                p[c] = two
+            run(f"mixed, decoder = {two}", p)
     else:
         p = uniform(args.base)
         for item in filter(None, args.policy.split(",")):

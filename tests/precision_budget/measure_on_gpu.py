@@ -21,21 +21,26 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-CLASSES = ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "head", "fusion_in")
+CLASSES = ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "fusion_proj", "head", "head_tail", "fusion_in")
+# round 4's mixed assignment: the whole projection path of the decoder at three passes
+R04_MIXED = {"fusion": 3, "fusion_proj": 3, "head": 3, "head_tail": 3}
 
 
 def policies():
     # the token-mean compensation is on by default in "mixed" and off in single-pass "fp16"; the per-class rows ("fp16c + ...") switch it on, as the
-    # table the mixed assignment was derived from did
+    # table the mixed assignment was derived from did. Pass counts: 3 = both operands split, 2 = activations split (weights one plane)
     out = [("bf16", "bf16", {}), ("fp16 (shipped: no compensation)", "fp16", {}), ("fp16c = fp16 + compensation", "fp16", {"wrc": True}),
-           ("mixed (shipped)", "mixed", {}), ("mixed, no compensation", "mixed", {"wrc": False})]
+           ("mixed (shipped)", "mixed", {}), ("mixed, no compensation", "mixed", {"wrc": False}),
+           ("mixed of round 4 (decoder classes at 3 passes)", "mixed", dict(R04_MIXED))]
+    # round 5: one decoder class at a time moved from the shipped count to 3 / 2 / 1 passes
+    for c, n in (("head_tail", 3), ("head_tail", 1), ("head", 3), ("head", 1), ("fusion", 3), ("fusion", 1), ("fusion_proj", 2), ("fusion_proj", 1),
+                 ("reasm", 2), ("reasm", 1), ("patch", 1), ("fusion_in", 2), ("fusion_in", 3)):
+        out.append((f"mixed, {c} = {n}", "mixed", {c: n}))
+    out += [("mixed, reasm + fusion_proj = 2 (whole decoder activation-split)", "mixed", {"reasm": 2, "fusion_proj": 2, "fusion_in": 2}),
+            ("mixed + proj x3", "mixed", {"proj": 3}), ("mixed + proj x2", "mixed", {"proj": 2})]
     for c in CLASSES:
         out.append((f"fp16c + {c} x3", "fp16", {c: 3, "wrc": True}))
-    out += [("fp16c + decoder x3", "fp16", {"reasm": 3, "fusion": 3, "fusion_in": 3, "head": 3, "wrc": True}),
-            ("mixed + fusion_in x3 (whole decoder)", "mixed", {"fusion_in": 3}),
-            ("fp16c + patch, reasm, fusion x3", "fp16", {"patch": 3, "reasm": 3, "fusion": 3, "wrc": True}),
-            ("mixed + proj x3", "mixed", {"proj": 3}),
-            ("mixed + proj, qkv x3", "mixed", {"proj": 3, "qkv": 3}),
+    out += [("fp16c + decoder x3", "fp16", {"reasm": 3, "fusion": 3, "fusion_proj": 3, "fusion_in": 3, "head": 3, "head_tail": 3, "wrc": True}),
             ("fp16c + encoder GEMMs x3", "fp16", {"patch": 3, "qkv": 3, "proj": 3, "fc1": 3, "fc2": 3, "wrc": True}),
             ("fp16x3", "fp16x3", {}), ("bf16x3", "bf16x3", {})]
     return out
@@ -75,6 +80,7 @@ def measure(args):
         y = model(xd)
         torch.cuda.synchronize()
         errs = [float((y[i].cpu().double() - ref[k].double()).abs().max() / ref[k].double().abs().max()) for k, i in enumerate(idx)]
+        rms = [float((y[i].cpu().double() - ref[k].double()).pow(2).mean().sqrt() / ref[k].double().abs().max()) for k, i in enumerate(idx)]
         for _ in range(2):
             model(xd)
         torch.cuda.synchronize()
@@ -83,8 +89,8 @@ def measure(args):
             model(xd)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
-        rows.append({"label": label, "precision": prec, "passes": passes, "rel_err": errs, "ms_per_step": dt * 1e3, "maps_per_s": args.batch / dt})
-        print(f"{label:34s} " + " ".join(f"{e:.2e}" for e in errs) + f"   {dt * 1e3:7.2f} ms  {args.batch / dt:7.1f} maps/s", flush=True)
+        rows.append({"label": label, "precision": prec, "passes": passes, "rel_err": errs, "rms_err": rms, "ms_per_step": dt * 1e3, "maps_per_s": args.batch / dt})
+        print(f"{label:58s} " + " ".join(f"{e:.2e}" for e in errs) + f" | rms {sum(rms) / len(rms):.2e}   {dt * 1e3:7.2f} ms  {args.batch / dt:7.1f} maps/s", flush=True)
     rep = {"model": args.model, "size": args.size, "batch": args.batch, "images": idx, "steps": args.steps, "device": torch.cuda.get_device_name(0), "rows": rows}
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
@@ -95,12 +101,14 @@ def measure(args):
 def render(path):
     rep = json.load(open(path))
     print(f"# Precision budget, measured: {rep['model']} {rep['size']}x{rep['size']}, batch {rep['batch']}, one {rep['device']}\n")
-    print("rel = max|y - ref| / max|ref| against the CPU fp32 oracle, images " + ", ".join(map(str, rep["images"])) +
+    print("rel = max|y - ref| / max|ref| (mean rms: rms(y - ref) / max|ref|, mean over the images) against the CPU fp32 oracle, images " + ", ".join(map(str, rep["images"])) +
           f" of the seeded batch; fp32 tensors at the boundary; {rep['steps']} timed steps per row (`tests/precision_budget/measure_on_gpu.py`).\n")
-    print("| policy | " + " | ".join(f"image {i}" for i in rep["images"]) + " | worst | ms / step | maps/s |")
-    print("|---|" + "---|" * (len(rep["images"]) + 3))
+    print("| policy | " + " | ".join(f"image {i}" for i in rep["images"]) + " | worst | mean rms | ms / step | maps/s |")
+    print("|---|" + "---|" * (len(rep["images"]) + 4))
     for r in rep["rows"]:
-        print(f"| {r['label']} | " + " | ".join(f"{e:.2e}" for e in r["rel_err"]) + f" | **{max(r['rel_err']):.2e}** | {r['ms_per_step']:.2f} | {r['maps_per_s']:.0f} |")
+        rms = r.get("rms_err")
+        print(f"| {r['label']} | " + " | ".join(f"{e:.2e}" for e in r["rel_err"]) + f" | **{max(r['rel_err']):.2e}** | " +
+              (f"{sum(rms) / len(rms):.2e}" if rms else "-") + f" | {r['ms_per_step']:.2f} | {r['maps_per_s']:.0f} |")
 
 
 if __name__ == "__main__":

@@ -161,6 +161,47 @@ def test_conv3h_bf16x3_mode_fp32_class_accuracy_and_bitwise_vs_implicit_gemm(var
             assert torch.equal(r32.view(torch.int32), o32.view(torch.int32)), f"fp32 map differs, tile {tile}"
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_conv3h_two_pass_activation_split_form_and_bitwise_vs_implicit_gemm(variant):
+    """Two passes (GemmParams::npass == 2, mdpt_set_class_passes(..., 2)): the input keeps its hi + lo planes, the weights ONE rounded plane,
+    A_lo W_hi + A_hi W_hi. Against an fp64 conv of the fp32 input with the ROUNDED weights it is fp32-class (only the weights' rounding is left of
+    the single-pass error); bit for bit against the implicit-GEMM kernels (same pass order)."""
+    from muggled_dpt_amd import native
+    lib = native.load()
+    B, H, W, Cin = 2, 32, 48, 128
+    has_skip, want_f32, relu, has_up = variant
+    g = torch.Generator().manual_seed(177 + 3 * int(has_skip) + 5 * int(has_up))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = (torch.randn(256, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).to(torch.bfloat16).float()  # one plane: already representable
+    bias = torch.randn(256, generator=g)
+    skip = torch.randn(B, H, W, 256, generator=g) if has_skip else None
+    up = torch.randn(B, H // 2, W // 2, 256, generator=g) if has_up else None
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), padding=1)
+    if has_up:
+        ref = ref + F.interpolate(up.double().permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=True)
+    if has_skip:
+        ref = ref + skip.double().permute(0, 3, 1, 2)
+    ref = ref.permute(0, 2, 3, 1)
+    xh, xl = _split(x)
+    wh = _pack(w).to(torch.bfloat16)
+    args = dict(x_lo=xl.cuda(), wp_lo=None)
+    sd = skip.cuda() if has_skip else None
+    ud = up.cuda() if has_up else None
+    o32, (ohi, olo) = _run(lib, native, 1, 0, xh.cuda(), wh.cuda(), bias.cuda(), sd, ud, want_f32, relu, **args)
+    got = ohi.double().cpu() + olo.double().cpu()
+    want = ref.clamp_min(0) if relu else ref
+    err = float((got - want).abs().max()) / float(ref.abs().max())
+    assert err < 3e-5, f"hi + lo planes: rel err {err:.3e}"
+    if want_f32:
+        e32 = float((o32.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+        assert e32 < 1e-5, f"fp32 map: rel err {e32:.3e}"
+    for tile in (6, 1, 0):
+        r32, (rhi, rlo) = _run(lib, native, 0, tile, xh.cuda(), wh.cuda(), bias.cuda(), sd, ud, want_f32, relu, **args)
+        assert torch.equal(rhi.view(torch.int16), ohi.view(torch.int16)) and torch.equal(rlo.view(torch.int16), olo.view(torch.int16)), f"tile {tile}"
+        if want_f32:
+            assert torch.equal(r32.view(torch.int32), o32.view(torch.int32)), f"fp32 map differs, tile {tile}"
+
+
 def test_conv3h_128_channels_fp32_map_bf16x3_head_form():
     """The bf16x3 head keeps conv 1's output as an fp32 map (its bilinear upsample reads fp32): 128 channels, fp32 store only."""
     from muggled_dpt_amd import native

@@ -3,8 +3,9 @@ golden fixtures. Run with `pytest -m gpu` on an MI355X.
 
 Tolerances (rel = max|y - ref| / max|ref|, the north-star metric) live in tests/helpers.py:
   * float32 model  = MDPT_PREC_BF16X3 (split-bf16 MFMA, fp32 accumulate): REL_TOL_X3 = 1e-4  (north-star bar 1e-3; measured 2-3.5e-5)
-  * bfloat16 model = MDPT_PREC_BF16 (single-pass bf16 MFMA):             REL_TOL_BF16 = 2e-2 (measured ~1e-2; PyTorch's own
-    bf16 CPU path is 1.9e-2 off its fp32 path on the same weights, BASELINE.md §2 - a pure-bf16 pipeline cannot meet 1e-3)
+  * bfloat16 model = MDPT_PREC_BF16 (single-pass bf16 MFMA):             REL_TOL_BF16 = min(1.25 x the reference's own bf16 error on the
+    same fixture, 1.3 x the worst error this code measured) (PyTorch's own bf16 CPU path is 2.1e-2 off its fp32 path on the same weights,
+    tests/golden/reference_lowprec_errors.json - a pure-bf16 pipeline cannot meet 1e-3)
 Every error a test measures is written to gpurun_out/parity_report.json (tests/conftest.py).
 """
 import os
@@ -13,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import REL_TOL_BF16, REL_TOL_BF16_TOY, REL_TOL_X3, record_err, rel_err, seeded_input, synthetic_model
+from tests.helpers import REL_TOL_BF16, REL_TOL_BF16_TOY, REL_TOL_X3, record_err, ref_lowprec_tol, rel_err, seeded_input, synthetic_model
 
 pytestmark = pytest.mark.gpu
 
@@ -123,7 +124,8 @@ def test_vits_504_vs_golden_fixture_and_inference(golden_dir, dtype, tol):
     d = model.inference(img)
     assert tuple(d.shape) == (1, 504, 504) and d.dtype == dtype
     # preprocessing runs in the model dtype (reference patch_embed.py:133): allow the bf16 input rounding on top
-    ptol = tol if dtype == torch.float32 else 3e-2  # bf16 input pixels on top of the bf16 pipeline (ViT-S measured 0.8e-2 without them)
+    # (1.25 x the reference's own bf16 error on this configuration with model AND image cast to bfloat16, which is what its inference() does)
+    ptol = tol if dtype == torch.float32 else ref_lowprec_tol("vits504")
     assert record_err(float((d.float().cpu()[:, ::4, ::4].double() - torch.from_numpy(g["inference518_strided"]).double()).abs().max()) / float(g["inference518_stats"][1])) <= ptol
 
 
@@ -164,8 +166,9 @@ def test_vitl_batch32_every_checked_image_vs_oracle():
     idx = [0, 7, 13, 31]
     torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
     ref = _oracle().forward(w, cfg, x[idx])
-    # bf16: measured per image over the whole batch 0.9e-2 ... 1.9e-2 (median 1.4e-2, tools/probes/gpu_vitl_batch32_parity.py) -> 2.5e-2 here
-    for dtype, tol in ((torch.float32, REL_TOL_X3), (torch.bfloat16, 2.5e-2)):
+    # bf16: measured per image over the whole batch 0.9e-2 ... 1.9e-2 (median 1.4e-2, tools/probes/gpu_vitl_batch32_parity.py); the bound is the
+    # reference-derived one of tests/helpers.py (the reference's own bf16 path: 2.15e-2 on image 0)
+    for dtype, tol in ((torch.float32, REL_TOL_X3), (torch.bfloat16, REL_TOL_BF16)):
         model, _, _ = _model("vitl", dtype)
         xd = x.to("cuda", dtype)
         y = model(xd)

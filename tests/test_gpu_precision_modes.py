@@ -145,6 +145,21 @@ def test_class_passes_all_three_equals_the_x3_mode_bitwise_and_each_class_switch
         ec = rel_err(y_c.cpu(), ref)
         assert ec <= 1.5 * e1 + 1e-5, f"class {c} at 3 passes: {ec:.3e} vs {e1:.3e} single-pass"
         assert not torch.equal(y_c, y_1), f"class {c}: three passes left every bit unchanged"
+    # two passes (activations split, weights one plane): between the single-pass and the three-pass result of the same class, never the
+    # bits of either; every class at once stays fp16-class or better
+    for c in native.OP_CLASSES:
+        if c == "attn":
+            with pytest.raises(ValueError):
+                model.set_class_passes({c: 2})
+            continue
+        model.set_class_passes({c: 2})
+        y_c = model(x.cuda())
+        ec = rel_err(y_c.cpu(), ref)
+        assert ec <= 1.5 * e1 + 1e-5, f"class {c} at 2 passes: {ec:.3e} vs {e1:.3e} single-pass"
+        assert not torch.equal(y_c, y_1), f"class {c}: two passes left every bit unchanged"
+    model.set_class_passes({c: 2 for c in native.OP_CLASSES if c != "attn"})
+    e2 = rel_err(model(x.cuda()).cpu(), ref)
+    assert e2 <= e1 + 1e-5, f"every class at 2 passes: {e2:.3e} vs {e1:.3e} single-pass"
     model.set_class_passes(None)
     assert torch.equal(model(x.cuda()), y_1)
     with pytest.raises(ValueError):
@@ -170,7 +185,7 @@ def test_raw_c_abi_class_passes_keep_bound_weights_and_reject_bad_arguments():
     got = ctypes.c_int32()
     for i in range(len(native.OP_CLASSES)):
         native.check(lib, lib.mdpt_get_class_passes(h, i, ctypes.byref(got)))
-        assert got.value == want[i] and got.value in (1, 3)
+        assert got.value == want[i] and got.value in (1, 2, 3)
     n0, b0 = lib.mdpt_num_weights(h), ctypes.c_size_t()
     native.check(lib, lib.mdpt_packed_bytes(h, ctypes.byref(b0)))
     t = torch.zeros(64, device="cuda")
@@ -189,7 +204,16 @@ def test_raw_c_abi_class_passes_keep_bound_weights_and_reject_bad_arguments():
     native.check(lib, lib.mdpt_packed_bytes(h, ctypes.byref(b3)))
     assert b3.value > b2.value
     assert lib.mdpt_set_class_passes(h, 99, 3) == -1  # MDPT_E_INVALID
-    assert lib.mdpt_set_class_passes(h, 0, 2) != 0
+    assert lib.mdpt_set_class_passes(h, 0, 4) != 0 and lib.mdpt_set_class_passes(h, 0, 0) != 0
+    assert lib.mdpt_set_class_passes(h, native.OP_CLASSES.index("attn"), 2) != 0  # both attention operands are activations: 1 or 3
+    # two passes = activations split, ONE weight plane: a class moved from 3 to 2 gives its weights' lo planes back
+    native.check(lib, lib.mdpt_set_class_passes(h, native.OP_CLASSES.index("reasm"), 3))
+    b4 = ctypes.c_size_t()
+    native.check(lib, lib.mdpt_packed_bytes(h, ctypes.byref(b4)))
+    native.check(lib, lib.mdpt_set_class_passes(h, native.OP_CLASSES.index("reasm"), 2))
+    b5 = ctypes.c_size_t()
+    native.check(lib, lib.mdpt_packed_bytes(h, ctypes.byref(b5)))
+    assert b5.value < b4.value
     lib.mdpt_destroy(h)
 
 
