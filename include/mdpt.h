@@ -120,7 +120,9 @@ void mdpt_destroy(mdpt_handle* h);
  * mdpt_get_class_passes reads the current assignment; mdpt_default_mixed_passes fills the table MDPT_PREC_MIXED uses. */
 int mdpt_set_class_passes(mdpt_handle* h, int32_t op_class, int32_t passes);
 int mdpt_get_class_passes(const mdpt_handle* h, int32_t op_class, int32_t* passes);
-void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]);
+void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]);                      /* the Depth-Anything families */
+void mdpt_default_mixed_passes_for(int32_t family, int32_t passes[MDPT_NUM_CLASSES]);  /* per MDPT_FAMILY_*: the MiDaS v3.1 families keep three
+                                                                                          passes on the decoder's whole projection path */
 /* Token-mean compensation of the weight rounding (fp16 operand modes; on by default in MDPT_PREC_MIXED, available in MDPT_PREC_FP16): a
  * single-pass Linear of the encoder (QKV, proj, fc1, fc2) computes A fp16(W)^T; what the weight rounding loses is dominated by the part all
  * tokens of an image share, mean_t(A) (W - fp16(W))^T, which two small kernels turn into a per-image bias table the GEMM epilogue adds

@@ -59,7 +59,7 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     h->f16 = cfg->precision == MDPT_PREC_FP16 || cfg->precision == MDPT_PREC_FP16X3 || cfg->precision == MDPT_PREC_MIXED;
     {
         int32_t mixed[NCLS];
-        mdpt_default_mixed_passes(mixed);
+        mdpt_default_mixed_passes_for(cfg->family, mixed);
         const bool all3 = cfg->precision == MDPT_PREC_BF16X3 || cfg->precision == MDPT_PREC_FP16X3;
         for (int i = 0; i < NCLS; ++i) h->np[i] = cfg->precision == MDPT_PREC_MIXED ? mixed[i] : (all3 ? 3 : 1);
     }
@@ -89,16 +89,23 @@ void mdpt_destroy(mdpt_handle* h) { delete h; }
 // decoder layer group by OPERAND: in the fusion blocks' 3x3 convs and in both head convs it is the ACTIVATIONS' rounding that reaches the map
 // (weights rounded once cost 3e-5 rms each on top of 7.4e-5), so they run the two-pass activation-split form; the reassembly convs and the
 // 1x1 fusion projections need their weights split too (three passes).
-void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]) {
+// The two-pass rows hold for the Depth-Anything families (ViT-L 504^2: worst checked image 9.1e-4, rms 9.1e-5 against 7.2e-5 with three passes).
+// The MiDaS v3.1 families keep three passes for the whole projection path: on their reference fixtures the activation-split form reads
+// 1.07e-3 (BEiT-L) / 1.08e-3 with twice the rms (SwinV2-L) against 8.4e-4 / 6.8e-4 (tools/probes/gpu_family_class_budget.py,
+// profiles/r05_family_class_budget.txt) - their decoders' weight rounding is not the smaller half of the budget.
+void mdpt_default_mixed_passes_for(int32_t family, int32_t passes[MDPT_NUM_CLASSES]) {
+    const bool midas = family == MDPT_FAMILY_BEIT || family == MDPT_FAMILY_SWINV2;
     for (int i = 0; i < NCLS; ++i) passes[i] = 1;
     passes[CLS_PATCH] = 3;  // 0.13 % of the FLOPs
     passes[CLS_REASM] = 3;
-    passes[CLS_FUSION] = 2;
+    passes[CLS_FUSION] = midas ? 3 : 2;
     passes[CLS_FUSION_PROJ] = 3;
-    passes[CLS_HEAD] = 2;
-    passes[CLS_HEAD_TAIL] = 2;
+    passes[CLS_HEAD] = midas ? 3 : 2;
+    passes[CLS_HEAD_TAIL] = midas ? 3 : 2;
     passes[CLS_FUSION_IN] = 1;  // 2 % of the decoder's squared error for a quarter of its FLOPs (profiles/r04_precision_budget.md)
 }
+
+void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]) { mdpt_default_mixed_passes_for(MDPT_FAMILY_DAV2, passes); }
 
 int mdpt_get_class_passes(const mdpt_handle* h, int32_t op_class, int32_t* passes) {
     if (!h || !passes || op_class < 0 || op_class >= NCLS) return fail(MDPT_E_INVALID, "bad argument");

@@ -242,7 +242,7 @@ void plan_decoder(Bump& bump, const mdpt_handle* h, Plan& p, size_t min_scratch_
     // bf16 mode with the fused head tail (run_head): conv 1 writes a bf16 map and the full-resolution upsampled map never exists (ViT-L,
     // 504x504, batch 32: 2.1 GB + 0.7 GB of workspace that used to be reserved and never touched)
     const bool bf16_head = head_tail_fused(h) && mdpt_head_tail_scale_ok(8 * p.gh, 8 * p.gw, p.H, p.W);
-    p.h1 = bump.take((size_t)B * fpx * h->C2p * (bf16_head ? 2 : 4));
+    p.h1 = bump.take((size_t)B * fpx * h->C2p * (bf16_head && h->np[CLS_HEAD_TAIL] == 1 ? 2 : 4));  // one 16-bit plane | hi + lo planes | fp32 map
     if (bf16_head) p.h1u[0] = p.h1u[1] = SIZE_MAX;
     else take_planes(bump, h->alo(CLS_HEAD_TAIL), (size_t)B * p.H * p.W * h->C2p, p.h1u);
     p.scratch_floats = (size_t)B * fpx * h->Cp;

@@ -142,6 +142,7 @@ struct BeitRelposBatch {
 // ------------------------------------------------------------------------------------------------
 struct HeadTailParams {
     const op_t* src;    // [B, Hi, Wi, cin] bf16 NHWC: output of the head's first conv (pad channels zero)
+    const op_t* src_lo; // lo plane of the same map (src = hi): non-null selects the two-pass form (activations split, weights one plane)
     const op_t* w_kc;   // MDPT_PACK_CONV3_KC32 image of the 3x3 conv weights
     const float* bias;    // [32]
     const float* head_w;  // [32] 1x1 conv weights

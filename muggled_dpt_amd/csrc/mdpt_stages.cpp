@@ -384,8 +384,9 @@ int rcu_conv(const Ctx& c, const std::string& wname, Planes in, int sh, int sw, 
 // bf16 upsample - same arithmetic, same bits (up_bf16.h). The stage-level API and the bf16x3 mode keep the fp32 map + fp32 upsample.
 bool head_upsamples_bf16(const mdpt_handle* h) { return h->np[CLS_HEAD] == 1 && (h->Cp & 7) == 0; }
 // everything behind the head's first conv as ONE kernel (head.hip: upsample + 3x3 conv + ReLU + 1x1 + ReLU | sigmoid out of LDS tiles): the
-// single-pass form of the tail class; conv 1 then writes a 16-bit map whatever its own pass count
-bool head_tail_fused(const mdpt_handle* h) { return h->np[CLS_HEAD_TAIL] == 1 && mdpt_head_tail_supported(h->C2p); }
+// single-pass form of the tail class (conv 1 then writes a 16-bit map whatever its own pass count) and its two-pass form (activations
+// split: conv 1 writes hi + lo 16-bit planes, head_tail2_kernel). Three passes run the unfused kernels.
+bool head_tail_fused(const mdpt_handle* h) { return h->np[CLS_HEAD_TAIL] <= 2 && mdpt_head_tail_supported(h->C2p); }
 
 int run_fusion(const Ctx& c, bool for_head) {
     const mdpt_handle* h = c.h;
@@ -449,15 +450,17 @@ int run_head(const Ctx& c, void* depth, int depth_dtype, bool from_flo0b) {
         fused_ready = true;
         return 0;
     };
-    // ---- conv 1 -> a 16-bit map (fused tail; the buffer of the fp32 map is reused) or the fp32 map (the tail's own upsample reads it)
+    // ---- conv 1 -> a 16-bit map (fused tail; the buffer of the fp32 map is reused; hi + lo planes for the two-pass tail) or the fp32 map
+    //      (the unfused tail's own upsample reads it)
     op_t* h1b = tail_fused ? c.at<op_t>(p.h1) : nullptr;
+    op_t* h1b_lo = tail_fused && h->np[CLS_HEAD_TAIL] == 2 ? h1b + (size_t)p.B * fh * fw * h->C2p : nullptr;
     float* h1f = tail_fused ? nullptr : c.at<float>(p.h1);
     bool done = false;
     if (halo_ok && big) {  // halo-staged form, 128 output channels
         Conv3hParams q;
         memset(&q, 0, sizeof(q));
         q.w = w1.hi; q.w_lo = np1 == 3 ? w1.lo : nullptr; q.bias = b1;
-        q.out_bf = h1b; q.out_f32 = h1f; q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
+        q.out_bf = h1b; q.out_bf_lo = h1b_lo; q.out_f32 = h1f; q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
 #ifndef MDPT_NO_UPIN  // (A/B builds: -DMDPT_NO_UPIN keeps the stand-alone upsample in front of the halo-staged conv)
         if (!fused_ready && np1 == 1 && h1b) {  // single pass: the x2 upsample folded into the conv's halo interpolation
             q.up_in = c.at<op_t>(p.flo[0]); q.Hs = fh / 2; q.Ws = fw / 2;
@@ -483,14 +486,14 @@ int run_head(const Ctx& c, void* depth, int depth_dtype, bool from_flo0b) {
         GemmParams g = base_params(c, w1, c.pl(p.fused), p.B * fh * fw, h->Cp);
         as_conv(g, fh, fw, h->Cp, fh, fw, 1);
         g.bias = b1;
-        g.out_hi = h1b; g.out_f32 = h1f; g.ldc = h->C2p;
+        g.out_hi = h1b; g.out_lo = h1b_lo; g.out_f32 = h1f; g.ldc = h->C2p;
         CHK(OPLC(mdpt_launch_gemm, g, c.s));
     }
     // ---- tail
     if (tail_fused) {
         HeadTailParams t;
         memset(&t, 0, sizeof(t));
-        t.src = h1b; t.w_kc = h->M("head.proj_1ch.0.weight@kc32").hi;
+        t.src = h1b; t.src_lo = h1b_lo; t.w_kc = h->M("head.proj_1ch.0.weight@kc32").hi;
         t.bias = h->V("head.proj_1ch.0.bias"); t.head_w = h->V("head.proj_1ch.2.weight"); t.head_b = h->V("head.proj_1ch.2.bias");
         t.out = depth; t.out_dtype = depth_dtype; t.sigmoid = h->cfg.is_metric;
         t.B = p.B; t.Hi = fh; t.Wi = fw; t.Ho = p.H; t.Wo = p.W;

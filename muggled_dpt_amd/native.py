@@ -203,6 +203,7 @@ SYMBOLS = {
     "mdpt_set_class_passes": (ctypes.c_int, [_VP, _I, _I]),
     "mdpt_get_class_passes": (ctypes.c_int, [_VP, _I, ctypes.POINTER(_I)]),
     "mdpt_default_mixed_passes": (None, [ctypes.POINTER(_I)]),
+    "mdpt_default_mixed_passes_for": (None, [_I, ctypes.POINTER(_I)]),
     "mdpt_set_weight_rounding_compensation": (ctypes.c_int, [_VP, _I]),
     "mdpt_debug_read": (ctypes.c_int, [_VP, ctypes.c_char_p, _VP, _SZ, _VP, _SZ, _VP]),
     "mdpt_allgather": (ctypes.c_int, [_VP, _VP, _VP, _SZ, _I, _VP]),

@@ -156,6 +156,9 @@ def test_class_passes_all_three_equals_the_x3_mode_bitwise_and_each_class_switch
         y_c = model(x.cuda())
         ec = rel_err(y_c.cpu(), ref)
         assert ec <= 1.5 * e1 + 1e-5, f"class {c} at 2 passes: {ec:.3e} vs {e1:.3e} single-pass"
+        if c == "proj":  # its activations come from the attention kernel, whose single-pass form writes no lo plane (a zero plane): nothing to add
+            assert torch.equal(y_c, y_1)
+            continue
         assert not torch.equal(y_c, y_1), f"class {c}: two passes left every bit unchanged"
     model.set_class_passes({c: 2 for c in native.OP_CLASSES if c != "attn"})
     e2 = rel_err(model(x.cuda()).cpu(), ref)
@@ -166,6 +169,41 @@ def test_class_passes_all_three_equals_the_x3_mode_bitwise_and_each_class_switch
         model.set_class_passes({"nope": 3})
     with pytest.raises(ValueError):
         model.set_precision("fp8")
+
+
+@pytest.mark.parametrize("name,hw,batch", [("tiny", (56, 84), 2), ("vits", (140, 112), 1), ("vitl", (112, 140), 3), ("vitl", (504, 504), 1)])
+def test_two_pass_head_tail_is_one_kernel_and_loses_only_the_weight_rounding(name, hw, batch):
+    """MDPT_CLASS_HEAD_TAIL at two passes = head_tail2_kernel (head.hip): the x(P/8) upsample interpolated from hi + lo planes of conv 1's output,
+    hi + lo halo planes against ONE rounded plane of the 3x3 conv's weights (head_model.py:78-85). The head stage alone on an fp32 fused map,
+    everything else at three passes: with fp16-REPRESENTABLE conv weights the two-pass tail is fp32-class like the three-pass kernels; with the
+    original weights what is left is their rounding - below the single-pass tail's error, above the three-pass one's."""
+    osd, cfg, w = synthetic_model(name, 0)
+    from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+    gh, gw = hw[0] // 14, hw[1] // 14
+    fused = seeded_input((batch, cfg["fusion_channels"], 8 * gh, 8 * gw), 17)
+    errs = {}
+    for rounded in (True, False):
+        osd_r = dict(osd)
+        key = next(k for k in osd_r if k.endswith("output_conv2.0.weight"))
+        if rounded:
+            osd_r[key] = osd_r[key].half().float()
+        _, model = make_depthanythingv2_dpt_from_original_state_dict(osd_r)
+        model = model.to("cuda", torch.float32)
+        model.set_precision("fp16x3")
+        wr = dict(w)
+        if rounded:
+            wr["head.proj_1ch.0.weight"] = w["head.proj_1ch.0.weight"].half().float()
+        ref = _oracle().head(wr, cfg, fused)
+        for passes in (3, 2, 1):
+            model.set_class_passes({"head_tail": passes})
+            y = model.head(fused.cuda())
+            assert tuple(y.shape) == tuple(ref.shape)
+            errs[(rounded, passes)] = rel_err(y.cpu(), ref)
+        del model
+    assert errs[(True, 3)] <= REL_TOL_X3 and errs[(True, 2)] <= REL_TOL_X3, errs   # representable weights: nothing is lost
+    assert errs[(False, 3)] <= REL_TOL_X3, errs
+    assert errs[(False, 2)] <= 0.9 * errs[(False, 1)] and errs[(False, 1)] <= REL_TOL_FP16_TOY, errs
+    torch.cuda.empty_cache()
 
 
 def test_raw_c_abi_class_passes_keep_bound_weights_and_reject_bad_arguments():

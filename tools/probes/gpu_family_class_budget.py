@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""BEiT-L / SwinV2-L (BASELINE configs[4], the reference fixtures of tests/golden/): error against the fixture and maps/s at batch 16 of the mixed
+mode with one decoder class at a time moved between 1 / 2 / 3 passes - the per-family budget behind mdpt_default_mixed_passes' family rows.
+   python tools/probes/gpu_family_class_budget.py [beitl swinl vitl]"""
+import os, sys, time
+import numpy as np
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import bench
+from helpers import seeded_input
+
+FIX = {"beitl": ("beit_large_384", 384, 16), "swinl": ("swin2_large_384", 384, 16), "vitl": ("vitl504", 504, 32)}
+R04 = {"fusion": 3, "fusion_proj": 3, "head": 3, "head_tail": 3}
+VARIANTS = [("shipped", {}), ("round 4 (3 passes)", R04), ("fusion=3", {"fusion": 3}), ("head=3", {"head": 3}), ("head_tail=3", {"head_tail": 3}),
+            ("fusion=3 head=3", {"fusion": 3, "head": 3}), ("fusion=3 head_tail=3", {"fusion": 3, "head_tail": 3}), ("head=3 head_tail=3", {"head": 3, "head_tail": 3}),
+            ("reasm=2", {"reasm": 2}), ("fusion_in=2", {"fusion_in": 2})]
+for name in (sys.argv[1:] or ["beitl", "swinl"]):
+    fixture, size, batch = FIX[name]
+    g = np.load(os.path.join(REPO, "tests", "golden", fixture + ".npz"))
+    model, _ = bench.make_model_and_weights(name)
+    # the fixture's weights (seed from the fixture, as the tests do)
+    if name != "vitl":
+        from muggled_dpt_amd import make_beit_dpt_from_midas_v31_state_dict, make_swinv2_dpt_from_midas_v31_state_dict
+        from muggled_dpt_amd.synthetic import make_synthetic_beit_state_dict, make_synthetic_swinv2_state_dict
+        make, synth = (make_beit_dpt_from_midas_v31_state_dict, make_synthetic_beit_state_dict) if name == "beitl" else (make_swinv2_dpt_from_midas_v31_state_dict, make_synthetic_swinv2_state_dict)
+        _, model = make(synth(fixture, int(g["weight_seed"])))
+    model = model.to("cuda", torch.float32)
+    x1 = seeded_input((1, 3, size, size), int(g["input_seed"]))
+    ref = torch.from_numpy(g["depth_strided"]).double()
+    xb = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(1)).cuda()
+    print(f"== {name} ({fixture}), batch {batch}")
+    for label, passes in VARIANTS:
+        model.set_precision("mixed")
+        model.set_class_passes(passes)
+        y = model(x1.cuda()).cpu()
+        d = y[:, ::4, ::4].double() - ref
+        err, rms = float(d.abs().max() / ref.abs().max()), float(d.pow(2).mean().sqrt() / ref.abs().max())
+        for _ in range(2):
+            model(xb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            model(xb)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 8
+        print(f"  {label:26s} max {err:.3e}  rms {rms:.3e}   {dt * 1e3:7.2f} ms  {batch / dt:7.1f} maps/s", flush=True)
