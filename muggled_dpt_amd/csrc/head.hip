@@ -520,7 +520,7 @@ __global__ __launch_bounds__(512, 1) void head_tail2_kernel(const HeadTailParams
                             const f32x2 o2 = t0[w] + ly * (t1[w] - t0[w]);
                             const opx2 hh = to_op2(o2);
                             outh[w] = __builtin_bit_cast(unsigned, hh);
-                            outl[w] = __builtin_bit_cast(unsigned, to_op2(o2 - __builtin_convertvector(hh, f32x2)));
+                            outl[w] = __builtin_bit_cast(unsigned, to_op2_bounded(o2 - __builtin_convertvector(hh, f32x2)))  /* |residue| <= ulp(hi) / 2: no saturation */;
                         }
                     }
                     *(u32x4*)(hcol + hy * ROWB) = outh;
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(512, 1) void head_tail2_kernel(const HeadTailParams
                             const f32x2 o2 = u0 + ly * (u1 - u0);
                             const opx2 hh = to_op2(o2);
                             outh[2 * hw + w] = __builtin_bit_cast(unsigned, hh);
-                            outl[2 * hw + w] = __builtin_bit_cast(unsigned, to_op2(o2 - __builtin_convertvector(hh, f32x2)));
+                            outl[2 * hw + w] = __builtin_bit_cast(unsigned, to_op2_bounded(o2 - __builtin_convertvector(hh, f32x2)))  /* |residue| <= ulp(hi) / 2: no saturation */;
                         }
                     }
                 }
