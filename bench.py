@@ -250,6 +250,28 @@ def time_model(model, x, steps, warmup=2, warmup_seconds=0.3):
     return (time.perf_counter() - t0) / steps, y
 
 
+def time_inference(model, side: int, steps: int) -> dict:
+    """DPTModel.inference(image_bgr) on a `side` x `side` uint8 host image: ms per call with the host waiting for every depth map
+    (`ms_per_call_sync`: the latency a frame-by-frame caller sees, run_video.py:344) and with `steps` calls queued back to back
+    (`ms_per_call_pipelined`)."""
+    import numpy as np
+    img = np.random.default_rng(5).integers(0, 256, (side, side, 3), dtype=np.uint8)
+    for _ in range(20):
+        y = model.inference(img)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        y = model.inference(img)
+        torch.cuda.synchronize()
+    t_sync = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        y = model.inference(img)
+    torch.cuda.synchronize()
+    t_pipe = (time.perf_counter() - t0) / steps
+    return {"ms_per_call_sync": round(t_sync * 1e3, 3), "ms_per_call_pipelined": round(t_pipe * 1e3, 3), "output": f"{tuple(y.shape)} {str(y.dtype).replace('torch.', '')} on the device"}
+
+
 def secondary_legs(args, dev, lib, vitl_model):
     """The other BASELINE.json configurations inside the default run (the driver only runs the default command): configs[1] ViT-S
     518x518 batch 1, the 1036x1036 north-star size (ViT-L, batch 8), configs[4] BEiT-L and SwinV2-L 384x384 batch 16 - each with
@@ -289,8 +311,13 @@ def secondary_legs(args, dev, lib, vitl_model):
             if batch == 1:  # the opt-in latency mode (mdpt_set_latency_mode: small launches may use forms that are not batch-invariant in the last bit)
                 model.set_latency_mode(True)
                 dt_l, _ = time_model(model, x, steps)
+                inf_l = time_inference(model, size + 14, steps)
                 model.set_latency_mode(False)
                 rec["latency_mode"] = {"ms_per_step": round(dt_l * 1e3, 3), "value": round(batch / dt_l, 3)}
+                # what every caller of the reference actually runs (run_image.py:204-207, run_video.py:344): DPTModel.inference on a uint8 HOST
+                # image - pageable numpy -> pinned staging -> H2D -> prepare_image kernel (model dtype) -> forward, depth left on the device
+                rec["inference_b1"] = {"input": f"uint8 host image {size + 14}x{size + 14}x3 (BGR) -> {size}x{size} tensor", **time_inference(model, size + 14, steps),
+                                       "latency_mode": inf_l}
             if want_err and ow is not None:
                 from oracle import dpt_oracle
                 ref = dpt_oracle.forward(ow[1], ow[0], x_cpu[:1])

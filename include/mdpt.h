@@ -209,6 +209,15 @@ int mdpt_head(mdpt_handle* h, const void* fused_in, int32_t B, int32_t gh, int32
  * accounts for the split. */
 int mdpt_set_batch_split(mdpt_handle* h, int32_t min_batch);
 
+/* The reference's `enable_cache` (make_*_dpt(..., enable_cache=True); v2_depthanything/components/position_encoder.py:152-227 GridCache,
+ * v31_beit/components/relative_positional_encoder.py, v31_swinv2 default True; run_video.py:144 switches it on). Off (default): every forward
+ * recomputes the per-grid constants - the bicubic-resized position embedding, BEiT's resized relative-position tables, SwinV2's
+ * continuous-position-bias tables, the zero pads of operand planes. On: the first mdpt_forward of a (workspace, B, H, W) leaves them in the
+ * workspace and the following mdpt_forward calls on the SAME workspace and shape skip the kernels that write them (same bits). The cached state is
+ * dropped by a different shape on that workspace, by any stage-level call on the handle, and by mdpt_finalize. With the cache on the caller must
+ * not write into the workspace between calls. */
+int mdpt_set_grid_cache(mdpt_handle* h, int32_t on);
+
 /* Latency mode (default off). Off: every image's result is bit-identical whatever batch it is part of (the kernels that run do
  * not depend on the batch size in any way that changes the arithmetic). On: launches that are too small to fill the GPU (batch 1 of
  * the small models) may use forms that change the summation order - today the attention kernel splits the key loop over the four
@@ -220,13 +229,14 @@ int mdpt_set_batch_split(mdpt_handle* h, int32_t min_batch);
 int mdpt_set_latency_mode(mdpt_handle* h, int32_t on);
 
 /* PatchEmbed.prepare_image (v2_depthanything/patch_embed.py:103-145): uint8 [in_h,in_w,3] BGR on the device ->
- * fp32 [3,out_h,out_w] RGB, antialiased-bilinear resized exactly like F.interpolate(..., antialias=True) and normalised with the
+ * [3,out_h,out_w] RGB in the element type out_dtype (MDPT_DTYPE_*: the model's dtype, what mdpt_forward takes next - no cast kernel in
+ * between), antialiased-bilinear resized exactly like F.interpolate(..., antialias=True) in fp32 and normalised with the
  * given per-channel mean/std (ImageNet values for Depth-Anything, 0.5/0.5 for BEiT). The caller picks out_h/out_w with the reference's size rule (multiples of 2*patch).
  * `interpolation` = the reference's interpolation_mode argument (patch_embed.py:108,141): bilinear (its default) or bicubic; torch itself
  * rejects antialias=True for every other mode, and so does this entry point (MDPT_E_UNSUPPORTED). */
 #define MDPT_INTERP_BILINEAR 0
 #define MDPT_INTERP_BICUBIC 1
-int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void* out_chw_f32, int32_t out_h, int32_t out_w,
+int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void* out_chw, int32_t out_dtype, int32_t out_h, int32_t out_w,
                        const float rgb_mean[3], const float rgb_std[3], int32_t interpolation, void* stream);
 
 /* Depth post-processing on the device (reference muggled_dpt/demo_helpers/postprocess.py and

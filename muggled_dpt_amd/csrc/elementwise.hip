@@ -46,6 +46,73 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     ln_row<NV>(x + (size_t)row * F, gamma, beta, out_hi, out_lo, out_f32, (size_t)row * F, F, lane);  // ln_row.h: shared with gemm.hip
 }
 
+// LayerNorm + the token sums of its OUTPUT in one launch (token-mean compensation of the weight rounding, mdpt_stages.cpp wrc_bias: the
+// single-pass QKV / fc1 GEMM behind this LayerNorm wants mean_t(A_r[b, t, :]) over every step-th token of image b, A_r = the rounded
+// operand plane written here). The first nimg * LNM_PARTS workgroups of the grid are "sum" workgroups: part p of image b re-normalises the
+// image's sampled rows j = 4 p + wave (mod 4 LNM_PARTS) with the same ln_row arithmetic (the same bits the row's own wave stores; the next
+// row's loads are in flight while the current one is reduced), sums the ROUNDED values column-wise in registers (wave order, then wave
+// 0 + 1 + 2 + 3 through LDS) and writes the fp32 partial sums part[b][p][F]; wrc_table_kernel adds the parts in the order 0, 1, ... and
+// scales. They are dispatched first and finish inside the LayerNorm's own duration: the stand-alone colmean launch (~9 us of dependent
+// launch latency per GEMM, 48 per forward) disappears. An image's sums depend on its own rows only.
+constexpr int LNM_PARTS = 4;
+
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_mean_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             op_t* out_hi, op_t* out_lo, float* out_f32, int rows, int F, int nimg, int rows_per_img,
+                                                             int nreal, int step, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= nimg * LNM_PARTS) {
+        const int row = ((int)blockIdx.x - nimg * LNM_PARTS) * 4 + wave;
+        if (row >= rows) return;
+        ln_row<NV>(x + (size_t)row * F, gamma, beta, out_hi, out_lo, out_f32, (size_t)row * F, F, lane);
+        return;
+    }
+    __shared__ float red[3][NV * 256];
+    const int b = (int)blockIdx.x / LNM_PARTS, pt = (int)blockIdx.x % LNM_PARTS, nsamp = (nreal + step - 1) / step;
+    const float* xb = x + (size_t)b * rows_per_img * F;
+    ln_f32x4 acc[NV], nxt[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = nxt[i] = ln_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    auto fetch = [&](int j) {
+        const float* xr = xb + (size_t)j * step * F;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if ((i * 64 + lane) * 4 < F) nxt[i] = *(const ln_f32x4*)(xr + (i * 64 + lane) * 4);
+    };
+    int j = pt * 4 + wave;
+    if (j < nsamp) fetch(j);
+    for (; j < nsamp; j += 4 * LNM_PARTS) {
+        ln_f32x4 cur[NV], y[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
+        if (j + 4 * LNM_PARTS < nsamp) fetch(j + 4 * LNM_PARTS);
+        ln_row_values<NV>([&](int, int i) { return cur[i]; }, gamma, beta, F, lane, y);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if ((i * 64 + lane) * 4 < F) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][e] += (float)to_op(y[i][e]);
+            }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *(ln_f32x4*)&red[wave - 1][(i * 64 + lane) * 4] = acc[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < F) {
+                ln_f32x4 t = acc[i];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) t += *(const ln_f32x4*)&red[w][c];
+                *(ln_f32x4*)(part + ((size_t)b * LNM_PARTS + pt) * F + c) = t;
+            }
+        }
+    }
+}
+
 // The same behind a K-split GEMM (GemmParams::ksplit, latency mode): the row is x + part[0] + part[1] + ... (the partial sums of the K
 // ranges 1 .. npart, added in that order), written back to x and normalised - the reduction of the split costs no launch of its own.
 template <int NV>
@@ -481,8 +548,10 @@ __device__ __forceinline__ void aa_span(int i, float scale, int in_size, int& lo
     n = hi - lo;
 }
 
+// The output is written in the MODEL's dtype (out_dtype = MDPT_DT_*; the reference builds the tensor in the model dtype too,
+// patch_embed.py:131-145 - here the filter runs in fp32 and rounds once): no cast kernel between this one and the patchify of mdpt_forward.
 template <int INTERP>
-__global__ __launch_bounds__(256) void prepare_image_kernel(const unsigned char* __restrict__ bgr, float* __restrict__ out, int ih,
+__global__ __launch_bounds__(256) void prepare_image_kernel(const unsigned char* __restrict__ bgr, void* __restrict__ out, int out_dtype, int ih,
                                                             int iw, int oh, int ow, float m0, float m1, float m2, float s0,
                                                             float s1, float s2) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -512,9 +581,19 @@ __global__ __launch_bounds__(256) void prepare_image_kernel(const unsigned char*
         acc_r += wy * rr;
     }
     const size_t plane = (size_t)oh * ow;
-    out[idx] = (acc_r / 255.0f - m0) * s0;              // channel 0 = R
-    out[plane + idx] = (acc_g / 255.0f - m1) * s1;      // channel 1 = G
-    out[2 * plane + idx] = (acc_b / 255.0f - m2) * s2;  // channel 2 = B
+    const float v0 = (acc_r / 255.0f - m0) * s0;  // channel 0 = R
+    const float v1 = (acc_g / 255.0f - m1) * s1;  // channel 1 = G
+    const float v2 = (acc_b / 255.0f - m2) * s2;  // channel 2 = B
+    if (out_dtype == MDPT_DT_BF16) {
+        __bf16* o = (__bf16*)out;
+        o[idx] = (__bf16)v0; o[plane + idx] = (__bf16)v1; o[2 * plane + idx] = (__bf16)v2;
+    } else if (out_dtype == MDPT_DT_F16) {
+        _Float16* o = (_Float16*)out;
+        o[idx] = (_Float16)v0; o[plane + idx] = (_Float16)v1; o[2 * plane + idx] = (_Float16)v2;
+    } else {
+        float* o = (float*)out;
+        o[idx] = v0; o[plane + idx] = v1; o[2 * plane + idx] = v2;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -650,8 +729,11 @@ __global__ __launch_bounds__(256) void colmean_kernel(const op_t* __restrict__ A
 // per pass) and latency-bound, so it gets its own kernel instead of a 64x64 GEMM tile per 64 columns: one workgroup = 16 columns of the
 // table, its four waves take a quarter of K each (v_mfma_f32_16x16x32: both operands are K-contiguous rows, a lane's fragment is one
 // 16-byte global load, no LDS staging), the four partial sums are added in a fixed order. A row of the table depends on its own image only.
-__global__ __launch_bounds__(256) void wrc_table_kernel(const op_t* __restrict__ mean, const op_t* __restrict__ w_lo, const float* __restrict__ bias,
-                                                        float* __restrict__ out, int B, int N, int K) {
+// PARTS > 0: the means come as PARTS fp32 partial SUMS per image (layernorm_mean_kernel: part[b][p][K]), added here in the order p = 0, 1, ... and
+// scaled by inv_n = 1 / (number of sampled rows) before the rounding to the operand format - instead of a ready operand-format mean row.
+template <int PARTS>
+__global__ __launch_bounds__(256) void wrc_table_kernel(const op_t* __restrict__ mean, const float* __restrict__ mean_part, float inv_n, const op_t* __restrict__ w_lo,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int B, int N, int K) {
     __shared__ float part[4][2][16][16];  // [wave][image block][image][column]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
     const int n = blockIdx.x * 16 + l15;
@@ -662,11 +744,21 @@ __global__ __launch_bounds__(256) void wrc_table_kernel(const op_t* __restrict__
         const int r0 = b0 + l15 < B ? b0 + l15 : B - 1, r1 = b0 + 16 + l15 < B ? b0 + 16 + l15 : B - 1;
         const op_t* a0 = mean + (size_t)r0 * K + kq * 8;
         const op_t* a1 = mean + (size_t)r1 * K + kq * 8;
+        auto from_parts = [&](int r, int k) -> opx8 {  // 8 consecutive columns of image r's mean row out of the partial sums
+            const float* pp = mean_part + (size_t)r * PARTS * K + kq * 8 + k;
+            f32x4 lo4 = *(const f32x4*)pp, hi4 = *(const f32x4*)(pp + 4);
+#pragma unroll
+            for (int q = 1; q < (PARTS > 0 ? PARTS : 1); ++q) { lo4 += *(const f32x4*)(pp + (size_t)q * K); hi4 += *(const f32x4*)(pp + (size_t)q * K + 4); }
+            opx8 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = to_op(lo4[e] * inv_n); v[e + 4] = to_op(hi4[e] * inv_n); }
+            return v;
+        };
         f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 4
         for (int k = k_lo; k < k_hi; k += 32) {
             const opx8 w = *(const opx8*)(wrow + k);
-            const opx8 x0 = *(const opx8*)(a0 + k), x1 = *(const opx8*)(a1 + k);
+            const opx8 x0 = PARTS > 0 ? from_parts(r0, k) : *(const opx8*)(a0 + k), x1 = PARTS > 0 ? from_parts(r1, k) : *(const opx8*)(a1 + k);
             acc0 = MDPT_MFMA_16x16x32(x0, w, acc0, 0, 0, 0);
             acc1 = MDPT_MFMA_16x16x32(x1, w, acc1, 0, 0, 0);
         }
@@ -712,6 +804,23 @@ int MDPT_FN(mdpt_launch_layernorm)(const float* x, const float* gamma, const flo
     LAUNCH_RET();
 }
 
+int MDPT_FN(mdpt_layernorm_mean_parts)() { return LNM_PARTS; }
+
+int MDPT_FN(mdpt_launch_layernorm_mean)(const float* x, const float* gamma, const float* beta, op_t* out_hi, op_t* out_lo, float* out_f32, int rows, int F,
+                                       int nimg, int rows_per_img, int nreal, int step, float* part, hipStream_t stream) {
+    if ((F & 3) || F > 64 * 4 * LN_MAXV || !part || nimg <= 0 || nreal <= 0 || nreal > rows_per_img || step <= 0 || (long)nimg * rows_per_img > rows) return (int)hipErrorInvalidValue;
+    MdptProfScope prof("layernorm_mean_kernel", 0.0, stream);
+    const dim3 grid(nimg * LNM_PARTS + (rows + 3) / 4), block(256);
+#define LN_CASE(NV) hipLaunchKernelGGL(layernorm_mean_kernel<NV>, grid, block, 0, stream, x, gamma, beta, out_hi, out_lo, out_f32, rows, F, nimg, rows_per_img, nreal, step, part)
+    if (F <= 256) LN_CASE(1);
+    else if (F <= 512) LN_CASE(2);
+    else if (F <= 1024) LN_CASE(4);
+    else if (F <= 1536) LN_CASE(6);
+    else LN_CASE(8);
+#undef LN_CASE
+    LAUNCH_RET();
+}
+
 int MDPT_FN(mdpt_launch_layernorm_addp)(float* x, const float* part, size_t part_stride, int npart, const float* gamma, const float* beta,
                                        op_t* out_hi, op_t* out_lo, float* out_f32, int rows, int F, hipStream_t stream) {
     if ((F & 3) || F > 64 * 4 * LN_MAXV || !part || npart < 1) return (int)hipErrorInvalidValue;
@@ -744,10 +853,11 @@ int MDPT_FN(mdpt_launch_colmean)(const op_t* A, int lda, int B, int rows_per_img
     LAUNCH_RET();
 }
 
-int MDPT_FN(mdpt_launch_wrc_table)(const op_t* mean, const op_t* w_lo, const float* bias, float* out, int B, int N, int K, hipStream_t stream) {
-    if (B <= 0 || N <= 0 || K <= 0 || (K & 31)) return (int)hipErrorInvalidValue;
+int MDPT_FN(mdpt_launch_wrc_table)(const op_t* mean, const float* mean_part, int nsamp, const op_t* w_lo, const float* bias, float* out, int B, int N, int K, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || K <= 0 || (K & 31) || (!mean && !mean_part) || (mean_part && nsamp <= 0)) return (int)hipErrorInvalidValue;
     MdptProfScope prof("wrc_table_kernel", 2.0 * B * N * K, stream);
-    hipLaunchKernelGGL(wrc_table_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, mean, w_lo, bias, out, B, N, K);
+    if (mean_part) hipLaunchKernelGGL(wrc_table_kernel<LNM_PARTS>, dim3((N + 15) / 16), dim3(256), 0, stream, nullptr, mean_part, 1.0f / (float)nsamp, w_lo, bias, out, B, N, K);
+    else hipLaunchKernelGGL(wrc_table_kernel<0>, dim3((N + 15) / 16), dim3(256), 0, stream, mean, nullptr, 0.0f, w_lo, bias, out, B, N, K);
     LAUNCH_RET();
 }
 
@@ -902,15 +1012,15 @@ int MDPT_FN(mdpt_launch_tokens_to_resid)(const float* tokens, const float* pos, 
     LAUNCH_RET();
 }
 
-int MDPT_FN(mdpt_launch_prepare_image)(const unsigned char* bgr, float* out, int ih, int iw, int oh, int ow, const float mean[3],
+int MDPT_FN(mdpt_launch_prepare_image)(const unsigned char* bgr, void* out, int out_dtype, int ih, int iw, int oh, int ow, const float mean[3],
                               const float inv_std[3], int interp, hipStream_t stream) {
-    if (ih <= 0 || iw <= 0 || oh <= 0 || ow <= 0 || (interp != 0 && interp != 1)) return (int)hipErrorInvalidValue;
+    if (ih <= 0 || iw <= 0 || oh <= 0 || ow <= 0 || (interp != 0 && interp != 1) || out_dtype < MDPT_DT_F32 || out_dtype > MDPT_DT_F16) return (int)hipErrorInvalidValue;
     MdptProfScope prof("prepare_image_kernel", 0.0, stream);
     if (interp == 0)
-        hipLaunchKernelGGL(prepare_image_kernel<0>, dim3((oh * ow + 255) / 256), dim3(256), 0, stream, bgr, out, ih, iw, oh, ow, mean[0], mean[1],
+        hipLaunchKernelGGL(prepare_image_kernel<0>, dim3((oh * ow + 255) / 256), dim3(256), 0, stream, bgr, out, out_dtype, ih, iw, oh, ow, mean[0], mean[1],
                            mean[2], inv_std[0], inv_std[1], inv_std[2]);
     else
-        hipLaunchKernelGGL(prepare_image_kernel<1>, dim3((oh * ow + 255) / 256), dim3(256), 0, stream, bgr, out, ih, iw, oh, ow, mean[0], mean[1],
+        hipLaunchKernelGGL(prepare_image_kernel<1>, dim3((oh * ow + 255) / 256), dim3(256), 0, stream, bgr, out, out_dtype, ih, iw, oh, ow, mean[0], mean[1],
                            mean[2], inv_std[0], inv_std[1], inv_std[2]);
     LAUNCH_RET();
 }

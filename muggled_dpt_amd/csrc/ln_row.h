@@ -15,10 +15,12 @@ __device__ __forceinline__ float ln_wave_sum(float v) {
     return v;
 }
 
-// `load(c)` returns the four row values at columns c .. c+3 (a plain row read, or the row plus pending partial sums: layernorm_addp_kernel)
+// `load(c)` returns the four row values at columns c .. c+3 (a plain row read, or the row plus pending partial sums: layernorm_addp_kernel).
+// ln_row_values: the normalised row y = (x - mean) * rstd * gamma + beta, in registers - the ONE definition of the row arithmetic; ln_row_from
+// stores it (operand planes and / or fp32), layernorm_mean_kernel also sums its rounded values column-wise (token-mean compensation).
 template <int NV, class Load>
-__device__ __forceinline__ void ln_row_from(Load load, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                            op_t* out_hi, op_t* out_lo, float* out_f32, size_t out_off, int F, int lane) {
+__device__ __forceinline__ void ln_row_values(Load load, const float* __restrict__ gamma, const float* __restrict__ beta, int F, int lane,
+                                              ln_f32x4 (&y)[NV]) {
 #pragma clang fp contract(off)
     ln_f32x4 v[NV];
     float s = 0.0f;
@@ -26,7 +28,7 @@ __device__ __forceinline__ void ln_row_from(Load load, const float* __restrict__
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < F) {
-            v[i] = load(c);
+            v[i] = load(c, i);  // (c = the column, i = the lane's vector index: a caller that holds the row in registers indexes by i)
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -49,9 +51,23 @@ __device__ __forceinline__ void ln_row_from(Load load, const float* __restrict__
         const int c = (i * 64 + lane) * 4;
         if (c < F) {
             const ln_f32x4 g = *(const ln_f32x4*)(gamma + c), bt = *(const ln_f32x4*)(beta + c);
-            ln_f32x4 y;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((v[i][e] - mean) * rstd, g[e], bt[e]);
+            for (int e = 0; e < 4; ++e) y[i][e] = __builtin_fmaf((v[i][e] - mean) * rstd, g[e], bt[e]);
+        }
+    }
+}
+
+template <int NV, class Load>
+__device__ __forceinline__ void ln_row_from(Load load, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                            op_t* out_hi, op_t* out_lo, float* out_f32, size_t out_off, int F, int lane) {
+#pragma clang fp contract(off)
+    ln_f32x4 yy[NV];
+    ln_row_values<NV>([&](int c, int) { return load(c); }, gamma, beta, F, lane, yy);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < F) {
+            const ln_f32x4 y = yy[i];
             if (out_hi) {
                 opx4 h;
 #pragma unroll

@@ -74,6 +74,10 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     h->dbg_block = h->dbg_step = -1;
     h->ks_min_ktiles = 16; h->ks_big_ktiles = 1 << 30;
     h->split_min = 8;
+    h->latency_mode = 0;
+    h->grid_cache = 0;
+    h->gen = 0;
+    h->cache_clear();
     h->side_stream = nullptr;
     h->ev_fork = h->ev_join = nullptr;
     build_inventory(h);
@@ -243,6 +247,7 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
     }
     h->finalized = true;
     h->has_last = false;
+    ++h->gen;  // cached per-grid constants were derived from the previous weights
     return 0;
 }
 
@@ -263,6 +268,13 @@ int mdpt_workspace_bytes(const mdpt_handle* h, int32_t B, int32_t H, int32_t W, 
 int mdpt_set_batch_split(mdpt_handle* h, int32_t min_batch) {
     if (!h || min_batch < 0) return fail(MDPT_E_INVALID, "bad argument");
     h->split_min = min_batch == 1 ? 2 : min_batch;
+    return 0;
+}
+
+int mdpt_set_grid_cache(mdpt_handle* h, int32_t on) {
+    if (!h) return fail(MDPT_E_INVALID, "null handle");
+    h->grid_cache = on ? 1 : 0;
+    h->cache_clear();
     return 0;
 }
 
@@ -307,6 +319,9 @@ int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t image_dtype, in
         Ctx c0, c1;
         c0.h = h; c0.p = p0; c0.ws = (char*)workspace; c0.s = s0; c0.split = true;
         c1.h = h; c1.p = p1; c1.ws = (char*)workspace + off1; c1.s = h->side_stream; c1.split = true;
+        c0.consts_cached = h->cache_hit(c0.ws, B0, H, W);
+        c1.consts_cached = h->cache_hit(c1.ws, B1, H, W);
+        h->cache_clear();
         const size_t in_stride = (size_t)3 * H * W * dtype_bytes(image_dtype), out_stride = (size_t)H * W * dtype_bytes(depth_dtype);
         // Whatever happens after the fork, the side stream is joined back into the caller's stream before returning: kernels already
         // queued there keep using the second half of the workspace and the caller's tensors, which the caller may free or reuse on its
@@ -319,11 +334,16 @@ int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t image_dtype, in
         h->has_last = false;  // taps live in two half-batch plans: mdpt_export_tap is for unsplit (small) batches
         if (rc != 0) return rc;
         CHK(ew);
+        if (h->grid_cache && h->dbg_block < 0) { h->cache_store(0, c0.ws, B0, H, W); h->cache_store(1, c1.ws, B1, H, W); }
         return 0;
     }
+    const bool hit = h->cache_hit(workspace, B, H, W);
     Ctx c;
     CHK(make_ctx(h, B, H, W, workspace, workspace_bytes, stream, &c));
-    return forward_one(h, c, image_bchw, image_dtype, depth_bhw, depth_dtype);
+    c.consts_cached = hit;
+    CHK(forward_one(h, c, image_bchw, image_dtype, depth_bhw, depth_dtype));
+    if (h->grid_cache && h->dbg_block < 0) h->cache_store(0, workspace, B, H, W);
+    return 0;
 }
 
 static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, int image_dtype, void* depth_bhw, int depth_dtype) {
@@ -648,14 +668,15 @@ int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspac
 }
 
 // ---- PatchEmbed.prepare_image (reference v2_depthanything/patch_embed.py:103-145): resize + BGR->RGB + normalise on the GPU
-int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void* out_chw_f32, int32_t out_h, int32_t out_w,
+int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void* out_chw, int32_t out_dtype, int32_t out_h, int32_t out_w,
                        const float rgb_mean[3], const float rgb_std[3], int32_t interpolation, void* stream) {
-    if (!bgr_u8_hwc || !out_chw_f32 || !rgb_mean || !rgb_std) return fail(MDPT_E_INVALID, "null argument");
+    if (!bgr_u8_hwc || !out_chw || !rgb_mean || !rgb_std) return fail(MDPT_E_INVALID, "null argument");
+    if (out_dtype != MDPT_DTYPE_F32 && out_dtype != MDPT_DTYPE_BF16 && out_dtype != MDPT_DTYPE_F16) return fail(MDPT_E_INVALID, "bad tensor dtype %d", out_dtype);
     if (interpolation != MDPT_INTERP_BILINEAR && interpolation != MDPT_INTERP_BICUBIC)
         return fail(MDPT_E_UNSUPPORTED, "interpolation %d: antialiased resize exists for bilinear and bicubic only (as in torch)", interpolation);
     if (in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) return fail(MDPT_E_INVALID, "bad image size %dx%d -> %dx%d", in_h, in_w, out_h, out_w);
     const float inv_std[3] = {1.0f / rgb_std[0], 1.0f / rgb_std[1], 1.0f / rgb_std[2]};  // patch_embed.py:38-39,62
-    CHK(mdpt_launch_prepare_image_bf16((const unsigned char*)bgr_u8_hwc, (float*)out_chw_f32, in_h, in_w, out_h, out_w, rgb_mean, inv_std, interpolation, (hipStream_t)stream));
+    CHK(mdpt_launch_prepare_image_bf16((const unsigned char*)bgr_u8_hwc, out_chw, out_dtype, in_h, in_w, out_h, out_w, rgb_mean, inv_std, interpolation, (hipStream_t)stream));
     return 0;
 }
 

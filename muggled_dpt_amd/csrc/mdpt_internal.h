@@ -48,6 +48,7 @@ extern "C" {
 #define mdpt_head_tail_supported mdpt_head_tail_supported_bf16
 #define mdpt_head_tail_scale_ok mdpt_head_tail_scale_ok_bf16
 #define mdpt_beit_relpos_elen mdpt_beit_relpos_elen_bf16
+#define mdpt_layernorm_mean_parts mdpt_layernorm_mean_parts_bf16
 
 namespace mdpt {
 
@@ -130,6 +131,7 @@ struct Plan {
     size_t scratch_floats;
     size_t tokr[2], cbuf, relpos_lut, relpos_tq, relpos_tk;  // BEiT: readout-projected tokens, per-image cls term, bias LUT
     size_t wrc_mean, wrc_tab;                                 // [B, wrc_maxk] operand-format column means, fp32 [B, wrc_maxn] per-image bias table
+    size_t wrc_part;                                          // fp32 [B, parts, F] partial column sums of a LayerNorm's output (mdpt_launch_layernorm_mean)
     size_t swi;                                               // ViT-G: fp32 [rows, 2*hidden] output of the doubled inner linear
     size_t kspart;                                            // small batches: 3 x fp32 [rows, F] partial sums of the K-split proj / fc2 (latency mode), else absent
     // SwinV2: stage-0 patch grid, per-stage residual streams (fp32, = the taps), shared GEMM fp32 output, token planes,
@@ -179,6 +181,20 @@ struct mdpt_handle {
     // events, no host sync) so that one half's kernels fill the tile-quantisation tails and epilogue phases of the other's
     int split_min;
     int latency_mode;  // mdpt_set_latency_mode: small launches may use summation orders that are not batch-invariant
+    // mdpt_set_grid_cache (the reference's enable_cache, position_encoder.py:152-227): per-grid constants - resized position embedding, BEiT's
+    // relative-position tables, SwinV2's position-bias tables, the zero pads of operand planes - stay in the workspace of the last forward of
+    // a (workspace, B, H, W) and are not recomputed by the next forward on the same workspace and shape (`gen` = finalize generation)
+    int grid_cache;
+    uint64_t gen;
+    struct CacheSlot { const void* ws; int B, H, W; uint64_t gen; bool valid; } cache_slot[2];
+    bool cache_hit(const void* ws, int B, int H, int W) const {
+        if (!grid_cache) return false;
+        for (const CacheSlot& s : cache_slot)
+            if (s.valid && s.ws == ws && s.B == B && s.H == H && s.W == W && s.gen == gen) return true;
+        return false;
+    }
+    void cache_store(int slot, const void* ws, int B, int H, int W) { cache_slot[slot] = CacheSlot{ws, B, H, W, gen, true}; }
+    void cache_clear() { cache_slot[0].valid = cache_slot[1].valid = false; }
     int ks_min_ktiles, ks_big_ktiles;  // ... proj / fc2 split K in two (64x64 tile) from ks_min K tiles on, in four from ks_big on (mdpt_debug_set_ksplit_min)
     hipStream_t side_stream;
     hipEvent_t ev_fork, ev_join;
@@ -243,6 +259,7 @@ struct Ctx {
     char* ws;
     hipStream_t s;
     bool split = false;  // this context is one half of a two-stream batch split
+    bool consts_cached = false;  // the per-grid constants of this (workspace, shape) are in place (mdpt_set_grid_cache): skip the kernels that write them
     void* const* attn_dump = nullptr;  // per block: where to write softmax(q k^T) as fp32 [B,H,N,N] (null entries: skip)
     void* const* block_dump = nullptr; // per block: where to write the block's output tokens as fp32 [B,N,F] (null entries: skip)
     template <class T> T* at(size_t off) const { return off == SIZE_MAX ? nullptr : (T*)(ws + off); }
@@ -277,7 +294,8 @@ GemmParams base_params(const Ctx& c, const Mat& w, Planes a, int M, int lda);
 void as_conv(GemmParams& g, int Hi, int Wi, int Cin, int Ho, int Wo, int stride);
 int run_pos(const Ctx& c);
 int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype);
-int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias, int rows_per_img = 0, int nreal = 0);
+int wrc_step(int nreal);
+int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias, int rows_per_img = 0, int nreal = 0, bool have_mean = false);
 bool fc2_ksplit_fits(int rows, int F);  // batch small enough for the K-split form of fc2 (the 64x64 tile's range): the plan then holds kspart
 int run_encoder(const Ctx& c, void* const taps_f32[4]);
 int run_reassemble(const Ctx& c);

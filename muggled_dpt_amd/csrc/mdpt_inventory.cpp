@@ -279,6 +279,7 @@ int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
     p.kspart = fc2_ksplit_fits((int)rows, F) ? bump.take(rows * F * 4 * 3) : SIZE_MAX;  // three partial-sum planes (a split in four); reserved whatever the latency switch says: it may flip later
     p.wrc_mean = h->wrc_maxk ? bump.take((size_t)B * h->wrc_maxk * 2) : SIZE_MAX;
     p.wrc_tab = h->wrc_maxn ? bump.take((size_t)B * h->wrc_maxn * 4) : SIZE_MAX;
+    p.wrc_part = h->wrc_maxk ? bump.take((size_t)B * mdpt_layernorm_mean_parts() * F * 4) : SIZE_MAX;
     const bool x3 = h->alo(CLS_REASM);
     for (int i = 0; i < 4; ++i) take_planes(bump, x3, rows * F, p.tap[i]);
     p.tapf32 = bump.take(rows * F * 4);
@@ -314,6 +315,7 @@ int make_ctx(mdpt_handle* h, int B, int H, int W, void* ws, size_t ws_bytes, voi
     CHK(make_plan(h, B, H, W, &p));
     CHK(check_ws(h, p, ws, ws_bytes));
     c->h = h; c->p = p; c->ws = (char*)ws; c->s = (hipStream_t)stream;
+    h->cache_clear();  // whoever builds a context may write the constant regions for another grid (stage-level calls): mdpt_forward re-validates its own
     return 0;
 }
 

@@ -196,14 +196,42 @@ class PatchEmbed(_Stage):
         if not (isinstance(image_bgr, np.ndarray) and image_bgr.dtype == np.uint8 and image_bgr.ndim == 3 and image_bgr.shape[2] == 3):
             raise TypeError("prepare_image expects an OpenCV-style uint8 HxWx3 BGR image (cv2.imread output)")
         lib = native.load()
-        src = torch.from_numpy(np.ascontiguousarray(image_bgr)).to(p.device, non_blocking=True)
-        out = torch.empty((1, 3, scaled_hw[0], scaled_hw[1]), device=p.device, dtype=torch.float32)
+        out_dtype = p.dtype if p.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32
         with torch.cuda.device(p.device):
+            src = self._stage_host_image(image_bgr, p.device)
+            out = torch.empty((1, 3, scaled_hw[0], scaled_hw[1]), device=p.device, dtype=out_dtype)
             stream = torch.cuda.current_stream(p.device).cuda_stream
             mean3, std3 = (ctypes.c_float * 3)(*self.rgb_offset), (ctypes.c_float * 3)(*self.rgb_stdev)
-            native.check(lib, lib.mdpt_prepare_image(src.data_ptr(), img_h, img_w, out.data_ptr(), scaled_hw[0], scaled_hw[1],
+            # the kernel writes the model's dtype (dtype-tagged like mdpt_forward's tensors): nothing but this launch between the copy and the forward
+            native.check(lib, lib.mdpt_prepare_image(src.data_ptr(), img_h, img_w, out.data_ptr(), native.dtype_code(out_dtype), scaled_hw[0], scaled_hw[1],
                                                      mean3, std3, interp, stream))
-        return out if p.dtype == torch.float32 else out.to(p.dtype)
+        return out if out.dtype == p.dtype else out.to(p.dtype)
+
+    def _stage_host_image(self, image_bgr: np.ndarray, device: torch.device) -> Tensor:
+        """uint8 host image -> device through a reusable PINNED staging buffer (an asynchronous copy from pageable memory is a synchronous
+        one in disguise): numpy -> pinned (host memcpy) -> device (non-blocking on the current stream). One (pinned, device) pair per
+        PatchEmbed, grown on demand; the pinned buffer is rewritten only after the previous call's copy has drained (event)."""
+        n = int(image_bgr.size)
+        stages = self.__dict__.setdefault("_host_stage", {})
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)  # per stream: the device buffer is reused in stream order
+        st = stages.get(key)
+        if st is None or st["pinned"].numel() < n:
+            if len(stages) >= 4:
+                torch.cuda.synchronize(device)
+                stages.clear()
+            st = {"pinned": torch.empty(max(n, 1 << 20), dtype=torch.uint8).pin_memory(), "dev": torch.empty(max(n, 1 << 20), dtype=torch.uint8, device=device),
+                  "event": None}
+            stages[key] = st
+        if st["event"] is not None:
+            st["event"].synchronize()
+        pinned = st["pinned"][:n]
+        pinned.view(image_bgr.shape).numpy()[...] = image_bgr  # (handles non-contiguous views: numpy does the strided copy)
+        dev = st["dev"][:n]
+        dev.copy_(pinned, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        st["event"] = ev
+        return dev
 
     def verify_input(self, image_tensor_bchw: Tensor) -> bool:
         _, c, h, w = image_tensor_bchw.shape
@@ -340,6 +368,38 @@ class MonocularDepthHead(_Stage):
         return eng.as_output(out)
 
 
+def model_precision_code(model: "DPTModel", dtype: torch.dtype) -> int:
+    """MDPT_PREC_* of a model: DPTModel.set_precision's override, else the default arithmetic of the model dtype: fp32 -> split-bf16 x3
+    (fp32 class), bf16 -> bf16 operands, fp16 -> fp16 operands (what each dtype means in the reference: demo_helpers/misc.py:61-77)."""
+    default_prec = {torch.float32: native.PREC_BF16X3, torch.bfloat16: native.PREC_BF16, torch.float16: native.PREC_FP16}
+    override = model.__dict__.get("_precision")
+    return native.PRECISIONS[override] if override else default_prec.get(dtype, native.PREC_BF16)
+
+
+def native_config(cfg: dict, family: str, precision: int) -> "native.MdptConfig":
+    """The reference's config dict (make_*_dpt keyword arguments) as the C ABI's mdpt_config (include/mdpt.h)."""
+    c = native.MdptConfig()
+    if family == "swinv2":
+        feats = [int(v) for v in cfg["features_per_stage"]]
+        c.features_per_token, c.num_heads, c.num_blocks = feats[0], int(cfg["heads_per_stage"][0]), int(sum(cfg["layers_per_stage"]))
+        for i in range(4):
+            c.reassembly_features[i] = feats[i]
+            c.swin_heads[i], c.swin_layers[i] = int(cfg["heads_per_stage"][i]), int(cfg["layers_per_stage"][i])
+            pre = cfg["pretrained_window_sizes_per_stage"][i]
+            c.swin_pretrained_window[i] = 0 if pre is None else int(pre)
+        c.swin_window_h, c.swin_window_w = (int(v) for v in cfg["window_size_hw"])
+    else:
+        c.features_per_token, c.num_heads, c.num_blocks = cfg["features_per_token"], cfg["num_heads"], cfg["num_blocks"]
+        for i in range(4):
+            c.reassembly_features[i] = int(cfg["reassembly_features_list"][i])
+    c.base_patch_grid_h, c.base_patch_grid_w = (int(v) for v in cfg["base_patch_grid_hw"])
+    c.fusion_channels, c.patch_size_px = cfg["fusion_channels"], cfg["patch_size_px"]
+    c.is_giant, c.is_metric = int(bool(cfg.get("is_giant", False))), int(bool(cfg.get("is_metric", False)))
+    c.precision = precision
+    c.family = {"v2": native.FAMILY_DAV2, "v1": native.FAMILY_DAV1, "beit": native.FAMILY_BEIT, "swinv2": native.FAMILY_SWINV2}[family]
+    return c
+
+
 class _Engine:
     """Owns the C handle, the packed-weight buffer and cached workspaces for one (device, dtype) of a DPTModel."""
 
@@ -352,32 +412,13 @@ class _Engine:
         self.device, self.dtype = device, dtype
         cfg = model.config
         self.swin = model.family == "swinv2"
-        c = native.MdptConfig()
         if self.swin:
             self.stage_features = [int(v) for v in cfg["features_per_stage"]]
             self.F, self.C, self.P, self.Pdec = self.stage_features[0], cfg["fusion_channels"], cfg["patch_size_px"], 4 * cfg["patch_size_px"]
-            c.features_per_token, c.num_heads, c.num_blocks = self.F, int(cfg["heads_per_stage"][0]), int(sum(cfg["layers_per_stage"]))
-            for i in range(4):
-                c.reassembly_features[i] = self.stage_features[i]
-                c.swin_heads[i], c.swin_layers[i] = int(cfg["heads_per_stage"][i]), int(cfg["layers_per_stage"][i])
-                pre = cfg["pretrained_window_sizes_per_stage"][i]
-                c.swin_pretrained_window[i] = 0 if pre is None else int(pre)
-            c.swin_window_h, c.swin_window_w = (int(v) for v in cfg["window_size_hw"])
         else:
             self.F, self.C, self.P = cfg["features_per_token"], cfg["fusion_channels"], cfg["patch_size_px"]
             self.Pdec = self.P
-            c.features_per_token, c.num_heads, c.num_blocks = cfg["features_per_token"], cfg["num_heads"], cfg["num_blocks"]
-            for i in range(4):
-                c.reassembly_features[i] = int(cfg["reassembly_features_list"][i])
-        c.base_patch_grid_h, c.base_patch_grid_w = (int(v) for v in cfg["base_patch_grid_hw"])
-        c.fusion_channels, c.patch_size_px = cfg["fusion_channels"], cfg["patch_size_px"]
-        c.is_giant, c.is_metric = int(bool(cfg.get("is_giant", False))), int(bool(cfg.get("is_metric", False)))
-        # default arithmetic per model dtype: fp32 -> split-bf16 x3 (fp32 class), bf16 -> bf16 operands, fp16 -> fp16 operands (what each
-        # dtype means in the reference: demo_helpers/misc.py:61-77); DPTModel.set_precision overrides it
-        default_prec = {torch.float32: native.PREC_BF16X3, torch.bfloat16: native.PREC_BF16, torch.float16: native.PREC_FP16}
-        override = model.__dict__.get("_precision")
-        c.precision = native.PRECISIONS[override] if override else default_prec.get(dtype, native.PREC_BF16)
-        c.family = {"v2": native.FAMILY_DAV2, "v1": native.FAMILY_DAV1, "beit": native.FAMILY_BEIT, "swinv2": native.FAMILY_SWINV2}[model.family]
+        c = native_config(cfg, model.family, model_precision_code(model, dtype))
         self.precision = c.precision
         handle = ctypes.c_void_p()
         native.check(self.lib, self.lib.mdpt_create(ctypes.byref(c), ctypes.byref(handle)))
@@ -393,6 +434,8 @@ class _Engine:
             native.check(self.lib, self.lib.mdpt_set_gemm_tile(self.handle, tile))
         if model.__dict__.get("_latency_mode", False):
             native.check(self.lib, self.lib.mdpt_set_latency_mode(self.handle, 1))
+        if model.config.get("enable_cache", False):  # the reference's make_*_dpt(..., enable_cache=True): per-grid constants computed once per (workspace, shape)
+            native.check(self.lib, self.lib.mdpt_set_grid_cache(self.handle, 1))
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             keep = []
@@ -634,6 +677,14 @@ class DPTModel(nn.Module):
         eng = self.__dict__.get("_engine_obj")
         if eng is not None:
             native.check(eng.lib, eng.lib.mdpt_set_latency_mode(eng.handle, int(bool(on))))
+
+    def export(self, path: str, dtype: torch.dtype | None = None) -> dict:
+        """Write the deployment artefact of this model: a `.mdpt` file (configuration incl. family, arithmetic mode and per-class passes,
+        preprocessing constants, every parameter under its reference key) that a host without PyTorch runs through the C ABI at any legal
+        image size - the native analogue of the reference's ONNX export with dynamic axes (experiments/export_onnx.py:119-148). Format and
+        readers: muggled_dpt_amd/export.py, tests/c_host/host_main.cpp, tools/mdpt_model_file.py."""
+        from .export import export_model
+        return export_model(self, path, dtype)
 
     # ---- reference API
     def forward(self, image_rgb_normalized_bchw: Tensor) -> Tensor:

@@ -36,9 +36,10 @@ def make_beit_dpt(
     enable_optimizations: bool = True,
     **unused_kwargs,
 ) -> DPTModel:
-    """Standard sizes: muggled_dpt_amd.synthetic.BEIT_CONFIGS (reference make_beit_dpt.py:86-113). `enable_cache` is accepted for
-    API compatibility: the relative-position table is re-derived per layer by a ~5 us kernel and lives in LDS during attention,
-    there is no [heads, N, N] bias tensor to cache (reference v31_beit/components/README.md:91)."""
+    """Standard sizes: muggled_dpt_amd.synthetic.BEIT_CONFIGS (reference make_beit_dpt.py:86-113). `enable_cache=True` (what the
+    reference's video demo asks for, run_video.py:144; v31_beit/components/README.md:91) keeps the relative-position tables of all blocks,
+    resized to the current grid, in the workspace between forwards of the same shape (mdpt_set_grid_cache); there is no [heads, N, N] bias
+    tensor - the tables are per-head LUTs that live in LDS during attention."""
     config = {
         "features_per_token": int(features_per_token),
         "num_heads": int(num_heads),

@@ -52,7 +52,8 @@ def make_depthanythingv2_dpt(
     vit-small/base/large numbers (reference make_depthanythingv2_dpt.py:88-122)."""
     # enable_optimizations=False: every block grows an `attn.softmax` module; forward hooks on it receive the [B, heads, N, N]
     # attention weights (dumped by mdpt_encoder_probe), like the reference's non-optimised Attention (transformer_block.py:101)
-    # enable_cache: position embeddings are recomputed per call by a ~10 us kernel; accepted for API compatibility
+    # enable_cache (reference position_encoder.py:152-227 GridCache): the resized position embedding and the zero pads of the operand planes stay in
+    # the workspace between forwards of the same shape (mdpt_set_grid_cache) instead of being recomputed by ~20 us of small launches per call
     config = {
         "features_per_token": int(features_per_token),
         "num_heads": int(num_heads),

@@ -36,9 +36,10 @@ def make_swinv2_dpt(
     enable_cache: bool = True,
     **unused_kwargs,
 ) -> DPTModel:
-    """Standard sizes: muggled_dpt_amd.synthetic.SWINV2_CONFIGS (reference make_swinv2_dpt.py:87-118). `enable_cache` is accepted
-    for API compatibility: the position-bias table is re-derived per layer by a small kernel into a per-head LUT that lives in
-    LDS during attention; no [heads, wa, wa] bias or [nW, wa, wa] mask tensor is ever materialised."""
+    """Standard sizes: muggled_dpt_amd.synthetic.SWINV2_CONFIGS (reference make_swinv2_dpt.py:87-118). `enable_cache` (default True
+    like the reference's) keeps the continuous-position-bias tables of all blocks - 16 sigmoid(MLP(log-coords)) per head, weights and
+    window geometry only - in the workspace between forwards of the same shape (mdpt_set_grid_cache: one 165 us launch per grid instead
+    of per forward); no [heads, wa, wa] bias or [nW, wa, wa] mask tensor is ever materialised."""
     config = {
         "features_per_stage": [int(v) for v in features_per_stage],
         "heads_per_stage": [int(v) for v in heads_per_stage],

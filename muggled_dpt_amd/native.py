@@ -184,7 +184,7 @@ SYMBOLS = {
     "mdpt_encoder_probe_blocks": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP4, _VP, _VP, _VP, _SZ, _VP]),
     "mdpt_fusion_block": (ctypes.c_int, [_VP, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_head": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
-    "mdpt_prepare_image": (ctypes.c_int, [_VP, _I, _I, _VP, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _I, _VP]),
+    "mdpt_prepare_image": (ctypes.c_int, [_VP, _I, _I, _VP, _I, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _I, _VP]),
     "mdpt_post_minmax": (ctypes.c_int, [_VP, _SZ, _VP, _VP, _VP]),
     "mdpt_post_scale_prediction": (ctypes.c_int, [_VP, _I, _I, _I, _VP, _I, _I, _VP, _VP, _VP]),
     "mdpt_post_normalize": (ctypes.c_int, [_VP, _SZ, _VP, _VP, _I, _I, _VP]),
@@ -200,6 +200,7 @@ SYMBOLS = {
     "mdpt_debug_set_stop": (ctypes.c_int, [_VP, _I, _I]),
     "mdpt_debug_set_ksplit_min": (ctypes.c_int, [_VP, _I, _I]),
     "mdpt_debug_set_operand_format": (ctypes.c_int, [_I]),
+    "mdpt_set_grid_cache": (ctypes.c_int, [_VP, _I]),
     "mdpt_set_class_passes": (ctypes.c_int, [_VP, _I, _I]),
     "mdpt_get_class_passes": (ctypes.c_int, [_VP, _I, ctypes.POINTER(_I)]),
     "mdpt_default_mixed_passes": (None, [ctypes.POINTER(_I)]),

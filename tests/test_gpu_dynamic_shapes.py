@@ -109,3 +109,45 @@ def test_in_place_parameter_edits_are_picked_up():
     w2["head.proj_1ch.2.bias"] = w["head.proj_1ch.2.bias"] + 0.25
     assert not torch.equal(y0, y1) and rel_err(y1.cpu(), dpt_oracle.forward(w2, cfg, x)) <= REL_TOL_X3
     assert model._get_engine() is model._get_engine(), "no edit, no re-pack"
+
+
+@pytest.mark.parametrize("family", ["v2", "beit", "swinv2"])
+def test_enable_cache_keeps_per_grid_constants_between_forwards_and_changes_no_bit(family):
+    """The reference's enable_cache (position_encoder.py:152-227 GridCache; run_video.py:144): with it the resized position embedding / BEiT's
+    relative-position tables / SwinV2's position-bias tables and the zero pads are computed by the first forward of a (workspace, shape) and reused.
+    Same bits as the uncached model on repeated calls, across a shape change and back, after an in-place weight edit (re-finalise), with the
+    two-stream batch split (batch 8) and through stage-level calls in between (they drop the cached state)."""
+    import muggled_dpt_amd as m
+    from muggled_dpt_amd.synthetic import make_synthetic_beit_state_dict, make_synthetic_original_state_dict, make_synthetic_swinv2_state_dict
+    if family == "beit":
+        make, osd, sizes = m.make_beit_dpt_from_midas_v31_state_dict, make_synthetic_beit_state_dict("beit_tiny", 0), [(64, 96), (96, 64)]
+    elif family == "swinv2":
+        make, osd, sizes = m.make_swinv2_dpt_from_midas_v31_state_dict, make_synthetic_swinv2_state_dict("swin2_tiny", 0), [(128, 192), (256, 128)]
+    else:
+        make, osd, sizes = m.make_depthanythingv2_dpt_from_original_state_dict, make_synthetic_original_state_dict("tiny", 0), [(56, 84), (112, 56)]
+    cfg_c, cached = make(osd, True)
+    _, plain = make(osd, False)
+    assert cfg_c["enable_cache"] is True
+    for dtype in (torch.bfloat16, torch.float32):
+        cached, plain = cached.to("cuda", dtype), plain.to("cuda", dtype)
+        from muggled_dpt_amd import native
+        lib = native.load()
+        xs = {hw: torch.randn(2, 3, *hw, generator=torch.Generator().manual_seed(hw[0])).to("cuda", dtype) for hw in sizes}
+        x8 = torch.randn(8, 3, *sizes[0], generator=torch.Generator().manual_seed(5)).to("cuda", dtype)
+        want = {hw: plain(x) for hw, x in xs.items()}
+        want8 = plain(x8)
+        for hw in (sizes[0], sizes[0], sizes[1], sizes[0], sizes[1], sizes[1]):
+            assert torch.equal(cached(xs[hw]), want[hw]), f"{family} {dtype} {hw}"
+        for _ in range(3):
+            assert torch.equal(cached(x8), want8)  # two half-batch plans, two cached slots
+        tokens, grid = cached.patch_embed(xs[sizes[1]])  # a stage-level call writes the constant regions for another grid
+        assert torch.equal(cached(xs[sizes[0]]), want[sizes[0]])
+        with torch.no_grad():
+            for mdl in (cached, plain):
+                next(p for n, p in mdl.named_parameters() if "posenc" in n or "relpos" in n or "bias_mlp" in n).mul_(1.5)
+        y = plain(xs[sizes[0]])
+        assert not torch.equal(y, want[sizes[0]])
+        assert torch.equal(cached(xs[sizes[0]]), y) and torch.equal(cached(xs[sizes[0]]), y)
+        with torch.no_grad():
+            for mdl in (cached, plain):
+                next(p for n, p in mdl.named_parameters() if "posenc" in n or "relpos" in n or "bias_mlp" in n).div_(1.5)

@@ -237,6 +237,28 @@ def test_prepare_image_kernel_vs_golden(golden_dir):
         np.testing.assert_allclose(stats(out.cpu()), g[f"{name}_stats"], rtol=2e-5, atol=2e-4)
 
 
+def test_prepare_image_writes_the_model_dtype_and_reuses_its_pinned_staging_buffer():
+    """mdpt_prepare_image's output is dtype-tagged - a bf16 / fp16 model gets its image from the kernel itself (the fp32
+    result rounded ONCE, no cast kernel), the uint8 host image travels through a reusable pinned buffer, and back-to-back calls with
+    different images do not overwrite an image whose copy is still in flight."""
+    rng = np.random.default_rng(3)
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in ((518, 518), (300, 411), (518, 518))]
+    model, _, _ = _model("tiny", torch.float32)
+    want = [model.prepare_image_bgr(im, 140) for im in imgs]
+    for dtype in (torch.bfloat16, torch.float16):
+        m16, _, _ = _model("tiny", dtype)
+        outs = [m16.prepare_image_bgr(im, 140) for im in imgs]  # queued back to back: no host synchronisation in between
+        torch.cuda.synchronize()
+        for o, w32 in zip(outs, want):
+            assert o.dtype == dtype and o.shape == w32.shape
+            assert torch.equal(o, w32.to(dtype)), "the 16-bit image must be the fp32 image rounded once"
+        stage = m16.patch_embed.__dict__["_host_stage"]
+        assert len(stage) == 1 and next(iter(stage.values()))["pinned"].is_pinned()
+        # a non-contiguous view (cv2 crops) takes the same path
+        crop = imgs[0][10:400, 20:300]
+        assert torch.equal(m16.prepare_image_bgr(crop, 140), model.prepare_image_bgr(np.ascontiguousarray(crop), 140).to(dtype))
+
+
 @pytest.mark.parametrize("dtype,tol", MODES_TOY)
 def test_depth_anything_v1_family(golden_dir, dtype, tol):
     """§8(f) row 3: Depth-Anything V1 (taps after the last four blocks) through make_dpt_from_state_dict's v1 route."""
