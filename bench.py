@@ -184,7 +184,8 @@ def profile_pass(lib, fn, steps):
 PRECISION_DTYPE = {"bf16": "bf16", "bf16x3": "bf16x3 (hi/lo split bf16 MFMA operands, 3 passes, fp32 accumulate)",
                    "fp16": "fp16 (fp16 MFMA operands, single pass, fp32 accumulate)",
                    "fp16x3": "fp16x3 (hi/lo split fp16 MFMA operands, 3 passes, fp32 accumulate)",
-                   "mixed": "mixed (fp16 MFMA operands; patch embed + decoder convs 3 passes, encoder 1 pass + token-mean compensation; fp32 accumulate)"}
+                   "mixed": "mixed (fp16 MFMA operands; patch embed, reassembly and 1x1 fusion projections 3 passes, fusion 3x3 convs and both head convs 2 passes "
+                            "(activations split; 3 for the MiDaS families), encoder 1 pass + token-mean compensation; fp32 accumulate)"}
 
 
 def model_for_precision(name: str, precision: str, dev):
@@ -278,7 +279,7 @@ def secondary_legs(args, dev, lib, vitl_model):
     >= 10 timed steps, the roofline of ITS dominant GEMM kernel (HIP events, split off) and the error against the CPU oracle on
     image 0 where that oracle run takes about ten seconds or less. Same JSON fields as `bench.py --model ... --size ...`."""
     out = {}
-    legs = [("vits_504_b1", "vits", 504, 1, True), ("vitl_504_b1", "vitl", 504, 1, False), ("vitl_1036_b8", "vitl", 1036, 8, False),
+    legs = [("vits_504_b1", "vits", 504, 1, True), ("vitl_504_b1", "vitl", 504, 1, False), ("vitl_1036_b8", "vitl", 1036, 8, True),
             ("beitl_384_b16", "beitl", 384, 16, True), ("swinl_384_b16", "swinl", 384, 16, True)]
     for key, name, size, batch, want_err in legs:
         t_leg = time.perf_counter()
@@ -286,6 +287,8 @@ def secondary_legs(args, dev, lib, vitl_model):
             sub = argparse.Namespace(**{**vars(args), "model": name, "size": size, "batch": batch})
             if name == "vitl":
                 model, ow = vitl_model, None
+                if want_err:  # (the oracle's weights: the same seeded checkpoint converted for the CPU restatement)
+                    _, ow = make_model_and_weights(name, want_weights=True)
             else:
                 model, ow = make_model_and_weights(name, want_weights=want_err)
                 model = model.to(dev, torch.bfloat16)
@@ -320,21 +323,26 @@ def secondary_legs(args, dev, lib, vitl_model):
                                        "latency_mode": inf_l}
             if want_err and ow is not None:
                 from oracle import dpt_oracle
+                torch.set_num_threads(max(1, min(32, (os.cpu_count() or 2) // 2)))
                 ref = dpt_oracle.forward(ow[1], ow[0], x_cpu[:1])
                 rec["error_vs_cpu_fp32"] = error_vs(ref, y.float())
             else:
                 rec["error_vs_cpu_fp32"] = None
-            if name in SYNTH_NAME and want_err and ow is not None:
+            if (name in SYNTH_NAME or size == 1036) and want_err and ow is not None:
                 # BASELINE configs[4] in the mixed-pass mode too (fp32 tensors at the boundary; SwinV2's window-major encoder runs it
                 # without the token-mean compensation)
-                del model  # (a float32 model built afresh: casting the bf16 model back would keep its bf16-rounded parameters)
+                if name != "vitl":
+                    del model  # (a float32 model built afresh: casting the bf16 model back would keep its bf16-rounded parameters)
                 torch.cuda.empty_cache()
                 model, _ = make_model_and_weights(name)
                 m32 = model.to(dev, torch.float32)
                 m32.set_precision("mixed")
                 dt_m, y_m = time_model(m32, x_cpu.to(dev), steps)
                 rec["mixed_mode"] = {"value": round(batch / dt_m, 3), "ms_per_step": round(dt_m * 1e3, 3), "error_vs_cpu_fp32": error_vs(ref, y_m.float())}
-                del y_m
+                del y_m, m32
+                if name == "vitl":
+                    del model
+                    model = vitl_model
             rec["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
             out[key] = rec
             if name != "vitl":

@@ -46,73 +46,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     ln_row<NV>(x + (size_t)row * F, gamma, beta, out_hi, out_lo, out_f32, (size_t)row * F, F, lane);  // ln_row.h: shared with gemm.hip
 }
 
-// LayerNorm + the token sums of its OUTPUT in one launch (token-mean compensation of the weight rounding, mdpt_stages.cpp wrc_bias: the
-// single-pass QKV / fc1 GEMM behind this LayerNorm wants mean_t(A_r[b, t, :]) over every step-th token of image b, A_r = the rounded
-// operand plane written here). The first nimg * LNM_PARTS workgroups of the grid are "sum" workgroups: part p of image b re-normalises the
-// image's sampled rows j = 4 p + wave (mod 4 LNM_PARTS) with the same ln_row arithmetic (the same bits the row's own wave stores; the next
-// row's loads are in flight while the current one is reduced), sums the ROUNDED values column-wise in registers (wave order, then wave
-// 0 + 1 + 2 + 3 through LDS) and writes the fp32 partial sums part[b][p][F]; wrc_table_kernel adds the parts in the order 0, 1, ... and
-// scales. They are dispatched first and finish inside the LayerNorm's own duration: the stand-alone colmean launch (~9 us of dependent
-// launch latency per GEMM, 48 per forward) disappears. An image's sums depend on its own rows only.
-constexpr int LNM_PARTS = 4;
-
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_mean_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             op_t* out_hi, op_t* out_lo, float* out_f32, int rows, int F, int nimg, int rows_per_img,
-                                                             int nreal, int step, float* __restrict__ part) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if ((int)blockIdx.x >= nimg * LNM_PARTS) {
-        const int row = ((int)blockIdx.x - nimg * LNM_PARTS) * 4 + wave;
-        if (row >= rows) return;
-        ln_row<NV>(x + (size_t)row * F, gamma, beta, out_hi, out_lo, out_f32, (size_t)row * F, F, lane);
-        return;
-    }
-    __shared__ float red[3][NV * 256];
-    const int b = (int)blockIdx.x / LNM_PARTS, pt = (int)blockIdx.x % LNM_PARTS, nsamp = (nreal + step - 1) / step;
-    const float* xb = x + (size_t)b * rows_per_img * F;
-    ln_f32x4 acc[NV], nxt[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = nxt[i] = ln_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    auto fetch = [&](int j) {
-        const float* xr = xb + (size_t)j * step * F;
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if ((i * 64 + lane) * 4 < F) nxt[i] = *(const ln_f32x4*)(xr + (i * 64 + lane) * 4);
-    };
-    int j = pt * 4 + wave;
-    if (j < nsamp) fetch(j);
-    for (; j < nsamp; j += 4 * LNM_PARTS) {
-        ln_f32x4 cur[NV], y[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
-        if (j + 4 * LNM_PARTS < nsamp) fetch(j + 4 * LNM_PARTS);
-        ln_row_values<NV>([&](int, int i) { return cur[i]; }, gamma, beta, F, lane, y);
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if ((i * 64 + lane) * 4 < F) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][e] += (float)to_op(y[i][e]);
-            }
-    }
-    if (wave > 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) *(ln_f32x4*)&red[wave - 1][(i * 64 + lane) * 4] = acc[i];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (i * 64 + lane) * 4;
-            if (c < F) {
-                ln_f32x4 t = acc[i];
-#pragma unroll
-                for (int w = 0; w < 3; ++w) t += *(const ln_f32x4*)&red[w][c];
-                *(ln_f32x4*)(part + ((size_t)b * LNM_PARTS + pt) * F + c) = t;
-            }
-        }
-    }
-}
-
 // The same behind a K-split GEMM (GemmParams::ksplit, latency mode): the row is x + part[0] + part[1] + ... (the partial sums of the K
 // ranges 1 .. npart, added in that order), written back to x and normalised - the reduction of the split costs no launch of its own.
 template <int NV>
@@ -387,9 +320,42 @@ __global__ __launch_bounds__(256) void upsample_tiled_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------------
 // one-time weight repack: fp32 PyTorch layouts -> bf16 hi(/lo) [Np][Kp], zero padded
 // ---------------------------------------------------------------------------------------------------
+// Power-of-two scale of a layer-scale-folded matrix (fp16 build; GemmParams::wscale): gamma_n * W[n][k] of a real checkpoint can sit anywhere
+// below fp16's normal range (gamma ~1e-2 ... 1e-5), where the hi plane loses bits and the lo plane - fp(v - hi), 2^-12 of the entry - is a
+// handful of subnormal quanta: the three-pass modes and the token-mean compensation (which reads W_lo) would silently degrade.
+// s = 2^e puts the matrix's largest |gamma_n W[n][k]| in [2^13, 2^14): entries down to 2^-16 of the largest keep a normal lo plane, and the
+// GEMM undoes the factor exactly (accumulators start at resid * s, epilogue multiplies by 1 / s). One workgroup, at finalize time only.
+__global__ __launch_bounds__(1024) void weight_scale_kernel(const void* __restrict__ src, int sdt, int N, int K, int src_ld, int src_col0,
+                                                            const void* __restrict__ row_scale, int rdt, float* __restrict__ scale2) {
+    __shared__ float red[1024];
+    float mx = 0.0f;
+    const size_t total = (size_t)N * K;
+    for (size_t idx = threadIdx.x; idx < total; idx += 1024) {
+        const int n = (int)(idx / K), k = (int)(idx - (size_t)n * K);
+        float v = ld_typed(src, (size_t)n * src_ld + src_col0 + k, sdt);
+        if (row_scale) v *= ld_typed(row_scale, n, rdt);
+        v = fabsf(v);
+        if (v == v && v <= 3.0e38f) mx = fmaxf(mx, v);  // (NaN / inf entries do not steer the scale: they propagate as they are)
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int x = 0;
+        int e = 0;
+        if (red[0] > 0.0f) { (void)frexpf(red[0], &x); e = 14 - x; }  // red[0] = m * 2^x, m in [0.5, 1)
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        scale2[0] = ldexpf(1.0f, e);
+        scale2[1] = ldexpf(1.0f, -e);
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_weight_kernel(const void* __restrict__ src, int sdt, op_t* dst_hi, op_t* dst_lo, int kind,
                                                           int N, int K, int Np, int Kp, int ksz, int src_ld, int src_col0,
-                                                          const void* __restrict__ row_scale, int rdt) {
+                                                          const void* __restrict__ row_scale, int rdt, const float* __restrict__ wscale) {
     const size_t total = (size_t)Np * Kp;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int kcol = (int)(idx % Kp);
@@ -398,6 +364,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const void* __restrict
         if (kind == MDPT_PACK_LINEAR) {
             if (nrow < N && kcol < K) v = ld_typed(src, (size_t)nrow * src_ld + src_col0 + kcol, sdt);
             if (row_scale && nrow < N) v *= ld_typed(row_scale, nrow, rdt);
+            if (wscale) v *= wscale[0];  // power of two: exact (weight_scale_kernel)
         } else if (kind == MDPT_PACK_CONV3) {
             // src [N=Cout][K=Cin][3][3]; Kp = 9*Cinp (Cinp % 64 == 0); kcol = (cb * 9 + tap) * 64 + c with ci = cb * 64 + c: the nine taps of
             // a 64-channel block are consecutive K tiles (the halo-staged conv kernel stages a block's input patch once for all of them)
@@ -729,11 +696,9 @@ __global__ __launch_bounds__(256) void colmean_kernel(const op_t* __restrict__ A
 // per pass) and latency-bound, so it gets its own kernel instead of a 64x64 GEMM tile per 64 columns: one workgroup = 16 columns of the
 // table, its four waves take a quarter of K each (v_mfma_f32_16x16x32: both operands are K-contiguous rows, a lane's fragment is one
 // 16-byte global load, no LDS staging), the four partial sums are added in a fixed order. A row of the table depends on its own image only.
-// PARTS > 0: the means come as PARTS fp32 partial SUMS per image (layernorm_mean_kernel: part[b][p][K]), added here in the order p = 0, 1, ... and
-// scaled by inv_n = 1 / (number of sampled rows) before the rounding to the operand format - instead of a ready operand-format mean row.
-template <int PARTS>
-__global__ __launch_bounds__(256) void wrc_table_kernel(const op_t* __restrict__ mean, const float* __restrict__ mean_part, float inv_n, const op_t* __restrict__ w_lo,
-                                                        const float* __restrict__ bias, float* __restrict__ out, int B, int N, int K) {
+// wscale: the lo plane carries the power-of-two factor of its matrix (weight_scale_kernel): the product is multiplied by 1 / s before the bias is added.
+__global__ __launch_bounds__(256) void wrc_table_kernel(const op_t* __restrict__ mean, const op_t* __restrict__ w_lo, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int B, int N, int K, const float* __restrict__ wscale) {
     __shared__ float part[4][2][16][16];  // [wave][image block][image][column]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
     const int n = blockIdx.x * 16 + l15;
@@ -744,21 +709,11 @@ __global__ __launch_bounds__(256) void wrc_table_kernel(const op_t* __restrict__
         const int r0 = b0 + l15 < B ? b0 + l15 : B - 1, r1 = b0 + 16 + l15 < B ? b0 + 16 + l15 : B - 1;
         const op_t* a0 = mean + (size_t)r0 * K + kq * 8;
         const op_t* a1 = mean + (size_t)r1 * K + kq * 8;
-        auto from_parts = [&](int r, int k) -> opx8 {  // 8 consecutive columns of image r's mean row out of the partial sums
-            const float* pp = mean_part + (size_t)r * PARTS * K + kq * 8 + k;
-            f32x4 lo4 = *(const f32x4*)pp, hi4 = *(const f32x4*)(pp + 4);
-#pragma unroll
-            for (int q = 1; q < (PARTS > 0 ? PARTS : 1); ++q) { lo4 += *(const f32x4*)(pp + (size_t)q * K); hi4 += *(const f32x4*)(pp + (size_t)q * K + 4); }
-            opx8 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = to_op(lo4[e] * inv_n); v[e + 4] = to_op(hi4[e] * inv_n); }
-            return v;
-        };
         f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 4
         for (int k = k_lo; k < k_hi; k += 32) {
             const opx8 w = *(const opx8*)(wrow + k);
-            const opx8 x0 = PARTS > 0 ? from_parts(r0, k) : *(const opx8*)(a0 + k), x1 = PARTS > 0 ? from_parts(r1, k) : *(const opx8*)(a1 + k);
+            const opx8 x0 = *(const opx8*)(a0 + k), x1 = *(const opx8*)(a1 + k);
             acc0 = MDPT_MFMA_16x16x32(x0, w, acc0, 0, 0, 0);
             acc1 = MDPT_MFMA_16x16x32(x1, w, acc1, 0, 0, 0);
         }
@@ -773,7 +728,7 @@ __global__ __launch_bounds__(256) void wrc_table_kernel(const op_t* __restrict__
             const int blk = item >> 8, img = (item >> 4) & 15, col = item & 15;
             const int ob = b0 + blk * 16 + img, on = blockIdx.x * 16 + col;
             if (ob < B && on < N)
-                out[(size_t)ob * N + on] = (((part[0][blk][img][col] + part[1][blk][img][col]) + part[2][blk][img][col]) + part[3][blk][img][col]) +
+                out[(size_t)ob * N + on] = (((part[0][blk][img][col] + part[1][blk][img][col]) + part[2][blk][img][col]) + part[3][blk][img][col]) * (wscale ? wscale[1] : 1.0f) +
                                            (bias ? bias[on] : 0.0f);
         }
     }
@@ -795,23 +750,6 @@ int MDPT_FN(mdpt_launch_layernorm)(const float* x, const float* gamma, const flo
     MdptProfScope prof("layernorm_kernel", 0.0, stream);
     const dim3 grid((rows + 3) / 4), block(256);
 #define LN_CASE(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, stream, x, gamma, beta, out_hi, out_lo, out_f32, rows, F)
-    if (F <= 256) LN_CASE(1);
-    else if (F <= 512) LN_CASE(2);
-    else if (F <= 1024) LN_CASE(4);
-    else if (F <= 1536) LN_CASE(6);
-    else LN_CASE(8);
-#undef LN_CASE
-    LAUNCH_RET();
-}
-
-int MDPT_FN(mdpt_layernorm_mean_parts)() { return LNM_PARTS; }
-
-int MDPT_FN(mdpt_launch_layernorm_mean)(const float* x, const float* gamma, const float* beta, op_t* out_hi, op_t* out_lo, float* out_f32, int rows, int F,
-                                       int nimg, int rows_per_img, int nreal, int step, float* part, hipStream_t stream) {
-    if ((F & 3) || F > 64 * 4 * LN_MAXV || !part || nimg <= 0 || nreal <= 0 || nreal > rows_per_img || step <= 0 || (long)nimg * rows_per_img > rows) return (int)hipErrorInvalidValue;
-    MdptProfScope prof("layernorm_mean_kernel", 0.0, stream);
-    const dim3 grid(nimg * LNM_PARTS + (rows + 3) / 4), block(256);
-#define LN_CASE(NV) hipLaunchKernelGGL(layernorm_mean_kernel<NV>, grid, block, 0, stream, x, gamma, beta, out_hi, out_lo, out_f32, rows, F, nimg, rows_per_img, nreal, step, part)
     if (F <= 256) LN_CASE(1);
     else if (F <= 512) LN_CASE(2);
     else if (F <= 1024) LN_CASE(4);
@@ -853,11 +791,10 @@ int MDPT_FN(mdpt_launch_colmean)(const op_t* A, int lda, int B, int rows_per_img
     LAUNCH_RET();
 }
 
-int MDPT_FN(mdpt_launch_wrc_table)(const op_t* mean, const float* mean_part, int nsamp, const op_t* w_lo, const float* bias, float* out, int B, int N, int K, hipStream_t stream) {
-    if (B <= 0 || N <= 0 || K <= 0 || (K & 31) || (!mean && !mean_part) || (mean_part && nsamp <= 0)) return (int)hipErrorInvalidValue;
+int MDPT_FN(mdpt_launch_wrc_table)(const op_t* mean, const op_t* w_lo, const float* bias, float* out, int B, int N, int K, hipStream_t stream, const float* wscale) {
+    if (B <= 0 || N <= 0 || K <= 0 || (K & 31)) return (int)hipErrorInvalidValue;
     MdptProfScope prof("wrc_table_kernel", 2.0 * B * N * K, stream);
-    if (mean_part) hipLaunchKernelGGL(wrc_table_kernel<LNM_PARTS>, dim3((N + 15) / 16), dim3(256), 0, stream, nullptr, mean_part, 1.0f / (float)nsamp, w_lo, bias, out, B, N, K);
-    else hipLaunchKernelGGL(wrc_table_kernel<0>, dim3((N + 15) / 16), dim3(256), 0, stream, mean, nullptr, 0.0f, w_lo, bias, out, B, N, K);
+    hipLaunchKernelGGL(wrc_table_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, mean, w_lo, bias, out, B, N, K, wscale);
     LAUNCH_RET();
 }
 
@@ -961,9 +898,16 @@ int MDPT_FN(mdpt_launch_upsample_bf16)(const op_t* in, op_t* out, int B, int Hi,
 }
 
 int MDPT_FN(mdpt_launch_pack_weight)(const void* src, int src_dtype, op_t* dst_hi, op_t* dst_lo, int kind, int N, int K, int Np, int Kp, int ksz,
-                            hipStream_t stream, int src_ld, int src_col0, const void* row_scale, int scale_dtype) {
+                            hipStream_t stream, int src_ld, int src_col0, const void* row_scale, int scale_dtype, const float* wscale) {
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)Np * Kp)), dim3(256), 0, stream, src, src_dtype, dst_hi, dst_lo, kind, N, K, Np, Kp,
-                       ksz, src_ld > 0 ? src_ld : K, src_col0, kind == MDPT_PACK_LINEAR ? row_scale : nullptr, scale_dtype);
+                       ksz, src_ld > 0 ? src_ld : K, src_col0, kind == MDPT_PACK_LINEAR ? row_scale : nullptr, scale_dtype, kind == MDPT_PACK_LINEAR ? wscale : nullptr);
+    LAUNCH_RET();
+}
+
+int MDPT_FN(mdpt_launch_weight_scale)(const void* src, int src_dtype, int N, int K, int src_ld, int src_col0, const void* row_scale, int scale_dtype, float* scale2,
+                                     hipStream_t stream) {
+    if (!src || !scale2 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1024), 0, stream, src, src_dtype, N, K, src_ld > 0 ? src_ld : K, src_col0, row_scale, scale_dtype, scale2);
     LAUNCH_RET();
 }
 

@@ -17,7 +17,7 @@ __device__ __forceinline__ float ln_wave_sum(float v) {
 
 // `load(c)` returns the four row values at columns c .. c+3 (a plain row read, or the row plus pending partial sums: layernorm_addp_kernel).
 // ln_row_values: the normalised row y = (x - mean) * rstd * gamma + beta, in registers - the ONE definition of the row arithmetic; ln_row_from
-// stores it (operand planes and / or fp32), layernorm_mean_kernel also sums its rounded values column-wise (token-mean compensation).
+// stores it (operand planes and / or fp32); a round-5 experiment also summed its rounded values column-wise inside the LayerNorm launch (not kept).
 template <int NV, class Load>
 __device__ __forceinline__ void ln_row_values(Load load, const float* __restrict__ gamma, const float* __restrict__ beta, int F, int lane,
                                               ln_f32x4 (&y)[NV]) {

@@ -219,8 +219,14 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
         }
         const WeightSpec& sp = h->specs[h->spec_index.at(src_name)];
         const WeightSpec* rs = m.row_scale.empty() ? nullptr : &h->specs[h->spec_index.at(m.row_scale)];
+        m.wscale = nullptr;
+        if (m.off_scale != SIZE_MAX) {
+            float* sc = (float*)(base + m.off_scale);
+            CHK(OPLH(mdpt_launch_weight_scale, sp.ptr, sp.dtype, m.N, m.K, src_ld, src_col0, rs ? rs->ptr : nullptr, rs ? rs->dtype : 0, sc, st));
+            m.wscale = sc;
+        }
         CHK(OPLH(mdpt_launch_pack_weight, sp.ptr, sp.dtype, m.hi, m.lo, m.kind, m.N, m.K, m.Np, m.Kp, m.ksz, st, src_ld, src_col0, rs ? rs->ptr : nullptr,
-                                    rs ? rs->dtype : 0));
+                                    rs ? rs->dtype : 0, m.wscale));
     }
     for (Vec& v : h->vecs) {
         v.ptr = (float*)(base + v.off);

@@ -48,7 +48,6 @@ extern "C" {
 #define mdpt_head_tail_supported mdpt_head_tail_supported_bf16
 #define mdpt_head_tail_scale_ok mdpt_head_tail_scale_ok_bf16
 #define mdpt_beit_relpos_elen mdpt_beit_relpos_elen_bf16
-#define mdpt_layernorm_mean_parts mdpt_layernorm_mean_parts_bf16
 
 namespace mdpt {
 
@@ -99,6 +98,8 @@ struct Mat {  // packed operand panel [Np][Kp]
     size_t off_hi, off_lo;
     op_t* hi;
     op_t* lo;
+    size_t off_scale;      // fp16 handles, layer-scale-folded matrices: 2 floats {s, 1 / s} in the packed buffer (SIZE_MAX = none), GemmParams::wscale
+    const float* wscale;
 };
 
 struct Vec {  // packed fp32 vector (zero padded)
@@ -131,7 +132,6 @@ struct Plan {
     size_t scratch_floats;
     size_t tokr[2], cbuf, relpos_lut, relpos_tq, relpos_tk;  // BEiT: readout-projected tokens, per-image cls term, bias LUT
     size_t wrc_mean, wrc_tab;                                 // [B, wrc_maxk] operand-format column means, fp32 [B, wrc_maxn] per-image bias table
-    size_t wrc_part;                                          // fp32 [B, parts, F] partial column sums of a LayerNorm's output (mdpt_launch_layernorm_mean)
     size_t swi;                                               // ViT-G: fp32 [rows, 2*hidden] output of the doubled inner linear
     size_t kspart;                                            // small batches: 3 x fp32 [rows, F] partial sums of the K-split proj / fc2 (latency mode), else absent
     // SwinV2: stage-0 patch grid, per-stage residual streams (fp32, = the taps), shared GEMM fp32 output, token planes,
@@ -226,6 +226,7 @@ struct mdpt_handle {
         if (x3c(m.cls) || wrc(m.cls)) {  // (a compensated single-pass class keeps the lo plane as the weight residue fp(W - fp(W)))
             if (wrc(m.cls)) { if (Np > wrc_maxn) wrc_maxn = Np; if (Kp > wrc_maxk) wrc_maxk = Kp; } m.off_lo = packed_total; packed_total += rup256((size_t)Np * Kp * 2); }
         m.hi = m.lo = nullptr;
+        m.off_scale = SIZE_MAX; m.wscale = nullptr;
         mat_index[src] = (int)mats.size();
         mats.push_back(m);
     }
@@ -294,8 +295,7 @@ GemmParams base_params(const Ctx& c, const Mat& w, Planes a, int M, int lda);
 void as_conv(GemmParams& g, int Hi, int Wi, int Cin, int Ho, int Wo, int stride);
 int run_pos(const Ctx& c);
 int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype);
-int wrc_step(int nreal);
-int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias, int rows_per_img = 0, int nreal = 0, bool have_mean = false);
+int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias, int rows_per_img = 0, int nreal = 0);
 bool fc2_ksplit_fits(int rows, int F);  // batch small enough for the K-split form of fc2 (the 64x64 tile's range): the plan then holds kspart
 int run_encoder(const Ctx& c, void* const taps_f32[4]);
 int run_reassemble(const Ctx& c);

@@ -129,6 +129,12 @@ int build_inventory(mdpt_handle* h) {
             const std::string fc2 = sh ? p + ".mlp.outer_linear" : p + ".mlp.layers.2";
             h->mats[h->mat_index.at(p + ".attn.proj.weight")].row_scale = p + ".scale_attn";
             h->mats[h->mat_index.at(fc2 + ".weight")].row_scale = p + ".scale_mlp";
+            if (h->f16)  // fp16 operands: a power-of-two factor keeps gamma * W (and its lo plane) in fp16's normal range (GemmParams::wscale)
+                for (const std::string& mn : {p + ".attn.proj.weight", fc2 + ".weight"}) {
+                    Mat& mm = h->mats[h->mat_index.at(mn)];
+                    mm.off_scale = h->packed_total;
+                    h->packed_total += 256;
+                }
             h->add_vec(p + ".attn.proj.bias@ls", F, F);
             h->vecs.back().scale = p + ".scale_attn";
             h->add_vec(fc2 + ".bias@ls", F, F);
@@ -279,7 +285,6 @@ int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
     p.kspart = fc2_ksplit_fits((int)rows, F) ? bump.take(rows * F * 4 * 3) : SIZE_MAX;  // three partial-sum planes (a split in four); reserved whatever the latency switch says: it may flip later
     p.wrc_mean = h->wrc_maxk ? bump.take((size_t)B * h->wrc_maxk * 2) : SIZE_MAX;
     p.wrc_tab = h->wrc_maxn ? bump.take((size_t)B * h->wrc_maxn * 4) : SIZE_MAX;
-    p.wrc_part = h->wrc_maxk ? bump.take((size_t)B * mdpt_layernorm_mean_parts() * F * 4) : SIZE_MAX;
     const bool x3 = h->alo(CLS_REASM);
     for (int i = 0; i < 4; ++i) take_planes(bump, x3, rows * F, p.tap[i]);
     p.tapf32 = bump.take(rows * F * 4);

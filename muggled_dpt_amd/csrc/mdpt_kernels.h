@@ -44,6 +44,9 @@ struct GemmParams {
     float* out_f32; op_t* out_hi; op_t* out_lo; int ldc;
     int relu_bf16;                            // apply ReLU to the bf16 planes only (fp32 copy stays raw)
     int acc_init;                             // 1: accumulators start at resid[m,n] (resid == out_f32, gamma folded into W / bias): out = (resid + A W^T) + bias
+    const float* wscale;                      // fp16 build, generic epilogue: device {s, 1 / s}, s a power of two the packed weight planes were multiplied by (the
+                                              // layer-scale-folded matrices, mdpt_launch_weight_scale): accumulators start at resid * s, v = acc * (1 / s) (+ bias ...)
+                                              // - exact rescalings, so the planes' lo halves stay out of fp16's subnormal range whatever gamma is. null = 1
     // E_QKV: scatter to head-major Q (pre-scaled), K and transposed V
     op_t* q_hi; op_t* q_lo; op_t* k_hi; op_t* k_lo; op_t* vt_hi; op_t* vt_lo;
     int F, heads, npad, npadv; float qscale;

@@ -11,6 +11,7 @@ GemmParams base_params(const Ctx& c, const Mat& w, Planes a, int M, int lda) {
     g.npass = c.h->np[w.cls];  // the class of the weight matrix decides; an A buffer shared with a 3-pass class may carry an unused lo plane
     g.A_hi = a.hi; g.A_lo = g.npass >= 2 ? a.lo : nullptr;
     g.W_hi = w.hi; g.W_lo = g.npass == 3 ? w.lo : nullptr;
+    g.wscale = w.wscale;
     g.M = M; g.N = w.Np; g.K = w.Kp; g.lda = lda;
     g.zero_page = c.h->zero_page;
     g.amode = MDPT_A_DENSE; g.ekind = MDPT_E_GENERIC; g.tile = c.h->gemm_tile;
@@ -57,21 +58,21 @@ int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype) {
 // the pack kernel already produces for the 3-pass modes) - build the table bias_img[b][n] = bias[n] + sum_k mean_t(A_r[b,t,k]) W_lo[n][k],
 // and the big GEMM's epilogue adds row (m / npad) of it instead of the bias vector. Measured on ViT-L
 // (tests/precision_budget/, profiles/r04_precision_budget.md): QKV error -90 %, proj -50 %, fc1 / fc2 -35 ... 40 %, for ~2 % of the step.
-// every step-th token estimates the shared component as well as all of them (tests/precision_budget/); the step depends on the token
-// count only, so an image's table does not depend on the batch it is part of
-int wrc_step(int nreal) { return nreal >= 1024 ? 8 : (nreal >= 256 ? 4 : 1); }
-
-// have_mean: the LayerNorm that produced the A operand already wrote the means (mdpt_launch_layernorm_mean)
-int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias, int rows_per_img, int nreal, bool have_mean) {  // (0, 0: the ViT families' padded token rows)
+// Measured and not kept (round 5, profiles/r05_kernel_share_mixed_lnsum.txt): the column sums of a LayerNorm's output taken inside the LayerNorm
+// launch (extra workgroups re-normalising the sampled rows) instead of mdpt_launch_colmean - the LayerNorm grew by 15 us and the table kernel,
+// reading fp32 partial sums, by 8 us against the 9 us launch it saved.
+int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias, int rows_per_img, int nreal) {  // (0, 0: the ViT families' padded token rows)
     const mdpt_handle* h = c.h;
     if (!h->wrc(w.cls) || !w.lo) return 0;
     const Plan& p = c.p;
     if (rows_per_img <= 0) { rows_per_img = p.npad; nreal = p.N; }
     op_t* mean = c.at<op_t>(p.wrc_mean);
     float* tab = c.at<float>(p.wrc_tab);
-    const int step = wrc_step(nreal);
-    if (!have_mean) CHK(OPLC(mdpt_launch_colmean, g.A_hi, g.lda, p.B, rows_per_img, nreal, step, w.Kp, mean, c.s));
-    CHK(OPLC(mdpt_launch_wrc_table, have_mean ? nullptr : mean, have_mean ? c.at<float>(p.wrc_part) : nullptr, (nreal + step - 1) / step, w.lo, bias, tab, p.B, w.Np, w.Kp, c.s));
+    // every step-th token estimates the shared component as well as all of them (tests/precision_budget/); the step depends on the token
+    // count only, so an image's table does not depend on the batch it is part of
+    const int step = nreal >= 1024 ? 8 : (nreal >= 256 ? 4 : 1);
+    CHK(OPLC(mdpt_launch_colmean, g.A_hi, g.lda, p.B, rows_per_img, nreal, step, w.Kp, mean, c.s));
+    CHK(OPLC(mdpt_launch_wrc_table, mean, w.lo, bias, tab, p.B, w.Np, w.Kp, c.s, w.wscale));
     g.bias = tab; g.bias_img_stride = w.Np; g.bias_img_rows = rows_per_img;
     return 0;
 }
@@ -112,14 +113,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
     // K-split fc2: `pending` = partial sums the residual stream still lacks; the next LayerNorm over it folds them in
     const float* pending = nullptr;
     int npending = 0;
-    // want_mean: the GEMM behind this LayerNorm runs the token-mean compensation - the means of the rows written here come out of the same launch
-    bool have_mean = false;
-    auto layernorm = [&](const float* gamma, const float* beta, op_t* ohi, op_t* olo, float* of32, bool want_mean = false) -> int {
-        have_mean = false;
-        if (!pending && want_mean) {
-            have_mean = true;
-            return OPLC(mdpt_launch_layernorm_mean, resid, gamma, beta, ohi, olo, of32, rows, F, p.B, p.npad, p.N, wrc_step(p.N), c.at<float>(p.wrc_part), c.s);
-        }
+    auto layernorm = [&](const float* gamma, const float* beta, op_t* ohi, op_t* olo, float* of32) -> int {
         if (!pending) return OPLC(mdpt_launch_layernorm, resid, gamma, beta, ohi, olo, of32, rows, F, c.s);
         const float* part = pending;
         pending = nullptr;
@@ -136,8 +130,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
     };
     for (int b = 0; b < h->nblocks; ++b) {
         const std::string n = blk_name(h, b);
-        CHK(layernorm(h->V(n + ".norm1.weight"), h->V(n + ".norm1.bias"), xn_qkv.hi, xn_qkv.lo, nullptr, h->wrc(CLS_QKV)));
-        const bool mean_qkv = have_mean;
+        CHK(layernorm(h->V(n + ".norm1.weight"), h->V(n + ".norm1.bias"), xn_qkv.hi, xn_qkv.lo, nullptr));
         DBG_STOP(0);
         {
             GemmParams g = base_params(c, h->M(n + ".attn.qkv.weight"), xn, rows, F);
@@ -146,7 +139,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             g.bias = h->V(is_beit(h) ? n + ".attn.qkv.bias@qv" : n + ".attn.qkv.bias");
             g.q_hi = q.hi; g.q_lo = q.lo; g.k_hi = k.hi; g.k_lo = k.lo; g.vt_hi = vt.hi; g.vt_lo = vt.lo;
             g.F = F; g.heads = h->heads; g.npad = p.npad; g.npadv = p.npadv; g.qscale = 0.125f;
-            CHK(wrc_bias(c, g, h->M(n + ".attn.qkv.weight"), g.bias, 0, 0, mean_qkv));
+            CHK(wrc_bias(c, g, h->M(n + ".attn.qkv.weight"), g.bias));
             CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         DBG_STOP(1);
@@ -180,15 +173,14 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         DBG_STOP(3);
-        CHK(layernorm(h->V(n + ".norm2.weight"), h->V(n + ".norm2.bias"), xn_fc1.hi, xn_fc1.lo, nullptr, h->wrc(CLS_FC1)));
-        const bool mean_fc1 = have_mean;
+        CHK(layernorm(h->V(n + ".norm2.weight"), h->V(n + ".norm2.bias"), xn_fc1.hi, xn_fc1.lo, nullptr));
         DBG_STOP(4);
         if (h->gh_hidden) {  // ViT-G: (a | b) = x W12^T + b12 ; hidden = silu(a) * b
             GemmParams g = base_params(c, h->M(n + ".mlp.inner_linear_doubled.weight"), xn, rows, F);
             g.M_alg = p.B * p.N;
             g.bias = h->V(n + ".mlp.inner_linear_doubled.bias");
             g.out_f32 = c.at<float>(p.swi); g.ldc = 2 * h->gh_hidden;
-            CHK(wrc_bias(c, g, h->M(n + ".mlp.inner_linear_doubled.weight"), g.bias, 0, 0, mean_fc1));
+            CHK(wrc_bias(c, g, h->M(n + ".mlp.inner_linear_doubled.weight"), g.bias));
             CHK(OPLC(mdpt_launch_gemm, g, c.s));
             CHK(OPLC(mdpt_launch_swiglu, c.at<float>(p.swi), hb.hi, hb.lo, (size_t)rows, h->gh_hidden, h->gh_hidden_p, c.s));
         } else {
@@ -197,7 +189,7 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             g.bias = h->V(n + ".mlp.layers.0.bias");
             g.act = MDPT_ACT_GELU;
             g.out_hi = hb.hi; g.out_lo = hb.lo; g.ldc = 4 * F;
-            CHK(wrc_bias(c, g, h->M(n + ".mlp.layers.0.weight"), g.bias, 0, 0, mean_fc1));
+            CHK(wrc_bias(c, g, h->M(n + ".mlp.layers.0.weight"), g.bias));
             CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         DBG_STOP(5);

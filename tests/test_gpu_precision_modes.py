@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import REL_TOL_BF16_TOY, REL_TOL_X3, record_err, rel_err, seeded_input, synthetic_model
+from tests.helpers import REL_TOL_BF16_TOY, REL_TOL_X3, record_err, ref_lowprec_tol, rel_err, seeded_input, synthetic_model
 
 pytestmark = pytest.mark.gpu
 
@@ -112,6 +112,10 @@ def test_vitl_batch32_fp16_and_mixed_every_checked_image_vs_oracle():
     # a float16 MODEL holds fp16-rounded parameters and sees an fp16-rounded image - in the reference too (run_image.py:158 casts the model,
     # patch_embed.py:133 the image): its cases are checked against the oracle on exactly those rounded tensors
     ref16 = _oracle().forward({k: v.half().float() for k, v in w.items()}, cfg, x[idx].half().float())
+    # ... and ALSO against the plain fp32 oracle: what a float16 MODEL loses to its fp16-rounded parameters and image comes on
+    # top of the operand arithmetic. The yardstick is the reference's own float16 path on this configuration (model and input cast to float16
+    # against its fp32 run: tests/golden/reference_lowprec_errors.json, 9.9e-3): at most HALF of that.
+    tol16_vs_fp32 = ref_lowprec_tol("vitl504", dtype="fp16", factor=0.5)
     for dtype, precision, tol in ((torch.float16, None, REL_TOL_FP16), (torch.float32, "mixed", REL_TOL_MIXED), (torch.float16, "mixed", REL_TOL_MIXED + 2.0 ** -11)):
         ref = ref32 if dtype == torch.float32 else ref16
         model, _, _ = _model("vitl", dtype, precision)
@@ -121,9 +125,30 @@ def test_vitl_batch32_fp16_and_mixed_every_checked_image_vs_oracle():
         for k, i in enumerate(idx):
             err = record_err(float((y[i].float().cpu().double() - ref[k].double()).abs().max() / ref[k].double().abs().max()), f"{dtype} {precision} image {i}")
             assert err <= tol, f"{dtype} {precision} image {i}: {err:.3e}"
+            if dtype == torch.float16:
+                e32 = record_err(float((y[i].float().cpu().double() - ref32[k].double()).abs().max() / ref32[k].double().abs().max()), f"{dtype} {precision} image {i} vs the fp32 oracle")
+                assert e32 <= tol16_vs_fp32, f"{dtype} {precision} image {i} vs the fp32 oracle: {e32:.3e} > {tol16_vs_fp32:.3e}"
             assert torch.equal(model(xd[i:i + 1])[0], y[i]), f"{dtype} {precision} image {i}: batch-of-1 result differs from its row in the batch of 32"
         del model, y, xd
         torch.cuda.empty_cache()
+
+
+def test_vitl_1036_fp16_and_mixed_vs_oracle():
+    """The other north-star size in the modes round 4 added: ViT-L, 1036x1036 (74x74 grid, N = 5477 tokens: reductions
+    4x longer than at 504), one image, single-pass fp16 and the mixed mode against the CPU fp32 oracle (~30 s of host time on the GPU box)."""
+    osd, cfg, w = synthetic_model("vitl", 0)
+    x = seeded_input((1, 3, 1036, 1036), 1)
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    ref = _oracle().forward(w, cfg, x)
+    model, _, _ = _model("vitl", torch.float32)
+    for precision, tol in (("fp16", REL_TOL_FP16), ("mixed", REL_TOL_MIXED)):
+        model.set_precision(precision)
+        y = model(x.cuda()).cpu()
+        assert tuple(y.shape) == (1, 1036, 1036)
+        err = record_err(rel_err(y, ref), f"1036 {precision}")
+        assert err <= tol, f"{precision} at 1036x1036: {err:.3e}"
+    del model
+    torch.cuda.empty_cache()
 
 
 def test_class_passes_all_three_equals_the_x3_mode_bitwise_and_each_class_switches_alone():
@@ -204,6 +229,61 @@ def test_two_pass_head_tail_is_one_kernel_and_loses_only_the_weight_rounding(nam
     assert errs[(False, 3)] <= REL_TOL_X3, errs
     assert errs[(False, 2)] <= 0.9 * errs[(False, 1)] and errs[(False, 1)] <= REL_TOL_FP16_TOY, errs
     torch.cuda.empty_cache()
+
+
+def _resid_after(model, x, block, step):
+    """fp32 residual stream [B * npad * F] after sub-step `step` of encoder block `block` (mdpt_debug_set_stop / mdpt_debug_read test hooks)."""
+    from muggled_dpt_amd import native
+    eng = model._get_engine()
+    b, _, h, w = x.shape
+    native.check(eng.lib, eng.lib.mdpt_debug_set_stop(eng.handle, block, step))
+    try:
+        model(x)
+        npad = -(-((h // eng.P) * (w // eng.P) + 1) // 8) * 8
+        out = torch.empty(b * npad * eng.F, device="cuda", dtype=torch.float32)
+        ws_ptr, ws_bytes = eng.workspace(b, (h, w))
+        native.check(eng.lib, eng.lib.mdpt_debug_read(eng.handle, b"resid", out.data_ptr(), out.numel(), ws_ptr, ws_bytes, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+    finally:
+        native.check(eng.lib, eng.lib.mdpt_debug_set_stop(eng.handle, -1, -1))
+    return out.cpu()
+
+
+def test_small_layer_scales_do_not_push_the_fp16_planes_into_the_subnormal_range():
+    """real checkpoints carry layer-scale gammas of 1e-2 ... 1e-5; folded into proj / fc2 at pack time, gamma * W (ViT-S: ~4e-5) sits
+    below fp16's normal range (6.1e-5), where the hi plane keeps ~10 bits and the lo plane - fp(v - hi), 2^-12 of the entry - none: fp16x3 and
+    the compensation's weight residue would silently degrade to single-pass (expected ~7e-4 of an update at gamma x 1e-3, ~1e-2 at 1e-4). The fp16
+    build packs such a matrix times a power of two and undoes it exactly in the GEMM (GemmParams::wscale: accumulators start at resid * s, the
+    epilogue multiplies by 1 / s). Checked on a model whose residual stream is as small as its layer-scaled updates (image, patch bias, cls, pos and
+    gammas x 1e-3 - with a stream of O(1) the fp32 stream's own resolution, 2e-3 of such an update, hides everything: tools/probes/gpu_wscale_check.py):
+    the depth map against the oracle per mode, and the UPDATE block 1's proj / fc2 add to the stream, fp16x3 against bf16x3 (fp32's exponent range)."""
+    from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+    from muggled_dpt_amd.state_dict_conversion import convert_state_dict_keys, flatten_components, get_model_config_from_state_dict
+    f = 1e-3
+    osd, _, _ = synthetic_model("vits", 0)
+    small = ("pretrained.cls_token", "pretrained.pos_embed", "pretrained.patch_embed.proj.bias")
+    osd = {k: (v * f if (".ls1.gamma" in k or ".ls2.gamma" in k or k in small) else v.clone()) for k, v in osd.items()}
+    cfg = get_model_config_from_state_dict(osd)
+    w = flatten_components(convert_state_dict_keys(cfg, osd))
+    x = seeded_input((2, 3, 140, 112), 23) * f
+    ref = _oracle().forward(w, cfg, x)
+    upd, errs = {}, {}
+    for prec in ("bf16x3", "fp16x3", "fp16", "mixed"):
+        _, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
+        model = model.to("cuda", torch.float32)
+        model.set_precision(prec)
+        errs[prec] = record_err(rel_err(model(x.cuda()).cpu(), ref), f"depth, {prec}")
+        if prec.endswith("x3"):
+            for name, before, after in (("proj", 2, 3), ("fc2", 5, 6)):
+                upd[(prec, name)] = (_resid_after(model, x.cuda(), 1, after).double() - _resid_after(model, x.cuda(), 1, before).double())
+        del model
+    assert errs["bf16x3"] <= REL_TOL_X3 and errs["fp16x3"] <= REL_TOL_X3, errs
+    assert errs["fp16"] <= REL_TOL_FP16_TOY and errs["mixed"] <= 1.5e-3, errs
+    for name in ("proj", "fc2"):
+        r, got = upd[("bf16x3", name)], upd[("fp16x3", name)]
+        assert float(r.abs().max()) > 0
+        err = record_err(float((got - r).abs().max() / r.abs().max()), f"{name} update, fp16x3 vs bf16x3")
+        assert err <= 1e-4, f"{name}: the fp16x3 update differs from the bf16x3 one by {err:.3e} of its size"
 
 
 def test_raw_c_abi_class_passes_keep_bound_weights_and_reject_bad_arguments():
