@@ -17,7 +17,16 @@
 #include <string.h>
 #include <vector>
 
+// -DPROBE_F16: the same loops on fp16 operands (v_mfma_*_f16; round 5: is the fp16 build's 3-4 % slower GEMM loop the MFMA pipe's power, or the kernels?)
+#ifdef PROBE_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;
+#define MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define MFMA32 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#define MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define MFMA32 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(NT, 1) void k16(const char* src, float* out, int it
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
-                for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < CB; ++j) acc[i][j] = MFMA16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
         }
     }
     f32x4 s = {0, 0, 0, 0};
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(NT, 1) void k32(const char* src, float* out, int it
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
-                for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < CB; ++j) acc[i][j] = MFMA32(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
         }
     }
     float s = 0;
@@ -161,9 +170,14 @@ int main() {
     srand(7);
     for (auto& v : h) {
         float f = (float)rand() / RAND_MAX * 2.0f - 1.0f;
+#ifdef PROBE_F16
+        _Float16 hf = (_Float16)f;
+        memcpy(&v, &hf, 2);
+#else
         unsigned u;
         memcpy(&u, &f, 4);
         v = (unsigned short)(u >> 16);
+#endif
     }
     char* src;
     float* out;
