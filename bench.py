@@ -44,7 +44,7 @@ FAMILY = {"vitl": "Depth-Anything-V2 ViT-L", "vits": "Depth-Anything-V2 ViT-S", 
 SYNTH_NAME = {"beitl": "beit_large_384", "swinl": "swin2_large_384"}
 
 
-def make_model_and_weights(name: str, want_weights: bool = False):
+def make_model_and_weights(name: str, want_weights: bool = False, enable_cache: bool = False):
     """(model on CPU, (cfg, flat weight dict) for the oracle or None). Seeded synthetic checkpoints in the ORIGINAL key layout go
     through the same factories a real .pth would (make_*_dpt_from_*_state_dict)."""
     from muggled_dpt_amd.state_dict_conversion import flatten_components
@@ -63,7 +63,7 @@ def make_model_and_weights(name: str, want_weights: bool = False):
         from muggled_dpt_amd import state_dict_conversion as conv
         from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict as synth
         osd = synth(name, 0)
-    cfg, model = make(osd)
+    cfg, model = make(osd, enable_cache)  # (run_video.py:144 builds its model with the cache on; run_image.py:129 without)
     ow = None
     if want_weights:
         ocfg = conv.get_model_config_from_state_dict(osd) if hasattr(conv, "get_model_config_from_state_dict") and name not in SYNTH_NAME else cfg
@@ -285,12 +285,15 @@ def secondary_legs(args, dev, lib, vitl_model):
         t_leg = time.perf_counter()
         try:
             sub = argparse.Namespace(**{**vars(args), "model": name, "size": size, "batch": batch})
-            if name == "vitl":
+            # batch 1 = the reference's frame-by-frame workload (run_video.py:336-349), whose model is built with enable_cache=True (:144): per-grid
+            # constants are computed by the first frame and kept (mdpt_set_grid_cache)
+            own_model = not (name == "vitl" and batch != 1)
+            if not own_model:
                 model, ow = vitl_model, None
                 if want_err:  # (the oracle's weights: the same seeded checkpoint converted for the CPU restatement)
                     _, ow = make_model_and_weights(name, want_weights=True)
             else:
-                model, ow = make_model_and_weights(name, want_weights=want_err)
+                model, ow = make_model_and_weights(name, want_weights=want_err, enable_cache=batch == 1)
                 model = model.to(dev, torch.bfloat16)
             x_cpu = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(11))
             x = x_cpu.to(dev).to(torch.bfloat16)
@@ -304,7 +307,7 @@ def secondary_legs(args, dev, lib, vitl_model):
                 native.check(lib, lib.mdpt_set_batch_split(handle, 8))
             gflop = GFLOP_PER_MAP.get((name, size))
             rec = {"metric": f"depth-maps/sec @{size}x{size}, {FAMILY[name]}", "value": round(batch / dt, 3), "unit": "depth-maps/s",
-                   "ms_per_step": round(dt * 1e3, 3), "steps": steps, "dtype": "bf16", "config": {"workload": f"{FAMILY[name]} ({name}), {size}x{size} tensor, batch {batch}, bf16"}}
+                   "ms_per_step": round(dt * 1e3, 3), "steps": steps, "dtype": "bf16", "config": {"workload": f"{FAMILY[name]} ({name}), {size}x{size} tensor, batch {batch}, bf16", "enable_cache": batch == 1}}
             if gflop:
                 rec["path_frac_of_mfma_peak"] = round(batch / dt * gflop / 1e3 / PEAK_BF16_TFLOPS, 4)
             if prof and prof["kernels"]:
@@ -331,7 +334,7 @@ def secondary_legs(args, dev, lib, vitl_model):
             if (name in SYNTH_NAME or size == 1036) and want_err and ow is not None:
                 # BASELINE configs[4] in the mixed-pass mode too (fp32 tensors at the boundary; SwinV2's window-major encoder runs it
                 # without the token-mean compensation)
-                if name != "vitl":
+                if own_model:
                     del model  # (a float32 model built afresh: casting the bf16 model back would keep its bf16-rounded parameters)
                 torch.cuda.empty_cache()
                 model, _ = make_model_and_weights(name)
@@ -340,12 +343,12 @@ def secondary_legs(args, dev, lib, vitl_model):
                 dt_m, y_m = time_model(m32, x_cpu.to(dev), steps)
                 rec["mixed_mode"] = {"value": round(batch / dt_m, 3), "ms_per_step": round(dt_m * 1e3, 3), "error_vs_cpu_fp32": error_vs(ref, y_m.float())}
                 del y_m, m32
-                if name == "vitl":
+                if not own_model:
                     del model
                     model = vitl_model
             rec["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
             out[key] = rec
-            if name != "vitl":
+            if own_model:
                 del model
             del x, y
             torch.cuda.empty_cache()

@@ -38,8 +38,11 @@ extern "C" {
 #define MDPT_PREC_BF16 0   /* bf16 MFMA operands - the reference's GPU default dtype (demo_helpers/misc.py:73-77) */
 #define MDPT_PREC_BF16X3 1 /* split-bf16 (hi+lo) operands, 3 MFMA passes: fp32-class accuracy (parity mode)        */
 #define MDPT_PREC_FP16 2   /* fp16 MFMA operands (v_mfma_*_f16: the bf16 rate, 11 instead of 8 significand bits; converts saturate at
-                              +-65504) - what the reference's device policy hands the model when bf16 is not preferred
-                              (demo_helpers/misc.py:61-77: float16)                                                  */
+                              +-65504 - and turn a NaN into a finite value: a NaN in the input never reaches the depth map as NaN in the
+                              fp16 operand modes; in the bf16 modes the conversions carry it on, the v_max ReLUs may still drop it) - what the reference's device policy hands the model when
+                              bf16 is not preferred (demo_helpers/misc.py:61-77: float16). The layer-scale-folded matrices are packed
+                              times a power of two that the GEMMs undo exactly, so checkpoints with gammas of 1e-2 ... 1e-5 keep their
+                              hi / lo planes in fp16's normal range                                                   */
 #define MDPT_PREC_FP16X3 3 /* split-fp16 (hi+lo) operands, 3 passes                                                 */
 #define MDPT_PREC_MIXED 4  /* fp16 operands; the op classes listed in mdpt_default_mixed_passes() run 3 or 2 passes, the others 1:
                               the cheapest per-class assignment that keeps the depth map within 1e-3 of the fp32 reference

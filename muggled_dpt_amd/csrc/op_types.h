@@ -29,7 +29,12 @@ typedef __attribute__((ext_vector_type(4))) op_t opx4;
 typedef __attribute__((ext_vector_type(2))) op_t opx2;
 typedef __attribute__((ext_vector_type(2))) float op_f32x2;
 
-// fp32 -> operand, round to nearest even; saturating in the fp16 build (bf16 has fp32's exponent range)
+// fp32 -> operand, round to nearest even; saturating in the fp16 build (bf16 has fp32's exponent range).
+// NaN: v_med3_f32 returns a FINITE value for a NaN input (min/max semantics), so in the fp16 operand modes a NaN produced upstream does not
+// propagate through an operand conversion - it becomes -65504 - where the bf16 build's conversions (and the reference's own float16 path) carry
+// it on. (The ReLUs of both builds are v_max_f32, which also map NaN to 0 where torch.relu propagates it.) A NaN-preserving clamp costs a
+// compare + select per converted value in VALU-bound epilogues; the behaviour is documented instead (include/mdpt.h MDPT_PREC_FP16,
+// tests/test_gpu_precision_modes.py::test_fp16_operand_converts_swallow_nan_documented): validate inputs with torch.isfinite where it matters.
 __device__ __forceinline__ float op_sat(float v) {
 #if MDPT_OP_IS_F16
     return __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);

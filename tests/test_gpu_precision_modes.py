@@ -286,6 +286,22 @@ def test_small_layer_scales_do_not_push_the_fp16_planes_into_the_subnormal_range
         assert err <= 1e-4, f"{name}: the fp16x3 update differs from the bf16x3 one by {err:.3e} of its size"
 
 
+def test_fp16_operand_converts_swallow_nan_documented():
+    """the saturating fp32 -> fp16 operand conversion (v_med3_f32) returns a finite value for NaN, so a NaN pixel does not reach the
+    depth map as NaN in the fp16 operand modes, while the bf16 modes carry it through like the reference would. Documented behaviour (include/mdpt.h,
+    csrc/op_types.h); this test pins it so that a change of either side is noticed."""
+    x = seeded_input((1, 3, 56, 56), 3)
+    x[0, 1, 20, 20] = float("nan")
+    m_h, _, _ = _model("tiny", torch.float16)
+    y = m_h(x.to("cuda", torch.float16)).float()
+    assert bool(torch.isfinite(y).all()), "fp16 operand modes: a NaN pixel becomes a saturated operand, never a NaN depth"
+    # stage level, where no ReLU sits behind the conversion: the bf16 build carries the NaN into the patch tokens, the fp16 build does not
+    m_bf, _, _ = _model("tiny", torch.bfloat16)
+    tok_bf, _ = m_bf.patch_embed(x.to("cuda", torch.bfloat16))
+    tok_h, _ = m_h.patch_embed(x.to("cuda", torch.float16))
+    assert bool(torch.isnan(tok_bf.float()).any()) and bool(torch.isfinite(tok_h.float()).all())
+
+
 def test_raw_c_abi_class_passes_keep_bound_weights_and_reject_bad_arguments():
     import ctypes
     from muggled_dpt_amd import native

@@ -7,7 +7,7 @@
 #   3. the driver-runnable secondary configurations (1036x1036, BEiT-L, SwinV2-L) as plain bench lines
 # Output: gpurun_out/profiles_<tag>/ ; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
@@ -47,8 +47,28 @@ python tools/probes/gpu_conv3h_small_batch.py 2>&1 | grep -v amdgpu.ids > "$OUT/
 python bench.py --size 1036 --steps 10 --warmup 2 > "$OUT/bench_1036.json" 2> "$OUT/bench_1036.err"
 python bench.py --model beitl --steps 10 --warmup 2 > "$OUT/bench_beitl.json" 2> "$OUT/bench_beitl.err"
 python bench.py --model swinl --steps 10 --warmup 2 > "$OUT/bench_swinl.json" 2> "$OUT/bench_swinl.err"
-# later in round 4: SwinV2-L / BEiT-L kernel stats, SwinV2-L kernel shares, determinism screens (default path and latency mode)
-bash tools/probes/gpu_r4_final_evidence.sh > "$OUT/final_evidence.log" 2>&1
-cp -r "$R/gpurun_out/final_evidence" "$OUT/" 2>/dev/null
+# SwinV2-L / BEiT-L kernel stats (batch split off), SQ counters of the SwinV2-L forward (window attention), determinism screens, kernel shares
+cd /tmp
+for m in swinl beitl; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$m" -- python "$R/bench.py" --model $m --no-split --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_${m}_nosplit_under_rocprof.json" 2> "$OUT/$m.log"
+  f=$(find "$OUT/$m" -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_${m}_nosplit.csv"
+  rm -rf "$OUT/$m"
+done
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS \
+  --kernel-trace --output-format csv -d "$OUT/pmc_SQ_swinl" -- python "$R/bench.py" --model swinl --no-split --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> "$OUT/pmc_SQ_swinl.log"
+python "$R/tools/summarize_sq.py" "$OUT/pmc_SQ_swinl" "$OUT/sq_counters_swinl.md" > "$OUT/sq_counters_swinl.log" 2>&1
+rm -rf "$OUT/pmc_SQ_swinl"
+cd "$R"
+python tools/probes/gpu_determinism_stress.py 60 2>&1 | grep -v amdgpu > "$OUT/determinism_default.txt"
+python tools/probes/gpu_ksplit_determinism.py 300 2>&1 | grep -v amdgpu > "$OUT/determinism_latency.txt"
+python tools/probes/gpu_kernel_share_any.py swinl 384 16 2>&1 | grep -v amdgpu > "$OUT/kernel_share_swinl.txt"
+# round 5: kernel shares of the mixed mode, per-family class budget of the mixed table, fp16 weight-scale check, fp16-vs-bf16 MFMA power probe
+python tools/probes/gpu_kernel_share_any.py vitl 504 32 mixed 2>&1 | grep -v amdgpu > "$OUT/kernel_share_mixed.txt"
+python tools/probes/gpu_family_class_budget.py beitl swinl 2>&1 | grep -v amdgpu > "$OUT/family_class_budget.txt"
+python tools/probes/gpu_wscale_check.py 2>&1 | grep -v amdgpu > "$OUT/wscale_check.txt"
+if [ -x tools/probes/_bin/mfma_power ] && [ -x tools/probes/_bin/mfma_power_f16 ]; then
+  { echo "== bf16"; tools/probes/_bin/mfma_power | head -3; echo "== fp16"; tools/probes/_bin/mfma_power_f16 | head -3; } > "$OUT/mfma_power_f16_vs_bf16.txt" 2>&1
+fi
 [ -x tools/probes/_bin/exp_throughput ] && tools/probes/_bin/exp_throughput > "$OUT/exp_throughput.txt" 2>&1
 ls -la "$OUT"
