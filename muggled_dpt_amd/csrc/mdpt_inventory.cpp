@@ -129,12 +129,14 @@ int build_inventory(mdpt_handle* h) {
             const std::string fc2 = sh ? p + ".mlp.outer_linear" : p + ".mlp.layers.2";
             h->mats[h->mat_index.at(p + ".attn.proj.weight")].row_scale = p + ".scale_attn";
             h->mats[h->mat_index.at(fc2 + ".weight")].row_scale = p + ".scale_mlp";
+#ifndef MDPT_NO_WSCALE  // (A/B builds)
             if (h->f16)  // fp16 operands: a power-of-two factor keeps gamma * W (and its lo plane) in fp16's normal range (GemmParams::wscale)
                 for (const std::string& mn : {p + ".attn.proj.weight", fc2 + ".weight"}) {
                     Mat& mm = h->mats[h->mat_index.at(mn)];
                     mm.off_scale = h->packed_total;
                     h->packed_total += 256;
                 }
+#endif
             h->add_vec(p + ".attn.proj.bias@ls", F, F);
             h->vecs.back().scale = p + ".scale_attn";
             h->add_vec(fc2 + ".bias@ls", F, F);

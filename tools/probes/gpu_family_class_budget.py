@@ -15,7 +15,10 @@ FIX = {"beitl": ("beit_large_384", 384, 16), "swinl": ("swin2_large_384", 384, 1
 R04 = {"fusion": 3, "fusion_proj": 3, "head": 3, "head_tail": 3}
 VARIANTS = [("shipped", {}), ("round 4 (3 passes)", R04), ("fusion=3", {"fusion": 3}), ("head=3", {"head": 3}), ("head_tail=3", {"head_tail": 3}),
             ("fusion=3 head=3", {"fusion": 3, "head": 3}), ("fusion=3 head_tail=3", {"fusion": 3, "head_tail": 3}), ("head=3 head_tail=3", {"head": 3, "head_tail": 3}),
-            ("reasm=2", {"reasm": 2}), ("fusion_in=2", {"fusion_in": 2})]
+            ("reasm=2", {"reasm": 2}), ("fusion_in=2", {"fusion_in": 2}), ("fusion_in=3", {"fusion_in": 3}), ("proj=3", {"proj": 3}), ("attn=3", {"attn": 3}),
+            ("fusion_in=3 proj=3", {"fusion_in": 3, "proj": 3})]
+if os.environ.get("MDPT_BUDGET_ENCODER"):  # encoder classes one at a time (what buys margin per ms on this family)
+    VARIANTS = [("shipped", {})] + [(f"{c}={n}", {c: n}) for c in ("qkv", "proj", "fc1", "fc2") for n in (2, 3)] + [("attn=3", {"attn": 3}), ("fusion_in=3", {"fusion_in": 3})]
 for name in (sys.argv[1:] or ["beitl", "swinl"]):
     fixture, size, batch = FIX[name]
     g = np.load(os.path.join(REPO, "tests", "golden", fixture + ".npz"))
