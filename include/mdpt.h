@@ -13,10 +13,11 @@
  *   - all `dev` pointers are device (HBM) pointers owned by the caller (PyTorch allocates them in our binding);
  *     the library allocates no device memory and never synchronises with the host.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream). Every kernel is ordered on the caller's stream. ONE
- *     exception, stated here because it is visible to tools: for batches >= 8 (mdpt_set_batch_split) mdpt_forward lazily creates
- *     ONE internal non-blocking side stream + two events per handle and runs the second half batch there, forked from and joined
- *     back into the caller's stream with events before it returns (also on the error path) - stream-ordering semantics for the
- *     caller are unchanged, the call stays capturable into a hipGraph, results are bit-identical to the unsplit form.
+ *     exception, stated here because it is visible to tools: mdpt_forward lazily creates ONE internal non-blocking side stream + two
+ *     events per handle. For batches >= 8 (mdpt_set_batch_split) it runs the second half batch there; for smaller batches it runs the four
+ *     reassembly branches there, each as soon as its encoder tap exists (mdpt_debug_set_reassemble_overlap). Either way the side stream is
+ *     forked from and joined back into the caller's stream with events before the call returns (also on the error path) - stream-ordering
+ *     semantics for the caller are unchanged, the call stays capturable into a hipGraph, results are bit-identical to the one-stream form.
  *   - tensors at this boundary use the REFERENCE layouts: images/maps BCHW, tokens B x N x F, depth B x H x W. The hot entry points
  *     (mdpt_bind_weight, mdpt_forward, mdpt_allgather) take a dtype tag per tensor (fp32, bf16 or fp16: whatever the caller's
  *     model dtype is - no cast kernels at the boundary); the stage-level / debug entry points are fp32.
@@ -273,6 +274,11 @@ int mdpt_debug_set_stop(mdpt_handle* h, int32_t block, int32_t step);
 /* Test hook: latency mode's K split of the residual GEMMs applies from `min_k_tiles` 64-wide K tiles on (two ranges) and from
  * `four_k_tiles` on as four ranges (toy models have 4 K tiles). */
 int mdpt_debug_set_ksplit_min(mdpt_handle* h, int32_t min_k_tiles, int32_t four_k_tiles);
+/* Test / A-B hook: unsplit forwards (batches below mdpt_set_batch_split's threshold, i.e. the reference's frame-by-frame workload) queue each
+ * reassembly branch (reassembly_model.py:61-94: four independent branches, one per encoder tap) on the handle's internal side stream as soon
+ * as its tap exists, beside the remaining encoder blocks, and join before the fusion stage - same kernels, same bits, stream-ordering
+ * semantics for the caller unchanged (as for the batch split). Default on; 0 runs the branches behind the encoder on the caller's stream. */
+int mdpt_debug_set_reassemble_overlap(mdpt_handle* h, int32_t on);
 int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_floats, void* workspace, size_t workspace_bytes,
                     void* stream);
 

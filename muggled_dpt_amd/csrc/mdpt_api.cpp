@@ -75,6 +75,7 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     h->ks_min_ktiles = 16; h->ks_big_ktiles = 1 << 30;
     h->split_min = 8;
     h->latency_mode = 0;
+    h->overlap_reasm = 1;
     h->grid_cache = 0;
     h->gen = 0;
     h->cache_clear();
@@ -298,6 +299,15 @@ int mdpt_set_gemm_tile(mdpt_handle* h, int32_t tile) {
 
 static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, int image_dtype, void* depth_bhw, int depth_dtype);
 
+static int ensure_side_stream(mdpt_handle* h) {  // one internal non-blocking stream + two events per handle, created on first use
+    if (!h->side_stream) {
+        CHK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        CHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        CHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    return 0;
+}
+
 static inline size_t dtype_bytes(int dt) { return dt == MDPT_DTYPE_F32 ? 4 : 2; }
 
 int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t image_dtype, int32_t B, int32_t H, int32_t W, void* depth_bhw,
@@ -314,11 +324,7 @@ int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t image_dtype, in
         CHK(check_ws(h, p0, workspace, workspace_bytes));
         const size_t off1 = rup256(p0.total);
         if (workspace_bytes < off1 + p1.total) return fail(MDPT_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", off1 + p1.total, workspace_bytes);
-        if (!h->side_stream) {
-            CHK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-            CHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            CHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        }
+        CHK(ensure_side_stream(h));
         hipStream_t s0 = (hipStream_t)stream;
         CHK(hipEventRecord(h->ev_fork, s0));
         CHK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
@@ -366,6 +372,22 @@ static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, int
     CHK(run_patch_embed_fused(c, image_bchw, image_dtype));
     h->last_plan = c.p;
     h->has_last = true;
+    if (!c.split && h->overlap_reasm && h->dbg_block < 0) {
+        // unsplit (small-batch) forward: reassembly branches run on the side stream beside the encoder (run_encoder, Ctx::tap_stream); whatever
+        // happens in between, the side stream is joined back into the caller's stream before anything else is queued or returned
+        CHK(ensure_side_stream(h));
+        Ctx ce = c;
+        ce.tap_stream = h->side_stream; ce.tap_event = h->ev_fork;
+        const int rc = run_encoder(ce, nullptr);
+        const hipError_t ej = hipEventRecord(h->ev_join, h->side_stream);
+        const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(c.s, h->ev_join, 0) : ej;
+        if (ew != hipSuccess) hipStreamSynchronize(h->side_stream);
+        if (rc != 0) return rc;
+        CHK(ew);
+        CHK(run_fusion(c, true));
+        CHK(run_head(c, depth_bhw, depth_dtype, head_upsamples_bf16(h)));
+        return 0;
+    }
     CHK(run_encoder(c, nullptr));
     if (h->dbg_block >= 0) return 0;  // test hook: encoder truncated, skip the decoder
     CHK(run_reassemble(c));

@@ -10,6 +10,12 @@ int mdpt_debug_set_stop(mdpt_handle* h, int32_t block, int32_t step) {
     return 0;
 }
 
+int mdpt_debug_set_reassemble_overlap(mdpt_handle* h, int32_t on) {
+    if (!h) return fail(MDPT_E_INVALID, "null handle");
+    h->overlap_reasm = on ? 1 : 0;
+    return 0;
+}
+
 int mdpt_debug_set_ksplit_min(mdpt_handle* h, int32_t min_k_tiles, int32_t four_k_tiles) {
     if (!h || min_k_tiles < 2 || four_k_tiles < 4) return fail(MDPT_E_INVALID, "null handle or thresholds below 2 / 4 K tiles");
     h->ks_min_ktiles = min_k_tiles;

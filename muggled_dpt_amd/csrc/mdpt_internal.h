@@ -181,6 +181,7 @@ struct mdpt_handle {
     // events, no host sync) so that one half's kernels fill the tile-quantisation tails and epilogue phases of the other's
     int split_min;
     int latency_mode;  // mdpt_set_latency_mode: small launches may use summation orders that are not batch-invariant
+    int overlap_reasm;  // unsplit forwards queue the reassembly branches on the side stream beside the encoder (default on; mdpt_debug_set_reassemble_overlap)
     // mdpt_set_grid_cache (the reference's enable_cache, position_encoder.py:152-227): per-grid constants - resized position embedding, BEiT's
     // relative-position tables, SwinV2's position-bias tables, the zero pads of operand planes - stay in the workspace of the last forward of
     // a (workspace, B, H, W) and are not recomputed by the next forward on the same workspace and shape (`gen` = finalize generation)
@@ -260,6 +261,9 @@ struct Ctx {
     char* ws;
     hipStream_t s;
     bool split = false;  // this context is one half of a two-stream batch split
+    hipStream_t tap_stream = nullptr;  // small-batch forward: every reassembly branch is queued here as soon as its tap exists (tap_event orders it)
+    hipEvent_t tap_event = nullptr;
+    bool side = false;  // this context runs on that side stream, beside the encoder
     bool consts_cached = false;  // the per-grid constants of this (workspace, shape) are in place (mdpt_set_grid_cache): skip the kernels that write them
     void* const* attn_dump = nullptr;  // per block: where to write softmax(q k^T) as fp32 [B,H,N,N] (null entries: skip)
     void* const* block_dump = nullptr; // per block: where to write the block's output tokens as fp32 [B,N,F] (null entries: skip)
@@ -299,6 +303,7 @@ int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias, int r
 bool fc2_ksplit_fits(int rows, int F);  // batch small enough for the K-split form of fc2 (the 64x64 tile's range): the plan then holds kspart
 int run_encoder(const Ctx& c, void* const taps_f32[4]);
 int run_reassemble(const Ctx& c);
+int run_reassemble_stage(const Ctx& c, int i);
 int rcu_conv(const Ctx& c, const std::string& wname, Planes in, int sh, int sw, const float* skip, const float* up_src, int Hu, int Wu,
              float* out_f32, Planes out, int relu_bf16);
 bool head_upsamples_bf16(const mdpt_handle* h);

@@ -226,6 +226,16 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
                 if (taps_f32)
                     CHK(OPLC(mdpt_launch_tokens_export, nullptr, nullptr, f32, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
             }
+            if (c.tap_stream) {
+                // small batches: the forward is a chain of ~215 dependent launches on a mostly idle GPU. Tap st's reassembly branch (3-4 launches)
+                // depends on nothing the rest of the encoder writes, so it goes to the side stream now and runs beside the next blocks; the branches
+                // share that one stream (BEiT's readout buffers are reused from branch to branch). Same kernels, same bits.
+                CHK(hipEventRecord(c.tap_event, c.s));
+                CHK(hipStreamWaitEvent(c.tap_stream, c.tap_event, 0));
+                Ctx cs = c;
+                cs.s = c.tap_stream; cs.tap_stream = nullptr; cs.side = true;
+                CHK(run_reassemble_stage(cs, st));
+            }
         }
     }
     return 0;
@@ -243,7 +253,7 @@ int try_ksplit_conv(const Ctx& c, const GemmParams& g, bool* done) {
     *done = false;
     const mdpt_handle* h = c.h;
     const Plan& p = c.p;
-    if (!h->latency_mode || c.split || p.kspart == SIZE_MAX || h->gemm_tile != MDPT_TILE_AUTO || h->dbg_block >= 0) return 0;
+    if (!h->latency_mode || c.split || c.side || p.kspart == SIZE_MAX || h->gemm_tile != MDPT_TILE_AUTO || h->dbg_block >= 0) return 0;  // (side: kspart belongs to the encoder running beside it)
     if (g.ekind != MDPT_E_GENERIC || g.resid || g.up_src || g.gamma || g.acc_init || g.act != MDPT_ACT_NONE || g.bias_img_stride) return 0;
     const long tiles = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
     const int kt = g.K / 64;
@@ -263,12 +273,18 @@ int try_ksplit_conv(const Ctx& c, const GemmParams& g, bool* done) {
     return 0;
 }
 
-// ---- stage: reassemble
+// ---- stage: reassemble. One branch per encoder tap; the four branches are independent of each other (reassembly_model.py:61-94), which the
+//      small-batch forward uses: branch i is queued on the side stream as soon as tap i exists (Ctx::tap_stream, mdpt_api.cpp forward_one)
 int run_reassemble(const Ctx& c) {
+    for (int i = 0; i < 4; ++i) CHK(run_reassemble_stage(c, i));
+    return 0;
+}
+
+int run_reassemble_stage(const Ctx& c, int i) {
     const mdpt_handle* h = c.h;
     const Plan& p = c.p;
     const int F = h->F, gh = p.gh, gw = p.gw;
-    for (int i = 0; i < 4; ++i) {
+    {
         const std::string n = std::string("reassemble.") + kStageNames[i];
         const int hp = h->hidp[i];
         Planes tp = c.pl(p.tap[i]), t = c.pl(p.t[i]);

@@ -199,6 +199,7 @@ SYMBOLS = {
     "mdpt_profile_report": (ctypes.c_int, [ctypes.c_char_p, _SZ]),
     "mdpt_debug_set_stop": (ctypes.c_int, [_VP, _I, _I]),
     "mdpt_debug_set_ksplit_min": (ctypes.c_int, [_VP, _I, _I]),
+    "mdpt_debug_set_reassemble_overlap": (ctypes.c_int, [_VP, _I]),
     "mdpt_debug_set_operand_format": (ctypes.c_int, [_I]),
     "mdpt_set_grid_cache": (ctypes.c_int, [_VP, _I]),
     "mdpt_set_class_passes": (ctypes.c_int, [_VP, _I, _I]),

@@ -196,3 +196,45 @@ def test_long_k_decoder_convs_split_with_a_finishing_kernel():
         model.set_latency_mode(False)
         assert torch.equal(model(xd), y_default)
         assert "ksplit_finish_kernel" not in _profile_names(lambda: model(xd))
+
+
+@pytest.mark.parametrize("family", ["v2", "v1", "beit"])
+def test_reassembly_branches_on_the_side_stream_change_no_bit(family):
+    """Unsplit (small-batch) forwards queue every reassembly branch (reassembly_model.py:61-94: four independent branches) on the handle's side
+    stream as soon as its encoder tap exists, beside the remaining blocks, and join before the fusion stage. Same kernels: bitwise equal to
+    the one-stream order (mdpt_debug_set_reassemble_overlap 0), in the default and the latency mode, at batches 1 / 3 / 7 and several sizes,
+    repeated (no race: 20 forwards each), and capturable into a hipGraph like the batch split."""
+    import muggled_dpt_amd as m
+    from muggled_dpt_amd import native
+    from muggled_dpt_amd.synthetic import STANDARD_CONFIGS, make_synthetic_beit_state_dict, make_synthetic_original_state_dict
+    if family == "beit":
+        model, unit = m.make_beit_dpt_from_midas_v31_state_dict(make_synthetic_beit_state_dict("beit_tiny", 0))[1], 32
+    elif family == "v1":
+        model, unit = m.make_depthanythingv1_dpt_from_original_state_dict(make_synthetic_original_state_dict(dict(STANDARD_CONFIGS["tiny"], num_blocks=8), 0))[1], 28
+    else:
+        model, unit = m.make_depthanythingv2_dpt_from_original_state_dict(make_synthetic_original_state_dict("tiny", 0))[1], 28
+    for dtype in (torch.bfloat16, torch.float32):
+        model = model.to("cuda", dtype)
+        eng = model._get_engine()
+        for latency in (False, True):
+            model.set_latency_mode(latency)
+            for b, hh, ww in ((1, 2 * unit, 2 * unit), (3, 4 * unit, 2 * unit), (7, 2 * unit, 6 * unit)):
+                x = torch.randn(b, 3, hh, ww, generator=torch.Generator().manual_seed(b)).to("cuda", dtype)
+                native.check(eng.lib, eng.lib.mdpt_debug_set_reassemble_overlap(eng.handle, 0))
+                want = model(x)
+                native.check(eng.lib, eng.lib.mdpt_debug_set_reassemble_overlap(eng.handle, 1))
+                for _ in range(20):
+                    assert torch.equal(model(x), want), f"{family} {dtype} latency={latency} batch {b}"
+        model.set_latency_mode(False)
+        x = torch.randn(1, 3, 2 * unit, 2 * unit, generator=torch.Generator().manual_seed(1)).to("cuda", dtype)
+        want = model(x)
+        g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            model(x)
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(g):
+            y_graph = model(x)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y_graph, want)
