@@ -324,16 +324,12 @@ def secondary_legs(args, dev, lib, vitl_model):
                 # image - pageable numpy -> pinned staging -> H2D -> prepare_image kernel (model dtype) -> forward, depth left on the device
                 rec["inference_b1"] = {"input": f"uint8 host image {size + 14}x{size + 14}x3 (BGR) -> {size}x{size} tensor", **time_inference(model, size + 14, steps),
                                        "latency_mode": inf_l}
-            if want_err and ow is not None:
-                from oracle import dpt_oracle
-                torch.set_num_threads(max(1, min(32, (os.cpu_count() or 2) // 2)))
-                ref = dpt_oracle.forward(ow[1], ow[0], x_cpu[:1])
-                rec["error_vs_cpu_fp32"] = error_vs(ref, y.float())
-            else:
-                rec["error_vs_cpu_fp32"] = None
+            y_m = dt_m = None
             if (name in SYNTH_NAME or size == 1036) and want_err and ow is not None:
                 # BASELINE configs[4] in the mixed-pass mode too (fp32 tensors at the boundary; SwinV2's window-major encoder runs it
-                # without the token-mean compensation)
+                # without the token-mean compensation). Timed BEFORE the CPU oracle below runs: the oracle's OpenMP pool keeps spinning
+                # for a while after a parallel region and starves the launch thread of a launch-heavy forward (SwinV2-L read 21 ms
+                # instead of 15 ms when this leg followed the oracle)
                 if own_model:
                     del model  # (a float32 model built afresh: casting the bf16 model back would keep its bf16-rounded parameters)
                 torch.cuda.empty_cache()
@@ -341,11 +337,20 @@ def secondary_legs(args, dev, lib, vitl_model):
                 m32 = model.to(dev, torch.float32)
                 m32.set_precision("mixed")
                 dt_m, y_m = time_model(m32, x_cpu.to(dev), steps)
-                rec["mixed_mode"] = {"value": round(batch / dt_m, 3), "ms_per_step": round(dt_m * 1e3, 3), "error_vs_cpu_fp32": error_vs(ref, y_m.float())}
-                del y_m, m32
+                y_m = y_m.float().cpu()
+                del m32
                 if not own_model:
                     del model
                     model = vitl_model
+            if want_err and ow is not None:
+                from oracle import dpt_oracle
+                torch.set_num_threads(max(1, min(32, (os.cpu_count() or 2) // 2)))
+                ref = dpt_oracle.forward(ow[1], ow[0], x_cpu[:1])
+                rec["error_vs_cpu_fp32"] = error_vs(ref, y.float())
+                if y_m is not None:
+                    rec["mixed_mode"] = {"value": round(batch / dt_m, 3), "ms_per_step": round(dt_m * 1e3, 3), "error_vs_cpu_fp32": error_vs(ref, y_m)}
+            else:
+                rec["error_vs_cpu_fp32"] = None
             rec["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
             out[key] = rec
             if own_model:

@@ -11,11 +11,14 @@
  * Conventions
  *   - return value: 0 = OK, otherwise a negative MDPT_E_* code or a positive hipError_t; mdpt_last_error() has text.
  *   - all `dev` pointers are device (HBM) pointers owned by the caller (PyTorch allocates them in our binding);
- *     the library allocates no device memory and never synchronises with the host.
+ *     the library allocates no device memory and does not synchronise with the host (one exception: the probe below).
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream). Every kernel is ordered on the caller's stream. ONE
- *     exception, stated here because it is visible to tools: mdpt_forward lazily creates ONE internal non-blocking side stream + two
- *     events per handle. For batches >= 8 (mdpt_set_batch_split) it runs the second half batch there; for smaller batches it runs the four
- *     reassembly branches there, each as soon as its encoder tap exists (mdpt_debug_set_reassemble_overlap). Either way the side stream is
+ *     exception, stated here because it is visible to tools: mdpt_forward lazily creates an internal non-blocking side stream + two events
+ *     per handle. The first forward on a caller stream picks that side stream among up to four candidates by PROBING, on the GPU, that it
+ *     runs beside the caller's stream and not behind it on a shared hardware queue (a few tiny launches and one host wait, once per handle
+ *     and caller stream, skipped inside a stream capture; mdpt_debug_set_side_stream_probe). For batches >= 8 (mdpt_set_batch_split) the
+ *     second half batch runs there; for smaller batches of the wide encoders (feature width >= 1024, default mode) the four reassembly
+ *     branches do, each as soon as its encoder tap exists (mdpt_debug_set_reassemble_overlap). Either way the side stream is
  *     forked from and joined back into the caller's stream with events before the call returns (also on the error path) - stream-ordering
  *     semantics for the caller are unchanged, the call stays capturable into a hipGraph, results are bit-identical to the one-stream form.
  *   - tensors at this boundary use the REFERENCE layouts: images/maps BCHW, tokens B x N x F, depth B x H x W. The hot entry points
@@ -277,8 +280,18 @@ int mdpt_debug_set_ksplit_min(mdpt_handle* h, int32_t min_k_tiles, int32_t four_
 /* Test / A-B hook: unsplit forwards (batches below mdpt_set_batch_split's threshold, i.e. the reference's frame-by-frame workload) queue each
  * reassembly branch (reassembly_model.py:61-94: four independent branches, one per encoder tap) on the handle's internal side stream as soon
  * as its tap exists, beside the remaining encoder blocks, and join before the fusion stage - same kernels, same bits, stream-ordering
- * semantics for the caller unchanged (as for the batch split). Default on; 0 runs the branches behind the encoder on the caller's stream. */
+ * semantics for the caller unchanged (as for the batch split). `on`: 0 = never (branches behind the encoder on the caller's stream), 1 = the
+ * library's rule (default: encoders of width >= 1024 outside latency mode, where it measured faster), 2 = always. */
 int mdpt_debug_set_reassemble_overlap(mdpt_handle* h, int32_t on);
+/* Test / A-B hooks of the internal side stream, to be set before the first forward creates it. The runtime multiplexes the streams of a process
+ * onto a few hardware queues; a side stream on the caller's queue would run the two halves of a split batch one after the other, so the first
+ * forward on a caller stream PROBES up to four candidate streams on the GPU and keeps one that really runs beside the caller's (one host wait,
+ * once per handle and caller stream, never inside a stream capture; csrc/stream_probe.hip). `probe` 0 takes the first candidate unseen.
+ * `prio`: priority class of the candidates, 0 = default class (default), 1 = the device's lowest, -1 = highest (own queue pool, but measured
+ * slower: the two classes do not overlap). mdpt_debug_side_stream_info: candidates created / candidates found on the caller's queue so far. */
+int mdpt_debug_set_side_stream_priority(mdpt_handle* h, int32_t prio);
+int mdpt_debug_set_side_stream_probe(mdpt_handle* h, int32_t on);
+int mdpt_debug_side_stream_info(mdpt_handle* h, int32_t* candidates, int32_t* rejected);
 int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_floats, void* workspace, size_t workspace_bytes,
                     void* stream);
 

@@ -76,6 +76,10 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     h->split_min = 8;
     h->latency_mode = 0;
     h->overlap_reasm = 1;
+    h->side_prio = 0;
+    h->side_probe = 1;
+    h->side_ncand = h->side_rejected = 0;
+    h->side_nfor = 0;
     h->grid_cache = 0;
     h->gen = 0;
     h->cache_clear();
@@ -299,12 +303,51 @@ int mdpt_set_gemm_tile(mdpt_handle* h, int32_t tile) {
 
 static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, int image_dtype, void* depth_bhw, int depth_dtype);
 
-static int ensure_side_stream(mdpt_handle* h) {  // one internal non-blocking stream + two events per handle, created on first use
-    if (!h->side_stream) {
-        CHK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+// The handle's internal side stream + two events, created on first use. WHICH stream: one that the GPU really runs beside the caller's stream
+// (stream_probe.hip has the why and the measurement): up to four candidates of the default priority class, the first that passes the probe is kept
+// for this caller stream. The probe costs a few launches and ONE host wait, once per (handle, caller stream) - the only host synchronisation of
+// the library, never inside a stream capture (there the current choice, or the first candidate, is used unprobed; the graph keeps no stream).
+// `scratch`: two words of the caller's workspace (free before the forward starts using it).
+static int ensure_side_stream(mdpt_handle* h, hipStream_t s0, void* scratch) {
+    if (!h->ev_fork) {
         CHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         CHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     }
+    auto candidate = [&](int i) -> int {
+        while (h->side_ncand <= i) {
+            int least = 0, greatest = 0;
+            CHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            const int prio = h->side_prio > 0 ? least : h->side_prio < 0 ? greatest : 0;
+            CHK(hipStreamCreateWithPriority(&h->side_cand[h->side_ncand], hipStreamNonBlocking, prio));
+            ++h->side_ncand;
+        }
+        return 0;
+    };
+    if (h->side_stream && !h->side_probe) return 0;
+    for (int k = 0; k < (h->side_nfor < 4 ? h->side_nfor : 4); ++k)
+        if (h->side_for[k] == s0) { h->side_stream = h->side_cand[h->side_pick[k]]; return 0; }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s0 && hipStreamIsCapturing(s0, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (!h->side_probe || cap != hipStreamCaptureStatusNone) {
+        if (!h->side_stream) { CHK(candidate(0)); h->side_stream = h->side_cand[0]; }
+        return 0;
+    }
+    int chosen = 0;
+    for (int i = 0; i < 4; ++i) {
+        CHK(candidate(i));
+        unsigned* words = (unsigned*)scratch;
+        unsigned seen = 0;
+        CHK(mdpt_launch_queue_probe(words, words + 1, s0, h->side_cand[i], h->ev_fork));
+        CHK(hipMemcpyAsync(&seen, words + 1, sizeof(seen), hipMemcpyDeviceToHost, s0));
+        CHK(hipStreamSynchronize(s0));
+        CHK(hipStreamSynchronize(h->side_cand[i]));
+        if (seen) { chosen = i; break; }
+        ++h->side_rejected;
+    }
+    h->side_stream = h->side_cand[chosen];
+    h->side_for[h->side_nfor & 3] = s0;
+    h->side_pick[h->side_nfor & 3] = chosen;
+    ++h->side_nfor;
     return 0;
 }
 
@@ -324,8 +367,8 @@ int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t image_dtype, in
         CHK(check_ws(h, p0, workspace, workspace_bytes));
         const size_t off1 = rup256(p0.total);
         if (workspace_bytes < off1 + p1.total) return fail(MDPT_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", off1 + p1.total, workspace_bytes);
-        CHK(ensure_side_stream(h));
         hipStream_t s0 = (hipStream_t)stream;
+        CHK(ensure_side_stream(h, s0, workspace));
         CHK(hipEventRecord(h->ev_fork, s0));
         CHK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
         Ctx c0, c1;
@@ -372,10 +415,14 @@ static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, int
     CHK(run_patch_embed_fused(c, image_bchw, image_dtype));
     h->last_plan = c.p;
     h->has_last = true;
-    if (!c.split && h->overlap_reasm && h->dbg_block < 0) {
+    // measured on one box (tools/probes/b1_overlap_ab.py, profiles/r05_b1_overlap_ab.txt): wide encoders in the default mode gain (ViT-L 3.89 -> 3.82 ms,
+    // BEiT-L 3.34 -> 3.23 ms), ViT-S loses (1.13 -> 1.16 ms: its blocks leave no idle CUs to fill, the fork / join events only add), latency mode
+    // loses or ties (its K-split decoder convs own the encoder's partial-sum planes and stand down on the side stream) - hence the rule
+    const bool overlap = h->overlap_reasm == 2 || (h->overlap_reasm == 1 && !h->latency_mode && h->F >= 1024);
+    if (!c.split && overlap && h->dbg_block < 0) {
         // unsplit (small-batch) forward: reassembly branches run on the side stream beside the encoder (run_encoder, Ctx::tap_stream); whatever
         // happens in between, the side stream is joined back into the caller's stream before anything else is queued or returned
-        CHK(ensure_side_stream(h));
+        CHK(ensure_side_stream(h, c.s, c.ws));
         Ctx ce = c;
         ce.tap_stream = h->side_stream; ce.tap_event = h->ev_fork;
         const int rc = run_encoder(ce, nullptr);
@@ -384,7 +431,9 @@ static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, int
         if (ew != hipSuccess) hipStreamSynchronize(h->side_stream);
         if (rc != 0) return rc;
         CHK(ew);
-        CHK(run_fusion(c, true));
+        Ctx cf = c;
+        cf.a1_done = true;
+        CHK(run_fusion(cf, true));
         CHK(run_head(c, depth_bhw, depth_dtype, head_upsamples_bf16(h)));
         return 0;
     }

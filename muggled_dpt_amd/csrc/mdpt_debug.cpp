@@ -12,7 +12,29 @@ int mdpt_debug_set_stop(mdpt_handle* h, int32_t block, int32_t step) {
 
 int mdpt_debug_set_reassemble_overlap(mdpt_handle* h, int32_t on) {
     if (!h) return fail(MDPT_E_INVALID, "null handle");
-    h->overlap_reasm = on ? 1 : 0;
+    if (on < 0 || on > 2) return fail(MDPT_E_INVALID, "reassemble overlap: 0 = off, 1 = the library's rule, 2 = always");
+    h->overlap_reasm = on;
+    return 0;
+}
+
+int mdpt_debug_set_side_stream_priority(mdpt_handle* h, int32_t prio) {
+    if (!h || prio < -1 || prio > 1) return fail(MDPT_E_INVALID, "null handle or priority class outside -1 .. 1");
+    if (h->side_ncand) return fail(MDPT_E_STATE, "the side stream exists already (set the class before the first forward)");
+    h->side_prio = prio;
+    return 0;
+}
+
+int mdpt_debug_set_side_stream_probe(mdpt_handle* h, int32_t on) {
+    if (!h) return fail(MDPT_E_INVALID, "null handle");
+    if (h->side_ncand) return fail(MDPT_E_STATE, "the side stream exists already (set this before the first forward)");
+    h->side_probe = on ? 1 : 0;
+    return 0;
+}
+
+int mdpt_debug_side_stream_info(mdpt_handle* h, int32_t* candidates, int32_t* rejected) {
+    if (!h || !candidates || !rejected) return fail(MDPT_E_INVALID, "null argument");
+    *candidates = h->side_ncand;
+    *rejected = h->side_rejected;
     return 0;
 }
 

@@ -181,7 +181,8 @@ struct mdpt_handle {
     // events, no host sync) so that one half's kernels fill the tile-quantisation tails and epilogue phases of the other's
     int split_min;
     int latency_mode;  // mdpt_set_latency_mode: small launches may use summation orders that are not batch-invariant
-    int overlap_reasm;  // unsplit forwards queue the reassembly branches on the side stream beside the encoder (default on; mdpt_debug_set_reassemble_overlap)
+    int side_prio;      // priority class of the side stream: 0 = the default class (default), 1 = lowest, -1 = highest (mdpt_debug_set_side_stream_priority; measured worse)
+    int overlap_reasm;  // unsplit forwards queue the reassembly branches on the side stream beside the encoder: 0 never, 1 = rule in forward_one (default), 2 always
     // mdpt_set_grid_cache (the reference's enable_cache, position_encoder.py:152-227): per-grid constants - resized position embedding, BEiT's
     // relative-position tables, SwinV2's position-bias tables, the zero pads of operand planes - stay in the workspace of the last forward of
     // a (workspace, B, H, W) and are not recomputed by the next forward on the same workspace and shape (`gen` = finalize generation)
@@ -197,10 +198,14 @@ struct mdpt_handle {
     void cache_store(int slot, const void* ws, int B, int H, int W) { cache_slot[slot] = CacheSlot{ws, B, H, W, gen, true}; }
     void cache_clear() { cache_slot[0].valid = cache_slot[1].valid = false; }
     int ks_min_ktiles, ks_big_ktiles;  // ... proj / fc2 split K in two (64x64 tile) from ks_min K tiles on, in four from ks_big on (mdpt_debug_set_ksplit_min)
-    hipStream_t side_stream;
+    // the side stream: chosen among up to four candidates as one that really runs beside the caller's stream (stream_probe.hip), per caller stream
+    hipStream_t side_stream, side_cand[4], side_for[4];  // side_for[k] -> side_cand[side_pick[k]]: the caller streams probed so far (ring of four)
+    int side_pick[4], side_nfor;
+    int side_ncand, side_rejected;  // candidates created; candidates found on the caller's hardware queue so far (mdpt_debug_side_stream_info)
+    int side_probe;                 // 1 (default): probe; 0: take the first candidate unseen (mdpt_debug_set_side_stream_probe)
     hipEvent_t ev_fork, ev_join;
     ~mdpt_handle() {
-        if (side_stream) hipStreamDestroy(side_stream);
+        for (int i = 0; i < side_ncand; ++i) hipStreamDestroy(side_cand[i]);
         if (ev_fork) hipEventDestroy(ev_fork);
         if (ev_join) hipEventDestroy(ev_join);
     }
@@ -264,6 +269,7 @@ struct Ctx {
     hipStream_t tap_stream = nullptr;  // small-batch forward: every reassembly branch is queued here as soon as its tap exists (tap_event orders it)
     hipEvent_t tap_event = nullptr;
     bool side = false;  // this context runs on that side stream, beside the encoder
+    bool a1_done = false;  // ... where the first conv of every conv_reassembly unit was queued too: run_fusion skips it
     bool consts_cached = false;  // the per-grid constants of this (workspace, shape) are in place (mdpt_set_grid_cache): skip the kernels that write them
     void* const* attn_dump = nullptr;  // per block: where to write softmax(q k^T) as fp32 [B,H,N,N] (null entries: skip)
     void* const* block_dump = nullptr; // per block: where to write the block's output tokens as fp32 [B,N,F] (null entries: skip)
@@ -309,6 +315,7 @@ int rcu_conv(const Ctx& c, const std::string& wname, Planes in, int sh, int sw, 
 bool head_upsamples_bf16(const mdpt_handle* h);
 bool head_tail_fused(const mdpt_handle* h);
 int run_fusion(const Ctx& c, bool for_head = false);
+int fusion_rcu_a_first(const Ctx& c, int i);
 int run_head(const Ctx& c, void* depth, int depth_dtype = MDPT_DTYPE_F32, bool from_flo0b = false);
 int swin_zero_pad_planes(const Ctx& c, int rows0);
 int run_patch_embed_swin(const Ctx& c, const void* image, int image_dtype, float* tokens_out);

@@ -175,6 +175,9 @@ int mdpt_launch_post_scale(const float* in, float* out, int B, int ih, int iw, i
 int mdpt_launch_post_normalize(const float* in, const float* minmax, void* out, size_t n, int mode, int lossy,
                                hipStream_t stream);
 
+// stream_probe.hip: does `candidate` run kernels beside `waiter_stream`? (*seen != 0 after synchronising with waiter_stream)
+int mdpt_launch_queue_probe(unsigned* flag, unsigned* seen, hipStream_t waiter_stream, hipStream_t candidate, hipEvent_t ready);
+
 // ------------------------------------------------------------------------------------------------
 // launchers: one set per operand format (op_types.h). A kernel file sees its own set through MDPT_FN; the host side (mdpt_internal.h)
 // includes mdpt_launchers.inc a second time for the other format and picks per handle (OPL). C linkage: the two

@@ -235,6 +235,8 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
                 Ctx cs = c;
                 cs.s = c.tap_stream; cs.tap_stream = nullptr; cs.side = true;
                 CHK(run_reassemble_stage(cs, st));
+                // ... and the first conv of the fusion block's conv_reassembly unit (fusion_model.py:148-150), which reads that branch's map only
+                if (st < 3) CHK(fusion_rcu_a_first(cs, st));
             }
         }
     }
@@ -409,6 +411,16 @@ bool head_upsamples_bf16(const mdpt_handle* h) { return h->np[CLS_HEAD] == 1 && 
 // split: conv 1 writes hi + lo 16-bit planes, head_tail2_kernel). Three passes run the unfused kernels.
 bool head_tail_fused(const mdpt_handle* h) { return h->np[CLS_HEAD_TAIL] <= 2 && mdpt_head_tail_supported(h->C2p); }
 
+// first conv of level i's conv_reassembly unit: relu(r_i) -> 3x3 conv -> ReLU'd planes a1[i] (fusion_model.py:148-150, 210-220)
+int fusion_rcu_a_first(const Ctx& c, int i) {
+    const mdpt_handle* h = c.h;
+    const Plan& p = c.p;
+    const int sh[4] = {4 * p.gh, 2 * p.gh, p.gh, p.gh / 2}, sw[4] = {4 * p.gw, 2 * p.gw, p.gw, p.gw / 2};
+    char pb[64];
+    snprintf(pb, sizeof(pb), "fusion.blocks.%d", i);
+    return rcu_conv(c, std::string(pb) + ".conv_reassembly." + rcu_seq(h) + ".1", c.pl(p.r_bf[i]), sh[i], sw[i], nullptr, nullptr, 0, 0, nullptr, c.pl(p.a1[i]), 1);
+}
+
 int run_fusion(const Ctx& c, bool for_head) {
     const mdpt_handle* h = c.h;
     const Plan& p = c.p;
@@ -425,7 +437,7 @@ int run_fusion(const Ctx& c, bool for_head) {
         } else {
             // x = RCU_a(r_i) + up2(prev)   (fusion_model.py:148-154)
             Planes a1 = c.pl(p.a1[i]);
-            CHK(rcu_conv(c, blk + ".conv_reassembly." + rcu_seq(h) + ".1", c.pl(p.r_bf[i]), sh[i], sw[i], nullptr, nullptr, 0, 0, nullptr, a1, 1));
+            if (!c.a1_done) CHK(fusion_rcu_a_first(c, i));
             x_bf = c.pl(p.x_bf[i]);
             CHK(rcu_conv(c, blk + ".conv_reassembly." + rcu_seq(h) + ".3", a1, sh[i], sw[i], c.at<float>(p.r_f32[i]), c.at<float>(p.flo[i + 1]),
                          sh[i + 1], sw[i + 1], c.at<float>(p.x_f32[i]), x_bf, 1));

@@ -495,7 +495,7 @@ class _Engine:
         nbytes = ctypes.c_size_t()  # asked every call (host-side arithmetic only): settings such as the batch split change the need
         native.check(self.lib, self.lib.mdpt_workspace_bytes(self.handle, batch, key[1], key[2], ctypes.byref(nbytes)))
         if ws is None or ws.numel() < nbytes.value + 256:
-            if len(self._workspaces) >= 4:
+            if len(self._workspaces) >= 4 and not torch.cuda.is_current_stream_capturing():  # (no device-wide wait inside a graph capture: keep all)
                 torch.cuda.synchronize(self.device)  # buffers of other streams may still be in use
                 self._workspaces.clear()
             ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)

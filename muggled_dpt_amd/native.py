@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(CSRC, "libmdpt.so")
 # kernel files that touch MFMA operand planes are compiled twice, once per operand format (csrc/op_types.h): bf16 and, with
 # -DMDPT_OP_F16, fp16; the launcher symbols carry the format as a suffix and the host side (mdpt_internal.h: OPL) picks per handle
 OPERAND_SOURCES = ("gemm.hip", "conv3h.hip", "attention.hip", "elementwise.hip", "swin.hip", "head.hip")
-PLAIN_SOURCES = ("postprocess.hip", "mdpt_api.cpp", "mdpt_inventory.cpp", "mdpt_stages.cpp", "mdpt_debug.cpp", "mdpt_prof.cpp")
+PLAIN_SOURCES = ("postprocess.hip", "stream_probe.hip", "mdpt_api.cpp", "mdpt_inventory.cpp", "mdpt_stages.cpp", "mdpt_debug.cpp", "mdpt_prof.cpp")
 SOURCES = OPERAND_SOURCES + PLAIN_SOURCES
 HEADERS = ("gemm_common.inc", "gemm_epilogue_strip.inc", "gemm_lockstep.inc", "gemm8_epilogues.inc", "gemm8.inc", "mdpt_kernels.h", "mdpt_launchers.inc", "op_types.h", "mdpt_prof.h", "mdpt_internal.h", "mdpt_swin_plan.inc", "mdpt_swin_stages.inc", "ln_row.h",
            "up_bf16.h",
@@ -200,6 +200,9 @@ SYMBOLS = {
     "mdpt_debug_set_stop": (ctypes.c_int, [_VP, _I, _I]),
     "mdpt_debug_set_ksplit_min": (ctypes.c_int, [_VP, _I, _I]),
     "mdpt_debug_set_reassemble_overlap": (ctypes.c_int, [_VP, _I]),
+    "mdpt_debug_set_side_stream_priority": (ctypes.c_int, [_VP, _I]),
+    "mdpt_debug_set_side_stream_probe": (ctypes.c_int, [_VP, _I]),
+    "mdpt_debug_side_stream_info": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "mdpt_debug_set_operand_format": (ctypes.c_int, [_I]),
     "mdpt_set_grid_cache": (ctypes.c_int, [_VP, _I]),
     "mdpt_set_class_passes": (ctypes.c_int, [_VP, _I, _I]),

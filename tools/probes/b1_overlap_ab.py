@@ -16,7 +16,7 @@ for name, size in (("vits", 504), ("vitl", 504), ("beitl", 384)):
     for rnd in range(3):
         for latency in (False, True):
             model.set_latency_mode(latency)
-            for ov in (0, 1):
+            for ov in (0, 2):
                 native.check(lib, lib.mdpt_debug_set_reassemble_overlap(h, ov))
                 dt, _ = bench.time_model(model, x, 300)
                 res.setdefault((latency, ov), []).append(dt * 1e3)
