@@ -327,9 +327,7 @@ def secondary_legs(args, dev, lib, vitl_model):
             y_m = dt_m = None
             if (name in SYNTH_NAME or size == 1036) and want_err and ow is not None:
                 # BASELINE configs[4] in the mixed-pass mode too (fp32 tensors at the boundary; SwinV2's window-major encoder runs it
-                # without the token-mean compensation). Timed BEFORE the CPU oracle below runs: the oracle's OpenMP pool keeps spinning
-                # for a while after a parallel region and starves the launch thread of a launch-heavy forward (SwinV2-L read 21 ms
-                # instead of 15 ms when this leg followed the oracle)
+                # without the token-mean compensation). (Timed before the CPU oracle so that all GPU timing of a leg is done when the CPU work starts.)
                 if own_model:
                     del model  # (a float32 model built afresh: casting the bf16 model back would keep its bf16-rounded parameters)
                 torch.cuda.empty_cache()
