@@ -70,5 +70,8 @@ python tools/probes/gpu_wscale_check.py 2>&1 | grep -v amdgpu > "$OUT/wscale_che
 if [ -x tools/probes/_bin/mfma_power ] && [ -x tools/probes/_bin/mfma_power_f16 ]; then
   { echo "== bf16"; tools/probes/_bin/mfma_power | head -3; echo "== fp16"; tools/probes/_bin/mfma_power_f16 | head -3; } > "$OUT/mfma_power_f16_vs_bf16.txt" 2>&1
 fi
+# side stream: hardware-queue collisions (first stream handed out vs probed), reassembly branches beside the encoder at batch 1
+python tools/probes/gpu_side_stream_queue.py 2>&1 | grep -v amdgpu > "$OUT/side_stream_queue.txt"
+python tools/probes/b1_overlap_ab.py 2>&1 | grep -v amdgpu > "$OUT/b1_overlap_ab.txt"
 [ -x tools/probes/_bin/exp_throughput ] && tools/probes/_bin/exp_throughput > "$OUT/exp_throughput.txt" 2>&1
 ls -la "$OUT"
