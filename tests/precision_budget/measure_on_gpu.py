@@ -52,7 +52,7 @@ def measure(args):
     from oracle import dpt_oracle
     osd, cfg, w = synthetic_model(args.model, 0)
     x = seeded_input((args.batch, 3, args.size, args.size), 1)
-    idx = [i for i in (0, 7, 13, 31) if i < args.batch]
+    idx = list(range(args.batch)) if args.all_images else [i for i in (0, 7, 13, 31) if i < args.batch]
     torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
     ref = dpt_oracle.forward(w, cfg, x[idx])
     _, model = make_depthanythingv2_dpt_from_original_state_dict(osd)
@@ -90,7 +90,8 @@ def measure(args):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
         rows.append({"label": label, "precision": prec, "passes": passes, "rel_err": errs, "rms_err": rms, "ms_per_step": dt * 1e3, "maps_per_s": args.batch / dt})
-        print(f"{label:58s} " + " ".join(f"{e:.2e}" for e in errs) + f" | rms {sum(rms) / len(rms):.2e}   {dt * 1e3:7.2f} ms  {args.batch / dt:7.1f} maps/s", flush=True)
+        shown = errs if len(errs) <= 4 else [max(errs), sorted(errs)[len(errs) // 2], min(errs)]  # (--all-images: worst, median, best)
+        print(f"{label:58s} " + " ".join(f"{e:.2e}" for e in shown) + f" | rms {sum(rms) / len(rms):.2e}   {dt * 1e3:7.2f} ms  {args.batch / dt:7.1f} maps/s", flush=True)
     rep = {"model": args.model, "size": args.size, "batch": args.batch, "images": idx, "steps": args.steps, "device": torch.cuda.get_device_name(0), "rows": rows}
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
@@ -119,6 +120,7 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--only", nargs="*", default=[], help="rows whose label contains one of these")
     ap.add_argument("--labels", nargs="*", default=[], help="rows with exactly these labels")
+    ap.add_argument("--all-images", action="store_true", help="every image of the batch against the oracle (default: images 0, 7, 13, 31)")
     ap.add_argument("--no-split", action="store_true", help="batch split off (per-kernel profiles)")
     ap.add_argument("--out", default="")
     ap.add_argument("--render", default="")
