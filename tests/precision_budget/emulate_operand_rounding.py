@@ -61,6 +61,39 @@ def rnd_w(x, mode):
     return rnd(x, mode)
 
 
+# ---- round-6 study: the CROSS TERMS of a split product (A_lo W_hi, A_hi W_lo) on block-scaled low-precision operands (gfx950's
+# v_mfma_scale_f32_32x32x64_f8f6f4: OCP MX formats, one power-of-two scale per 32 consecutive K elements; fp8 at 2x, fp6 / fp4 at 4x the fp16 MFMA
+# rate). Mode "f16x2a@mxfp6" = A_hi W_hi in fp16 + Q(A_lo) Q(W_hi) with Q = MX e2m3; "f16x3@..." adds Q(A_hi) Q(W_lo).
+MX = {"mxfp8": (4, 3, -6, 8, 448.0), "mxfp6": (2, 3, 0, 2, 7.5), "mxbf6": (3, 2, -2, 4, 28.0), "mxfp4": (2, 1, 0, 2, 6.0)}  # (E, M, emin, emax, max)
+
+
+def mx_quant(x: torch.Tensor, fmt: str, dim: int) -> torch.Tensor:
+    """OCP MX quantisation of x along `dim` in blocks of 32 (zero padded): shared scale 2^(floor(log2 max|v|) - emax), elements rounded to
+    nearest (ties to even) in the element format, saturating."""
+    _, m, emin, emax, vmax = MX[fmt]
+    xt = x.movedim(dim, -1)
+    k = xt.shape[-1]
+    pad = (-k) % 32
+    if pad:
+        xt = torch.nn.functional.pad(xt, (0, pad))
+    blk = xt.reshape(*xt.shape[:-1], -1, 32).double()
+    amax = blk.abs().amax(dim=-1, keepdim=True)
+    scale = torch.exp2(torch.floor(torch.log2(amax.clamp_min(1e-300))) - emax)
+    v = blk / scale
+    e = torch.floor(torch.log2(v.abs().clamp_min(1e-300))).clamp(emin, emax)
+    q = torch.exp2(e - m)
+    r = (torch.round(v / q) * q).clamp(-vmax, vmax)  # torch.round: half to even
+    out = torch.where(amax > 0, r * scale, torch.zeros_like(r)).reshape(*xt.shape).float()
+    if pad:
+        out = out[..., :k]
+    return out.movedim(-1, dim)
+
+
+def split_modes(mode: str):
+    """"f16x2a@mxfp6" -> ("f16x2a", "mxfp6"); plain modes -> (mode, None)"""
+    return tuple(mode.split("@")) if "@" in mode else (mode, None)
+
+
 FINE = False  # --fine: split the decoder classes by layer (study only; the library switches whole classes)
 FINE_CLASSES = ("reasm_1x1", "reasm_resample", "reasm_fuse3x3", "fusion_rcu_a", "fusion_rcu_b", "fusion_proj1x1", "head_conv1", "head_conv2")
 
@@ -116,8 +149,19 @@ class _FProxy:
         cls = self.idmap.get(id(weight))
         return "f32" if cls is None else self.policy[cls]
 
+    def _contract(self, fn, x, weight, bias, m, kdim_x, kdim_w, **kw):
+        """split product with its cross terms on MX operands (see MX above)"""
+        base, fmt = split_modes(m)
+        xh, wh = rnd(x, "f16"), rnd(weight, "f16")
+        y = fn(xh, wh, bias, **kw) + fn(mx_quant(x - xh, fmt, kdim_x), mx_quant(wh, fmt, kdim_w), None, **kw)
+        if base == "f16x3":
+            y = y + fn(mx_quant(xh, fmt, kdim_x), mx_quant(weight - wh, fmt, kdim_w), None, **kw)
+        return y
+
     def linear(self, x, weight, bias=None):
         m = self._mode(weight)
+        if "@" in m:
+            return self._contract(TF.linear, x, weight, bias, m, -1, -1)
         if m == "f16c":  # single fp16 pass + the token-mean compensation of the weight rounding (mdpt_stages.cpp wrc_bias)
             xr, wr = rnd(x, "f16"), rnd(weight, "f16")
             wlo = rnd(weight - wr, "f16")
@@ -129,10 +173,14 @@ class _FProxy:
 
     def conv2d(self, x, weight, bias=None, **kw):
         m = self._mode(weight)
+        if "@" in m:
+            return self._contract(TF.conv2d, x, weight, bias, m, 1, 1, **kw)
         return TF.conv2d(rnd_a(x, m), rnd_w(weight, m), bias, **kw)
 
     def conv_transpose2d(self, x, weight, bias=None, **kw):
         m = self._mode(weight)
+        if "@" in m:
+            return self._contract(TF.conv_transpose2d, x, weight, bias, m, 1, 0, **kw)
         return TF.conv_transpose2d(rnd_a(x, m), rnd_w(weight, m), bias, **kw)
 
 
@@ -170,7 +218,7 @@ def main():
     ap.add_argument("--model", default="vitl")
     ap.add_argument("--size", type=int, default=504)
     ap.add_argument("--images", type=int, nargs="+", default=[0])
-    ap.add_argument("--study", default="budget", choices=["budget", "modes", "policy", "twopass"])
+    ap.add_argument("--study", default="budget", choices=["budget", "modes", "policy", "twopass", "lowlo"])
     ap.add_argument("--policy", default="", help="study=policy: comma list class=mode, others take --base")
     ap.add_argument("--base", default="f16")
     ap.add_argument("--out", default="")
@@ -237,6 +285,32 @@ def main():
             for c in dec:
                 p[c] = two
             run(f"mixed, decoder = {two}", p)
+    elif args.study == "lowlo":
+        # the shipped mixed table (Depth-Anything families: reasm / 1x1 fusion projections 3 passes, fusion 3x3 convs and both head convs 2 passes
+        # with the activations split, conv_reassembly units 1 pass, encoder 1 pass + compensation), then the SAME table with every cross term on
+        # block-scaled low-precision operands
+        assert FINE, "--study lowlo needs --fine"
+        def table(fmt):
+            at = "" if fmt is None else "@" + fmt
+            p = uniform("f16x3")
+            for c in ("qkv", "proj", "fc1", "fc2"):
+                p[c] = "f16c"
+            p["attn"] = "f16"
+            p["fusion_rcu_a"] = "f16"
+            for c in ("reasm_1x1", "reasm_resample", "reasm_fuse3x3", "fusion_proj1x1"):
+                p[c] = "f16x3" + at
+            for c in ("fusion_rcu_b", "head_conv1", "head_conv2"):
+                p[c] = "f16x2a" + at
+            if fmt is not None:
+                p["patch"] = "f16x3" + at
+            return p
+        run("mixed (shipped table, fp16 cross terms)", table(None))
+        for fmt in ("mxfp8", "mxfp6", "mxbf6", "mxfp4"):
+            run(f"mixed, cross terms in {fmt}", table(fmt))
+        p = table(None)
+        for c in ("reasm_1x1", "reasm_resample", "reasm_fuse3x3", "fusion_proj1x1", "fusion_rcu_b", "head_conv1", "head_conv2", "patch"):
+            p[c] = "f16"
+        run("(decoder + patch at one fp16 pass)", p)
     else:
         p = uniform(args.base)
         for item in filter(None, args.policy.split(",")):
