@@ -5,6 +5,9 @@
 //  (2) the scale operand is NOT per lane: the E8M0 byte of lane r (< 32) scales bytes 0-15 of lanes r AND r + 32, the byte of lane r + 32
 //      scales bytes 16-31 of both - i.e. the hardware's K order is k = 32 (j >> 4) + 16 (l >> 5) + (j & 15) and an MX block of 32 consecutive
 //      k sits in TWO lanes, 16 bytes each;
+//  (2b) the 16x16x128 form (the accumulator shape of the 8-phase kernels): lane l = row / column l & 15, lane group g = l >> 4 holds 32 of the 128 K
+//      bytes, C/D as every 16x16 MFMA; scales: lane r scales bytes 0-15 of lane groups 0 and 1, lane r + 16 bytes 0-15 of groups 2 and 3,
+//      lane r + 32 bytes 16-31 of groups 0 and 1, lane r + 48 bytes 16-31 of groups 2 and 3;
 //  (3) issue rate against v_mfma_f32_32x32x16_f16: fp8 x fp8 2.2x, fp6 x fp6 and fp4 x fp4 4.1-4.2x (K = 64 per instruction against 16).
 //   hipcc --offload-arch=gfx950 -O2 -o mfma_scale_probe mfma_scale_probe.hip && ./mfma_scale_probe
 #include <hip/hip_runtime.h>
@@ -31,6 +34,18 @@ __global__ void one_mfma(const uint8_t* a, const uint8_t* b, const uint8_t* sa, 
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 0, 0, 0, (int)sa[lane], 0, (int)sb[lane]);
     for (int r = 0; r < 16; ++r) d[lane * 16 + r] = acc[r];
+}
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+// one wave of the 16x16x128 form: a, b = 64 lanes x 32 bytes (fp8), d = 64 lanes x 4 floats
+__global__ void one_mfma16(const uint8_t* a, const uint8_t* b, const uint8_t* sa, const uint8_t* sb, float* d) {
+    const int lane = threadIdx.x;
+    i32x8 av, bv;
+    memcpy(&av, a + lane * 32, 32);
+    memcpy(&bv, b + lane * 32, 32);
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, acc, 0, 0, 0, (int)sa[lane], 0, (int)sb[lane]);
+    for (int r = 0; r < 4; ++r) d[lane * 4 + r] = acc[r];
 }
 
 template <int FMT>
@@ -170,6 +185,63 @@ int main() {
                 worst = fmax(worst, fabs(ref - d[l * 16 + r]));
             }
         printf("random scales, semantics 'lane r scales bytes 0-15 of lanes r and r+32, lane r+32 bytes 16-31': max |D - ref| = %g (%s)\n", worst, worst == 0 ? "EXACT" : "MISMATCH");
+    }
+    {   // ---- the 16x16x128 form (the accumulator shape of the 8-phase kernels): rows / columns l & 15, four lane groups of 32 K bytes each
+        std::vector<float> A2(16 * 128), B2(128 * 16);
+        for (auto& v : A2) v = (float)(rand() % 9 - 4);
+        for (auto& v : B2) v = (float)(rand() % 7 - 3) * 0.5f;
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 32; ++j) {
+                a[l * 32 + j] = enc_e4m3(A2[(l & 15) * 128 + 32 * (l >> 4) + j]);
+                b[l * 32 + j] = enc_e4m3(B2[(32 * (l >> 4) + j) * 16 + (l & 15)]);
+            }
+        CK(hipMemcpy(da, a.data(), a.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), b.size(), hipMemcpyHostToDevice));
+        std::vector<float> e(64 * 4), e0;
+        auto run16 = [&]() {
+            CK(hipMemcpy(dsa, sa.data(), 64, hipMemcpyHostToDevice)); CK(hipMemcpy(dsb, sb.data(), 64, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(one_mfma16, dim3(1), dim3(64), 0, 0, da, db, dsa, dsb, dd);
+            CK(hipMemcpy(e.data(), dd, e.size() * 4, hipMemcpyDeviceToHost));
+        };
+        std::fill(sa.begin(), sa.end(), 127); std::fill(sb.begin(), sb.end(), 127);
+        run16();
+        e0 = e;
+        std::vector<double> eighth(8 * 16 * 16);  // [lane group * 2 + byte half][row][col]
+        for (int row = 0; row < 16; ++row)
+            for (int col = 0; col < 16; ++col)
+                for (int k = 0; k < 128; ++k) eighth[((k >> 4) * 16 + row) * 16 + col] += (double)A2[row * 128 + k] * B2[k * 16 + col];
+        double w16 = 0;
+        for (int l = 0; l < 64; ++l)
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * (l >> 4) + r, col = l & 15;
+                double ref = 0;
+                for (int q = 0; q < 8; ++q) ref += eighth[(q * 16 + row) * 16 + col];
+                w16 = fmax(w16, fabs(ref - e0[l * 4 + r]));
+            }
+        printf("16x16x128, unit scales: max |D - ref| = %g (lane l byte j <-> row / column l & 15, k = 32 (l >> 4) + j; D[row = 4 (l >> 4) + r][col = l & 15])\n", w16);
+        for (int side = 0; side < 2; ++side)
+            for (int L : {3, 19, 35, 51}) {
+                std::fill(sa.begin(), sa.end(), 127); std::fill(sb.begin(), sb.end(), 127);
+                (side ? sb : sa)[L] = 129;
+                run16();
+                int hits[256] = {0}, moved = 0, idx_moved = -1;
+                for (int row = 0; row < 16; ++row)
+                    for (int col = 0; col < 16; ++col) {
+                        const int l = col + 16 * (row >> 2), r = row & 3;
+                        const double diff = e[l * 4 + r] - e0[l * 4 + r];
+                        if (diff == 0) continue;
+                        ++moved; idx_moved = side ? col : row;
+                        for (int sub = 1; sub < 256; ++sub) {
+                            double x = 0;
+                            for (int q = 0; q < 8; ++q) if (sub >> q & 1) x += 3 * eighth[(q * 16 + row) * 16 + col];
+                            if (fabs(diff - x) < 1e-3) ++hits[sub];
+                        }
+                    }
+                int best = 1;
+                for (int sub = 1; sub < 256; ++sub) if (hits[sub] > hits[best]) best = sub;
+                printf("16x16x128 %c scale x4 on lane %2d: %s %d moved; scaled part = (lane group, byte half) {", side ? 'B' : 'A', L, side ? "column" : "row", idx_moved);
+                for (int q = 0; q < 8; ++q) if (best >> q & 1) printf(" (%d,%d)", q >> 1, q & 1);
+                printf(" } - explains %d of %d moved elements\n", hits[best], moved);
+            }
     }
     // ---- (3) issue rate
     float* dout;
