@@ -169,6 +169,15 @@ def roofline(args, pr, how):
     return r
 
 
+def set_alone(lib, handle, alone: bool):
+    """`alone` = nothing runs on the library's side stream: the two-stream half-batch split off AND the reassembly branches behind the
+    encoder instead of beside it (mdpt_debug_set_reassemble_overlap 0; the default rule queues them on the side stream for every unsplit
+    forward of a wide encoder, so `mdpt_set_batch_split(0)` alone leaves launches 47+ of a ViT-L forward sharing the GPU - VERDICT r05).
+    Every per-kernel roofline figure is taken in this state; the timed region runs the library's defaults."""
+    native.check(lib, lib.mdpt_set_batch_split(handle, 0 if alone else 8))
+    native.check(lib, lib.mdpt_debug_set_reassemble_overlap(handle, 0 if alone else 1))
+
+
 def profile_pass(lib, fn, steps):
     torch.cuda.synchronize()
     lib.mdpt_profile_enable(1)
@@ -217,10 +226,10 @@ def parity_mode_legs(args, dev, x_cpu, ref, lib):
         dt, y = time_model(model, x, steps)
         with torch.inference_mode():
             handle = model._get_engine().handle
-            native.check(lib, lib.mdpt_set_batch_split(handle, 0))
+            set_alone(lib, handle, True)
             model(x)
             prof = profile_pass(lib, lambda: model(x), 2)
-            native.check(lib, lib.mdpt_set_batch_split(handle, 8))
+            set_alone(lib, handle, False)
         sub = argparse.Namespace(**{**vars(args), "precision": prec})
         rec = {"value": round(args.batch / dt, 3), "unit": "depth-maps/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
                "dtype": PRECISION_DTYPE[prec], "boundary": "fp32 image in, fp32 depth out", "error_vs_cpu_fp32": error_vs(ref, y.float())}
@@ -301,10 +310,10 @@ def secondary_legs(args, dev, lib, vitl_model):
             dt, y = time_model(model, x, steps)
             handle = model._get_engine().handle
             with torch.inference_mode():
-                native.check(lib, lib.mdpt_set_batch_split(handle, 0))
+                set_alone(lib, handle, True)
                 model(x)
                 prof = profile_pass(lib, lambda: model(x), 3)
-                native.check(lib, lib.mdpt_set_batch_split(handle, 8))
+                set_alone(lib, handle, False)
             gflop = GFLOP_PER_MAP.get((name, size))
             rec = {"metric": f"depth-maps/sec @{size}x{size}, {FAMILY[name]}", "value": round(batch / dt, 3), "unit": "depth-maps/s",
                    "ms_per_step": round(dt * 1e3, 3), "steps": steps, "dtype": "bf16", "config": {"workload": f"{FAMILY[name]} ({name}), {size}x{size} tensor, batch {batch}, bf16", "enable_cache": batch == 1}}
@@ -381,7 +390,7 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event passes behind the timed region (no roofline object)")
-    ap.add_argument("--no-split", action="store_true", help="disable the two-stream half-batch split inside mdpt_forward")
+    ap.add_argument("--no-split", action="store_true", help="nothing on the library's side stream: no two-stream half-batch split inside mdpt_forward, reassembly branches behind the encoder (every kernel alone on the GPU)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configurations the default run reports under `secondary`")
     ap.add_argument("--fake-model", action="store_true", help="test hook (tests/test_parallel.py): run the N-rank control flow - barriers, timed region, "
                     "max-over-ranks reduction, rank-0 JSON line - on CPU tensors with a stand-in model and the gloo backend; measures nothing")
@@ -426,7 +435,7 @@ def main():
         if args.tile:
             model.set_gemm_tile(args.tile)
         if args.no_split:
-            native.check(lib, lib.mdpt_set_batch_split(model._get_engine().handle, 0))
+            set_alone(lib, model._get_engine().handle, True)
     x_cpu = torch.randn(args.batch, 3, args.size, args.size, generator=torch.Generator().manual_seed(1 + rank))
     x = x_cpu.to(dev).to(dtype)
     dp = DataParallelDepth(model, rank, world)
@@ -484,10 +493,10 @@ def main():
         with torch.inference_mode():
             prof = profile_pass(lib, lambda: model(x), args.steps)
             if not args.no_split:
-                native.check(lib, lib.mdpt_set_batch_split(handle, 0))
+                set_alone(lib, handle, True)
                 model(x)
                 prof_alone = profile_pass(lib, lambda: model(x), args.steps)
-                native.check(lib, lib.mdpt_set_batch_split(handle, 8))
+                set_alone(lib, handle, False)
 
     if rank == 0:
         maps = world * args.batch * args.steps
@@ -528,8 +537,8 @@ def main():
             line["path_frac_of_mfma_peak"] = round(value * gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
         if prof and prof["kernels"]:
             if prof_alone and prof_alone["kernels"]:
-                line["roofline"] = roofline(args, prof_alone, "HIP events, extra pass of the same steps after the timed region with the batch split off (kernel alone on the "
-                                                              "GPU; `bench.py --no-split` + rocprofv3 reproduce it)")
+                line["roofline"] = roofline(args, prof_alone, "HIP events, extra pass of the same steps after the timed region with the batch split AND the reassembly-beside-encoder overlap off (nothing on the side "
+                                                              "stream: kernel alone on the GPU; `bench.py --no-split` + rocprofv3 reproduce it)")
                 line["roofline_in_timed_region"] = roofline(args, prof, "HIP events, extra pass of the same steps as timed (batch split on): two half-batch kernels overlap, "
                                                                         "durations include sharing")
                 shares = prof_alone

@@ -11,9 +11,11 @@ _, model = make_depthanythingv2_dpt_from_original_state_dict(make_synthetic_orig
 model = model.to("cuda", torch.bfloat16)
 x = torch.randn(32, 3, 504, 504, generator=torch.Generator().manual_seed(1)).to("cuda", torch.bfloat16)
 native.check(lib, lib.mdpt_set_batch_split(model._get_engine().handle, 0))
+native.check(lib, lib.mdpt_debug_set_reassemble_overlap(model._get_engine().handle, 0))  # nothing on the side stream: every kernel alone
 if os.environ.get("X3"):
     model = model.to(torch.float32); x = x.float()
     native.check(lib, lib.mdpt_set_batch_split(model._get_engine().handle, 0))
+    native.check(lib, lib.mdpt_debug_set_reassemble_overlap(model._get_engine().handle, 0))  # nothing on the side stream: every kernel alone
 if os.environ.get("TILE"):
     model.set_gemm_tile(int(os.environ["TILE"]))  # force one tile variant for every GEMM (MDPT_TILE_*)
 with torch.inference_mode():

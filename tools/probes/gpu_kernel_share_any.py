@@ -17,6 +17,7 @@ if opt == "latency":
 elif opt in native.PRECISIONS:
     model.set_precision(opt)
 native.check(lib, lib.mdpt_set_batch_split(model._get_engine().handle, 0))
+native.check(lib, lib.mdpt_debug_set_reassemble_overlap(model._get_engine().handle, 0))  # nothing on the side stream: every kernel alone
 with torch.inference_mode():
     for _ in range(2): model(x)
     torch.cuda.synchronize()
