@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MDPT_ABI_VERSION 5
+#define MDPT_ABI_VERSION 6
 
 /* arithmetic modes (all accumulate in fp32; residual stream, LayerNorm and softmax statistics are fp32) */
 #define MDPT_PREC_BF16 0   /* bf16 MFMA operands - the reference's GPU default dtype (demo_helpers/misc.py:73-77) */
@@ -122,11 +122,21 @@ void mdpt_destroy(mdpt_handle* h);
 /* Per-class MFMA pass count on top of whatever mdpt_config.precision chose: 1 = one rounded 16-bit plane per operand; 3 = hi + lo planes
  * for both operands (A_lo W_hi + A_hi W_lo + A_hi W_hi, fp32-class); 2 = ACTIVATIONS split, weights one plane (A_lo W_hi + A_hi W_hi) -
  * for the decoder classes whose error is the rounding of their activations, two thirds of the cost of 3 (not for MDPT_CLASS_ATTN, whose
- * operands are both activations). Changes the packed-weight layout and the workspace
+ * operands are both activations).
+ * MDPT_PASSES_2F8 / MDPT_PASSES_3F8 (fp16 operand modes; MDPT_CLASS_REASM, _FUSION, _FUSION_IN, _FUSION_PROJ, _HEAD): the same two / three
+ * products with the CROSS TERMS (A_lo W_hi, A_hi W_lo: 2^-11 of the main term) on fp8 operands through gfx950's block-scaled MFMA at twice
+ * the fp16 rate - activations E5M2 with one constant power-of-two scale, weights E4M3 with one power-of-two scale per output row
+ * (csrc/f8_cross.h) - i.e. 1.5 / 2 pass-equivalents instead of 2 / 3 at the accuracy of the fp16 cross terms
+ * (tests/precision_budget/emulate_operand_rounding.py, format "sf8"). A class whose contraction lengths are not all multiples of 128 (the
+ * small encoders' reassembly widths, fusion widths below 128), the SwinV2 family and the bf16 operand modes run the fp16-plane form of the
+ * same term count instead (mdpt_get_class_f8 tells). Changes the packed-weight layout and the workspace
  * plan: call it after mdpt_create and BEFORE mdpt_packed_bytes / mdpt_finalize / mdpt_workspace_bytes (bound pointers are kept).
  * mdpt_get_class_passes reads the current assignment; mdpt_default_mixed_passes fills the table MDPT_PREC_MIXED uses. */
+#define MDPT_PASSES_2F8 4 /* A_hi W_hi on fp16 planes + A_lo W_hi on fp8 planes */
+#define MDPT_PASSES_3F8 5 /* A_hi W_hi on fp16 planes + A_lo W_hi + A_hi W_lo on fp8 planes */
 int mdpt_set_class_passes(mdpt_handle* h, int32_t op_class, int32_t passes);
 int mdpt_get_class_passes(const mdpt_handle* h, int32_t op_class, int32_t* passes);
+int mdpt_get_class_f8(const mdpt_handle* h, int32_t op_class, int32_t* on); /* 1: the class's cross terms really run on fp8 planes */
 void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]);                      /* the Depth-Anything families */
 void mdpt_default_mixed_passes_for(int32_t family, int32_t passes[MDPT_NUM_CLASSES]);  /* per MDPT_FAMILY_*: the MiDaS v3.1 families keep three
                                                                                           passes on the decoder's whole projection path */

@@ -31,8 +31,10 @@
 #include "mdpt_kernels.h"
 #include "mdpt_prof.h"
 #include "up_bf16.h"
+#include "f8_cross.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -74,9 +76,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* base, s
 // exists in memory - the 18x18 halo patch of a channel block is INTERPOLATED in LDS from the <= 11x11 source pixels it touches (arithmetic
 // of up_bf16.h, rounded to bf16 like the stand-alone upsample kernel): SpatialUpsampleLayer + head conv 1, fusion_model.py:182 ->
 // head_model.py:74-76 fused.
-template <int NQN, int NP, bool SKIP, bool F32OUT, bool RELU, bool UP, bool BFOUT, bool UPIN = false>
+// F8 (fp16 build, NP = 2 or 3, Cin % 256 == 0): the cross-term passes run on fp8 planes (f8_cross.h, Conv3hParams::f8): in_lo is the e5m2 residue
+// plane, the e5m2 plane of the values sits a8_off bytes behind it, the weights come as e4m3 planes in 128-channel-block K order with one E8M0
+// scale per output row. A "virtual channel block" of a cross-term pass is 128 channels - the same 41 KB halo patch and the same 32 KB weight
+// K tiles as a 64-channel fp16 block, half as many of them per pass, 8 block-scaled 16x16x128 MFMAs per phase instead of 16.
+template <int NQN, int NP, bool SKIP, bool F32OUT, bool RELU, bool UP, bool BFOUT, bool UPIN = false, bool F8 = false>
 __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     static_assert(NP >= 1 && NP <= 3, "passes");
+    static_assert(!F8 || (MDPT_HAVE_F8 && NP >= 2 && !UPIN), "fp8 cross terms: fp16 build, two or three terms");
     constexpr bool X3 = NP >= 2;   // the input has a lo plane (pass 0 reads it) and the output planes are split
     constexpr bool W3 = NP == 3;   // the weights have a lo plane (pass 1 of 3)
     static_assert(!UPIN || (NQN == 1 && !X3 && BFOUT && !F32OUT), "the upsampled-input form exists for the bf16 head conv");
@@ -117,15 +124,58 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     const __amdgpu_buffer_rsrc_t rs_w_hi = plane_rsrc(p.w, (size_t)COUT * Kw * 2);
     const __amdgpu_buffer_rsrc_t rs_w_lo = plane_rsrc(W3 ? p.w_lo : p.w, (size_t)COUT * Kw * 2);
     const __amdgpu_buffer_rsrc_t rs_in_hi = plane_rsrc(in_img, UPIN ? (size_t)p.Hs * p.Ws * p.Cin * 2 : (size_t)p.H * p.W * p.Cin * 2);
-    const __amdgpu_buffer_rsrc_t rs_in_lo = plane_rsrc(X3 ? p.in_lo + (size_t)img * p.H * p.W * p.Cin : in_img, (size_t)p.H * p.W * p.Cin * 2);
-    const int nvcb = NP * ncb;  // channel blocks of all passes
-    const int T = 9 * ncb;                // K tiles per pass; ncb is even (the launcher checks Cin % 128 == 0)
+    const __amdgpu_buffer_rsrc_t rs_in_lo = F8 ? plane_rsrc((const unsigned char*)p.in_lo + (size_t)img * p.H * p.W * p.Cin, (size_t)p.H * p.W * p.Cin)
+                                               : plane_rsrc(X3 ? p.in_lo + (size_t)img * p.H * p.W * p.Cin : in_img, (size_t)p.H * p.W * p.Cin * 2);
+    // F8: e5m2 plane of the values (three terms), e4m3 weight planes
+    const __amdgpu_buffer_rsrc_t rs_in_a8 = (F8 && NP == 3) ? plane_rsrc((const unsigned char*)p.in_lo + p.a8_off + (size_t)img * p.H * p.W * p.Cin, (size_t)p.H * p.W * p.Cin) : rs_in_hi;
+    const __amdgpu_buffer_rsrc_t rs_w8 = F8 ? plane_rsrc(p.w8, (size_t)COUT * Kw) : rs_w_hi;
+    const __amdgpu_buffer_rsrc_t rs_w8_lo = (F8 && NP == 3) ? plane_rsrc(p.w8_lo, (size_t)COUT * Kw) : rs_w_hi;
+    const int ncb8 = F8 ? p.Cin >> 7 : 0;                 // 128-channel blocks of a cross-term pass (even: launcher)
+    const int nvcb8 = (NP - 1) * ncb8;                    // ... of all cross-term passes
+    const int nvcb = F8 ? nvcb8 + ncb : NP * ncb;         // channel blocks of all passes
+    const int T = F8 ? 9 * ncb8 : 9 * ncb;                // K tiles per (cross-term) pass; ncb is even (the launcher checks Cin % 128 == 0)
     // K tile kt of the whole loop -> (operand plane of the weights, byte offset of its K tile inside the plane)
-    auto w_pass = [&](int kt) -> int { return NP == 3 ? (kt >= 2 * T ? 2 : (kt >= T ? 1 : 0)) : (NP == 2 ? (kt >= T ? 1 : 0) : 0); };
+    auto w_pass = [&](int kt) __attribute__((always_inline)) -> int { return NP == 3 ? (kt >= 2 * T ? 2 : (kt >= T ? 1 : 0)) : (NP == 2 ? (kt >= T ? 1 : 0) : 0); };
     // B (weights): DMA instruction i of a wave stages rows r = 8 * (wave + 8 i) + lane / 8 = r0 + 64 i; 16-byte slot lane % 8 holds k-chunk
     // slot ^ ((r >> 1) & 7) (the key is the same for all four i). One lane constant; (K tile kt, i) enter through the scalar offset.
     const unsigned b_voff = (unsigned)((wave * 8 + (lane >> 3)) * Kw + (((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)) << 3)) * 2u;
-    auto issue_b = [&](int half, int buf, int kt) {  // half-tile `half` (128 weight rows) of K tile kt -> B buffer `buf`
+    // F8: byte planes - the row part of a lane offset (a multiple of 256 bytes in the fp16 plane: Kw and Cin are multiples of 128) halves, the
+    // 16-byte slot inside the 128-byte K tile stays: off8 = (off16 & ~255) / 2 | (off16 & 255); an out-of-range marker stays out of range
+    // (computed where it is used: `salt` is 0, derived from the loop counter so that the conversion is not loop-invariant - hoisted out of the
+    // loops the seven converted offsets would be seven more registers for the whole kernel, which the 256-channel forms do not have: 249 of 256 are taken)
+    auto to8 = [](unsigned off16, unsigned salt) __attribute__((always_inline)) -> unsigned { return ((off16 & ~255u) >> (1u + salt)) | (off16 & 255u); };
+    // F8: the pass a loop belongs to is a COMPILE-TIME constant of the call site (one loop per pass), and what it stages - K tile kt + 2, channel
+    // block cb + 1 - lies in that pass or at the start of the next one: every descriptor choice is a two-way scalar select (a three-way
+    // choice among descriptors by computed conditions becomes a table in private memory and a waterfall loop around every DMA instruction).
+    auto rs_w_of = [&](auto pc) __attribute__((always_inline)) -> __amdgpu_buffer_rsrc_t {
+        constexpr int P = decltype(pc)::value;
+        if constexpr (!F8) return rs_w_hi;
+        else if constexpr (P >= NP - 1) return rs_w_hi;
+        else if constexpr (P == 1) return rs_w8_lo;
+        else return rs_w8;
+    };
+    auto rs_a_of = [&](auto pc) __attribute__((always_inline)) -> __amdgpu_buffer_rsrc_t {
+        constexpr int P = decltype(pc)::value;
+        if constexpr (!F8) return rs_in_hi;
+        else if constexpr (P >= NP - 1) return rs_in_hi;
+        else if constexpr (P == 1) return rs_in_a8;
+        else return rs_in_lo;
+    };
+    auto issue_b = [&](auto pc, int half, int buf, int kt) __attribute__((always_inline)) {  // half-tile `half` (128 weight rows) of K tile kt -> B buffer `buf`
+        if constexpr (F8) {
+            constexpr int P = decltype(pc)::value, PN = P + 1 < NP ? P + 1 : P;
+            const bool nxt = P + 1 < NP && kt >= (P + 1) * T;              // (wave-uniform) the tile opens the next pass
+            const __amdgpu_buffer_rsrc_t rs = nxt ? rs_w_of(std::integral_constant<int, PN>{}) : rs_w_of(pc);
+            const bool f8t = nxt ? PN < NP - 1 : P < NP - 1;
+            const int soff = (kt - (nxt ? PN : P) * T) * 128;
+            const unsigned vo = f8t ? to8(b_voff, (unsigned)kt >> 30) : b_voff;
+            const int rstep = f8t ? 64 * Kw : 128 * Kw;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if ((i >> 1) == half)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf * BTILE + (wave + 8 * i) * 1024), 16, vo, soff + i * rstep, 0, 0);
+            return;
+        }
         const int ps = w_pass(kt);
         const __amdgpu_buffer_rsrc_t rs = (W3 && ps == 1) ? rs_w_lo : rs_w_hi;
         const int soff = (kt - ps * T) * 128;
@@ -134,7 +184,20 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
             if ((i >> 1) == half)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf * BTILE + (wave + 8 * i) * 1024), 16, b_voff, soff + i * 128 * Kw, 0, 0);
     };
-    auto issue_b128 = [&](int buf4, int kt) {  // COUT = 128: the whole 16 KB K tile kt -> slot buf4 of a FOUR-deep ring (two instructions per wave)
+    auto issue_b128 = [&](auto pc, int buf4, int kt) __attribute__((always_inline)) {  // COUT = 128: the whole 16 KB K tile kt -> slot buf4 of a FOUR-deep ring (two instructions per wave)
+        if constexpr (F8) {
+            constexpr int P = decltype(pc)::value, PN = P + 1 < NP ? P + 1 : P;
+            const bool nxt = P + 1 < NP && kt >= (P + 1) * T;
+            const __amdgpu_buffer_rsrc_t rs = nxt ? rs_w_of(std::integral_constant<int, PN>{}) : rs_w_of(pc);
+            const bool f8t = nxt ? PN < NP - 1 : P < NP - 1;
+            const int soff = (kt - (nxt ? PN : P) * T) * 128;
+            const unsigned vo = f8t ? to8(b_voff, (unsigned)kt >> 30) : b_voff;
+            const int rstep = f8t ? 64 * Kw : 128 * Kw;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf4 * (BTILE / 2) + (wave + 8 * i) * 1024), 16, vo, soff + i * rstep, 0, 0);
+            return;
+        }
         const int ps = w_pass(kt);
         const __amdgpu_buffer_rsrc_t rs = (W3 && ps == 1) ? rs_w_lo : rs_w_hi;
         const int soff = (kt - ps * T) * 128;
@@ -154,9 +217,21 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
         const bool ok = c < HALO_INSTR && q < 324 && (unsigned)Y < (unsigned)p.H && (unsigned)X < (unsigned)p.W;
         h_voff[j] = ok ? ((unsigned)(Y * p.W + X) * (unsigned)p.Cin + (unsigned)((slot ^ (xx & 7)) << 3)) * 2u : OOB;
     }
-    auto issue_halo = [&](int j, int vcbn, int hbn, bool dummy) {  // dummy (wave-uniform): no next channel block - zeros into the scratch KiB
+    auto issue_halo = [&](auto pc, int j, int vcbn, int hbn, bool dummy) __attribute__((always_inline)) {  // dummy (wave-uniform): no next channel block - zeros into the scratch KiB
         const int c = wave + 8 * j;
         const bool real = c < HALO_INSTR && !dummy;
+        if constexpr (F8) {
+            // virtual blocks [0, ncb8): residue plane, [ncb8, nvcb8) (three terms): the values' e5m2 plane, then the fp16 hi plane's 64-channel blocks
+            constexpr int P = decltype(pc)::value, PN = P + 1 < NP ? P + 1 : P;
+            const int endp = P < NP - 1 ? (P + 1) * ncb8 : nvcb;
+            const bool nxt = P + 1 < NP && vcbn >= endp;               // (wave-uniform) the block opens the next pass
+            const __amdgpu_buffer_rsrc_t rs = nxt ? rs_a_of(std::integral_constant<int, PN>{}) : rs_a_of(pc);
+            const bool f8b = nxt ? PN < NP - 1 : P < NP - 1;
+            const int cbn = vcbn - (nxt ? PN : P) * ncb8;                // (the fp16 pass starts at virtual block (NP - 1) ncb8)
+            const unsigned voff = dummy ? OOB : (f8b ? to8(h_voff[j], (unsigned)vcbn >> 30) : h_voff[j]);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + (real ? OFF_H + hbn * HALO_BYTES + c * 1024 : OFF_SCR)), 16, voff, cbn * 128, 0, 0);
+            return;
+        }
         const unsigned voff = dummy ? OOB : h_voff[j];
         const bool lo_plane = X3 && vcbn < ncb;  // pass 0 reads the lo plane of the input
         const int cbn = X3 ? (vcbn >= 2 * ncb ? vcbn - 2 * ncb : (vcbn >= ncb ? vcbn - ncb : vcbn)) : vcbn;  // (NP == 2: vcbn < 2 ncb)
@@ -168,7 +243,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     // scratch KiB and is ignored: an L2 / MALL prefetch), so the epilogue's loads do not start from HBM with nothing to hide behind.
     const __amdgpu_buffer_rsrc_t rs_skip = plane_rsrc(SKIP ? p.skip + (size_t)img * p.H * p.W * 256 : nullptr, SKIP ? (size_t)p.H * p.W * 1024 : 0);
     const unsigned pf_voff = (unsigned)lane << 4;
-    auto issue_prefetch = [&](int slot) {
+    auto issue_prefetch = [&](int slot) __attribute__((always_inline)) {
         const int pp = slot * 8 + wave;  // tile pixel (row pp >> 4, column pp & 15); slot outside [0, 32): nothing to fetch
         const int Y = Y0 + (pp >> 4), X = X0 + (pp & 15);
         const bool ok = (unsigned)slot < 32u && Y < p.H && X < p.W;  // wave-uniform
@@ -194,6 +269,9 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
                 for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     opx8 fa[4][2], fb0[2][2], fb1[2][2];
+#define PC0 (std::integral_constant<int, 0>{})
+#define PC1 (std::integral_constant<int, 1>{})
+#define PCL (std::integral_constant<int, NP - 1>{}) /* the fp16 pass (the only pass of the single-pass forms) */
 #define PIN() __builtin_amdgcn_sched_barrier(0)
 #define BAR() do { PIN(); __builtin_amdgcn_s_barrier(); PIN(); } while (0)
 #define LOAD_A(QM_, VA_, ROW0_)                                                                                       \
@@ -226,6 +304,32 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
                     acc[QM_][QN_][i][j] = MDPT_MFMA_16x16x32(FB_[j][kk], fa[i][kk], acc[QM_][QN_][i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                                \
     } while (0)
+#if MDPT_HAVE_F8
+    // E8M0 scales of the weight rows this lane's 16-channel blocks read: byte 2 qn + j = output channel 128 qn + 32 wc + 16 j + l15
+    int wsc = 0, wsc_lo = 0;
+    const int asc = F8_A_SCALE;  // the activations' constant E8M0 scale (a VGPR operand of every scaled MFMA)
+    if constexpr (F8) {
+#pragma unroll
+        for (int b4 = 0; b4 < 2 * NQN; ++b4) {
+            const int n = (b4 >> 1) * 128 + wc * 32 + (b4 & 1) * 16 + l15;
+            wsc |= (int)p.s8[n] << (8 * b4);
+            if (NP == 3) wsc_lo |= (int)p.s8_lo[n] << (8 * b4);
+        }
+    }
+#define MFMA_Q8_ONE(QM_, QN_, FB_, I_, J_, WS_)                                                                       \
+    f8_mfma16_w_first<2 * (QN_) + (J_)>(acc[QM_][QN_][I_][J_], f8_cat(FB_[J_][0], FB_[J_][1]), f8_cat(fa[I_][0], fa[I_][1]), WS_, asc)
+#define MFMA_Q8(QM_, QN_, FB_, WS_)                                                                                   \
+    do {                                                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                                \
+        MFMA_Q8_ONE(QM_, QN_, FB_, 0, 0, WS_); MFMA_Q8_ONE(QM_, QN_, FB_, 0, 1, WS_);                                 \
+        MFMA_Q8_ONE(QM_, QN_, FB_, 1, 0, WS_); MFMA_Q8_ONE(QM_, QN_, FB_, 1, 1, WS_);                                 \
+        MFMA_Q8_ONE(QM_, QN_, FB_, 2, 0, WS_); MFMA_Q8_ONE(QM_, QN_, FB_, 2, 1, WS_);                                 \
+        MFMA_Q8_ONE(QM_, QN_, FB_, 3, 0, WS_); MFMA_Q8_ONE(QM_, QN_, FB_, 3, 1, WS_);                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                                \
+    } while (0)
+#define MQ8A(QM_, QN_, FB_) MFMA_Q8(QM_, QN_, FB_, wsc)
+#define MQ8B(QM_, QN_, FB_) MFMA_Q8(QM_, QN_, FB_, wsc_lo)
+#endif
 #define WAIT_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory")
 #define WAIT_VM_IMM(N_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory")
 
@@ -291,8 +395,8 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 
         // prologue: patch 0 and K tiles 0, 1; then every thread builds its items of halo patch 0
         issue_patch(0);
-        issue_b128(0, 0);
-        issue_b128(1, 1);
+        issue_b128(PC0, 0, 0);
+        issue_b128(PC0, 1, 1);
         WAIT_VM_IMM(0);
         BAR();
 #pragma unroll
@@ -314,7 +418,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
             const bool next_cb = cbl == 0 || !last;          /* channel block cb + 1 exists */                        \
             const int va = a_lane[kx] + cbl * HALO_BYTES;                                                             \
             LOAD_B_AT(fb0, slot * (BTILE / 2)); PIN(); LOAD_A(0, va, ky); PIN();                                      \
-            if (more) issue_b128(slot2, kt + 2);                                                                      \
+            if (more) issue_b128(PC0, slot2, kt + 2);                                                                 \
             if constexpr (p_now != 0) { if (next_cb) issue_patch(cbp + cbl + 1); }                                    \
             if constexpr (ritem >= 0) { if (next_cb) item_reads(ritem); }                                             \
             BAR(); WAIT_LGKM(0); PIN();                                                                               \
@@ -340,15 +444,15 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
         // vmcnt at P2: what this K tile and the previous one issued may stay in flight (2 weight + 0/1 halo instructions each); everything
         // older - tile kt+1's weights above all - has landed one phase and >= one workgroup barrier before P1 of tile kt+1 reads it.
 #pragma unroll
-        for (int j = 0; j < 6; ++j) issue_halo(j, 0, 0, false);
-        issue_b128(0, 0);
-        issue_b128(1, 1);
-        issue_b128(2, 2);
+        for (int j = 0; j < 6; ++j) issue_halo(PC0, j, 0, 0, false);
+        issue_b128(PC0, 0, 0);
+        issue_b128(PC0, 1, 1);
+        issue_b128(PC0, 2, 2);
         WAIT_VM_IMM(4);
         BAR();
         if (p.dbg_times) t_first = memtime_now();
         if (grp == 1) BAR();
-#define CONV_KT128(U_)                                                                                                \
+#define CONV_KT128(U_, MQ, PC_)                                                                                          \
         do {                                                                                                          \
             constexpr int cbl = (U_) / 9, t9 = (U_) % 9, ky = t9 / 3, kx = t9 % 3;                                     \
             constexpr int h_now = t9 < 6 ? 1 : 0, h_prev = ((U_) % 9 == 0) ? 0 : (((U_) - 1) % 9 < 6 ? 1 : 0);         \
@@ -357,28 +461,38 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
             const int va = a_lane[kx] + cbl * HALO_BYTES;                                                             \
             const int bslot = (kt & 3) * (BTILE / 2);                                                                 \
             LOAD_B_AT(fb0, bslot); PIN(); LOAD_A(0, va, ky); PIN();                                                   \
-            if constexpr (h_now) { if (more) issue_halo(t9, cbp + cbl + 1, cbl ^ 1, cbl == 1 && last); }              \
+            if constexpr (h_now) { if (more) issue_halo(PC_, t9, cbp + cbl + 1, cbl ^ 1, cbl == 1 && last); }         \
             BAR(); WAIT_LGKM(0); PIN();                                                                               \
-            MFMA_Q(0, 0, fb0); BAR();                                                                                 \
+            MQ(0, 0, fb0); BAR();                                                                                 \
             LOAD_A(1, va, ky); PIN();                                                                                 \
-            if (more) { issue_b128((kt + 3) & 3, kt + 3); PIN(); WAIT_VM_IMM(4 + h_now + h_prev); } else { WAIT_VM_IMM(0); } \
+            if (more) { issue_b128(PC_, (kt + 3) & 3, kt + 3); PIN(); WAIT_VM_IMM(4 + h_now + h_prev); } else { WAIT_VM_IMM(0); } \
             BAR(); WAIT_LGKM(0); PIN();                                                                               \
-            MFMA_Q(1, 0, fb0); BAR();                                                                                 \
+            MQ(1, 0, fb0); BAR();                                                                                 \
         } while (0)
-        for (int cbp = 0; cbp < nvcb; cbp += 2) {
-            const bool last = cbp + 2 >= nvcb;
-            CONV_KT128(0); CONV_KT128(1); CONV_KT128(2); CONV_KT128(3); CONV_KT128(4); CONV_KT128(5); CONV_KT128(6); CONV_KT128(7); CONV_KT128(8);
-            CONV_KT128(9); CONV_KT128(10); CONV_KT128(11); CONV_KT128(12); CONV_KT128(13); CONV_KT128(14); CONV_KT128(15); CONV_KT128(16); CONV_KT128(17);
+#define CONV_PAIR128(MQ, PC_) CONV_KT128(0, MQ, PC_); CONV_KT128(1, MQ, PC_); CONV_KT128(2, MQ, PC_); CONV_KT128(3, MQ, PC_); CONV_KT128(4, MQ, PC_); CONV_KT128(5, MQ, PC_); CONV_KT128(6, MQ, PC_); CONV_KT128(7, MQ, PC_); CONV_KT128(8, MQ, PC_); \
+            CONV_KT128(9, MQ, PC_); CONV_KT128(10, MQ, PC_); CONV_KT128(11, MQ, PC_); CONV_KT128(12, MQ, PC_); CONV_KT128(13, MQ, PC_); CONV_KT128(14, MQ, PC_); CONV_KT128(15, MQ, PC_); CONV_KT128(16, MQ, PC_); CONV_KT128(17, MQ, PC_)
+        int cbp = 0;
+#if MDPT_HAVE_F8
+        if constexpr (F8) {  // the cross-term passes (one loop per pass: the fp16 pass always follows, nothing drains here)
+            constexpr bool last = false;
+            for (; cbp < ncb8; cbp += 2) { CONV_PAIR128(MQ8A, PC0); }
+            if constexpr (NP == 3) { for (; cbp < nvcb8; cbp += 2) { CONV_PAIR128(MQ8B, PC1); } }
         }
+#endif
+        for (; cbp < nvcb; cbp += 2) {
+            const bool last = cbp + 2 >= nvcb;
+            CONV_PAIR128(MFMA_Q, PCL);
+        }
+#undef CONV_PAIR128
 #undef CONV_KT128
     } else {
     // ---- prologue: the whole halo patch of channel block 0 (6 instructions per wave), K tile 0 -> even B buffer, K tile 1 -> odd B buffer
 #pragma unroll
-    for (int j = 0; j < 6; ++j) issue_halo(j, 0, 0, false);
-    issue_b(0, 0, 0);
-    issue_b(1, 0, 0);
-    issue_b(0, 1, 1);
-    issue_b(1, 1, 1);
+    for (int j = 0; j < 6; ++j) issue_halo(PC0, j, 0, 0, false);
+    issue_b(PC0, 0, 0, 0);
+    issue_b(PC0, 1, 0, 0);
+    issue_b(PC0, 0, 1, 1);
+    issue_b(PC0, 1, 1, 1);
     WAIT_VM_IMM(4);
     BAR();
     if (p.dbg_times) t_first = memtime_now();
@@ -393,7 +507,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     // vmcnt at P4: the operations issued during this K tile may stay in flight (B0 + B1 of tile kt+2 = 4, + 1 halo instruction, + 1 skip
     // prefetch); everything older (tile kt+1's weights, the halo instructions of earlier K tiles) has landed - one phase and >= one
     // workgroup barrier before its first read. The halo patch of block cb+1 (t9 = 0..5 of block cb) has three more K tiles to land.
-#define CONV_KT(U_)                                                                                                   \
+#define CONV_KT(U_, MQ, PC_)                                                                                             \
     do {                                                                                                              \
         constexpr int cbl = (U_) / 9, t9 = (U_) % 9, ky = t9 / 3, kx = t9 % 3, bi = (U_) & 1;                          \
         constexpr bool halo_slot = t9 < 6;                                                                            \
@@ -403,31 +517,50 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
         const int va = a_lane[kx] + cbl * HALO_BYTES;                                                                 \
         LOAD_B(fb0, 0, bi); PIN(); LOAD_A(0, va, ky); PIN();                                                          \
         WAIT_LGKM(8); BAR(); WAIT_LGKM(0); PIN();                                                                     \
-        MFMA_Q(0, 0, fb0); BAR();                                                                                     \
+        MQ(0, 0, fb0); BAR();                                                                                     \
         LOAD_B(fb1, 1, bi); PIN();                                                                                    \
-        if (more) { issue_b(0, bi, kt + 2); if constexpr (SKIP) issue_prefetch(kt - (9 * nvcb - 34)); }                             \
+        if (more) { issue_b(PC_, 0, bi, kt + 2); if constexpr (SKIP) issue_prefetch(kt - (9 * nvcb - 34)); }                        \
         BAR(); WAIT_LGKM(0); PIN();                                                                                   \
-        MFMA_Q(0, 1, fb1); BAR();                                                                                     \
+        MQ(0, 1, fb1); BAR();                                                                                     \
         LOAD_A(1, va, ky); PIN();                                                                                     \
-        if constexpr (halo_slot) { if (more) issue_halo(t9, cbp + cbl + 1, cbl ^ 1, cbl == 1 && last); }              \
+        if constexpr (halo_slot) { if (more) issue_halo(PC_, t9, cbp + cbl + 1, cbl ^ 1, cbl == 1 && last); }         \
         BAR(); WAIT_LGKM(0); PIN();                                                                                   \
-        MFMA_Q(1, 1, fb1); BAR();                                                                                     \
-        if (more) { issue_b(1, bi, kt + 2); PIN(); WAIT_VM_IMM(inflight); } else { WAIT_VM_IMM(0); }                  \
+        MQ(1, 1, fb1); BAR();                                                                                     \
+        if (more) { issue_b(PC_, 1, bi, kt + 2); PIN(); WAIT_VM_IMM(inflight); } else { WAIT_VM_IMM(0); }             \
         BAR();                                                                                                        \
-        MFMA_Q(1, 0, fb0); BAR();                                                                                     \
+        MQ(1, 0, fb0); BAR();                                                                                     \
     } while (0)
-    for (int cbp = 0; cbp < nvcb; cbp += 2) {
-        const bool last = cbp + 2 >= nvcb;  // wave-uniform: the last two K tiles issue nothing and drain
-        CONV_KT(0); CONV_KT(1); CONV_KT(2); CONV_KT(3); CONV_KT(4); CONV_KT(5); CONV_KT(6); CONV_KT(7); CONV_KT(8);
-        CONV_KT(9); CONV_KT(10); CONV_KT(11); CONV_KT(12); CONV_KT(13); CONV_KT(14); CONV_KT(15); CONV_KT(16); CONV_KT(17);
+#define CONV_PAIR(MQ, PC_) CONV_KT(0, MQ, PC_); CONV_KT(1, MQ, PC_); CONV_KT(2, MQ, PC_); CONV_KT(3, MQ, PC_); CONV_KT(4, MQ, PC_); CONV_KT(5, MQ, PC_); CONV_KT(6, MQ, PC_); CONV_KT(7, MQ, PC_); CONV_KT(8, MQ, PC_); \
+        CONV_KT(9, MQ, PC_); CONV_KT(10, MQ, PC_); CONV_KT(11, MQ, PC_); CONV_KT(12, MQ, PC_); CONV_KT(13, MQ, PC_); CONV_KT(14, MQ, PC_); CONV_KT(15, MQ, PC_); CONV_KT(16, MQ, PC_); CONV_KT(17, MQ, PC_)
+    int cbp = 0;
+#if MDPT_HAVE_F8
+    if constexpr (F8) {  // the cross-term passes (one loop per pass: the fp16 pass always follows, nothing drains here)
+        constexpr bool last = false;
+        for (; cbp < ncb8; cbp += 2) { CONV_PAIR(MQ8A, PC0); }
+        if constexpr (NP == 3) { for (; cbp < nvcb8; cbp += 2) { CONV_PAIR(MQ8B, PC1); } }
     }
+#endif
+    for (; cbp < nvcb; cbp += 2) {
+        const bool last = cbp + 2 >= nvcb;  // wave-uniform: the last two K tiles issue nothing and drain
+        CONV_PAIR(MFMA_Q, PCL);
+    }
+#undef CONV_PAIR
 #undef CONV_KT
     }
     if (grp == 0) BAR();  // re-join the two groups
+#if MDPT_HAVE_F8
+    if constexpr (F8) f8_mfma_settle();  // (the compiler does not see the asm MFMAs: f8_cross.h)
+#endif
 #undef LOAD_A
 #undef LOAD_B
 #undef LOAD_B_AT
 #undef MFMA_Q
+#if MDPT_HAVE_F8
+#undef MQ8A
+#undef MQ8B
+#undef MFMA_Q8
+#undef MFMA_Q8_ONE
+#endif
     if (p.dbg_times) t_loop = memtime_now();
 
     // ---- epilogue. Lane (l15, lh) of wave (grp, wc) holds, for tile row y = 8 qm + 4 grp + i, pixel x = l15, the four consecutive channels
@@ -441,6 +574,10 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     constexpr bool LO_DYN = MDPT_OP_IS_F16 && !X3 && BFOUT && !UPIN;
     const bool want_lo = BFOUT && (X3 || LO_DYN) && p.out_bf_lo != nullptr;
     const __amdgpu_buffer_rsrc_t rs_bl = plane_rsrc(want_lo ? p.out_bf_lo + (size_t)img * plane_px * COUT : nullptr, want_lo ? plane_px * COUT * 2 : 0);
+    // ... or, for an F8 consumer (Conv3hParams::out_f8), byte planes: the e5m2 residue plane and (out_a8) the e5m2 plane of the values out_f8 bytes behind it
+    const bool lo8 = MDPT_HAVE_F8 && want_lo && p.out_f8 != 0;
+    const __amdgpu_buffer_rsrc_t rs_l8 = plane_rsrc(lo8 ? (const unsigned char*)p.out_bf_lo + (size_t)img * plane_px * COUT : nullptr, lo8 ? plane_px * COUT : 0);
+    const __amdgpu_buffer_rsrc_t rs_a8 = plane_rsrc(lo8 && p.out_a8 ? (const unsigned char*)p.out_bf_lo + p.out_f8 + (size_t)img * plane_px * COUT : nullptr, lo8 && p.out_a8 ? plane_px * COUT : 0);
     const bool xok = X0 + l15 < p.W;
 
     // bilinear x2 (align_corners=True) add of the coarser fusion level (fusion_model.py:151,178): stage the <= 10x10 coarse pixels this
@@ -577,6 +714,23 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
                 // (no branch around the stores: hipcc would wait for every store's acknowledgement)
                 const unsigned boff = ok ? pix * (unsigned)(COUT * 2) + colb : OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{ph[0], ph[1], ph[2], ph[3]}, rs_b, boff, 0, 0);
+#if MDPT_HAVE_F8
+                if ((X3 || LO_DYN) && lo8) {  // (wave-uniform) fp8 form: 8 e5m2 bytes of the residue (and of the values) per lane, from the same fp32 values / fp16 roundings
+                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2v;
+                    unsigned l8[2], a8[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x2 h0 = __builtin_convertvector(__builtin_bit_cast(opx2, hw_[j][0]), f32x2), h1 = __builtin_convertvector(__builtin_bit_cast(opx2, hw_[j][1]), f32x2);
+                        l8[j] = f8_lo8x4(v[j][0], v[j][1], v[j][2], v[j][3], h0[0], h0[1], h1[0], h1[1]);
+                        a8[j] = f8_a8x4(h0[0], h0[1], h1[0], h1[1]);
+                    }
+                    auto rl8 = __builtin_amdgcn_permlane16_swap(l8[0], l8[1], false, false);
+                    const unsigned boff8 = ok ? pix * (unsigned)COUT + (colb >> 1) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2v{rl8[0], rl8[1]}, rs_l8, boff8, 0, 0);
+                    auto ra8 = __builtin_amdgcn_permlane16_swap(a8[0], a8[1], false, false);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2v{ra8[0], ra8[1]}, rs_a8, boff8, 0, 0);  // (zero records without an a8 plane: dropped)
+                } else
+#endif
                 // (unconditional where the form can have a lo plane at all: without one the descriptor has zero records and the store is dropped)
                 if constexpr (X3 || LO_DYN) __builtin_amdgcn_raw_buffer_store_b128(u32x4{pl[0], pl[1], pl[2], pl[3]}, rs_bl, boff, 0, 0);
             }
@@ -619,10 +773,13 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
 #undef BAR
 #undef WAIT_LGKM
 #undef WAIT_VM_IMM
+#undef PC0
+#undef PC1
+#undef PCL
 
-template <int NQN, int NP, bool SKIP, bool F32OUT, bool RELU, bool UP, bool BFOUT = true, bool UPIN = false>
+template <int NQN, int NP, bool SKIP, bool F32OUT, bool RELU, bool UP, bool BFOUT = true, bool UPIN = false, bool F8 = false>
 int launch_variant(const Conv3hParams& p, hipStream_t stream) {
-    auto kern = conv3h_kernel<NQN, NP, SKIP, F32OUT, RELU, UP, BFOUT, UPIN>;
+    auto kern = conv3h_kernel<NQN, NP, SKIP, F32OUT, RELU, UP, BFOUT, UPIN, F8>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -632,7 +789,7 @@ int launch_variant(const Conv3hParams& p, hipStream_t stream) {
     const int tiles = p.B * ((p.H + 15) / 16) * ((p.W + 15) / 16);
     static char prof_name[80] = "";
     if (!prof_name[0])
-        snprintf(prof_name, sizeof(prof_name), "conv3h_kernel<%d, %s, %d, %d, %d, %d>", 128 * NQN, UPIN ? "bf16 up2-in" : (NP == 3 ? "x3" : (NP == 2 ? "x2a" : "bf16")), (int)SKIP, (int)F32OUT, (int)RELU,
+        snprintf(prof_name, sizeof(prof_name), "conv3h_kernel<%d, %s, %d, %d, %d, %d>", 128 * NQN, UPIN ? "bf16 up2-in" : (F8 ? (NP == 3 ? "x3f8" : "x2f8") : (NP == 3 ? "x3" : (NP == 2 ? "x2a" : "bf16"))), (int)SKIP, (int)F32OUT, (int)RELU,
                  (int)UP);
     MdptProfScope prof(prof_name, 2.0 * p.B * p.H * p.W * (128.0 * NQN) * 9.0 * p.Cin, stream);  // algorithmic flops (one pass, whatever the mode)
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS_BYTES, stream, p);
@@ -640,7 +797,7 @@ int launch_variant(const Conv3hParams& p, hipStream_t stream) {
 }
 
 // the epilogue combinations the decoder uses
-template <int NP>
+template <int NP, bool F8 = false>
 int launch_mode(const Conv3hParams& p, hipStream_t stream) {
     constexpr int X3 = NP;  // (pass count of every variant below)
     const bool skip = p.skip != nullptr, f32 = p.out_f32 != nullptr, up = p.up_src != nullptr;
@@ -648,13 +805,13 @@ int launch_mode(const Conv3hParams& p, hipStream_t stream) {
         if constexpr (NP == 1) {
             if (p.up_in) return launch_variant<1, 1, false, false, false, false, true, true>(p, stream);
         }
-        if (p.out_bf) return launch_variant<1, X3, false, false, false, false>(p, stream);
-        return launch_variant<1, X3, false, true, false, false, false>(p, stream);
+        if (p.out_bf) return launch_variant<1, X3, false, false, false, false, true, false, F8>(p, stream);
+        return launch_variant<1, X3, false, true, false, false, false, false, F8>(p, stream);
     }
-    if (up) return launch_variant<2, X3, true, true, true, true>(p, stream);
-    if (!skip && !f32) return launch_variant<2, X3, false, false, true, false>(p, stream);
-    if (skip && !f32) return launch_variant<2, X3, true, false, false, false>(p, stream);
-    return launch_variant<2, X3, false, true, true, false>(p, stream);
+    if (up) return launch_variant<2, X3, true, true, true, true, true, false, F8>(p, stream);
+    if (!skip && !f32) return launch_variant<2, X3, false, false, true, false, true, false, F8>(p, stream);
+    if (skip && !f32) return launch_variant<2, X3, true, false, false, false, true, false, F8>(p, stream);
+    return launch_variant<2, X3, false, true, true, false, true, false, F8>(p, stream);
 }
 
 }  // namespace
@@ -671,6 +828,10 @@ bool MDPT_FN(mdpt_conv3h_supported)(const Conv3hParams& p) {
     }
     if (p.Cout != 256 && p.Cout != 128) return false;
     if ((size_t)p.H * p.W * p.Cout * 4 >= 0xFFFFFFF0ull || (size_t)p.H * p.W * p.Cin * 2 >= 0xFFFFFFF0ull) return false;  // 32-bit byte offsets inside one image plane
+    if (p.f8) {  // fp8 cross terms: fp16 build, pairs of 128-channel blocks, byte planes within 32-bit offsets (implied by the fp16 plane's check below)
+        if (!MDPT_OP_IS_F16 || !p.in_lo || p.up_in || (p.Cin & 255) || !p.w8 || !p.s8 || p.w_lo || ((p.w8_lo != nullptr) != (p.s8_lo != nullptr)) || (p.w8_lo && !p.a8_off)) return false;
+    }
+    if (p.out_f8 && (!MDPT_OP_IS_F16 || !p.out_bf_lo)) return false;
     const bool x3 = p.in_lo != nullptr;  // multi-pass: three passes with a lo plane of the weights, two (activation-split) without
     // (a multi-pass conv whose consumer runs one pass writes no lo plane: out_bf_lo may be null)
     if (!x3 && (p.w_lo || (p.out_bf_lo && (!MDPT_OP_IS_F16 || p.up_in || !p.out_bf)))) return false;  // single pass + lo output: fp16 build only
@@ -690,5 +851,8 @@ bool MDPT_FN(mdpt_conv3h_supported)(const Conv3hParams& p) {
 
 int MDPT_FN(mdpt_launch_conv3h)(const Conv3hParams& p, hipStream_t stream) {
     if (!MDPT_FN(mdpt_conv3h_supported)(p)) return (int)hipErrorInvalidValue;
+#if MDPT_OP_IS_F16
+    if (p.f8) return p.w8_lo ? launch_mode<3, true>(p, stream) : launch_mode<2, true>(p, stream);
+#endif
     return p.in_lo ? (p.w_lo ? launch_mode<3>(p, stream) : launch_mode<2>(p, stream)) : launch_mode<1>(p, stream);
 }

@@ -6,22 +6,18 @@
 #include "up_bf16.h"
 #include "mdpt_prof.h"
 #include "ln_row.h"
+#include "f8_cross.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 
-__device__ __forceinline__ void split_store4(op_t* hi, op_t* lo, size_t off, f32x4 v) {
+__device__ __forceinline__ void split_store4(op_t* hi, op_t* lo, size_t off, f32x4 v, size_t lo_f8 = 0, int lo_a8 = 0) {
     opx4 h;
 #pragma unroll
     for (int e = 0; e < 4; ++e) h[e] = to_op(v[e]);
     *(opx4*)(hi + off) = h;
-    if (lo) {
-        opx4 l;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) l[e] = to_op(v[e] - (float)h[e]);
-        *(opx4*)(lo + off) = l;
-    }
+    if (lo) lo_store4(lo, off, lo_f8, lo_a8, v, h);  // 16-bit residue plane, or the fp8 form an F8 consumer reads (f8_cross.h)
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -39,11 +35,11 @@ constexpr int LN_MAXV = 8;  // up to F = 2048
 template <int NV>  // NV float4 per lane: F <= 256*NV
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, op_t* out_hi, op_t* out_lo,
-                                                        float* out_f32, int rows, int F) {
+                                                        float* out_f32, int rows, int F, size_t out_f8, int out_a8) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    ln_row<NV>(x + (size_t)row * F, gamma, beta, out_hi, out_lo, out_f32, (size_t)row * F, F, lane);  // ln_row.h: shared with gemm.hip
+    ln_row<NV>(x + (size_t)row * F, gamma, beta, out_hi, out_lo, out_f32, (size_t)row * F, F, lane, out_f8, out_a8);  // ln_row.h: shared with gemm.hip
 }
 
 // The same behind a K-split GEMM (GemmParams::ksplit, latency mode): the row is x + part[0] + part[1] + ... (the partial sums of the K
@@ -51,7 +47,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_addp_kernel(float* __restrict__ x, const float* __restrict__ part, size_t part_stride, int npart,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, op_t* out_hi,
-                                                             op_t* out_lo, float* out_f32, int rows, int F) {
+                                                             op_t* out_lo, float* out_f32, int rows, int F, size_t out_f8, int out_a8) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -62,13 +58,13 @@ __global__ __launch_bounds__(256) void layernorm_addp_kernel(float* __restrict__
         for (int z = 0; z < npart; ++z) v += *(const ln_f32x4*)(pr + z * part_stride + c);
         *(ln_f32x4*)(xr + c) = v;
         return v;
-    }, gamma, beta, out_hi, out_lo, out_f32, (size_t)row * F, F, lane);
+    }, gamma, beta, out_hi, out_lo, out_f32, (size_t)row * F, F, lane, out_f8, out_a8);
 }
 
 // Behind a K-split GEMM whose ranges ALL stored bare partial sums (GemmParams::ks_all): v = ((part[0] + part[1]) + ...) [+ bias] -> fp32 rows and / or
 // operand planes (ReLU'd if relu_planes) - the plain generic epilogue, with the launch boundary as the fence between the ranges and their sum.
 __global__ __launch_bounds__(256) void ksplit_finish_kernel(const float* __restrict__ part, size_t part_stride, int nparts, const float* __restrict__ bias,
-                                                            float* out_f32, op_t* out_hi, op_t* out_lo, int relu_planes, int M, int N, int ldc) {
+                                                            float* out_f32, op_t* out_hi, op_t* out_lo, int relu_planes, int M, int N, int ldc, size_t out_f8, int out_a8) {
     const size_t n4 = (size_t)M * (N / 4);
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * blockDim.x) {
         const size_t m = idx / (N / 4);
@@ -83,7 +79,7 @@ __global__ __launch_bounds__(256) void ksplit_finish_kernel(const float* __restr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
             }
-            split_store4(out_hi, out_lo, o, v);
+            split_store4(out_hi, out_lo, o, v, out_f8, out_a8);
         }
     }
 }
@@ -201,7 +197,7 @@ __global__ __launch_bounds__(256) void zero_vt_pad_kernel(op_t* vt_hi, op_t* vt_
 // ---------------------------------------------------------------------------------------------------
 template <int CPT>
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, op_t* out_hi, op_t* out_lo,
-                                                       float* out_f32, int B, int Hi, int Wi, int Ho, int Wo, int C) {
+                                                       float* out_f32, int B, int Hi, int Wi, int Ho, int Wo, int C, size_t out_f8, int out_a8) {
 #pragma clang fp contract(off)  // the direct and the tiled kernel must round identically (batch-size independent bits)
     const int cq = C / CPT;
     const size_t total = (size_t)B * Ho * Wo * cq;
@@ -238,14 +234,9 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { h[e] = h0[e]; h[e + 4] = h1[e]; }
                 *(opx8*)(out_hi + o) = h;
-                if (out_lo) {
-                    opx8 l;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { l[e] = to_op(v[0][e] - (float)h0[e]); l[e + 4] = to_op(v[CPT / 4 - 1][e] - (float)h1[e]); }
-                    *(opx8*)(out_lo + o) = l;
-                }
+                if (out_lo) lo_store8(out_lo, o, out_f8, out_a8, v[0], v[CPT / 4 - 1], h);
             } else {
-                split_store4(out_hi, out_lo, o, v[0]);
+                split_store4(out_hi, out_lo, o, v[0], out_f8, out_a8);
             }
         }
     }
@@ -260,7 +251,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------
 template <int C8>  // channels / 8 (lanes per pixel): 32 -> C = 256, 16 -> C = 128, 8 -> C = 64
 __global__ __launch_bounds__(256) void upsample_tiled_kernel(const float* __restrict__ in, op_t* out_hi, op_t* out_lo, int B, int Hi,
-                                                             int Wi, int Ho, int Wo) {
+                                                             int Wi, int Ho, int Wo, size_t out_f8, int out_a8) {
 #pragma clang fp contract(off)
     constexpr int C = C8 * 8, TS = 8, PS = 7;  // tile side, max patch side
     extern __shared__ __attribute__((aligned(16))) float patch[];  // [PS*PS][C]
@@ -305,15 +296,11 @@ __global__ __launch_bounds__(256) void upsample_tiled_kernel(const float* __rest
             v[q] = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
         }
         const size_t o = (((size_t)b * Ho + y) * Wo + x) * C + lane_c;
-        opx8 h, l;
+        opx8 h;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { h[e] = to_op(v[0][e]); h[e + 4] = to_op(v[1][e]); }
         *(opx8*)(out_hi + o) = h;
-        if (out_lo) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { l[e] = to_op(v[0][e] - (float)h[e]); l[e + 4] = to_op(v[1][e] - (float)h[e + 4]); }
-            *(opx8*)(out_lo + o) = l;
-        }
+        if (out_lo) lo_store8(out_lo, o, out_f8, out_a8, v[0], v[1], h);
     }
 }
 
@@ -360,6 +347,30 @@ __global__ __launch_bounds__(1024) void weight_scale_kernel(const void* __restri
     }
 }
 
+// value of packed element (nrow, kcol) of a [Np][Kp] panel; CB = channels per block of the conv K order (64: the fp16 planes, 128: the fp8 planes)
+template <int CB>
+__device__ __forceinline__ float pack_value(const void* __restrict__ src, int sdt, int kind, int nrow, int kcol, int N, int K, int Np, int ksz, int src_ld,
+                                            int src_col0, const void* __restrict__ row_scale, int rdt, const float* __restrict__ wscale) {
+    float v = 0.0f;
+    if (kind == MDPT_PACK_LINEAR) {
+        if (nrow < N && kcol < K) v = ld_typed(src, (size_t)nrow * src_ld + src_col0 + kcol, sdt);
+        if (row_scale && nrow < N) v *= ld_typed(row_scale, nrow, rdt);
+        if (wscale) v *= wscale[0];  // power of two: exact (weight_scale_kernel)
+    } else if (kind == MDPT_PACK_CONV3) {
+        // src [N=Cout][K=Cin][3][3]; Kp = 9*Cinp (Cinp % CB == 0); kcol = (cb * 9 + tap) * CB + c with ci = cb * CB + c: the nine taps of
+        // a channel block are consecutive K tiles (the halo-staged conv kernel stages a block's input patch once for all of them)
+        const int blk = kcol / (9 * CB), rem = kcol - blk * (9 * CB);
+        const int tap = rem / CB, ci = blk * CB + (rem - tap * CB);
+        if (nrow < N && ci < K) v = ld_typed(src, ((size_t)nrow * K + ci) * 9 + tap, sdt);
+    } else {
+        // ConvTranspose2d weight [Cin=K][Cout=N][ksz][ksz]; rows = (ky*ksz+kx)*Coutp + co with Np = ksz*ksz*Coutp
+        const int coutp = Np / (ksz * ksz);
+        const int kidx = nrow / coutp, co = nrow - kidx * coutp;
+        if (co < N && kcol < K) v = ld_typed(src, ((size_t)kcol * N + co) * (ksz * ksz) + kidx, sdt);
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(256) void pack_weight_kernel(const void* __restrict__ src, int sdt, op_t* dst_hi, op_t* dst_lo, int kind,
                                                           int N, int K, int Np, int Kp, int ksz, int src_ld, int src_col0,
                                                           const void* __restrict__ row_scale, int rdt, const float* __restrict__ wscale) {
@@ -368,32 +379,72 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const void* __restrict
         const int kcol = (int)(idx % Kp);
         const int nrow = (int)(idx / Kp);
         float v = 0.0f;
-        if (kind == MDPT_PACK_LINEAR) {
-            if (nrow < N && kcol < K) v = ld_typed(src, (size_t)nrow * src_ld + src_col0 + kcol, sdt);
-            if (row_scale && nrow < N) v *= ld_typed(row_scale, nrow, rdt);
-            if (wscale) v *= wscale[0];  // power of two: exact (weight_scale_kernel)
-        } else if (kind == MDPT_PACK_CONV3) {
-            // src [N=Cout][K=Cin][3][3]; Kp = 9*Cinp (Cinp % 64 == 0); kcol = (cb * 9 + tap) * 64 + c with ci = cb * 64 + c: the nine taps of
-            // a 64-channel block are consecutive K tiles (the halo-staged conv kernel stages a block's input patch once for all of them)
-            const int blk = kcol / 576, rem = kcol - blk * 576;
-            const int tap = rem >> 6, ci = blk * 64 + (rem & 63);
-            if (nrow < N && ci < K) v = ld_typed(src, ((size_t)nrow * K + ci) * 9 + tap, sdt);
-        } else if (kind == MDPT_PACK_CONV3_KC32) {
+        if (kind == MDPT_PACK_CONV3_KC32) {
             // dst [Kp/8][32][8]: idx = (chunk*32 + n)*8 + e with k = chunk*8 + e = tap*Cinp + ci; src [N=32][K=Cin][3][3]
             const int el = (int)(idx & 7), n = (int)((idx >> 3) & 31), chunk = (int)(idx >> 8);
             const int cinp = Kp / 9, k = chunk * 8 + el;
             const int tap = k / cinp, ci = k - tap * cinp;
             if (n < N && ci < K) v = ld_typed(src, ((size_t)n * K + ci) * 9 + tap, sdt);
         } else {
-            // ConvTranspose2d weight [Cin=K][Cout=N][ksz][ksz]; rows = (ky*ksz+kx)*Coutp + co with Np = ksz*ksz*Coutp
-            const int coutp = Np / (ksz * ksz);
-            const int kidx = nrow / coutp, co = nrow - kidx * coutp;
-            if (co < N && kcol < K) v = ld_typed(src, ((size_t)kcol * N + co) * (ksz * ksz) + kidx, sdt);
+            v = pack_value<64>(src, sdt, kind, nrow, kcol, N, K, Np, ksz, src_ld, src_col0, row_scale, rdt, wscale);
         }
         const op_t h = to_op(v);
         dst_hi[idx] = h;
         if (dst_lo) dst_lo[idx] = to_op(v - (float)h);
     }
+}
+
+// fp8 planes of an F8 class (f8_cross.h): one workgroup per packed row. w8[n][k] = e4m3(W_hi[n][k] / 2^e_n), wlo8 = e4m3((W - W_hi)[n][k] / 2^e'_n)
+// with the row's largest magnitude in [128, 256) (e4m3's largest finite value is 448: the conversion turns anything beyond 464 into NaN, so the
+// row maximum stays a binade below it), K in the fp8 planes' order (conv: 128-channel blocks). scales[n] = E8M0(e_n), scales[Np + n] =
+// E8M0(e'_n + 16): the activations' constant 2^-16 (F8_A_SCALE) belongs to the residue plane only, the second term's a8 plane is unshifted.
+__global__ __launch_bounds__(256) void pack_weight_f8_kernel(const void* __restrict__ src, int sdt, unsigned char* w8, unsigned char* wlo8, unsigned char* scales,
+                                                             int kind, int N, int K, int Np, int Kp, int ksz, int src_ld, int src_col0,
+                                                             const void* __restrict__ row_scale, int rdt, const float* __restrict__ wscale) {
+#if MDPT_HAVE_F8
+    __shared__ float red[2][256];
+    const int nrow = blockIdx.x;
+    float mh = 0.0f, ml = 0.0f;
+    for (int k = threadIdx.x; k < Kp; k += 256) {
+        const float v = pack_value<128>(src, sdt, kind, nrow, k, N, K, Np, ksz, src_ld, src_col0, row_scale, rdt, wscale);
+        const float h = (float)to_op(v), l = fabsf(v - h);
+        if (fabsf(h) <= 3.0e38f) mh = fmaxf(mh, fabsf(h));  // (NaN / inf entries do not steer the scale)
+        if (l <= 3.0e38f) ml = fmaxf(ml, l);
+    }
+    red[0][threadIdx.x] = mh; red[1][threadIdx.x] = ml;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            red[0][threadIdx.x] = fmaxf(red[0][threadIdx.x], red[0][threadIdx.x + s]);
+            red[1][threadIdx.x] = fmaxf(red[1][threadIdx.x], red[1][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    auto row_exp = [](float m) -> int {  // e with m / 2^e in [128, 256); 0 for an all-zero row
+        if (!(m > 0.0f)) return 0;
+        int x;
+        (void)frexpf(m, &x);  // m = f * 2^x, f in [0.5, 1)  ->  m / 2^(x - 8) in [128, 256)
+        const int e = x - 8;
+        return e < -110 ? -110 : (e > 100 ? 100 : e);
+    };
+    const int eh = row_exp(red[0][0]), el = row_exp(red[1][0]);
+    if (threadIdx.x == 0) {
+        scales[nrow] = (unsigned char)(eh + 127);
+        scales[Np + nrow] = (unsigned char)(el + F8_LO_SHIFT + 127);
+    }
+    const float ih = ldexpf(1.0f, -eh), il = ldexpf(1.0f, -el);
+    for (int k = threadIdx.x * 2; k < Kp; k += 512) {  // Kp is even: two bytes per thread and step
+        const float v0 = pack_value<128>(src, sdt, kind, nrow, k, N, K, Np, ksz, src_ld, src_col0, row_scale, rdt, wscale);
+        const float v1 = pack_value<128>(src, sdt, kind, nrow, k + 1, N, K, Np, ksz, src_ld, src_col0, row_scale, rdt, wscale);
+        const float h0 = (float)to_op(v0), h1 = (float)to_op(v1);
+        const float a0 = __builtin_amdgcn_fmed3f(h0 * ih, -448.0f, 448.0f), a1 = __builtin_amdgcn_fmed3f(h1 * ih, -448.0f, 448.0f);
+        *(unsigned short*)(w8 + (size_t)nrow * Kp + k) = (unsigned short)(__builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, 0, false) & 0xFFFF);
+        if (wlo8) {
+            const float b0 = __builtin_amdgcn_fmed3f((v0 - h0) * il, -448.0f, 448.0f), b1 = __builtin_amdgcn_fmed3f((v1 - h1) * il, -448.0f, 448.0f);
+            *(unsigned short*)(wlo8 + (size_t)nrow * Kp + k) = (unsigned short)(__builtin_amdgcn_cvt_pk_fp8_f32(b0, b1, 0, false) & 0xFFFF);
+        }
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void pad_copy_kernel(const void* __restrict__ src, int sdt, float* dst, int n, int np, const void* __restrict__ scale, int cdt) {
@@ -429,7 +480,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in_f32, 
 }
 
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* out_f32, op_t* out_hi,
-                                                           op_t* out_lo, int relu_bf16, int B, int H, int W, int C, int Cp) {
+                                                           op_t* out_lo, int relu_bf16, int B, int H, int W, int C, int Cp, size_t out_f8, int out_a8) {
     const size_t total = (size_t)B * H * W * Cp;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % Cp);
@@ -443,13 +494,22 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
             if (relu_bf16) v = fmaxf(v, 0.0f);
             const op_t h = to_op(v);
             out_hi[idx] = h;
+#if MDPT_HAVE_F8
+            if (out_lo && out_f8) {  // the fp8 form an F8 consumer reads (f8_cross.h); stage-level entry points only: one element at a time
+                unsigned char* b8 = (unsigned char*)out_lo;
+                b8[idx] = (unsigned char)(f8_pk_e5m2((v - (float)h) * 65536.0f, 0.0f, 0u, false) & 0xFF);
+                if (out_a8) b8[out_f8 + idx] = (unsigned char)(f8_pk_e5m2((float)h, 0.0f, 0u, false) & 0xFF);
+                continue;
+            }
+#endif
             if (out_lo) out_lo[idx] = to_op(v - (float)h);
         }
     }
 }
 
+// lo_f8 != 0: in_lo is the e5m2 residue plane of an F8 consumer (bytes; f8_cross.h): value = hi + e5m2(byte) * 2^-16 (an e5m2 byte is the top byte of an fp16)
 __global__ __launch_bounds__(256) void tokens_export_kernel(const op_t* in_hi, const op_t* in_lo, const float* in_f32,
-                                                            float* __restrict__ out, int B, int N, int npad, int F, int skip_cls) {
+                                                            float* __restrict__ out, int B, int N, int npad, int F, int skip_cls, size_t lo_f8) {
     const int nout = N - skip_cls;
     const size_t total = (size_t)B * nout * F;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -459,13 +519,17 @@ __global__ __launch_bounds__(256) void tokens_export_kernel(const op_t* in_hi, c
         const size_t o = ((size_t)b * npad + t + skip_cls) * F + f;
         float v;
         if (in_f32) v = in_f32[o];
+        else if (in_lo && lo_f8) {
+            const unsigned short b16 = (unsigned short)(((const unsigned char*)in_lo)[o] << 8);
+            v = (float)in_hi[o] + (float)__builtin_bit_cast(_Float16, b16) * (1.0f / 65536.0f);
+        }
         else { v = (float)in_hi[o]; if (in_lo) v += (float)in_lo[o]; }
         out[idx] = v;
     }
 }
 
 __global__ __launch_bounds__(256) void tokens_import_kernel(const float* __restrict__ in, op_t* out_hi, op_t* out_lo, int B,
-                                                            int N, int npad, int F) {
+                                                            int N, int npad, int F, size_t out_f8, int out_a8) {
     const size_t total = (size_t)B * npad * F;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int f = (int)(idx % F);
@@ -474,6 +538,14 @@ __global__ __launch_bounds__(256) void tokens_import_kernel(const float* __restr
         const float v = t < N ? in[((size_t)b * N + t) * F + f] : 0.0f;
         const op_t h = to_op(v);
         out_hi[idx] = h;
+#if MDPT_HAVE_F8
+        if (out_lo && out_f8) {  // the fp8 form an F8 consumer reads (f8_cross.h), one element at a time (stage-level / BEiT tap path: not hot)
+            unsigned char* b8 = (unsigned char*)out_lo;
+            b8[idx] = (unsigned char)(f8_pk_e5m2((v - (float)h) * 65536.0f, 0.0f, 0u, false) & 0xFF);
+            if (out_a8) b8[out_f8 + idx] = (unsigned char)(f8_pk_e5m2((float)h, 0.0f, 0u, false) & 0xFF);
+            continue;
+        }
+#endif
         if (out_lo) out_lo[idx] = to_op(v - (float)h);
     }
 }
@@ -751,12 +823,12 @@ inline int grid_for(size_t total, int block = 256) {
 #define LAUNCH_RET() return (int)hipGetLastError()
 
 int MDPT_FN(mdpt_launch_layernorm)(const float* x, const float* gamma, const float* beta, op_t* out_hi, op_t* out_lo, float* out_f32,
-                          int rows, int F, hipStream_t stream) {
+                          int rows, int F, hipStream_t stream, size_t out_f8, int out_a8) {
     if ((F & 3) || F > 64 * 4 * LN_MAXV) return (int)hipErrorInvalidValue;
     if (rows <= 0) return 0;
     MdptProfScope prof("layernorm_kernel", 0.0, stream);
     const dim3 grid((rows + 3) / 4), block(256);
-#define LN_CASE(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, stream, x, gamma, beta, out_hi, out_lo, out_f32, rows, F)
+#define LN_CASE(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, stream, x, gamma, beta, out_hi, out_lo, out_f32, rows, F, out_f8, out_a8)
     if (F <= 256) LN_CASE(1);
     else if (F <= 512) LN_CASE(2);
     else if (F <= 1024) LN_CASE(4);
@@ -767,12 +839,12 @@ int MDPT_FN(mdpt_launch_layernorm)(const float* x, const float* gamma, const flo
 }
 
 int MDPT_FN(mdpt_launch_layernorm_addp)(float* x, const float* part, size_t part_stride, int npart, const float* gamma, const float* beta,
-                                       op_t* out_hi, op_t* out_lo, float* out_f32, int rows, int F, hipStream_t stream) {
+                                       op_t* out_hi, op_t* out_lo, float* out_f32, int rows, int F, hipStream_t stream, size_t out_f8, int out_a8) {
     if ((F & 3) || F > 64 * 4 * LN_MAXV || !part || npart < 1) return (int)hipErrorInvalidValue;
     if (rows <= 0) return 0;
     MdptProfScope prof("layernorm_addp_kernel", 0.0, stream);
     const dim3 grid((rows + 3) / 4), block(256);
-#define LN_CASE(NV) hipLaunchKernelGGL(layernorm_addp_kernel<NV>, grid, block, 0, stream, x, part, part_stride, npart, gamma, beta, out_hi, out_lo, out_f32, rows, F)
+#define LN_CASE(NV) hipLaunchKernelGGL(layernorm_addp_kernel<NV>, grid, block, 0, stream, x, part, part_stride, npart, gamma, beta, out_hi, out_lo, out_f32, rows, F, out_f8, out_a8)
     if (F <= 256) LN_CASE(1);
     else if (F <= 512) LN_CASE(2);
     else if (F <= 1024) LN_CASE(4);
@@ -783,11 +855,11 @@ int MDPT_FN(mdpt_launch_layernorm_addp)(float* x, const float* part, size_t part
 }
 
 int MDPT_FN(mdpt_launch_ksplit_finish)(const float* part, size_t part_stride, int nparts, const float* bias, float* out_f32, op_t* out_hi, op_t* out_lo,
-                                      int relu_planes, int M, int N, int ldc, hipStream_t stream) {
+                                      int relu_planes, int M, int N, int ldc, hipStream_t stream, size_t out_f8, int out_a8) {
     if (!part || nparts < 1 || (N & 3) || (ldc & 3) || M <= 0) return (int)hipErrorInvalidValue;
     MdptProfScope prof("ksplit_finish_kernel", 0.0, stream);
     const size_t n4 = (size_t)M * (N / 4);
-    hipLaunchKernelGGL(ksplit_finish_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, part, part_stride, nparts, bias, out_f32, out_hi, out_lo, relu_planes, M, N, ldc);
+    hipLaunchKernelGGL(ksplit_finish_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, part, part_stride, nparts, bias, out_f32, out_hi, out_lo, relu_planes, M, N, ldc, out_f8, out_a8);
     LAUNCH_RET();
 }
 
@@ -866,7 +938,7 @@ __global__ __launch_bounds__(256) void upsample_bf16src_kernel(const op_t* __res
 }
 
 int MDPT_FN(mdpt_launch_upsample)(const float* in, op_t* out_hi, op_t* out_lo, float* out_f32, int B, int Hi, int Wi, int Ho, int Wo,
-                         int C, hipStream_t stream) {
+                         int C, hipStream_t stream, size_t out_f8, int out_a8) {
     if (C & 3) return (int)hipErrorInvalidValue;
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
     MdptProfScope prof("upsample_kernel", 0.0, stream);
@@ -882,18 +954,18 @@ int MDPT_FN(mdpt_launch_upsample)(const float* in, op_t* out_hi, op_t* out_lo, f
                 if (e != hipSuccess) return (int)e;
                 attr_done = true;
             }
-            hipLaunchKernelGGL(upsample_tiled_kernel<32>, dim3(tiles), dim3(256), lds, stream, in, out_hi, out_lo, B, Hi, Wi, Ho, Wo);
+            hipLaunchKernelGGL(upsample_tiled_kernel<32>, dim3(tiles), dim3(256), lds, stream, in, out_hi, out_lo, B, Hi, Wi, Ho, Wo, out_f8, out_a8);
         } else if (C == 128) {
-            hipLaunchKernelGGL(upsample_tiled_kernel<16>, dim3(tiles), dim3(256), lds, stream, in, out_hi, out_lo, B, Hi, Wi, Ho, Wo);
+            hipLaunchKernelGGL(upsample_tiled_kernel<16>, dim3(tiles), dim3(256), lds, stream, in, out_hi, out_lo, B, Hi, Wi, Ho, Wo, out_f8, out_a8);
         } else {
-            hipLaunchKernelGGL(upsample_tiled_kernel<8>, dim3(tiles), dim3(256), lds, stream, in, out_hi, out_lo, B, Hi, Wi, Ho, Wo);
+            hipLaunchKernelGGL(upsample_tiled_kernel<8>, dim3(tiles), dim3(256), lds, stream, in, out_hi, out_lo, B, Hi, Wi, Ho, Wo, out_f8, out_a8);
         }
         LAUNCH_RET();
     }
     if ((C & 7) == 0 && out_hi)
-        hipLaunchKernelGGL(upsample_kernel<8>, dim3(grid_for(total / 2)), dim3(256), 0, stream, in, out_hi, out_lo, out_f32, B, Hi, Wi, Ho, Wo, C);
+        hipLaunchKernelGGL(upsample_kernel<8>, dim3(grid_for(total / 2)), dim3(256), 0, stream, in, out_hi, out_lo, out_f32, B, Hi, Wi, Ho, Wo, C, out_f8, out_a8);
     else
-        hipLaunchKernelGGL(upsample_kernel<4>, dim3(grid_for(total)), dim3(256), 0, stream, in, out_hi, out_lo, out_f32, B, Hi, Wi, Ho, Wo, C);
+        hipLaunchKernelGGL(upsample_kernel<4>, dim3(grid_for(total)), dim3(256), 0, stream, in, out_hi, out_lo, out_f32, B, Hi, Wi, Ho, Wo, C, out_f8, out_a8);
     LAUNCH_RET();
 }
 
@@ -908,6 +980,14 @@ int MDPT_FN(mdpt_launch_pack_weight)(const void* src, int src_dtype, op_t* dst_h
                             hipStream_t stream, int src_ld, int src_col0, const void* row_scale, int scale_dtype, const float* wscale) {
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)Np * Kp)), dim3(256), 0, stream, src, src_dtype, dst_hi, dst_lo, kind, N, K, Np, Kp,
                        ksz, src_ld > 0 ? src_ld : K, src_col0, kind == MDPT_PACK_LINEAR ? row_scale : nullptr, scale_dtype, kind == MDPT_PACK_LINEAR ? wscale : nullptr);
+    LAUNCH_RET();
+}
+
+int MDPT_FN(mdpt_launch_pack_weight_f8)(const void* src, int src_dtype, unsigned char* w8, unsigned char* wlo8, unsigned char* scales, int kind, int N, int K,
+                                       int Np, int Kp, int ksz, hipStream_t stream, int src_ld, int src_col0, const void* row_scale, int scale_dtype, const float* wscale) {
+    if (!MDPT_OP_IS_F16 || !w8 || !scales || (Kp & 127) || kind == MDPT_PACK_CONV3_KC32) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_weight_f8_kernel, dim3(Np), dim3(256), 0, stream, src, src_dtype, w8, wlo8, scales, kind, N, K, Np, Kp, ksz, src_ld > 0 ? src_ld : K,
+                       src_col0, kind == MDPT_PACK_LINEAR ? row_scale : nullptr, scale_dtype, kind == MDPT_PACK_LINEAR ? wscale : nullptr);
     LAUNCH_RET();
 }
 
@@ -942,19 +1022,19 @@ int MDPT_FN(mdpt_launch_nhwc_to_nchw)(const float* in_f32, const op_t* in_hi, co
 }
 
 int MDPT_FN(mdpt_launch_nchw_to_nhwc)(const float* in, float* out_f32, op_t* out_hi, op_t* out_lo, int relu_bf16, int B, int H, int W,
-                             int C, int Cp, hipStream_t stream) {
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)B * H * W * Cp)), dim3(256), 0, stream, in, out_f32, out_hi, out_lo, relu_bf16, B, H, W, C, Cp);
+                             int C, int Cp, hipStream_t stream, size_t out_f8, int out_a8) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)B * H * W * Cp)), dim3(256), 0, stream, in, out_f32, out_hi, out_lo, relu_bf16, B, H, W, C, Cp, out_f8, out_a8);
     LAUNCH_RET();
 }
 
 int MDPT_FN(mdpt_launch_tokens_export)(const op_t* in_hi, const op_t* in_lo, const float* in_f32, float* out, int B, int N, int npad,
-                              int F, int skip_cls, hipStream_t stream) {
-    hipLaunchKernelGGL(tokens_export_kernel, dim3(grid_for((size_t)B * (N - skip_cls) * F)), dim3(256), 0, stream, in_hi, in_lo, in_f32, out, B, N, npad, F, skip_cls);
+                              int F, int skip_cls, hipStream_t stream, size_t lo_f8) {
+    hipLaunchKernelGGL(tokens_export_kernel, dim3(grid_for((size_t)B * (N - skip_cls) * F)), dim3(256), 0, stream, in_hi, in_lo, in_f32, out, B, N, npad, F, skip_cls, lo_f8);
     LAUNCH_RET();
 }
 
-int MDPT_FN(mdpt_launch_tokens_import)(const float* in, op_t* out_hi, op_t* out_lo, int B, int N, int npad, int F, hipStream_t stream) {
-    hipLaunchKernelGGL(tokens_import_kernel, dim3(grid_for((size_t)B * npad * F)), dim3(256), 0, stream, in, out_hi, out_lo, B, N, npad, F);
+int MDPT_FN(mdpt_launch_tokens_import)(const float* in, op_t* out_hi, op_t* out_lo, int B, int N, int npad, int F, hipStream_t stream, size_t out_f8, int out_a8) {
+    hipLaunchKernelGGL(tokens_import_kernel, dim3(grid_for((size_t)B * npad * F)), dim3(256), 0, stream, in, out_hi, out_lo, B, N, npad, F, out_f8, out_a8);
     LAUNCH_RET();
 }
 

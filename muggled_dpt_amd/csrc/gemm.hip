@@ -48,6 +48,7 @@
 
 #include "mdpt_kernels.h"
 #include "mdpt_prof.h"
+#include "f8_cross.h"
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -68,10 +69,13 @@ namespace {
 #include "gemm8_epilogues.inc"        // direct epilogues of the 8-phase kernel
 #include "gemm8.inc"                  // gemm8_kernel: 8-phase main loop
 
-template <int AMODE, int EKIND, int DMODE>
+template <int AMODE, int EKIND, int DMODE, bool F8 = false>
 int launch_pp_mode(const GemmParams& p, hipStream_t stream) {
     constexpr unsigned LDS = 2 * 65536;
-    auto kern = gemm8_kernel<AMODE, EKIND, DMODE>;
+    if constexpr (MDPT_OP_IS_F16 && !F8 && (EKIND == MDPT_E_GENERIC || EKIND == MDPT_E_D2S) && DMODE != DM_RINIT) {
+        if (p.f8) return launch_pp_mode<AMODE, EKIND, DMODE, true>(p, stream);  // fp8 cross terms: their own kernels
+    }
+    auto kern = gemm8_kernel<AMODE, EKIND, DMODE, F8>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -80,7 +84,7 @@ int launch_pp_mode(const GemmParams& p, hipStream_t stream) {
     }
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     static char prof_name[64] = "";
-    if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), "gemm8_kernel<%d, %d, %d>", AMODE, EKIND, DMODE);
+    if (!prof_name[0]) snprintf(prof_name, sizeof(prof_name), F8 ? "gemm8_kernel<%d, %d, %d, f8>" : "gemm8_kernel<%d, %d, %d>", AMODE, EKIND, DMODE);
     MdptProfScope prof(prof_name, 2.0 * (p.M_alg > 0 ? p.M_alg : p.M) * p.N * p.K, stream);  // algorithmic rows (token pad rows are not work)
     const int ks = (AMODE == MDPT_A_DENSE && EKIND == MDPT_E_GENERIC && DMODE == DM_F32 && p.ksplit > 1) ? p.ksplit : 1;
     hipLaunchKernelGGL(kern, dim3(tiles, ks), dim3(512), LDS, stream, p);
@@ -135,7 +139,7 @@ int resolve_tile(const GemmParams& p) {
         // the K split exists on the 64x64 tile and in the DM_F32 form of the 8-phase kernel (>= 4 K tiles per range, in pairs; same sums, same bits):
         // the big tile when all ranges together make enough workgroups (the rule of the unsplit launches, counted over the ranges)
         const long wgs = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.ksplit;
-        const int kt = (p.K / 64 / p.ksplit) * p.npass;
+        const int kt = (p.K / 64 / p.ksplit) * p.npass;  // (no fp8 cross terms with a K split: mdpt_launch_gemm)
         const bool pp = p.tile == MDPT_TILE_PP256 || (p.tile == MDPT_TILE_AUTO && wgs >= (p.throughput_mode ? 70 : 140));
         return (pp && p.amode == MDPT_A_DENSE && generic_direct_mode(p) == DM_F32 && kt >= 4 && !(kt & 1) && (p.N & 255) == 0) ? MDPT_TILE_PP256 : MDPT_TILE_64x64;
     }
@@ -164,7 +168,9 @@ int resolve_tile(const GemmParams& p) {
     // odd number of K tiles: the 8-phase loop handles pairs. Three K tiles or fewer (SwinV2's 192-wide first stage) are all prologue and
     // epilogue on a big tile: the 64x64 tile wins there (M = 147456, K = 192: N = 576 93.8 vs 116.4 us, N = 192 33.0 vs 47.3 us, N = 768 a tie;
     // tools/probes/gpu_swin_tile_sweep.py, profiles/r04_swin_tile_sweep.txt), the lockstep 256x256 tile from five K tiles on
-    if (tile == MDPT_TILE_PP256 && (((p.K / 64) * p.npass) & 1)) tile = (p.K / 64) * p.npass <= 3 && p.tile == MDPT_TILE_AUTO ? MDPT_TILE_64x64 : MDPT_TILE_256x256;
+    if (tile == MDPT_TILE_PP256 && (((p.K / 64) * p.npass) & 1) && !p.f8) tile = (p.K / 64) * p.npass <= 3 && p.tile == MDPT_TILE_AUTO ? MDPT_TILE_64x64 : MDPT_TILE_256x256;
+    // fp8 cross terms: a pair of K tiles must not straddle a pass - every pass an even number of tiles (K % 256 == 0), else the lockstep tile
+    if (tile == MDPT_TILE_PP256 && p.f8 && (p.K & 255)) tile = MDPT_TILE_256x256;
     // per-image bias table: the direct epilogues of the 8-phase kernel take it in the fp16 build for images of >= 256 rows (two images per
     // tile at most); everything else goes through the strip epilogues of the lockstep kernels (same arithmetic, same bits)
     if (tile == MDPT_TILE_PP256 && p.bias_img_stride && p.ekind == MDPT_E_QKV && !(HAVE_IMGB && p.bias_img_rows >= 256)) tile = MDPT_TILE_256x256;
@@ -178,7 +184,7 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
         // residual-initialised accumulators: the 8-phase kernel has them in its DM_RINIT form only (dense A, >= 4 K tiles, 32-bit tile
         // offsets); anything else runs the lockstep 256x256 tile, whose prologue loads the residual the same way
         if (tile == MDPT_TILE_PP256 && p.acc_init &&
-            !(AMODE == MDPT_A_DENSE && generic_direct_mode(p) == DM_RINIT && (p.K / 64) * p.npass >= 4))
+            !(AMODE == MDPT_A_DENSE && generic_direct_mode(p) == DM_RINIT && (p.K / 64) * p.npass >= 4 && !p.f8))
             tile = MDPT_TILE_256x256;
     }
     if (tile == MDPT_TILE_64x64) {
@@ -186,7 +192,7 @@ int launch_tile(const GemmParams& p, hipStream_t stream) {
         // per step - same K order, same bits. Measured on the bare kernels (profiles/r04_b1_tile_sweep.txt, column t7): K = 4096 32.6 -> 28.5 us
         // (ViT-L, M = 1304), 30.7 -> 22.4 us (BEiT-L, M = 584); K <= 1536 is 2-8 % slower with the deeper ring and keeps the 2-deep one.
         if constexpr ((AMODE == MDPT_A_DENSE || AMODE == MDPT_A_CONV3) && EKIND == MDPT_E_GENERIC) {
-            if ((p.K / 64 / (p.ksplit > 1 ? p.ksplit : 1)) * p.npass >= 32) return launch_cfg<64, 64, 2, 2, 64, 3, 1, AMODE, EKIND>(p, stream);
+            if (ktiles_total(p, p.K / (p.ksplit > 1 ? p.ksplit : 1)) >= 32) return launch_cfg<64, 64, 2, 2, 64, 3, 1, AMODE, EKIND>(p, stream);
         }
         return launch_cfg<64, 64, 2, 2, 64, 2, 1, AMODE, EKIND>(p, stream);
     }
@@ -205,7 +211,13 @@ int MDPT_FN(mdpt_launch_gemm)(const GemmParams& p_in, hipStream_t stream) {
     if (p.ldw <= 0) p.ldw = p.K;  // packed panels: rows are K wide
     if (p.M <= 0 || p.N <= 0) return 0;
     if (p.K <= 0 || (p.K & 63) || (p.N & 7)) return (int)hipErrorInvalidValue;
-    if (p.npass < 1 || p.npass > 3 || (p.npass >= 2 && !p.A_lo) || (p.npass == 3 && !p.W_lo)) return (int)hipErrorInvalidValue;
+    if (p.npass < 1 || p.npass > 3 || (p.npass >= 2 && !p.A_lo) || (p.npass == 3 && !p.f8 && !p.W_lo)) return (int)hipErrorInvalidValue;
+    if (p.f8) {  // fp8 cross terms (f8_cross.h): fp16 build, 128-element K tiles of byte planes, packed panels, the generic / depth-to-space epilogues, no K split
+        if (!MDPT_OP_IS_F16 || p.npass < 2 || (p.K & 127) || !p.W8 || !p.S8 || (p.npass == 3 && (!p.W8_lo || !p.S8_lo || !p.a8_off)) || p.ksplit > 1 || p.ldw != p.K ||
+            (p.ekind != MDPT_E_GENERIC && p.ekind != MDPT_E_D2S) || p.acc_init || p.tile == MDPT_TILE_256x128 || p.tile == MDPT_TILE_128x32)
+            return (int)hipErrorInvalidValue;
+    }
+    if (p.out_f8 && (!MDPT_OP_IS_F16 || !p.out_lo)) return (int)hipErrorInvalidValue;
     if (p.ksplit > 1 && p.ks_all) {
         if (p.ekind != MDPT_E_GENERIC || (p.amode != MDPT_A_DENSE && p.amode != MDPT_A_CONV3) || !p.ks_part || (p.K / 64) % p.ksplit || p.ldw != p.K || p.acc_init)
             return (int)hipErrorInvalidValue;

@@ -6,6 +6,7 @@
 // separate operation and contraction is off inside this function, whatever the translation unit's setting is.
 #pragma once
 #include "mdpt_kernels.h"
+#include "f8_cross.h"
 
 typedef __attribute__((ext_vector_type(4))) float ln_f32x4;
 
@@ -59,7 +60,7 @@ __device__ __forceinline__ void ln_row_values(Load load, const float* __restrict
 
 template <int NV, class Load>
 __device__ __forceinline__ void ln_row_from(Load load, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                            op_t* out_hi, op_t* out_lo, float* out_f32, size_t out_off, int F, int lane) {
+                                            op_t* out_hi, op_t* out_lo, float* out_f32, size_t out_off, int F, int lane, size_t out_f8 = 0, int out_a8 = 0) {
 #pragma clang fp contract(off)
     ln_f32x4 yy[NV];
     ln_row_values<NV>([&](int c, int) { return load(c); }, gamma, beta, F, lane, yy);
@@ -73,12 +74,7 @@ __device__ __forceinline__ void ln_row_from(Load load, const float* __restrict__
 #pragma unroll
                 for (int e = 0; e < 4; ++e) h[e] = to_op(y[e]);
                 *(opx4*)(out_hi + out_off + c) = h;
-                if (out_lo) {
-                    opx4 l;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) l[e] = to_op(y[e] - (float)h[e]);
-                    *(opx4*)(out_lo + out_off + c) = l;
-                }
+                if (out_lo) lo_store4(out_lo, out_off + c, out_f8, out_a8, y, h);  // 16-bit residue plane, or the fp8 form of an F8 consumer (f8_cross.h)
             }
             if (out_f32) *(ln_f32x4*)(out_f32 + out_off + c) = y;
         }
@@ -87,6 +83,6 @@ __device__ __forceinline__ void ln_row_from(Load load, const float* __restrict__
 
 template <int NV>
 __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       op_t* out_hi, op_t* out_lo, float* out_f32, size_t out_off, int F, int lane) {
-    ln_row_from<NV>([&](int c) { return *(const ln_f32x4*)(xr + c); }, gamma, beta, out_hi, out_lo, out_f32, out_off, F, lane);
+                                       op_t* out_hi, op_t* out_lo, float* out_f32, size_t out_off, int F, int lane, size_t out_f8 = 0, int out_a8 = 0) {
+    ln_row_from<NV>([&](int c) { return *(const ln_f32x4*)(xr + c); }, gamma, beta, out_hi, out_lo, out_f32, out_off, F, lane, out_f8, out_a8);
 }

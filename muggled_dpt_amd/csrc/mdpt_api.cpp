@@ -122,12 +122,20 @@ int mdpt_get_class_passes(const mdpt_handle* h, int32_t op_class, int32_t* passe
     return 0;
 }
 
+int mdpt_get_class_f8(const mdpt_handle* h, int32_t op_class, int32_t* on) {
+    if (!h || !on || op_class < 0 || op_class >= NCLS) return fail(MDPT_E_INVALID, "bad argument");
+    *on = h->f8(op_class) ? 1 : 0;
+    return 0;
+}
+
 static void rebuild_inventory_keeping_bindings(mdpt_handle* h);
 
 int mdpt_set_class_passes(mdpt_handle* h, int32_t op_class, int32_t passes) {
     if (!h || op_class < 0 || op_class >= NCLS) return fail(MDPT_E_INVALID, "bad op class %d", op_class);
-    if (passes < 1 || passes > 3) return fail(MDPT_E_INVALID, "passes must be 1, 2 (activations split) or 3, got %d", passes);
+    if (passes < 1 || passes > MDPT_PASSES_3F8) return fail(MDPT_E_INVALID, "passes must be 1, 2 (activations split), 3, MDPT_PASSES_2F8 (4) or MDPT_PASSES_3F8 (5), got %d", passes);
     if (passes == 2 && op_class == CLS_ATTN) return fail(MDPT_E_INVALID, "the attention kernel's operands are both activations: 1 or 3 passes");
+    if (passes >= MDPT_PASSES_2F8 && op_class != CLS_REASM && op_class != CLS_FUSION && op_class != CLS_FUSION_IN && op_class != CLS_FUSION_PROJ && op_class != CLS_HEAD)
+        return fail(MDPT_E_INVALID, "fp8 cross terms (MDPT_PASSES_2F8 / _3F8) exist for the reasm, fusion, fusion_in, fusion_proj and head classes, not for class %d", op_class);
     if (h->np[op_class] == passes) return 0;
     h->np[op_class] = passes;
     rebuild_inventory_keeping_bindings(h);  // the packed-weight inventory depends on the pass counts (lo planes)
@@ -232,6 +240,15 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
         }
         CHK(OPLH(mdpt_launch_pack_weight, sp.ptr, sp.dtype, m.hi, m.lo, m.kind, m.N, m.K, m.Np, m.Kp, m.ksz, st, src_ld, src_col0, rs ? rs->ptr : nullptr,
                                     rs ? rs->dtype : 0, m.wscale));
+        m.w8 = m.wlo8 = m.s8 = m.slo8 = nullptr;
+        if (m.off_w8 != SIZE_MAX) {  // the fp8 planes of an F8 class (f8_cross.h): e4m3 of W_hi (and of W - W_hi), per-row E8M0 scales
+            unsigned char* w8 = (unsigned char*)(base + m.off_w8);
+            unsigned char* wlo8 = m.off_wlo8 == SIZE_MAX ? nullptr : (unsigned char*)(base + m.off_wlo8);
+            unsigned char* s8 = (unsigned char*)(base + m.off_s8);
+            CHK(mdpt_launch_pack_weight_f8_f16(sp.ptr, sp.dtype, w8, wlo8, s8, m.kind, m.N, m.K, m.Np, m.Kp, m.ksz, st, src_ld, src_col0, rs ? rs->ptr : nullptr,
+                                               rs ? rs->dtype : 0, m.wscale));
+            m.w8 = w8; m.wlo8 = wlo8; m.s8 = s8; m.slo8 = s8 + m.Np;
+        }
     }
     for (Vec& v : h->vecs) {
         v.ptr = (float*)(base + v.off);
@@ -594,7 +611,7 @@ int mdpt_reassemble(mdpt_handle* h, const void* const stage_in[4], int32_t B, in
     }
     for (int i = 0; i < 4; ++i) {
         Planes tp = c.pl(p.tap[i]);
-        CHK(OPLC(mdpt_launch_tokens_import, (const float*)stage_in[i], tp.hi, tp.lo, B, p.N, p.npad, h->F, c.s));
+        CHK(OPLC(mdpt_launch_tokens_import, (const float*)stage_in[i], tp.hi, tp.lo, B, p.N, p.npad, h->F, c.s, tp.lo ? tp.f8 : 0, tp.f8_a8));
     }
     CHK(run_reassemble(c));
     const int sh[4] = {4 * gh, 2 * gh, gh, gh / 2}, sw[4] = {4 * gw, 2 * gw, gw, gw / 2};
@@ -614,7 +631,7 @@ int mdpt_fusion(mdpt_handle* h, const void* const maps_in[4], int32_t B, int32_t
     for (int i = 0; i < 4; ++i) {
         if (!maps_in[i]) return fail(MDPT_E_INVALID, "null map %d", i);
         Planes rb = c.pl(p.r_bf[i]);
-        CHK(OPLC(mdpt_launch_nchw_to_nhwc, (const float*)maps_in[i], c.at<float>(p.r_f32[i]), rb.hi, rb.lo, 1, B, sh[i], sw[i], h->C, h->Cp, c.s));
+        CHK(OPLC(mdpt_launch_nchw_to_nhwc, (const float*)maps_in[i], c.at<float>(p.r_f32[i]), rb.hi, rb.lo, 1, B, sh[i], sw[i], h->C, h->Cp, c.s, rb.lo ? rb.f8 : 0, rb.f8_a8));
     }
     if (head_upsamples_bf16(h)) {
         // single-pass head: the fused forward hands the head the 16-bit output of the last projection and upsamples THAT (run_fusion(c, true) +
@@ -661,7 +678,7 @@ int mdpt_fusion_block(mdpt_handle* h, int32_t index, const void* reasm_in, const
     const std::string blk = pb;
     const size_t elems = (size_t)B * sh * sw * h->Cp;
     Planes rb = c.pl(p.r_bf[i]);
-    CHK(OPLC(mdpt_launch_nchw_to_nhwc, (const float*)reasm_in, c.at<float>(p.r_f32[i]), rb.hi, rb.lo, 1, B, sh, sw, h->C, h->Cp, c.s));
+    CHK(OPLC(mdpt_launch_nchw_to_nhwc, (const float*)reasm_in, c.at<float>(p.r_f32[i]), rb.hi, rb.lo, 1, B, sh, sw, h->C, h->Cp, c.s, rb.lo ? rb.f8 : 0, rb.f8_a8));
     const float* x_f32 = c.at<float>(p.r_f32[i]);
     Planes x_bf = rb;
     if (i != 3) {
@@ -706,7 +723,7 @@ int mdpt_head(mdpt_handle* h, const void* fused_in, int32_t B, int32_t gh, int32
     Ctx c;
     CHK(make_ctx(h, B, gh * h->Pv, gw * h->Pv, workspace, workspace_bytes, stream, &c));
     Planes fu = c.pl(c.p.fused);
-    CHK(OPLC(mdpt_launch_nchw_to_nhwc, (const float*)fused_in, nullptr, fu.hi, fu.lo, 0, B, 8 * gh, 8 * gw, h->C, h->Cp, c.s));
+    CHK(OPLC(mdpt_launch_nchw_to_nhwc, (const float*)fused_in, nullptr, fu.hi, fu.lo, 0, B, 8 * gh, 8 * gw, h->C, h->Cp, c.s, fu.lo ? fu.f8 : 0, fu.f8_a8));
     CHK(run_head(c, (float*)depth_bhw));
     h->has_last = false;
     return 0;
@@ -725,7 +742,7 @@ int mdpt_export_tap(mdpt_handle* h, int32_t which, void* out_f32, void* workspac
         CHK(hipMemcpyAsync(out_f32, c.at<float>(p.sw.resid[which]), n * 4, hipMemcpyDeviceToDevice, c.s));
     } else if (which >= 0 && which < 4) {
         Planes tp = c.pl(p.tap[which]);
-        CHK(OPLC(mdpt_launch_tokens_export, tp.hi, tp.lo, nullptr, (float*)out_f32, p.B, p.N, p.npad, h->F, 0, c.s));
+        CHK(OPLC(mdpt_launch_tokens_export, tp.hi, tp.lo, nullptr, (float*)out_f32, p.B, p.N, p.npad, h->F, 0, c.s, tp.lo ? tp.f8 : 0));
     } else if (which >= 4 && which < 8) {
         const int i = which - 4;
         CHK(OPLC(mdpt_launch_nhwc_to_nchw, c.at<float>(p.r_f32[i]), nullptr, nullptr, (float*)out_f32, p.B, sh[i], sw[i], h->C, h->Cp, c.s));

@@ -73,7 +73,7 @@ int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_
     else if (n == "h1") {
         // bf16 mode with the fused head tail: the first conv writes a bf16 map into the fp32 map's buffer (run_head)
         elems = (size_t)p.B * 64 * p.Np * h->C2p;
-        if (bf16_head) { bf16_only[0] = p.h1; if (h->np[CLS_HEAD_TAIL] == 2) bf16_only[1] = p.h1 + elems * 2; planes = bf16_only; } else { f32_off = p.h1; }
+        if (bf16_head) { bf16_only[0] = p.h1; if (h->terms(CLS_HEAD_TAIL) == 2) bf16_only[1] = p.h1 + elems * 2; planes = bf16_only; } else { f32_off = p.h1; }
     }
     else if (n == "h1u") {
         if (bf16_head) return fail(MDPT_E_STATE, "h1u does not exist on the fused head-tail path (the upsampled map only ever lives in LDS tiles)");
@@ -102,7 +102,7 @@ int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_
     // reuse the token exporter as a flat converter: B=1, N=npad=elems/F' with F'=4 keeps indices simple
     if (planes) {
         Planes pl = c.pl(planes);
-        CHK(OPLC(mdpt_launch_tokens_export, pl.hi, pl.lo, nullptr, (float*)out_f32, 1, (int)(elems / 4), (int)(elems / 4), 4, 0, c.s));
+        CHK(OPLC(mdpt_launch_tokens_export, pl.hi, pl.lo, nullptr, (float*)out_f32, 1, (int)(elems / 4), (int)(elems / 4), 4, 0, c.s, pl.lo && planes != bf16_only ? pl.f8 : 0));
     } else {
         CHK(OPLC(mdpt_launch_tokens_export, nullptr, nullptr, c.at<float>(f32_off), (float*)out_f32, 1, (int)(elems / 4), (int)(elems / 4), 4, 0, c.s));
     }

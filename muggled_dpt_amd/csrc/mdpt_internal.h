@@ -100,6 +100,10 @@ struct Mat {  // packed operand panel [Np][Kp]
     op_t* lo;
     size_t off_scale;      // fp16 handles, layer-scale-folded matrices: 2 floats {s, 1 / s} in the packed buffer (SIZE_MAX = none), GemmParams::wscale
     const float* wscale;
+    // fp8 cross-term planes of an F8 class (f8_cross.h; SIZE_MAX = none): [Np][Kp] e4m3 bytes of W_hi (K order of the 128-wide fp8 K tiles),
+    // of W - W_hi (3 terms only), and the per-row E8M0 scale bytes of both ([Np] each, the second with the activations' 2^16 folded in)
+    size_t off_w8, off_wlo8, off_s8;
+    const uint8_t* w8; const uint8_t* wlo8; const uint8_t* s8; const uint8_t* slo8;
 };
 
 struct Vec {  // packed fp32 vector (zero padded)
@@ -113,6 +117,9 @@ struct Vec {  // packed fp32 vector (zero padded)
 struct Planes {
     op_t* hi = nullptr;
     op_t* lo = nullptr;
+    size_t f8 = 0;  // != 0: the CONSUMING class runs its cross terms on fp8 planes (f8_cross.h) and `lo` holds BYTES - the e5m2 residue plane
+                    // [elems], then (consumers with three terms) the e5m2 plane of the values themselves at byte offset f8 = elems
+    int f8_a8 = 0;  // the second plane is wanted
 };
 
 extern const char* const kStageNames[4];
@@ -124,13 +131,15 @@ struct Plan {
     int B, H, W, gh, gw, Np, N, npad, npadv;
     size_t total;
     // byte offsets (SIZE_MAX = absent)
-    size_t im2col[2], pos, resid, xn[2], q[2], k[2], vt[2], att[2], hbuf[2], tap[4][2], tapf32;
-    size_t t[4][2], u0[2], u1[2], d3[2];
-    size_t r_f32[4], r_bf[4][2];
-    size_t a1[4][2], x_f32[4], x_bf[4][2], b1[4][2], b2[4][2], flo[4];
-    size_t fused[2], h1, h1u[2], scratch;
+    // operand planes: [0] hi, [1] lo (SIZE_MAX = none), [2] fp8 form of the lo plane: 0 = 16-bit residue plane, else element count | (1 << 63 if the
+    // consumer also reads the e5m2 plane of the values), see Planes
+    size_t im2col[3], pos, resid, xn[3], q[3], k[3], vt[3], att[3], hbuf[3], tap[4][3], tapf32;
+    size_t t[4][3], u0[3], u1[3], d3[3];
+    size_t r_f32[4], r_bf[4][3];
+    size_t a1[4][3], x_f32[4], x_bf[4][3], b1[4][3], b2[4][3], flo[4];
+    size_t fused[3], h1, h1u[3], scratch;
     size_t scratch_floats;
-    size_t tokr[2], cbuf, relpos_lut, relpos_tq, relpos_tk;  // BEiT: readout-projected tokens, per-image cls term, bias LUT
+    size_t tokr[3], cbuf, relpos_lut, relpos_tq, relpos_tk;  // BEiT: readout-projected tokens, per-image cls term, bias LUT
     size_t wrc_mean, wrc_tab;                                 // [B, wrc_maxk] operand-format column means, fp32 [B, wrc_maxn] per-image bias table
     size_t swi;                                               // ViT-G: fp32 [rows, 2*hidden] output of the doubled inner linear
     size_t kspart;                                            // small batches: 3 x fp32 [rows, F] partial sums of the K-split proj / fc2 (latency mode), else absent
@@ -138,7 +147,7 @@ struct Plan {
     // window operands, window maps (plain / shifted) and the position-bias LUT
     struct {
         int g0h, g0w;
-        size_t resid[4], x, xn[2], q[2], k[2], vt[2], att[2], hb[2], lut, lut_stride, tq, tk, rowmap[2], region[2], tokmap[2], vtokmap[2];
+        size_t resid[4], x, xn[3], q[3], k[3], vt[3], att[3], hb[3], lut, lut_stride, tq, tk, rowmap[2], region[2], tokmap[2], vtokmap[2];
     } sw;
 };
 
@@ -155,9 +164,12 @@ struct mdpt_handle {
     int gh_hidden, gh_hidden_p;  // ViT-G SwiGLU hidden width (and padded to 64), 0 otherwise
     int sH[4], sL[4], swh, sww, spre[4];  // SwinV2: heads / layers per stage, target window, pretrained window sizes (0 = None)
     bool f16;       // operand format: fp16 (v_mfma_*_f16, *_f16 launchers) instead of bf16
-    int np[NCLS];   // MFMA passes per op class: 1, 2 (activations split) or 3
-    bool x3c(int cls) const { return np[cls] == 3; }   // the class's WEIGHTS have a lo plane
-    bool alo(int cls) const { return np[cls] >= 2; }   // the class reads a lo plane of its ACTIVATIONS (its producers write one)
+    int np[NCLS];   // per op class as set (mdpt_set_class_passes): 1, 2 (activations split), 3, MDPT_PASSES_2F8, MDPT_PASSES_3F8
+    bool f8ok[NCLS];  // the class CAN run its cross terms on fp8 planes (fp16 operands, every contraction length a multiple of 128, not SwinV2): build_inventory
+    int terms(int cls) const { return np[cls] >= MDPT_PASSES_2F8 ? np[cls] - 2 : np[cls]; }  // products per contraction: 1, 2 or 3
+    bool f8(int cls) const { return np[cls] >= MDPT_PASSES_2F8 && f8ok[cls]; }  // cross terms on fp8 planes (f8_cross.h)
+    bool x3c(int cls) const { return terms(cls) == 3 && !f8(cls); }   // the class's WEIGHTS have a 16-bit lo plane
+    bool alo(int cls) const { return terms(cls) >= 2; }   // the class reads a lo plane of its ACTIVATIONS (its producers write one)
     // token-mean compensation of the weight rounding (fp16 operand modes, single-pass encoder Linears): see wrc_bias() below
     bool wrc_on;
     bool wrc(int cls) const { return wrc_on && f16 && np[cls] == 1 && (cls == CLS_QKV || cls == CLS_PROJ || cls == CLS_FC1 || cls == CLS_FC2); }
@@ -233,6 +245,13 @@ struct mdpt_handle {
             if (wrc(m.cls)) { if (Np > wrc_maxn) wrc_maxn = Np; if (Kp > wrc_maxk) wrc_maxk = Kp; } m.off_lo = packed_total; packed_total += rup256((size_t)Np * Kp * 2); }
         m.hi = m.lo = nullptr;
         m.off_scale = SIZE_MAX; m.wscale = nullptr;
+        m.off_w8 = m.off_wlo8 = m.off_s8 = SIZE_MAX;
+        m.w8 = m.wlo8 = m.s8 = m.slo8 = nullptr;
+        if (f8(m.cls) && kind != MDPT_PACK_CONV3_KC32) {
+            m.off_w8 = packed_total; packed_total += rup256((size_t)Np * Kp);
+            if (terms(m.cls) == 3) { m.off_wlo8 = packed_total; packed_total += rup256((size_t)Np * Kp); }
+            m.off_s8 = packed_total; packed_total += rup256((size_t)Np * 2);
+        }
         mat_index[src] = (int)mats.size();
         mats.push_back(m);
     }
@@ -274,10 +293,12 @@ struct Ctx {
     void* const* attn_dump = nullptr;  // per block: where to write softmax(q k^T) as fp32 [B,H,N,N] (null entries: skip)
     void* const* block_dump = nullptr; // per block: where to write the block's output tokens as fp32 [B,N,F] (null entries: skip)
     template <class T> T* at(size_t off) const { return off == SIZE_MAX ? nullptr : (T*)(ws + off); }
-    Planes pl(const size_t o[2]) const {
+    Planes pl(const size_t o[3]) const {
         Planes r;
         r.hi = at<op_t>(o[0]);
         r.lo = at<op_t>(o[1]);
+        r.f8 = o[1] == SIZE_MAX ? 0 : (o[2] & ~((size_t)1 << 63));
+        r.f8_a8 = o[1] != SIZE_MAX && (o[2] >> 63);
         return r;
     }
 };

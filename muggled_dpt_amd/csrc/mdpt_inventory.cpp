@@ -54,6 +54,18 @@ int build_inventory(mdpt_handle* h) {
     h->wrc_maxn = h->wrc_maxk = 0;
     h->zero_off = 0;
     h->packed_total += 256;
+    // which classes CAN run their cross terms on fp8 planes (MDPT_PASSES_2F8 / _3F8, f8_cross.h): fp16 operands, every contraction length of
+    // the class a multiple of the 128-element fp8 K tile, ViT / BEiT encoders (the SwinV2 tap producers write 16-bit planes only). A class that
+    // cannot runs the fp16-plane form of the same term count. A property of the configuration: never of the batch or the image size.
+    {
+        for (int i = 0; i < NCLS; ++i) h->f8ok[i] = false;
+        const bool base = h->f16 && !h->swin;
+        const bool cp = base && h->Cp % 128 == 0;
+        bool re = base && h->F % 128 == 0;
+        for (int i = 0; i < 4; ++i) re = re && h->hidp[i] % 128 == 0;
+        h->f8ok[CLS_REASM] = re;
+        h->f8ok[CLS_FUSION] = h->f8ok[CLS_FUSION_IN] = h->f8ok[CLS_FUSION_PROJ] = h->f8ok[CLS_HEAD] = cp;
+    }
 
     h->add_spec("patch_embed.proj.weight", {F, 3, P, P});
     h->add_spec("patch_embed.proj.bias", {F});
@@ -222,10 +234,14 @@ int build_inventory_decoder(mdpt_handle* h) {
 // ------------------------------------------------------------------------------------------------------------
 // workspace planning
 // ------------------------------------------------------------------------------------------------------------
-void take_planes(Bump& bump, bool x3, size_t elems, size_t out[2]) {
+// f8mode (fm() of the CONSUMING class): 0 = 16-bit residue plane, 1 = e5m2 residue bytes, 2 = + the e5m2 plane of the values (three terms);
+// the buffer is the same 2 bytes per element either way (Planes, f8_cross.h)
+void take_planes(Bump& bump, bool x3, size_t elems, size_t out[3], int f8mode = 0) {
     out[0] = bump.take(elems * 2);
     out[1] = x3 ? bump.take(elems * 2) : SIZE_MAX;
+    out[2] = x3 && f8mode ? (elems | (f8mode == 2 ? (size_t)1 << 63 : 0)) : 0;
 }
+static int fm(const mdpt_handle* h, int cls) { return h->f8(cls) ? (h->terms(cls) == 3 ? 2 : 1) : 0; }
 
 // reassembly outputs, fusion and head buffers; p.Np / p.gh / p.gw = the "noscale" level (1/Pv of the image)
 void plan_decoder(Bump& bump, const mdpt_handle* h, Plan& p, size_t min_scratch_floats) {
@@ -237,20 +253,20 @@ void plan_decoder(Bump& bump, const mdpt_handle* h, Plan& p, size_t min_scratch_
     for (int i = 0; i < 4; ++i) {
         const size_t e = (size_t)B * px[i] * h->Cp;
         p.r_f32[i] = bump.take(e * 4);
-        take_planes(bump, i == 3 ? x3 : x3i, e, p.r_bf[i]);
-        take_planes(bump, x3i, e, p.a1[i]);
+        take_planes(bump, i == 3 ? x3 : x3i, e, p.r_bf[i], fm(h, i == 3 ? CLS_FUSION : CLS_FUSION_IN));
+        take_planes(bump, x3i, e, p.a1[i], fm(h, CLS_FUSION_IN));
         p.x_f32[i] = bump.take(e * 4);
-        take_planes(bump, x3, e, p.x_bf[i]);
-        take_planes(bump, x3, e, p.b1[i]);
-        take_planes(bump, x3p, e, p.b2[i]);
+        take_planes(bump, x3, e, p.x_bf[i], fm(h, CLS_FUSION));
+        take_planes(bump, x3, e, p.b1[i], fm(h, CLS_FUSION));
+        take_planes(bump, x3p, e, p.b2[i], fm(h, CLS_FUSION_PROJ));
         p.flo[i] = bump.take(e * 4);
     }
     const size_t fpx = (size_t)64 * p.Np;  // (8gh)*(8gw)
-    take_planes(bump, x3h, (size_t)B * fpx * h->Cp, p.fused);
+    take_planes(bump, x3h, (size_t)B * fpx * h->Cp, p.fused, fm(h, CLS_HEAD));
     // bf16 mode with the fused head tail (run_head): conv 1 writes a bf16 map and the full-resolution upsampled map never exists (ViT-L,
     // 504x504, batch 32: 2.1 GB + 0.7 GB of workspace that used to be reserved and never touched)
     const bool bf16_head = head_tail_fused(h) && mdpt_head_tail_scale_ok(8 * p.gh, 8 * p.gw, p.H, p.W);
-    p.h1 = bump.take((size_t)B * fpx * h->C2p * (bf16_head && h->np[CLS_HEAD_TAIL] == 1 ? 2 : 4));  // one 16-bit plane | hi + lo planes | fp32 map
+    p.h1 = bump.take((size_t)B * fpx * h->C2p * (bf16_head && h->terms(CLS_HEAD_TAIL) == 1 ? 2 : 4));  // one 16-bit plane | hi + lo planes | fp32 map
     if (bf16_head) p.h1u[0] = p.h1u[1] = SIZE_MAX;
     else take_planes(bump, h->alo(CLS_HEAD_TAIL), (size_t)B * p.H * p.W * h->C2p, p.h1u);
     p.scratch_floats = (size_t)B * fpx * h->Cp;
@@ -288,17 +304,18 @@ int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl) {
     p.wrc_mean = h->wrc_maxk ? bump.take((size_t)B * h->wrc_maxk * 2) : SIZE_MAX;
     p.wrc_tab = h->wrc_maxn ? bump.take((size_t)B * h->wrc_maxn * 4) : SIZE_MAX;
     const bool x3 = h->alo(CLS_REASM);
-    for (int i = 0; i < 4; ++i) take_planes(bump, x3, rows * F, p.tap[i]);
+    const int fr = fm(h, CLS_REASM);
+    for (int i = 0; i < 4; ++i) take_planes(bump, x3, rows * F, p.tap[i], fr);
     p.tapf32 = bump.take(rows * F * 4);
     const size_t px[4] = {(size_t)16 * p.Np, (size_t)4 * p.Np, (size_t)p.Np, (size_t)p.Np / 4};
-    for (int i = 0; i < 4; ++i) take_planes(bump, x3, (size_t)B * p.Np * h->hidp[i], p.t[i]);
-    take_planes(bump, x3, (size_t)B * px[0] * h->hidp[0], p.u0);
-    take_planes(bump, x3, (size_t)B * px[1] * h->hidp[1], p.u1);
-    take_planes(bump, x3, (size_t)B * px[3] * h->hidp[3], p.d3);
+    for (int i = 0; i < 4; ++i) take_planes(bump, x3, (size_t)B * p.Np * h->hidp[i], p.t[i], fr);
+    take_planes(bump, x3, (size_t)B * px[0] * h->hidp[0], p.u0, fr);
+    take_planes(bump, x3, (size_t)B * px[1] * h->hidp[1], p.u1, fr);
+    take_planes(bump, x3, (size_t)B * px[3] * h->hidp[3], p.d3, fr);
     plan_decoder(bump, h, p, rows * F);
     p.tokr[0] = p.tokr[1] = p.cbuf = p.relpos_lut = p.relpos_tq = p.relpos_tk = SIZE_MAX;
     if (is_beit(h)) {
-        take_planes(bump, x3, (size_t)B * p.Np * F, p.tokr);
+        take_planes(bump, x3, (size_t)B * p.Np * F, p.tokr, fr);
         p.cbuf = bump.take((size_t)B * F * 4);
         p.relpos_lut = bump.take((size_t)h->heads * mdpt_beit_relpos_elen(gh, gw) * 4 * (h->nblocks <= 32 ? h->nblocks : 1));  // one table per block
         p.relpos_tq = bump.take((size_t)p.npadv * 4);

@@ -72,6 +72,15 @@ struct GemmParams {
     //    (four ranges on the 128x128 tile - half the operand traffic per flop - measured 7 % slower: profiles/r04_b1_ksplit_sweep.txt);
     //  * SwinV2 fc2 with K >= 3072 at EVERY batch size (stages of few, long-K tiles: 108 8-phase tiles at batch 16): fp32 output without
     //    residual (DM_F32 form of the 8-phase kernel from 140 workgroups on, the 64x64 tile below - same sums, same bits).
+    // fp8 cross terms (f8_cross.h, fp16 build; npass 2 or 3): f8 != 0 -> A_lo points at the e5m2 RESIDUE plane of the activations (bytes, rows of lda
+    // bytes) and the cross terms run on the block-scaled MFMA: A_lo8 W8^T, then (npass == 3) A8 W8_lo^T with the e5m2 plane of the values at
+    // (bytes) A_lo + a8_off, then A_hi W_hi^T on the fp16 planes. K % 128 == 0; conv K order of the fp8 planes: k = (cb128 * 9 + tap) * 128 + c.
+    int f8; size_t a8_off;
+    const unsigned char* W8; const unsigned char* W8_lo;   // [N][K] e4m3 bytes (row stride K)
+    const unsigned char* S8; const unsigned char* S8_lo;   // [N] E8M0 bytes: power-of-two scale of every weight row
+    // output planes for an F8 consumer: out_f8 != 0 -> out_lo receives BYTES: the e5m2 residue plane (element index = out_hi's) and, out_a8 != 0,
+    // the e5m2 plane of the values themselves at byte offset out_f8 (= the plane's element count)
+    size_t out_f8; int out_a8;
     int ksplit; float* ks_part;
     int ks_all;  // 1: EVERY range (z = 0 too) stores its bare partial sums, plane z at ks_part + z * M * ldc, and nothing else is written: a finishing
                  // kernel (mdpt_launch_ksplit_finish) adds the planes in the order z = 0, 1, ... and applies bias / ReLU / the output planes.
@@ -101,6 +110,11 @@ struct Conv3hParams {
     int relu_bf;
     int B, H, W, Cin;
     int Cout;                  // 256 (every epilogue form) or 128 (bias-only bf16 output: the head's first conv)
+    // fp8 cross terms (GemmParams::f8 has the description): in_lo = e5m2 residue plane (bytes, NHWC), values' plane at in_lo + a8_off (three terms:
+    // w8_lo != null), weights [Cout][9 * Cin] e4m3 bytes in 128-channel-block K order + per-row E8M0 scales; output planes as GemmParams::out_f8
+    int f8; size_t a8_off;
+    const unsigned char* w8; const unsigned char* w8_lo; const unsigned char* s8; const unsigned char* s8_lo;
+    size_t out_f8; int out_a8;
     unsigned long long* dbg_times;  // test hook: per-workgroup s_memtime stamps [start, first barrier, loop done, stores acknowledged, stores issued, XCC id]
 };
 

@@ -8,9 +8,13 @@ namespace mdpt {
 GemmParams base_params(const Ctx& c, const Mat& w, Planes a, int M, int lda) {
     GemmParams g;
     memset(&g, 0, sizeof(g));
-    g.npass = c.h->np[w.cls];  // the class of the weight matrix decides; an A buffer shared with a 3-pass class may carry an unused lo plane
+    g.npass = c.h->terms(w.cls);  // the class of the weight matrix decides; an A buffer shared with a 3-pass class may carry an unused lo plane
     g.A_hi = a.hi; g.A_lo = g.npass >= 2 ? a.lo : nullptr;
     g.W_hi = w.hi; g.W_lo = g.npass == 3 ? w.lo : nullptr;
+    if (g.npass >= 2 && c.h->f8(w.cls) && a.f8 && w.w8) {  // cross terms on fp8 planes (f8_cross.h): the A planes were written in that form for this class
+        g.f8 = 1; g.a8_off = a.f8;
+        g.W8 = w.w8; g.W8_lo = w.wlo8; g.S8 = w.s8; g.S8_lo = w.slo8;
+    }
     g.wscale = w.wscale;
     g.M = M; g.N = w.Np; g.K = w.Kp; g.lda = lda;
     g.zero_page = c.h->zero_page;
@@ -18,6 +22,12 @@ GemmParams base_params(const Ctx& c, const Mat& w, Planes a, int M, int lda) {
     g.throughput_mode = c.split ? 1 : 0;
     g.ldc = w.Np; g.ldr = w.Np;
     return g;
+}
+
+// output planes of a GEMM: hi, lo and the form of the lo plane (16-bit residue, or the fp8 planes an F8 consumer reads: Planes::f8)
+static void out_planes(GemmParams& g, const Planes& o) {
+    g.out_hi = o.hi; g.out_lo = o.lo;
+    g.out_f8 = o.lo ? o.f8 : 0; g.out_a8 = o.f8_a8;
 }
 
 void as_conv(GemmParams& g, int Hi, int Wi, int Cin, int Ho, int Wo, int stride) {
@@ -113,11 +123,11 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
     // K-split fc2: `pending` = partial sums the residual stream still lacks; the next LayerNorm over it folds them in
     const float* pending = nullptr;
     int npending = 0;
-    auto layernorm = [&](const float* gamma, const float* beta, op_t* ohi, op_t* olo, float* of32) -> int {
-        if (!pending) return OPLC(mdpt_launch_layernorm, resid, gamma, beta, ohi, olo, of32, rows, F, c.s);
+    auto layernorm = [&](const float* gamma, const float* beta, op_t* ohi, op_t* olo, float* of32, size_t of8 = 0, int oa8 = 0) -> int {
+        if (!pending) return OPLC(mdpt_launch_layernorm, resid, gamma, beta, ohi, olo, of32, rows, F, c.s, of8, oa8);
         const float* part = pending;
         pending = nullptr;
-        return OPLC(mdpt_launch_layernorm_addp, resid, part, (size_t)rows * F, npending, gamma, beta, ohi, olo, of32, rows, F, c.s);
+        return OPLC(mdpt_launch_layernorm_addp, resid, part, (size_t)rows * F, npending, gamma, beta, ohi, olo, of32, rows, F, c.s, of8, oa8);
     };
     // latency mode, small batch, enough K tiles; never in a debug-stop run. Two ranges from ks_min_ktiles K tiles on, four from ks_big_ktiles on
     auto ksplit_setup = [&](GemmParams& g) -> bool {
@@ -219,10 +229,10 @@ int run_encoder(const Ctx& c, void* const taps_f32[4]) {
             Planes tp = c.pl(p.tap[st]);
             float* f32 = taps_f32 ? c.at<float>(p.tapf32) : nullptr;
             if (is_beit(h)) {  // BEiT taps the raw residual stream (no out-norm, v31_beit/image_encoder_model.py:84-91)
-                CHK(OPLC(mdpt_launch_tokens_import, resid, tp.hi, tp.lo, p.B, p.npad, p.npad, F, c.s));
+                CHK(OPLC(mdpt_launch_tokens_import, resid, tp.hi, tp.lo, p.B, p.npad, p.npad, F, c.s, tp.lo ? tp.f8 : 0, tp.f8_a8));
                 if (taps_f32) CHK(OPLC(mdpt_launch_tokens_export, nullptr, nullptr, resid, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
             } else {
-                CHK(layernorm(h->V("imgencoder.outnorm.weight"), h->V("imgencoder.outnorm.bias"), tp.hi, tp.lo, f32));
+                CHK(layernorm(h->V("imgencoder.outnorm.weight"), h->V("imgencoder.outnorm.bias"), tp.hi, tp.lo, f32, tp.lo ? tp.f8 : 0, tp.f8_a8));
                 if (taps_f32)
                     CHK(OPLC(mdpt_launch_tokens_export, nullptr, nullptr, f32, (float*)taps_f32[st], p.B, p.N, p.npad, F, 0, c.s));
             }
@@ -256,7 +266,7 @@ int try_ksplit_conv(const Ctx& c, const GemmParams& g, bool* done) {
     const mdpt_handle* h = c.h;
     const Plan& p = c.p;
     if (!h->latency_mode || c.split || c.side || p.kspart == SIZE_MAX || h->gemm_tile != MDPT_TILE_AUTO || h->dbg_block >= 0) return 0;  // (side: kspart belongs to the encoder running beside it)
-    if (g.ekind != MDPT_E_GENERIC || g.resid || g.up_src || g.gamma || g.acc_init || g.act != MDPT_ACT_NONE || g.bias_img_stride) return 0;
+    if (g.ekind != MDPT_E_GENERIC || g.resid || g.up_src || g.gamma || g.acc_init || g.act != MDPT_ACT_NONE || g.bias_img_stride || g.f8) return 0;  // (f8: 128-element K tiles, no K split)
     const long tiles = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
     const int kt = g.K / 64;
     if (tiles >= 256 || kt < 64) return 0;
@@ -268,9 +278,9 @@ int try_ksplit_conv(const Ctx& c, const GemmParams& g, bool* done) {
     float* part = c.at<float>(p.kspart);
     GemmParams q = g;
     q.ksplit = ks; q.ks_all = 1; q.ks_part = part;
-    q.bias = nullptr; q.out_f32 = nullptr; q.out_hi = nullptr; q.out_lo = nullptr;
+    q.bias = nullptr; q.out_f32 = nullptr; q.out_hi = nullptr; q.out_lo = nullptr; q.out_f8 = 0; q.out_a8 = 0;
     CHK(OPLC(mdpt_launch_gemm, q, c.s));
-    CHK(OPLC(mdpt_launch_ksplit_finish, part, plane, ks, g.bias, g.out_f32, g.out_hi, g.out_lo, g.relu_bf16, g.M, g.N, g.ldc, c.s));
+    CHK(OPLC(mdpt_launch_ksplit_finish, part, plane, ks, g.bias, g.out_f32, g.out_hi, g.out_lo, g.relu_bf16, g.M, g.N, g.ldc, c.s, g.out_f8, g.out_a8));
     *done = true;
     return 0;
 }
@@ -305,7 +315,7 @@ int run_reassemble_stage(const Ctx& c, int i) {
                 g.amode = MDPT_A_TOKENS; g.tok_np = p.Np; g.tok_stride = p.npad;
                 g.bias = c.at<float>(p.cbuf); g.bias_img_stride = F; g.bias_img_rows = p.Np;
                 g.act = MDPT_ACT_GELU;
-                g.out_hi = tr.hi; g.out_lo = tr.lo; g.ldc = F;
+                out_planes(g, tr); g.ldc = F;
                 CHK(OPLC(mdpt_launch_gemm, g, c.s));
             }
             tp = tr;
@@ -315,7 +325,7 @@ int run_reassemble_stage(const Ctx& c, int i) {
             GemmParams g = base_params(c, h->M(n + ".resample.0.weight"), tp, p.B * p.Np, F);
             if (tokens_mode) { g.amode = MDPT_A_TOKENS; g.tok_np = p.Np; g.tok_stride = p.npad; }
             g.bias = h->V(n + ".resample.0.bias");
-            g.out_hi = t.hi; g.out_lo = t.lo; g.ldc = hp;
+            out_planes(g, t); g.ldc = hp;
             CHK(OPLC(mdpt_launch_gemm, g, c.s));
         }
         Planes src = t;
@@ -327,7 +337,7 @@ int run_reassemble_stage(const Ctx& c, int i) {
             g.ekind = MDPT_E_D2S;
             g.bias = h->V(n + ".resample.1.bias");
             g.Ho = gh; g.Wo = gw; g.d2s_k = kk; g.d2s_cout = hp;
-            g.out_hi = u.hi; g.out_lo = u.lo;
+            out_planes(g, u);
             CHK(OPLC(mdpt_launch_gemm, g, c.s));
             src = u; sh = gh * kk; sw = gw * kk;
         } else if (i == 3) {  // 3x3 stride-2
@@ -335,7 +345,7 @@ int run_reassemble_stage(const Ctx& c, int i) {
             GemmParams g = base_params(c, h->M(n + ".resample.1.weight"), t, p.B * (gh / 2) * (gw / 2), hp);
             as_conv(g, gh, gw, hp, gh / 2, gw / 2, 2);
             g.bias = h->V(n + ".resample.1.bias");
-            g.out_hi = d.hi; g.out_lo = d.lo; g.ldc = hp;
+            out_planes(g, d); g.ldc = hp;
             bool split_done = false;
             CHK(try_ksplit_conv(c, g, &split_done));
             if (!split_done) CHK(OPLC(mdpt_launch_gemm, g, c.s));
@@ -374,9 +384,12 @@ int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int 
     if (eligible && h->gemm_tile == MDPT_TILE_AUTO) {
         Conv3hParams q;
         memset(&q, 0, sizeof(q));
-        const int np = h->np[w.cls];  // the weight's class decides (an input buffer may carry a lo plane this conv does not use)
-        q.in = in.hi; q.in_lo = np >= 2 ? in.lo : nullptr; q.w = w.hi; q.w_lo = np == 3 ? w.lo : nullptr; q.bias = bias; q.skip = skip; q.up_src = up_src; q.Hu = Hu; q.Wu = Wu;
+        const int np = h->terms(w.cls);  // the weight's class decides (an input buffer may carry a lo plane this conv does not use)
+        const bool f8 = np >= 2 && h->f8(w.cls) && in.f8 && w.w8;  // cross terms on fp8 planes (f8_cross.h)
+        q.in = in.hi; q.in_lo = np >= 2 ? in.lo : nullptr; q.w = w.hi; q.w_lo = np == 3 && !f8 ? w.lo : nullptr; q.bias = bias; q.skip = skip; q.up_src = up_src; q.Hu = Hu; q.Wu = Wu;
+        if (f8) { q.f8 = 1; q.a8_off = in.f8; q.w8 = w.w8; q.w8_lo = np == 3 ? w.wlo8 : nullptr; q.s8 = w.s8; q.s8_lo = np == 3 ? w.slo8 : nullptr; }
         q.out_f32 = out_f32; q.out_bf = out.hi; q.out_bf_lo = out.lo; q.relu_bf = relu_bf16;
+        q.out_f8 = out.lo ? out.f8 : 0; q.out_a8 = out.f8_a8;
         q.B = c.p.B; q.H = sh; q.W = sw; q.Cin = Cin; q.Cout = 256;
         const long tiles256 = ((long)c.p.B * sh * sw + 255) / 256;
         if (tiles256 >= conv3h_min_tiles(c) && OPLC(mdpt_conv3h_supported, q)) return OPLC(mdpt_launch_conv3h, q, c.s);
@@ -386,7 +399,7 @@ int conv3_to_fusion(const Ctx& c, const Mat& w, Planes in, int Cin, int sh, int 
     g.bias = bias;
     g.resid = skip; g.ldr = h->Cp;
     g.up_src = up_src; g.Hu = Hu; g.Wu = Wu;
-    g.out_f32 = out_f32; g.out_hi = out.hi; g.out_lo = out.lo; g.relu_bf16 = relu_bf16; g.ldc = h->Cp;
+    g.out_f32 = out_f32; out_planes(g, out); g.relu_bf16 = relu_bf16; g.ldc = h->Cp;
     bool split_done = false;
     CHK(try_ksplit_conv(c, g, &split_done));
     if (split_done) return 0;
@@ -405,11 +418,11 @@ int rcu_conv(const Ctx& c, const std::string& wname, Planes in, int sh, int sw, 
 // bf16 mode, forward path (for_head): the last projection (level 0) writes its output as bf16 and the x2 upsample in front of the head is
 // left to run_head, which either interpolates it inside the head's first conv (halo-staged kernel, big launches) or runs the stand-alone
 // bf16 upsample - same arithmetic, same bits (up_bf16.h). The stage-level API and the bf16x3 mode keep the fp32 map + fp32 upsample.
-bool head_upsamples_bf16(const mdpt_handle* h) { return h->np[CLS_HEAD] == 1 && (h->Cp & 7) == 0; }
+bool head_upsamples_bf16(const mdpt_handle* h) { return h->terms(CLS_HEAD) == 1 && (h->Cp & 7) == 0; }
 // everything behind the head's first conv as ONE kernel (head.hip: upsample + 3x3 conv + ReLU + 1x1 + ReLU | sigmoid out of LDS tiles): the
 // single-pass form of the tail class (conv 1 then writes a 16-bit map whatever its own pass count) and its two-pass form (activations
 // split: conv 1 writes hi + lo 16-bit planes, head_tail2_kernel). Three passes run the unfused kernels.
-bool head_tail_fused(const mdpt_handle* h) { return h->np[CLS_HEAD_TAIL] <= 2 && mdpt_head_tail_supported(h->C2p); }
+bool head_tail_fused(const mdpt_handle* h) { return h->terms(CLS_HEAD_TAIL) <= 2 && mdpt_head_tail_supported(h->C2p); }
 
 // first conv of level i's conv_reassembly unit: relu(r_i) -> 3x3 conv -> ReLU'd planes a1[i] (fusion_model.py:148-150, 210-220)
 int fusion_rcu_a_first(const Ctx& c, int i) {
@@ -458,7 +471,7 @@ int run_fusion(const Ctx& c, bool for_head) {
     }
     if (for_head && head_upsamples_bf16(h)) return 0;
     Planes fu = c.pl(p.fused);
-    CHK(OPLC(mdpt_launch_upsample, c.at<float>(p.flo[0]), fu.hi, fu.lo, nullptr, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s));
+    CHK(OPLC(mdpt_launch_upsample, c.at<float>(p.flo[0]), fu.hi, fu.lo, nullptr, p.B, sh[0], sw[0], 2 * sh[0], 2 * sw[0], h->Cp, c.s, fu.lo ? fu.f8 : 0, fu.f8_a8));
     return 0;
 }
 
@@ -471,7 +484,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype, bool from_flo0b) {
     const mdpt_handle* h = c.h;
     const Plan& p = c.p;
     const int fh = 8 * p.gh, fw = 8 * p.gw;
-    const int np1 = h->np[CLS_HEAD];
+    const int np1 = h->terms(CLS_HEAD);
     const Mat& w1 = h->M("head.spatial_upsampler.0.weight");
     const float* b1 = h->V("head.spatial_upsampler.0.bias");
     const bool tail_fused = head_tail_fused(h) && mdpt_head_tail_scale_ok(fh, fw, p.H, p.W);
@@ -486,13 +499,14 @@ int run_head(const Ctx& c, void* depth, int depth_dtype, bool from_flo0b) {
     // ---- conv 1 -> a 16-bit map (fused tail; the buffer of the fp32 map is reused; hi + lo planes for the two-pass tail) or the fp32 map
     //      (the unfused tail's own upsample reads it)
     op_t* h1b = tail_fused ? c.at<op_t>(p.h1) : nullptr;
-    op_t* h1b_lo = tail_fused && h->np[CLS_HEAD_TAIL] == 2 ? h1b + (size_t)p.B * fh * fw * h->C2p : nullptr;
+    op_t* h1b_lo = tail_fused && h->terms(CLS_HEAD_TAIL) == 2 ? h1b + (size_t)p.B * fh * fw * h->C2p : nullptr;
     float* h1f = tail_fused ? nullptr : c.at<float>(p.h1);
     bool done = false;
     if (halo_ok && big) {  // halo-staged form, 128 output channels
         Conv3hParams q;
         memset(&q, 0, sizeof(q));
-        q.w = w1.hi; q.w_lo = np1 == 3 ? w1.lo : nullptr; q.bias = b1;
+        const bool f8h = np1 >= 2 && h->f8(CLS_HEAD) && w1.w8;  // cross terms on fp8 planes (the `fused` planes were written in that form)
+        q.w = w1.hi; q.w_lo = np1 == 3 && !f8h ? w1.lo : nullptr; q.bias = b1;
         q.out_bf = h1b; q.out_bf_lo = h1b_lo; q.out_f32 = h1f; q.B = p.B; q.H = fh; q.W = fw; q.Cin = h->Cp; q.Cout = 128;
 #ifndef MDPT_NO_UPIN  // (A/B builds: -DMDPT_NO_UPIN keeps the stand-alone upsample in front of the halo-staged conv)
         if (!fused_ready && np1 == 1 && h1b) {  // single pass: the x2 upsample folded into the conv's halo interpolation
@@ -508,6 +522,7 @@ int run_head(const Ctx& c, void* depth, int depth_dtype, bool from_flo0b) {
             CHK(materialise_fused());
             Planes fu = c.pl(p.fused);
             q.in = fu.hi; q.in_lo = np1 >= 2 ? fu.lo : nullptr;
+            if (f8h && fu.f8) { q.f8 = 1; q.a8_off = fu.f8; q.w8 = w1.w8; q.w8_lo = np1 == 3 ? w1.wlo8 : nullptr; q.s8 = w1.s8; q.s8_lo = np1 == 3 ? w1.slo8 : nullptr; }
             if (OPLC(mdpt_conv3h_supported, q)) {
                 CHK(OPLC(mdpt_launch_conv3h, q, c.s));
                 done = true;

@@ -651,9 +651,11 @@ class DPTModel(nn.Module):
     def set_class_passes(self, passes: dict[str, int] | None) -> None:
         """Per op class (native.OP_CLASSES: "patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "fusion_in", "fusion_proj", "head",
         "head_tail") MFMA pass count on top of the precision mode (mdpt_set_class_passes): 1, 3 (both operands split) or 2 (activations split,
-        weights one plane; not for "attn"): the knob the error-budget study turns."""
+        weights one plane; not for "attn"): the knob the error-budget study turns. native.PASSES_2F8 (4) / PASSES_3F8 (5), for the classes in
+        native.F8_CLASSES: the same two / three products with the cross terms on fp8 operands (1.5 / 2 pass-equivalents; fp16 operand modes)."""
         for k, v in (passes or {}).items():
-            if k not in native.OP_CLASSES or int(v) not in (1, 2, 3) or (k == "attn" and int(v) == 2):
+            ok = k in native.OP_CLASSES and (int(v) in (1, 2, 3) or (int(v) in (native.PASSES_2F8, native.PASSES_3F8) and k in native.F8_CLASSES))
+            if not ok or (k == "attn" and int(v) == 2):
                 raise ValueError(f"bad class pass entry {k!r}: {v!r}")
         self.__dict__["_class_passes"] = dict(passes) if passes else None
         self._invalidate()

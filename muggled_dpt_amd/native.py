@@ -29,7 +29,7 @@ HEADERS = ("gemm_common.inc", "gemm_epilogue_strip.inc", "gemm_lockstep.inc", "g
 UNITS = tuple((s, (), os.path.splitext(s)[0]) for s in SOURCES) + tuple((s, ("-DMDPT_OP_F16",), os.path.splitext(s)[0] + "_f16")
                                                                         for s in OPERAND_SOURCES)
 
-ABI_VERSION = 5  # MDPT_ABI_VERSION in include/mdpt.h
+ABI_VERSION = 6  # MDPT_ABI_VERSION in include/mdpt.h
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 PREC_BF16 = 0
 PREC_BF16X3 = 1
@@ -37,6 +37,8 @@ PREC_FP16 = 2
 PREC_FP16X3 = 3
 PREC_MIXED = 4
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3, "mixed": PREC_MIXED}
+PASSES_2F8, PASSES_3F8 = 4, 5  # MDPT_PASSES_2F8 / _3F8: two / three products with the cross terms on fp8 planes (csrc/f8_cross.h)
+F8_CLASSES = ("reasm", "fusion", "fusion_in", "fusion_proj", "head")  # the classes that have the fp8 form
 OP_CLASSES = ("patch", "qkv", "attn", "proj", "fc1", "fc2", "reasm", "fusion", "head", "fusion_in", "head_tail", "fusion_proj")  # MDPT_CLASS_* of include/mdpt.h
 FAMILY_DAV2 = 0
 FAMILY_DAV1 = 1
@@ -207,6 +209,7 @@ SYMBOLS = {
     "mdpt_set_grid_cache": (ctypes.c_int, [_VP, _I]),
     "mdpt_set_class_passes": (ctypes.c_int, [_VP, _I, _I]),
     "mdpt_get_class_passes": (ctypes.c_int, [_VP, _I, ctypes.POINTER(_I)]),
+    "mdpt_get_class_f8": (ctypes.c_int, [_VP, _I, ctypes.POINTER(_I)]),
     "mdpt_default_mixed_passes": (None, [ctypes.POINTER(_I)]),
     "mdpt_default_mixed_passes_for": (None, [_I, ctypes.POINTER(_I)]),
     "mdpt_set_weight_rounding_compensation": (ctypes.c_int, [_VP, _I]),

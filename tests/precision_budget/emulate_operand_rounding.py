@@ -89,6 +89,33 @@ def mx_quant(x: torch.Tensor, fmt: str, dim: int) -> torch.Tensor:
     return out.movedim(-1, dim)
 
 
+# ---- the form round 6 BUILT (csrc/f8_cross.h): fp8 cross terms with STATIC scales - no per-block scale arithmetic in any kernel.
+#   activations: E5M2 (fp16's exponent range, 2 significand bits). lo plane = e5m2((A - A_hi) * 2^16) with the constant E8M0 scale 2^-16 in
+#                the MFMA's scale operand (A_lo <= 2^-11 |A|: the shift keeps the residue of every normal fp16 value inside e5m2's NORMAL range);
+#                the A_hi W_lo term of the 3-pass classes reads a8 = e5m2(A_hi), scale 1. Saturating.
+#   weights:     E4M3 with ONE power-of-two scale per output row (row maximum into [256, 448]): a float format keeps 3 significand bits
+#                over 15 binades below the row maximum, so the MX block scale buys nothing here; per-row = a register constant of the kernel.
+def _fp_quant(v: torch.Tensor, m: int, emin: int, vmax: float) -> torch.Tensor:
+    e = torch.floor(torch.log2(v.abs().clamp_min(1e-300))).clamp_min(emin)
+    q = torch.exp2(e - m)
+    return (torch.round(v / q) * q).clamp(-vmax, vmax)
+
+
+def sf8_act(x: torch.Tensor, shift: int) -> torch.Tensor:
+    """e5m2(x * 2^shift) * 2^-shift, round to nearest even, saturating at 57344"""
+    return (_fp_quant(x.double() * 2.0 ** shift, 2, -14, 57344.0) * 2.0 ** -shift).float()
+
+
+def sf8_weight(w: torch.Tensor, rows_dim: int) -> torch.Tensor:
+    """e4m3 with one power-of-two scale per output row (`rows_dim` = the output-channel dimension of the tensor)"""
+    wt = w.movedim(rows_dim, 0).double()
+    flat = wt.reshape(wt.shape[0], -1)
+    amax = flat.abs().amax(dim=1, keepdim=True)
+    scale = torch.exp2(torch.floor(torch.log2(amax.clamp_min(1e-300))) - 8)
+    out = torch.where(amax > 0, _fp_quant(flat / scale, 3, -6, 448.0) * scale, torch.zeros_like(flat))
+    return out.reshape(wt.shape).movedim(0, rows_dim).float()
+
+
 def split_modes(mode: str):
     """"f16x2a@mxfp6" -> ("f16x2a", "mxfp6"); plain modes -> (mode, None)"""
     return tuple(mode.split("@")) if "@" in mode else (mode, None)
@@ -153,6 +180,12 @@ class _FProxy:
         """split product with its cross terms on MX operands (see MX above)"""
         base, fmt = split_modes(m)
         xh, wh = rnd(x, "f16"), rnd(weight, "f16")
+        if fmt == "sf8":  # static-scale fp8 (the built form): rows of a Linear / conv weight = dim 0, of a transposed-conv weight = dim 1
+            rows = 1 if fn is TF.conv_transpose2d else 0
+            y = fn(xh, wh, bias, **kw) + fn(sf8_act(x - xh, 16), sf8_weight(wh, rows), None, **kw)
+            if base == "f16x3":
+                y = y + fn(sf8_act(xh, 0), sf8_weight(weight - wh, rows), None, **kw)
+            return y
         y = fn(xh, wh, bias, **kw) + fn(mx_quant(x - xh, fmt, kdim_x), mx_quant(wh, fmt, kdim_w), None, **kw)
         if base == "f16x3":
             y = y + fn(mx_quant(xh, fmt, kdim_x), mx_quant(weight - wh, fmt, kdim_w), None, **kw)
@@ -305,7 +338,7 @@ def main():
                 p["patch"] = "f16x3" + at
             return p
         run("mixed (shipped table, fp16 cross terms)", table(None))
-        for fmt in ("mxfp8", "mxfp6", "mxbf6", "mxfp4"):
+        for fmt in ("sf8", "mxfp8", "mxfp6", "mxbf6", "mxfp4"):
             run(f"mixed, cross terms in {fmt}", table(fmt))
         p = table(None)
         for c in ("reasm_1x1", "reasm_resample", "reasm_fuse3x3", "fusion_proj1x1", "fusion_rcu_b", "head_conv1", "head_conv2", "patch"):
