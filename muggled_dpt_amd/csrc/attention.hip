@@ -128,23 +128,40 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 
     // ---- BEiT relative position bias: this head's resized table (ext LUT) and the per-key index terms live in LDS
     //      behind the K/V ring; bias(q,k) = lut[tq[q] - tk[k]] (see beit_relpos_kernel)
+    // RUN4, re-strided table (AttnParams::bias_row = R = 2 ww - 1, bias_ww = ww; round 6): the reversed table's index of (query q, key k) is
+    // [(wh - 1 - yq) R + (ww - 1 - xq)] + [yk R + xk], a row term plus a column term on both sides. Consecutive query tokens of a window row differ
+    // by one table entry, the next window row starts R - ww + 1 entries further: with R = 47 (window 24) the 32 queries of a half wave hit 8 ... 9
+    // banks twice in every ds_read2_b32 of the bias gather (844 M bank-conflict cycles per 168 launches on SwinV2-L, profiles/r05_sq_counters_swinl.md).
+    // The LDS image uses the row stride S = the smallest S >= R with S = ww (mod 32): token i of the window then sits at C - i (mod 32) - 32 consecutive
+    // queries read 32 different banks for each of the four keys of a run. Indices are converted where they are loaded; the global table is unchanged.
+    const int brow = (RUN4 && p.bias_row > 0) ? p.bias_row : 0;
+    const int bstride = brow ? brow + ((p.bias_ww - brow) & 31) : 0;
+    const int belen = brow ? (p.bias_elen / brow) * bstride : p.bias_elen;  // entries of the LDS image
+    auto restride = [&](int idx) __attribute__((always_inline)) -> int { return brow ? (idx / brow) * bstride + idx % brow : idx; };
     float* lds_lut = (float*)(smem + RINGS * 2 * STAGE);
-    int* lds_tk = (int*)(lds_lut + (BIAS ? p.bias_elen : 0));
+    int* lds_tk = (int*)(lds_lut + (BIAS ? belen : 0));
     int* lds_reg = lds_tk + (((p.N + 63) >> 6) << 6);  // MODE 2: shifted-window region id of every key
     int tqv[QB], rqv[QB];
     const bool masked = MODE == 2 && p.region != nullptr;
     if (BIAS) {
         const float* lut = p.bias_lut + (size_t)h * p.bias_elen;
-        for (int i = tid; i < p.bias_elen; i += 256) lds_lut[i] = lut[RUN4 ? p.bias_elen - 1 - i : i];
+        if (brow) {
+            for (int i = tid; i < belen; i += 256) {
+                const int r = i / bstride, c = i - r * bstride;
+                lds_lut[i] = c < brow ? lut[p.bias_elen - 1 - (r * brow + c)] : 0.0f;
+            }
+        } else {
+            for (int i = tid; i < p.bias_elen; i += 256) lds_lut[i] = lut[RUN4 ? p.bias_elen - 1 - i : i];
+        }
         const int nk = ((p.N + 63) >> 6) << 6;
-        for (int i = tid; i < nk; i += 256) lds_tk[i] = p.tk[i < p.npad ? i : p.npad - 1];
+        for (int i = tid; i < nk; i += 256) lds_tk[i] = restride(p.tk[i < p.npad ? i : p.npad - 1]);
         if (MODE == 2)
             for (int i = tid; i < nk; i += 256) lds_reg[i] = masked ? p.region[(size_t)win * p.region_ld + (i < p.N ? i : p.N - 1)] : 0;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             const int q = q0 + qb * 32 + l31;
             tqv[qb] = p.tq[q < p.npad ? q : p.npad - 1];
-            if (RUN4) tqv[qb] = p.bias_elen - 1 - tqv[qb];  // index into the reversed table: lut[tq - tk - e] = rev[(elen - 1 - tq) + tk + e]
+            if (RUN4) tqv[qb] = restride(p.bias_elen - 1 - tqv[qb]);  // index into the reversed table: lut[tq - tk - e] = rev[(elen - 1 - tq) + tk + e]
             rqv[qb] = masked ? p.region[(size_t)win * p.region_ld + (q < p.N ? q : p.N - 1)] : 0;
         }
     }
@@ -551,7 +568,10 @@ int MDPT_FN(mdpt_launch_attention)(const AttnParams& p, hipStream_t stream) {
     const bool wide = !p.x3 && (wide_env >= 0 ? wide_env != 0 : (blocks256 >= 512 && fills));
     const bool bias = p.bias_lut != nullptr;
     const int ntk = ((p.N + 63) / 64) * 64;
-    const size_t extra = bias ? (size_t)p.bias_elen * 4 + (size_t)ntk * 4 * (swin ? 2 : 1) : 0;
+    // (window attention with the re-strided table image: rows of stride S >= 2 ww - 1, S = ww mod 32 - see the kernel)
+    const bool restr = swin && p.bias_run4 && p.bias_row > 0 && p.bias_ww > 0 && p.bias_elen % p.bias_row == 0;
+    const size_t lut_entries = restr ? (size_t)(p.bias_elen / p.bias_row) * (p.bias_row + ((p.bias_ww - p.bias_row) & 31)) : (size_t)p.bias_elen;
+    const size_t extra = bias ? lut_entries * 4 + (size_t)ntk * 4 * (swin ? 2 : 1) : 0;
     const size_t ring = (size_t)2 * 2 * (p.x3 ? 2 : 1) * 64 * hd * 2;
     if (ring + extra > 160 * 1024) return (int)hipErrorInvalidValue;  // relative-position table does not fit in LDS
     // latency form (opt-in, mdpt_set_latency_mode: the merge changes the summation order): a launch of at most ~one workgroup per CU

@@ -80,9 +80,13 @@ template <int WSEL>
 __device__ __forceinline__ void f8_mfma16_a_first(f8_f32x4& acc, f8_i32x8 first, f8_i32x8 second, int s_first, int s_second) {
     F8_MFMA_ASM("v_mfma_scale_f32_16x16x128_f8f6f4", " cbsz:1", "[0,%5,0]", "[0,%6,0]");
 }
+// The 32x32x64 form of the lockstep GEMM tiles is the BUILTIN: those kernels keep their accumulators in AGPRs between the fp16 MFMAs, an asm
+// statement with "+v" makes hipcc copy them to VGPRs and back around it - and the copy back (v_accvgpr_write) reads the MFMA's result one cycle
+// after an instruction the compiler does not know to be an MFMA: the last MFMA of every fp8 K tile was lost (found by tests/test_gpu_f8_cross.py
+// as cross terms that were "half there"). The lockstep kernels have the registers the untied builtin wants.
 template <int WSEL>
 __device__ __forceinline__ void f8_mfma32_a_first(f8_f32x16& acc, f8_i32x8 first, f8_i32x8 second, int s_first, int s_second) {
-    F8_MFMA_ASM("v_mfma_scale_f32_32x32x64_f8f6f4", " cbsz:1", "[0,%5,0]", "[0,%6,0]");
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(first, second, acc, 1, 0, 0, s_first, WSEL, s_second);
 }
 #undef F8_MFMA_ASM
 // (16 passes of 4 cycles at most before a result may be read by anything but the matrix pipe)

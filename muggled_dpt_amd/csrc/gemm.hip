@@ -111,11 +111,14 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int NST, int MINW, int AMODE, int EKIND>
+template <int BM, int BN, int WM, int WN, int BK, int NST, int MINW, int AMODE, int EKIND, bool F8 = false>
 int launch_cfg(const GemmParams& p, hipStream_t stream) {
     constexpr int LDS = NST * (BM + BN) * BK * 2;
+    if constexpr (MDPT_OP_IS_F16 && !F8 && BK == 64 && (EKIND == MDPT_E_GENERIC || EKIND == MDPT_E_D2S) && !(BM == 256 && BN == 256)) {
+        if (p.f8) return launch_cfg<BM, BN, WM, WN, BK, NST, MINW, AMODE, EKIND, true>(p, stream);  // fp8 cross terms: their own kernels
+    }
     static bool attr_done = false;
-    auto kern = gemm_kernel<BM, BN, WM, WN, BK, NST, MINW, AMODE, EKIND>;
+    auto kern = gemm_kernel<BM, BN, WM, WN, BK, NST, MINW, AMODE, EKIND, F8>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
@@ -124,7 +127,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     static char prof_name[112] = "";
     if (!prof_name[0])
-        snprintf(prof_name, sizeof(prof_name), "gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, BK, NST, MINW, AMODE, EKIND);
+        snprintf(prof_name, sizeof(prof_name), F8 ? "gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, f8>" : "gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, BK, NST, MINW, AMODE, EKIND);
     MdptProfScope prof(prof_name, 2.0 * (p.M_alg > 0 ? p.M_alg : p.M) * p.N * p.K, stream);  // algorithmic flops (real rows, one pass whatever npass is)
     const int ks = ((AMODE == MDPT_A_DENSE || AMODE == MDPT_A_CONV3) && EKIND == MDPT_E_GENERIC && BM == 64 && BN == 64 && BK == 64 && p.ksplit > 1) ? p.ksplit : 1;
     hipLaunchKernelGGL(kern, dim3(tiles, ks), dim3(64 * WM * WN), LDS, stream, p);
@@ -170,7 +173,8 @@ int resolve_tile(const GemmParams& p) {
     // tools/probes/gpu_swin_tile_sweep.py, profiles/r04_swin_tile_sweep.txt), the lockstep 256x256 tile from five K tiles on
     if (tile == MDPT_TILE_PP256 && (((p.K / 64) * p.npass) & 1) && !p.f8) tile = (p.K / 64) * p.npass <= 3 && p.tile == MDPT_TILE_AUTO ? MDPT_TILE_64x64 : MDPT_TILE_256x256;
     // fp8 cross terms: a pair of K tiles must not straddle a pass - every pass an even number of tiles (K % 256 == 0), else the lockstep tile
-    if (tile == MDPT_TILE_PP256 && p.f8 && (p.K & 255)) tile = MDPT_TILE_256x256;
+    if (tile == MDPT_TILE_PP256 && p.f8 && (p.K & 255)) tile = MDPT_TILE_128x128;
+    if (tile == MDPT_TILE_256x256 && p.f8) tile = MDPT_TILE_128x128;  // (the 256x256 lockstep tile has no registers left for the second MFMA family)
     // per-image bias table: the direct epilogues of the 8-phase kernel take it in the fp16 build for images of >= 256 rows (two images per
     // tile at most); everything else goes through the strip epilogues of the lockstep kernels (same arithmetic, same bits)
     if (tile == MDPT_TILE_PP256 && p.bias_img_stride && p.ekind == MDPT_E_QKV && !(HAVE_IMGB && p.bias_img_rows >= 256)) tile = MDPT_TILE_256x256;

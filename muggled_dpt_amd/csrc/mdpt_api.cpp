@@ -726,6 +726,7 @@ int mdpt_head(mdpt_handle* h, const void* fused_in, int32_t B, int32_t gh, int32
     CHK(OPLC(mdpt_launch_nchw_to_nhwc, (const float*)fused_in, nullptr, fu.hi, fu.lo, 0, B, 8 * gh, 8 * gw, h->C, h->Cp, c.s, fu.lo ? fu.f8 : 0, fu.f8_a8));
     CHK(run_head(c, (float*)depth_bhw));
     h->has_last = false;
+    h->stage_plan = c.p; h->has_stage_plan = true;  // (mdpt_debug_read "h1" / "fused" / "h1u" of this call: tools/probes/gpu_f8_h1_check.py)
     return 0;
 }
 

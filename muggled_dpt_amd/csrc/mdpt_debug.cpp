@@ -48,10 +48,10 @@ int mdpt_debug_set_ksplit_min(mdpt_handle* h, int32_t min_k_tiles, int32_t four_
 int mdpt_debug_read(mdpt_handle* h, const char* name, void* out_f32, size_t out_floats, void* workspace, size_t workspace_bytes,
                     void* stream) {
     if (!h || !name || !out_f32) return fail(MDPT_E_INVALID, "null argument");
-    if (!h->has_last) return fail(MDPT_E_STATE, "mdpt_debug_read needs a preceding mdpt_forward");
+    if (!h->has_last && !h->has_stage_plan) return fail(MDPT_E_STATE, "mdpt_debug_read needs a preceding mdpt_forward");
     if (h->swin) return fail(MDPT_E_UNSUPPORTED, "mdpt_debug_read: internal buffer names are defined for the ViT families only");
     Ctx c;
-    c.h = h; c.p = h->last_plan; c.ws = (char*)workspace; c.s = (hipStream_t)stream;
+    c.h = h; c.p = h->has_last ? h->last_plan : h->stage_plan; c.ws = (char*)workspace; c.s = (hipStream_t)stream;
     CHK(check_ws(h, c.p, workspace, workspace_bytes));
     const Plan& p = c.p;
     const size_t rows = (size_t)p.B * p.npad;

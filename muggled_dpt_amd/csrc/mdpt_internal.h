@@ -188,6 +188,8 @@ struct mdpt_handle {
     // last forward (for export taps)
     Plan last_plan;
     bool has_last;
+    Plan stage_plan;      // test hook: plan of the last stage-level mdpt_head call (mdpt_debug_read of its buffers)
+    bool has_stage_plan = false;
     int dbg_block, dbg_step;  // test hook: stop the encoder after (block, step); -1 = off
     // batch split: batches >= split_min run as two halves on the caller's stream and an internal side stream (fork / join with
     // events, no host sync) so that one half's kernels fill the tile-quantisation tails and epilogue phases of the other's

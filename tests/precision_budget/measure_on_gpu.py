@@ -38,6 +38,14 @@ def policies():
         out.append((f"mixed, {c} = {n}", "mixed", {c: n}))
     out += [("mixed, reasm + fusion_proj = 2 (whole decoder activation-split)", "mixed", {"reasm": 2, "fusion_proj": 2, "fusion_in": 2}),
             ("mixed + proj x3", "mixed", {"proj": 3}), ("mixed + proj x2", "mixed", {"proj": 2})]
+    # round 6: cross terms on fp8 planes (MDPT_PASSES_2F8 = 4 / _3F8 = 5, csrc/f8_cross.h) - 1.5 / 2 pass-equivalents instead of 2 / 3
+    out += [("f8: shipped table, cross terms on fp8 (reasm, fusion_proj 3F8; fusion, head 2F8)", "mixed", {"reasm": 5, "fusion_proj": 5, "fusion": 4, "head": 4}),
+            ("f8: reasm, fusion_proj, fusion 3F8; head 2F8", "mixed", {"reasm": 5, "fusion_proj": 5, "fusion": 5, "head": 4}),
+            ("f8: reasm, fusion_proj, fusion, head 3F8", "mixed", {"reasm": 5, "fusion_proj": 5, "fusion": 5, "head": 5}),
+            ("f8: reasm, fusion_proj, fusion, head 3F8; head_tail 3", "mixed", {"reasm": 5, "fusion_proj": 5, "fusion": 5, "head": 5, "head_tail": 3}),
+            ("f8: reasm, fusion_proj, fusion, head 3F8; fusion_in 2F8", "mixed", {"reasm": 5, "fusion_proj": 5, "fusion": 5, "head": 5, "fusion_in": 4}),
+            ("f8: reasm, fusion_proj, fusion, head, fusion_in 3F8", "mixed", {"reasm": 5, "fusion_proj": 5, "fusion": 5, "head": 5, "fusion_in": 5}),
+            ("f8: reasm, fusion_proj 3F8; fusion 2F8; head 3F8", "mixed", {"reasm": 5, "fusion_proj": 5, "fusion": 4, "head": 5})]
     for c in CLASSES:
         out.append((f"fp16c + {c} x3", "fp16", {c: 3, "wrc": True}))
     out += [("fp16c + decoder x3", "fp16", {"reasm": 3, "fusion": 3, "fusion_proj": 3, "fusion_in": 3, "head": 3, "head_tail": 3, "wrc": True}),
