@@ -193,8 +193,9 @@ def profile_pass(lib, fn, steps):
 PRECISION_DTYPE = {"bf16": "bf16", "bf16x3": "bf16x3 (hi/lo split bf16 MFMA operands, 3 passes, fp32 accumulate)",
                    "fp16": "fp16 (fp16 MFMA operands, single pass, fp32 accumulate)",
                    "fp16x3": "fp16x3 (hi/lo split fp16 MFMA operands, 3 passes, fp32 accumulate)",
-                   "mixed": "mixed (fp16 MFMA operands; patch embed, reassembly and 1x1 fusion projections 3 passes, fusion 3x3 convs and both head convs 2 passes "
-                            "(activations split; 3 for the MiDaS families), encoder 1 pass + token-mean compensation; fp32 accumulate)"}
+                   "mixed": "mixed (fp16 MFMA operands; decoder classes as split products A_hi W_hi + A_lo W_hi [+ A_hi W_lo] with the cross terms on fp8 planes "
+                            "through the block-scaled MFMA: reassembly, fusion convs and 1x1 fusion projections 3 terms, head conv 1 2 terms; patch embed 3 fp16 "
+                            "passes, head tail 2; encoder 1 pass + token-mean compensation; fp32 accumulate)"}
 
 
 def model_for_precision(name: str, precision: str, dev):

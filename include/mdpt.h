@@ -139,7 +139,10 @@ int mdpt_get_class_passes(const mdpt_handle* h, int32_t op_class, int32_t* passe
 int mdpt_get_class_f8(const mdpt_handle* h, int32_t op_class, int32_t* on); /* 1: the class's cross terms really run on fp8 planes */
 void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]);                      /* the Depth-Anything families */
 void mdpt_default_mixed_passes_for(int32_t family, int32_t passes[MDPT_NUM_CLASSES]);  /* per MDPT_FAMILY_*: the MiDaS v3.1 families keep three
-                                                                                          passes on the decoder's whole projection path */
+                                                                                          terms on the decoder's whole projection path. Round 6: the
+                                                                                          decoder classes name the fp8 forms (MDPT_PASSES_*F8) */
+void mdpt_default_mixed_passes_r05(int32_t family, int32_t passes[MDPT_NUM_CLASSES]);  /* the 16-bit-plane table of round 5: what MDPT_PREC_MIXED gives a class
+                                                                                          of a configuration that cannot run the fp8 forms (mdpt_get_class_f8) */
 /* Token-mean compensation of the weight rounding (fp16 operand modes; on by default in MDPT_PREC_MIXED, available in MDPT_PREC_FP16): a
  * single-pass Linear of the encoder (QKV, proj, fc1, fc2) computes A fp16(W)^T; what the weight rounding loses is dominated by the part all
  * tokens of an image share, mean_t(A) (W - fp16(W))^T, which two small kernels turn into a per-image bias table the GEMM epilogue adds

@@ -173,7 +173,7 @@ int resolve_tile(const GemmParams& p) {
     // tools/probes/gpu_swin_tile_sweep.py, profiles/r04_swin_tile_sweep.txt), the lockstep 256x256 tile from five K tiles on
     if (tile == MDPT_TILE_PP256 && (((p.K / 64) * p.npass) & 1) && !p.f8) tile = (p.K / 64) * p.npass <= 3 && p.tile == MDPT_TILE_AUTO ? MDPT_TILE_64x64 : MDPT_TILE_256x256;
     // fp8 cross terms: a pair of K tiles must not straddle a pass - every pass an even number of tiles (K % 256 == 0), else the lockstep tile
-    if (tile == MDPT_TILE_PP256 && p.f8 && (p.K & 255)) tile = MDPT_TILE_128x128;
+    if (tile == MDPT_TILE_PP256 && p.f8 && ((p.K & 255) || (p.N & 255))) tile = MDPT_TILE_128x128;  // (and whole 256-column tiles: HalfStager steps one weight pointer)
     if (tile == MDPT_TILE_256x256 && p.f8) tile = MDPT_TILE_128x128;  // (the 256x256 lockstep tile has no registers left for the second MFMA family)
     // per-image bias table: the direct epilogues of the 8-phase kernel take it in the fp16 build for images of >= 256 rows (two images per
     // tile at most); everything else goes through the strip epilogues of the lockstep kernels (same arithmetic, same bits)

@@ -58,10 +58,15 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     h->swh = cfg->swin_window_h; h->sww = cfg->swin_window_w;
     h->f16 = cfg->precision == MDPT_PREC_FP16 || cfg->precision == MDPT_PREC_FP16X3 || cfg->precision == MDPT_PREC_MIXED;
     {
-        int32_t mixed[NCLS];
+        // MDPT_PREC_MIXED: the table of mdpt_default_mixed_passes_for where the configuration can run the fp8 forms it names, the 16-bit-plane table of
+        // round 5 for a class that cannot (the small encoders' reassembly widths, fusion widths below 128, SwinV2): there "3 terms on fp8" would
+        // silently become three fp16 passes where two were the measured choice
+        int32_t mixed[NCLS], mixed16[NCLS];
         mdpt_default_mixed_passes_for(cfg->family, mixed);
+        mdpt_default_mixed_passes_r05(cfg->family, mixed16);
+        compute_f8ok(h);
         const bool all3 = cfg->precision == MDPT_PREC_BF16X3 || cfg->precision == MDPT_PREC_FP16X3;
-        for (int i = 0; i < NCLS; ++i) h->np[i] = cfg->precision == MDPT_PREC_MIXED ? mixed[i] : (all3 ? 3 : 1);
+        for (int i = 0; i < NCLS; ++i) h->np[i] = cfg->precision == MDPT_PREC_MIXED ? ((mixed[i] >= MDPT_PASSES_2F8 && !h->f8ok[i]) ? mixed16[i] : mixed[i]) : (all3 ? 3 : 1);
     }
     // token-mean compensation: on where the encoder's single-pass Linears are what is left of the error (mixed). With a single-pass decoder behind
     // them (MDPT_PREC_FP16) the map does not get better - encoder taps -25 %, map rms +10 ... +37 % on BEiT-L / SwinV2-L, -15 % on ViT-L,
@@ -102,16 +107,36 @@ void mdpt_destroy(mdpt_handle* h) { delete h; }
 // The MiDaS v3.1 families keep three passes for the whole projection path: on their reference fixtures the activation-split form reads
 // 1.07e-3 (BEiT-L) / 1.08e-3 with twice the rms (SwinV2-L) against 8.4e-4 / 6.8e-4 (tools/probes/gpu_family_class_budget.py,
 // profiles/r05_family_class_budget.txt) - their decoders' weight rounding is not the smaller half of the budget.
+// Round 6: the cross terms of the decoder classes on fp8 planes (MDPT_PASSES_2F8 / _3F8, csrc/f8_cross.h) - 1.5 / 2 pass-equivalents where the table
+// above paid 2 / 3. Measured on ViT-L 504^2 batch 32, one box, images 0 / 7 / 13 / 31 (tests/precision_budget/measure_on_gpu.py, profiles/r06_precision_budget_f8.md):
+//   round 5's table                                   worst 9.05e-4  rms 9.12e-5  52.40 ms
+//   the same table with fp8 cross terms               worst 9.26e-4  rms 9.15e-5  49.73 ms  (the accuracy of the fp16 cross terms, as the emulation said)
+//   + fusion at THREE terms (its weights split too)   worst 7.97e-4  rms 8.38e-5  50.64 ms  <- shipped: part of the gain is spent on margin
+//   + head at three terms                             worst 7.60e-4  rms 7.96e-5  51.46 ms
+// A configuration that cannot run the fp8 forms (mdpt_get_class_f8) keeps round 5's table (mdpt_create).
 void mdpt_default_mixed_passes_for(int32_t family, int32_t passes[MDPT_NUM_CLASSES]) {
     const bool midas = family == MDPT_FAMILY_BEIT || family == MDPT_FAMILY_SWINV2;
     for (int i = 0; i < NCLS; ++i) passes[i] = 1;
     passes[CLS_PATCH] = 3;  // 0.13 % of the FLOPs
+    passes[CLS_REASM] = MDPT_PASSES_3F8;
+    passes[CLS_FUSION] = MDPT_PASSES_3F8;
+    passes[CLS_FUSION_PROJ] = MDPT_PASSES_3F8;
+    passes[CLS_HEAD] = midas ? MDPT_PASSES_3F8 : MDPT_PASSES_2F8;
+    passes[CLS_HEAD_TAIL] = midas ? 3 : 2;  // (its own kernel, VALU-bound in the halo interpolation: fp16 planes)
+    passes[CLS_FUSION_IN] = 1;  // 2 % of the decoder's squared error for a quarter of its FLOPs (profiles/r04_precision_budget.md)
+}
+
+// round 5's table (16-bit planes only): what a configuration without the fp8 forms runs
+void mdpt_default_mixed_passes_r05(int32_t family, int32_t passes[MDPT_NUM_CLASSES]) {
+    const bool midas = family == MDPT_FAMILY_BEIT || family == MDPT_FAMILY_SWINV2;
+    for (int i = 0; i < NCLS; ++i) passes[i] = 1;
+    passes[CLS_PATCH] = 3;
     passes[CLS_REASM] = 3;
     passes[CLS_FUSION] = midas ? 3 : 2;
     passes[CLS_FUSION_PROJ] = 3;
     passes[CLS_HEAD] = midas ? 3 : 2;
     passes[CLS_HEAD_TAIL] = midas ? 3 : 2;
-    passes[CLS_FUSION_IN] = 1;  // 2 % of the decoder's squared error for a quarter of its FLOPs (profiles/r04_precision_budget.md)
+    passes[CLS_FUSION_IN] = 1;
 }
 
 void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]) { mdpt_default_mixed_passes_for(MDPT_FAMILY_DAV2, passes); }

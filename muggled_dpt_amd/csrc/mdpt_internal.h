@@ -316,6 +316,7 @@ inline bool is_midas(const mdpt_handle* h) { return h->cfg.family == MDPT_FAMILY
 // reference attribute names differ between the families (v2: fusion_model.py:100,138 / v31_beit, v31_swinv2 fusion_model.py)
 inline const char* rcu_seq(const mdpt_handle* h) { return is_midas(h) ? "conv_seq" : "resconv_seq"; }
 inline const char* proj_seq(const mdpt_handle* h) { return is_midas(h) ? "proj_seq" : "scale_proj_seq"; }
+void compute_f8ok(mdpt_handle* h);
 int build_inventory(mdpt_handle* h);
 int make_plan(const mdpt_handle* h, int B, int H, int W, Plan* pl);
 int check_ws(const mdpt_handle* h, const Plan& p, const void* ws, size_t bytes);

@@ -43,6 +43,19 @@ std::string blk_name(const mdpt_handle* h, int block) {
 }
 
 
+// which classes CAN run their cross terms on fp8 planes (MDPT_PASSES_2F8 / _3F8, f8_cross.h): fp16 operands, every contraction length of
+// the class a multiple of the 128-element fp8 K tile, ViT / BEiT encoders (the SwinV2 tap producers write 16-bit planes only). A class that
+// cannot runs the fp16-plane form of the same term count. A property of the configuration: never of the batch or the image size.
+void compute_f8ok(mdpt_handle* h) {
+    for (int i = 0; i < NCLS; ++i) h->f8ok[i] = false;
+    const bool base = h->f16 && !h->swin;
+    const bool cp = base && h->Cp % 128 == 0;
+    bool re = base && h->F % 128 == 0;
+    for (int i = 0; i < 4; ++i) re = re && h->hidp[i] % 128 == 0;
+    h->f8ok[CLS_REASM] = re;
+    h->f8ok[CLS_FUSION] = h->f8ok[CLS_FUSION_IN] = h->f8ok[CLS_FUSION_PROJ] = h->f8ok[CLS_HEAD] = cp;
+}
+
 int build_inventory_swin_encoder(mdpt_handle* h);
 
 int build_inventory_decoder(mdpt_handle* h);
@@ -54,18 +67,7 @@ int build_inventory(mdpt_handle* h) {
     h->wrc_maxn = h->wrc_maxk = 0;
     h->zero_off = 0;
     h->packed_total += 256;
-    // which classes CAN run their cross terms on fp8 planes (MDPT_PASSES_2F8 / _3F8, f8_cross.h): fp16 operands, every contraction length of
-    // the class a multiple of the 128-element fp8 K tile, ViT / BEiT encoders (the SwinV2 tap producers write 16-bit planes only). A class that
-    // cannot runs the fp16-plane form of the same term count. A property of the configuration: never of the batch or the image size.
-    {
-        for (int i = 0; i < NCLS; ++i) h->f8ok[i] = false;
-        const bool base = h->f16 && !h->swin;
-        const bool cp = base && h->Cp % 128 == 0;
-        bool re = base && h->F % 128 == 0;
-        for (int i = 0; i < 4; ++i) re = re && h->hidp[i] % 128 == 0;
-        h->f8ok[CLS_REASM] = re;
-        h->f8ok[CLS_FUSION] = h->f8ok[CLS_FUSION_IN] = h->f8ok[CLS_FUSION_PROJ] = h->f8ok[CLS_HEAD] = cp;
-    }
+    compute_f8ok(h);
 
     h->add_spec("patch_embed.proj.weight", {F, 3, P, P});
     h->add_spec("patch_embed.proj.bias", {F});

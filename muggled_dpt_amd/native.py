@@ -210,6 +210,7 @@ SYMBOLS = {
     "mdpt_set_class_passes": (ctypes.c_int, [_VP, _I, _I]),
     "mdpt_get_class_passes": (ctypes.c_int, [_VP, _I, ctypes.POINTER(_I)]),
     "mdpt_get_class_f8": (ctypes.c_int, [_VP, _I, ctypes.POINTER(_I)]),
+    "mdpt_default_mixed_passes_r05": (None, [_I, ctypes.POINTER(_I)]),
     "mdpt_default_mixed_passes": (None, [ctypes.POINTER(_I)]),
     "mdpt_default_mixed_passes_for": (None, [_I, ctypes.POINTER(_I)]),
     "mdpt_set_weight_rounding_compensation": (ctypes.c_int, [_VP, _I]),

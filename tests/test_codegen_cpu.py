@@ -39,8 +39,7 @@ def test_hot_kernels_do_not_spill(tmp_path, src, pattern, at_least, operands):
     stats = {k: v for k, v in _kernel_stats(src, tmp_path, extra).items() if pattern in k}
     assert len(stats) >= at_least, sorted(stats)
     for name, s in stats.items():
-        # the fp8 cross-term forms of the 8-phase kernel (gemm8_kernel<..., true>: MDPT_PASSES_2F8 / _3F8, decoder only) carry the fp16 loop AND the
-        # fp8 loops: a few dwords of their pass-switch state live in scratch (outside the K loops) - bounded, not zero
-        limit = 80 if "gemm8_kernel" in name and name.endswith("ELb1EEEv10GemmParams") else 0
-        assert s["ScratchSize"] <= limit, f"{name} spills {s['ScratchSize']} bytes of scratch per lane ({s['NumVgprs']} VGPRs)"
+        # (incl. the fp8 cross-term forms gemm8_kernel<..., true>, MDPT_PASSES_2F8 / _3F8: with four weight pointers instead of one they reloaded spilled
+        #  pointer pairs inside the fp16 loop - a vmcnt(0) each, 370 us against 310 us for three fp16 passes on the 36x36 fusion convs)
+        assert s["ScratchSize"] == 0, f"{name} spills {s['ScratchSize']} bytes of scratch per lane ({s['NumVgprs']} VGPRs)"
         assert s["NumVgprs"] <= 256

@@ -135,9 +135,11 @@ def test_fusion_blocks_with_f8_cross_terms_match_the_cpu_emulation(batch, size):
         e_emu, e_16, e_1 = rel_err(y8, ref_emu), rel_err(y8, y16), rel_err(y1, y16)
         print(f"block {i} batch {batch}: fp8 cross terms vs emulation {e_emu:.2e}, vs fp16 cross terms {e_16:.2e}; dropping the cross terms {e_1:.2e}; "
               f"vs fp32 {rel_err(y8, ref_f32):.2e} (fp16 cross terms {rel_err(y16, ref_f32):.2e})")
-        assert e_emu <= 4e-5, f"block {i}"
+        # (the library applies the 1x1 projection before the x2 upsample, the emulation after it: other values get rounded, the two differ at
+        #  the level of the fp8 rounding itself - head conv 1 and the reassembly convs, which have no such step, agree to 1e-5 and better)
+        assert e_emu <= 6e-5, f"block {i}"
         assert e_16 <= 0.25 * e_1, f"block {i}: the fp8 cross terms must carry what the fp16 cross terms carry"
-        assert rel_err(y8, ref_f32) <= 1.5 * rel_err(y16, ref_f32) + 2e-5
+        assert rel_err(y8, ref_f32) <= 0.15 * e_1, f"block {i}: what the fp8 rounding of the cross terms leaves (measured 5 ... 7 % of dropping them)"
         prev = orc.fusion_block(w, i, reasm[i], prev)  # feed the exact previous map so errors do not compound
 
 

@@ -314,8 +314,13 @@ def test_raw_c_abi_class_passes_keep_bound_weights_and_reject_bad_arguments():
     c.fusion_channels, c.patch_size_px, c.precision, c.family = 32, 14, native.PREC_MIXED, native.FAMILY_DAV2
     h = ctypes.c_void_p()
     native.check(lib, lib.mdpt_create(ctypes.byref(c), ctypes.byref(h)))
+    # (a 64-feature toy cannot run the fp8 forms of round 6's table - contraction lengths that are not multiples of 128 - and gets round 5's
+    #  16-bit-plane table; tests/test_gpu_f8_cross.py has the eligible configuration)
     want = (ctypes.c_int32 * len(native.OP_CLASSES))()
-    lib.mdpt_default_mixed_passes(want)
+    lib.mdpt_default_mixed_passes_r05(native.FAMILY_DAV2, want)
+    new = (ctypes.c_int32 * len(native.OP_CLASSES))()
+    lib.mdpt_default_mixed_passes(new)
+    assert {native.OP_CLASSES[i]: new[i] for i in range(len(native.OP_CLASSES)) if new[i] != want[i]} == {"reasm": 5, "fusion": 5, "fusion_proj": 5, "head": 4}
     got = ctypes.c_int32()
     for i in range(len(native.OP_CLASSES)):
         native.check(lib, lib.mdpt_get_class_passes(h, i, ctypes.byref(got)))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-kernel table (in-library HIP-event profile, batch split off) of any bench.py model: python tools/probes/gpu_kernel_share_any.py swinl 384 16 [latency | bf16 | fp16 | mixed | bf16x3 | fp16x3]"""
+"""Per-kernel table (in-library HIP-event profile, batch split off) of any bench.py model:
+   python tools/probes/gpu_kernel_share_any.py swinl 384 16 [latency | bf16 | fp16 | mixed | bf16x3 | fp16x3] [class=passes,...]"""
 import ctypes, json, os, sys, torch
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
@@ -16,6 +17,8 @@ if opt == "latency":
     model.set_latency_mode(True)
 elif opt in native.PRECISIONS:
     model.set_precision(opt)
+if len(sys.argv) > 5:  # per-class pass counts on top of the mode, e.g. reasm=5,fusion_proj=5,fusion=4,head=4 (4 / 5 = fp8 cross terms)
+    model.set_class_passes({k: int(v) for k, v in (kv.split("=") for kv in sys.argv[5].split(","))})
 native.check(lib, lib.mdpt_set_batch_split(model._get_engine().handle, 0))
 native.check(lib, lib.mdpt_debug_set_reassemble_overlap(model._get_engine().handle, 0))  # nothing on the side stream: every kernel alone
 with torch.inference_mode():
