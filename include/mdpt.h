@@ -140,7 +140,9 @@ int mdpt_get_class_f8(const mdpt_handle* h, int32_t op_class, int32_t* on); /* 1
 void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]);                      /* the Depth-Anything families */
 void mdpt_default_mixed_passes_for(int32_t family, int32_t passes[MDPT_NUM_CLASSES]);  /* per MDPT_FAMILY_*: the MiDaS v3.1 families keep three
                                                                                           terms on the decoder's whole projection path. Round 6: the
-                                                                                          decoder classes name the fp8 forms (MDPT_PASSES_*F8) */
+                                                                                          decoder classes name the fp8 forms (MDPT_PASSES_*F8); BEiT adds
+                                                                                          fc1 at 3 and fusion_in at 2F8 (margin under either rounding of
+                                                                                          the fp16 weight scale, profiles/r06_beitl_class_budget.txt) */
 void mdpt_default_mixed_passes_r05(int32_t family, int32_t passes[MDPT_NUM_CLASSES]);  /* the 16-bit-plane table of round 5: what MDPT_PREC_MIXED gives a class
                                                                                           of a configuration that cannot run the fp8 forms (mdpt_get_class_f8) */
 /* Token-mean compensation of the weight rounding (fp16 operand modes; on by default in MDPT_PREC_MIXED, available in MDPT_PREC_FP16): a
@@ -302,6 +304,7 @@ int mdpt_debug_set_reassemble_overlap(mdpt_handle* h, int32_t on);
  * once per handle and caller stream, never inside a stream capture; csrc/stream_probe.hip). `probe` 0 takes the first candidate unseen.
  * `prio`: priority class of the candidates, 0 = default class (default), 1 = the device's lowest, -1 = highest (own queue pool, but measured
  * slower: the two classes do not overlap). mdpt_debug_side_stream_info: candidates created / candidates found on the caller's queue so far. */
+int mdpt_debug_set_wscale_policy(mdpt_handle* h, int32_t all);  /* 1: scale every layer-scale-folded matrix of the fp16 build (the other valid rounding) */
 int mdpt_debug_set_side_stream_priority(mdpt_handle* h, int32_t prio);
 int mdpt_debug_set_side_stream_probe(mdpt_handle* h, int32_t on);
 int mdpt_debug_side_stream_info(mdpt_handle* h, int32_t* candidates, int32_t* rejected);

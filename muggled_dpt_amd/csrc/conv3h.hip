@@ -242,6 +242,9 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     // epilogue); one more DMA instruction per wave and K tile pulls pixel `8 slot + wave` of it towards the CU (its 1 KiB lands in the
     // scratch KiB and is ignored: an L2 / MALL prefetch), so the epilogue's loads do not start from HBM with nothing to hide behind.
     const __amdgpu_buffer_rsrc_t rs_skip = plane_rsrc(SKIP ? p.skip + (size_t)img * p.H * p.W * 256 : nullptr, SKIP ? (size_t)p.H * p.W * 1024 : 0);
+    // (not in the fp8 forms: two main loops at the 256-register limit - with the prefetch's operands live the fp16 loop reloaded a dozen spilled
+    //  registers per pair of channel blocks, a vmcnt(0) each)
+    constexpr bool PFSKIP = SKIP && !F8;
     const unsigned pf_voff = (unsigned)lane << 4;
     auto issue_prefetch = [&](int slot) __attribute__((always_inline)) {
         const int pp = slot * 8 + wave;  // tile pixel (row pp >> 4, column pp & 15); slot outside [0, 32): nothing to fetch
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
     do {                                                                                                              \
         constexpr int cbl = (U_) / 9, t9 = (U_) % 9, ky = t9 / 3, kx = t9 % 3, bi = (U_) & 1;                          \
         constexpr bool halo_slot = t9 < 6;                                                                            \
-        constexpr int inflight = 4 + (halo_slot ? 1 : 0) + (SKIP ? 1 : 0);                                            \
+        constexpr int inflight = 4 + (halo_slot ? 1 : 0) + (PFSKIP ? 1 : 0);                                          \
         const int kt = cbp * 9 + (U_);                                                                                \
         const bool more = (U_) < 16 || !last;      /* K tile kt + 2 exists */                                         \
         const int va = a_lane[kx] + cbl * HALO_BYTES;                                                                 \
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(512, 1) void conv3h_kernel(const Conv3hParams p) {
         WAIT_LGKM(8); BAR(); WAIT_LGKM(0); PIN();                                                                     \
         MQ(0, 0, fb0); BAR();                                                                                     \
         LOAD_B(fb1, 1, bi); PIN();                                                                                    \
-        if (more) { issue_b(PC_, 0, bi, kt + 2); if constexpr (SKIP) issue_prefetch(kt - (9 * nvcb - 34)); }                        \
+        if (more) { issue_b(PC_, 0, bi, kt + 2); if constexpr (PFSKIP) issue_prefetch(kt - (9 * nvcb - 34)); }                      \
         BAR(); WAIT_LGKM(0); PIN();                                                                                   \
         MQ(0, 1, fb1); BAR();                                                                                     \
         LOAD_A(1, va, ky); PIN();                                                                                     \

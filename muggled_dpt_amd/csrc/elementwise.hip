@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void upsample_tiled_kernel(const float* __rest
 // not far above it). What it does NOT buy is margin: BEiT-L in the mixed mode sits AT the 1e-3 bar - 0.84e-3 or 1.01e-3 depending on an
 // equally valid rounding of the same weights - and should be read that way (mdpt_default_mixed_passes_for).
 __global__ __launch_bounds__(1024) void weight_scale_kernel(const void* __restrict__ src, int sdt, int N, int K, int src_ld, int src_col0,
-                                                            const void* __restrict__ row_scale, int rdt, float* __restrict__ scale2) {
+                                                            const void* __restrict__ row_scale, int rdt, float* __restrict__ scale2, int always) {
     __shared__ float red[1024];
     float mx = 0.0f;
     const size_t total = (size_t)N * K;
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(1024) void weight_scale_kernel(const void* __restri
     if (threadIdx.x == 0) {
         int x = 0;
         int e = 0;
-        if (red[0] > 0.0f && red[0] < 0.03125f) { (void)frexpf(red[0], &x); e = 14 - x; }  // red[0] = m * 2^x, m in [0.5, 1)
+        if (red[0] > 0.0f && (always || red[0] < 0.03125f)) { (void)frexpf(red[0], &x); e = 14 - x; }  // red[0] = m * 2^x, m in [0.5, 1); always: test policy "scale every folded matrix"
         e = e < -100 ? -100 : (e > 100 ? 100 : e);
         scale2[0] = ldexpf(1.0f, e);
         scale2[1] = ldexpf(1.0f, -e);
@@ -992,9 +992,9 @@ int MDPT_FN(mdpt_launch_pack_weight_f8)(const void* src, int src_dtype, unsigned
 }
 
 int MDPT_FN(mdpt_launch_weight_scale)(const void* src, int src_dtype, int N, int K, int src_ld, int src_col0, const void* row_scale, int scale_dtype, float* scale2,
-                                     hipStream_t stream) {
+                                     hipStream_t stream, int always) {
     if (!src || !scale2 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1024), 0, stream, src, src_dtype, N, K, src_ld > 0 ? src_ld : K, src_col0, row_scale, scale_dtype, scale2);
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1024), 0, stream, src, src_dtype, N, K, src_ld > 0 ? src_ld : K, src_col0, row_scale, scale_dtype, scale2, always);
     LAUNCH_RET();
 }
 

@@ -17,6 +17,16 @@ int mdpt_debug_set_reassemble_overlap(mdpt_handle* h, int32_t on) {
     return 0;
 }
 
+// The power-of-two weight scale of the fp16 build (GemmParams::wscale) has two equally valid roundings of the same weights: the shipped rule scales a
+// folded matrix only when its largest entry is below 2^-5, "all" scales every one. The tolerance claims of the mixed mode are asserted under BOTH
+// (tests/test_gpu_precision_modes.py). Takes effect at the next mdpt_finalize.
+int mdpt_debug_set_wscale_policy(mdpt_handle* h, int32_t all) {
+    if (!h) return fail(MDPT_E_INVALID, "null handle");
+    h->wscale_all = all ? 1 : 0;
+    h->finalized = false;
+    return 0;
+}
+
 int mdpt_debug_set_side_stream_priority(mdpt_handle* h, int32_t prio) {
     if (!h || prio < -1 || prio > 1) return fail(MDPT_E_INVALID, "null handle or priority class outside -1 .. 1");
     if (h->side_ncand) return fail(MDPT_E_STATE, "the side stream exists already (set the class before the first forward)");

@@ -194,6 +194,7 @@ struct mdpt_handle {
     // batch split: batches >= split_min run as two halves on the caller's stream and an internal side stream (fork / join with
     // events, no host sync) so that one half's kernels fill the tile-quantisation tails and epilogue phases of the other's
     int split_min;
+    int wscale_all = 0;  // test policy (mdpt_debug_set_wscale_policy): scale EVERY layer-scale-folded matrix of the fp16 build, not only those below 2^-5
     int latency_mode;  // mdpt_set_latency_mode: small launches may use summation orders that are not batch-invariant
     int side_prio;      // priority class of the side stream: 0 = the default class (default), 1 = lowest, -1 = highest (mdpt_debug_set_side_stream_priority; measured worse)
     int overlap_reasm;  // unsplit forwards queue the reassembly branches on the side stream beside the encoder: 0 never, 1 = rule in forward_one (default), 2 always

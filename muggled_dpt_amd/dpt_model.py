@@ -425,6 +425,8 @@ class _Engine:
         self.handle = handle
         for cls_name, passes in (model.__dict__.get("_class_passes") or {}).items():
             native.check(self.lib, self.lib.mdpt_set_class_passes(self.handle, native.OP_CLASSES.index(cls_name), int(passes)))
+        if model.__dict__.get("_dbg_wscale_all", False):  # test hook: the other valid rounding of the fp16 build's weight scale (mdpt_debug_set_wscale_policy)
+            native.check(self.lib, self.lib.mdpt_debug_set_wscale_policy(self.handle, 1))
         wrc = model.__dict__.get("_wrc")
         if wrc is not None:
             native.check(self.lib, self.lib.mdpt_set_weight_rounding_compensation(self.handle, int(bool(wrc))))
@@ -658,6 +660,12 @@ class DPTModel(nn.Module):
             if not ok or (k == "attn" and int(v) == 2):
                 raise ValueError(f"bad class pass entry {k!r}: {v!r}")
         self.__dict__["_class_passes"] = dict(passes) if passes else None
+        self._invalidate()
+
+    def _debug_set_wscale_policy(self, scale_all: bool) -> None:
+        """Test hook (mdpt_debug_set_wscale_policy): the fp16 build's power-of-two weight scale applied to EVERY layer-scale-folded matrix instead of
+        only those whose largest entry is below 2^-5 - an equally valid rounding of the same weights, under which the mixed mode's tolerance is asserted too."""
+        self.__dict__["_dbg_wscale_all"] = bool(scale_all)
         self._invalidate()
 
     def set_weight_rounding_compensation(self, on: bool | None) -> None:

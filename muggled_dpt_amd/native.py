@@ -202,6 +202,7 @@ SYMBOLS = {
     "mdpt_debug_set_stop": (ctypes.c_int, [_VP, _I, _I]),
     "mdpt_debug_set_ksplit_min": (ctypes.c_int, [_VP, _I, _I]),
     "mdpt_debug_set_reassemble_overlap": (ctypes.c_int, [_VP, _I]),
+    "mdpt_debug_set_wscale_policy": (ctypes.c_int, [_VP, _I]),
     "mdpt_debug_set_side_stream_priority": (ctypes.c_int, [_VP, _I]),
     "mdpt_debug_set_side_stream_probe": (ctypes.c_int, [_VP, _I]),
     "mdpt_debug_side_stream_info": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),

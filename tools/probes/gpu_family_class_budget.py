@@ -19,6 +19,14 @@ VARIANTS = [("shipped", {}), ("round 4 (3 passes)", R04), ("fusion=3", {"fusion"
             ("fusion_in=3 proj=3", {"fusion_in": 3, "proj": 3})]
 if os.environ.get("MDPT_BUDGET_ENCODER"):  # encoder classes one at a time (what buys margin per ms on this family)
     VARIANTS = [("shipped", {})] + [(f"{c}={n}", {c: n}) for c in ("qkv", "proj", "fc1", "fc2") for n in (2, 3)] + [("attn=3", {"attn": 3}), ("fusion_in=3", {"fusion_in": 3})]
+if os.environ.get("MDPT_BUDGET_R06"):  # round 6: the fp8 table (shipped) against round 5's, and what buys margin under BOTH roundings of the fp16 weight scale
+    R05 = {"reasm": 3, "fusion": 3, "fusion_proj": 3, "head": 3, "head_tail": 3}
+    VARIANTS = [("shipped (fp8 cross terms)", {}), ("round 5's table (fp16 planes)", R05), ("fusion_in=4", {"fusion_in": 4}), ("fusion_in=5", {"fusion_in": 5}), ("fc1=2", {"fc1": 2}),
+                ("fc2=2", {"fc2": 2}), ("fc1=2 fc2=2", {"fc1": 2, "fc2": 2}), ("fc1=3", {"fc1": 3}), ("fc2=3", {"fc2": 3}), ("qkv=2", {"qkv": 2}), ("fc2=2 fusion_in=4", {"fc2": 2, "fusion_in": 4}),
+                ("fc1=3 fusion_in=4", {"fc1": 3, "fusion_in": 4}), ("fc1=3 fc2=3", {"fc1": 3, "fc2": 3}), ("fc1=3 proj=3", {"fc1": 3, "proj": 3}), ("fc1=3 qkv=3", {"fc1": 3, "qkv": 3})]
+    if os.environ.get("MDPT_BUDGET_R06") == "2":
+        VARIANTS = [VARIANTS[0]] + VARIANTS[-4:]
+BOTH = bool(os.environ.get("MDPT_BUDGET_R06"))
 for name in (sys.argv[1:] or ["beitl", "swinl"]):
     fixture, size, batch = FIX[name]
     g = np.load(os.path.join(REPO, "tests", "golden", fixture + ".npz"))
@@ -37,6 +45,12 @@ for name in (sys.argv[1:] or ["beitl", "swinl"]):
     for label, passes in VARIANTS:
         model.set_precision("mixed")
         model.set_class_passes(passes)
+        other = ""
+        if BOTH:  # the other valid rounding of the weight scale (mdpt_debug_set_wscale_policy)
+            model._debug_set_wscale_policy(True)
+            d = model(x1.cuda()).cpu()[:, ::4, ::4].double() - ref
+            other = f"   | every folded matrix scaled: max {float(d.abs().max() / ref.abs().max()):.3e}  rms {float(d.pow(2).mean().sqrt() / ref.abs().max()):.3e}"
+            model._debug_set_wscale_policy(False)
         y = model(x1.cuda()).cpu()
         d = y[:, ::4, ::4].double() - ref
         err, rms = float(d.abs().max() / ref.abs().max()), float(d.pow(2).mean().sqrt() / ref.abs().max())
@@ -48,4 +62,4 @@ for name in (sys.argv[1:] or ["beitl", "swinl"]):
             model(xb)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 8
-        print(f"  {label:26s} max {err:.3e}  rms {rms:.3e}   {dt * 1e3:7.2f} ms  {batch / dt:7.1f} maps/s", flush=True)
+        print(f"  {label:30s} max {err:.3e}  rms {rms:.3e}   {dt * 1e3:7.2f} ms  {batch / dt:7.1f} maps/s{other}", flush=True)
