@@ -148,7 +148,8 @@ void mdpt_default_mixed_passes_r05(int32_t family, int32_t passes[MDPT_NUM_CLASS
 /* Token-mean compensation of the weight rounding (fp16 operand modes; on by default in MDPT_PREC_MIXED, available in MDPT_PREC_FP16): a
  * single-pass Linear of the encoder (QKV, proj, fc1, fc2) computes A fp16(W)^T; what the weight rounding loses is dominated by the part all
  * tokens of an image share, mean_t(A) (W - fp16(W))^T, which two small kernels turn into a per-image bias table the GEMM epilogue adds
- * (transformer_block.py:160,168, misc_helpers.py:111-115 restated with that term). Same call-order rule as mdpt_set_class_passes. */
+ * (transformer_block.py:160,168, misc_helpers.py:111-115 restated with that term). Same call-order rule as mdpt_set_class_passes.
+ * on: 0 off, 1 all four classes, or a mask (1 << MDPT_CLASS_QKV) | (1 << MDPT_CLASS_PROJ) | (1 << MDPT_CLASS_FC1) | (1 << MDPT_CLASS_FC2) of the classes to compensate. */
 int mdpt_set_weight_rounding_compensation(mdpt_handle* h, int32_t on);
 
 /* Parameter inventory, named with the reference's converted ("new format") keys, prefixed by component:
@@ -261,6 +262,14 @@ int mdpt_set_latency_mode(mdpt_handle* h, int32_t on);
 int mdpt_prepare_image(const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, void* out_chw, int32_t out_dtype, int32_t out_h, int32_t out_w,
                        const float rgb_mean[3], const float rgb_std[3], int32_t interpolation, void* stream);
 
+/* DPTModel.inference's device half in ONE call (dpt_model.py:87-109: prepare_image_bgr -> forward; SURVEY §8(f) row 1 "fused with patchify"):
+ * uint8 [in_h,in_w,3] BGR on the device -> depth [H,W]. The patch embedding's im2col kernel computes every pixel of the [3,H,W] model tensor from
+ * the uint8 image itself (the arithmetic of mdpt_prepare_image, rounded to image_dtype = the model's dtype) and stores it straight into its rows:
+ * the normalised image never exists in memory, one launch and one HBM round trip fewer than mdpt_prepare_image + mdpt_forward, bit-identical to
+ * that pair. One image per call (the reference's inference is per image); H, W by the reference's size rule; workspace as for mdpt_forward(B = 1). */
+int mdpt_forward_bgr(mdpt_handle* h, const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, int32_t image_dtype, int32_t H, int32_t W, const float rgb_mean[3],
+                     const float rgb_std[3], int32_t interpolation, void* depth_hw, int32_t depth_dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Depth post-processing on the device (reference muggled_dpt/demo_helpers/postprocess.py and
  * run_3dviewer.py:576-590). All buffers are device pointers; `minmax` is a 2-float device buffer {min, max} and
  * `scratch8` 8 bytes of device scratch - nothing is read back to the host, nothing synchronises.
@@ -302,6 +311,9 @@ int mdpt_debug_set_reassemble_overlap(mdpt_handle* h, int32_t on);
  * onto a few hardware queues; a side stream on the caller's queue would run the two halves of a split batch one after the other, so the first
  * forward on a caller stream PROBES up to four candidate streams on the GPU and keeps one that really runs beside the caller's (one host wait,
  * once per handle and caller stream, never inside a stream capture; csrc/stream_probe.hip). `probe` 0 takes the first candidate unseen.
+ * Caveats of the probe: its host wait would invalidate a GLOBAL-mode stream capture another thread has open at that moment (run one forward before
+ * capturing, or switch the probe off); a probe in which every candidate was rejected (GPU busy with other work) is repeated by the next forward, three
+ * times at most; a stream handle recycled by the runtime after hipStreamDestroy keeps the pick of its predecessor.
  * `prio`: priority class of the candidates, 0 = default class (default), 1 = the device's lowest, -1 = highest (own queue pool, but measured
  * slower: the two classes do not overlap). mdpt_debug_side_stream_info: candidates created / candidates found on the caller's queue so far. */
 int mdpt_debug_set_wscale_policy(mdpt_handle* h, int32_t all);  /* 1: scale every layer-scale-folded matrix of the fp16 build (the other valid rounding) */

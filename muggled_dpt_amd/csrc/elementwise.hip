@@ -596,13 +596,10 @@ __device__ __forceinline__ void aa_span(int i, float scale, int in_size, int& lo
 
 // The output is written in the MODEL's dtype (out_dtype = MDPT_DT_*; the reference builds the tensor in the model dtype too,
 // patch_embed.py:131-145 - here the filter runs in fp32 and rounds once): no cast kernel between this one and the patchify of mdpt_forward.
+// One output pixel (all three channels, R G B): the arithmetic both kernels below share, so that the fused form's values equal the stand-alone one's bit for bit.
 template <int INTERP>
-__global__ __launch_bounds__(256) void prepare_image_kernel(const unsigned char* __restrict__ bgr, void* __restrict__ out, int out_dtype, int ih,
-                                                            int iw, int oh, int ow, float m0, float m1, float m2, float s0,
-                                                            float s1, float s2) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= oh * ow) return;
-    const int ox = idx % ow, oy = idx / ow;
+__device__ __forceinline__ void aa_pixel_rgb(const unsigned char* __restrict__ bgr, int ih, int iw, int oh, int ow, int oy, int ox, float m0, float m1, float m2,
+                                             float s0, float s1, float s2, float& v0, float& v1, float& v2) {
     const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
     int ylo, yn, xlo, xn;
     float yc, yinv, xc, xinv;
@@ -626,10 +623,21 @@ __global__ __launch_bounds__(256) void prepare_image_kernel(const unsigned char*
         acc_g += wy * rg;
         acc_r += wy * rr;
     }
+    v0 = (acc_r / 255.0f - m0) * s0;  // channel 0 = R
+    v1 = (acc_g / 255.0f - m1) * s1;  // channel 1 = G
+    v2 = (acc_b / 255.0f - m2) * s2;  // channel 2 = B
+}
+
+template <int INTERP>
+__global__ __launch_bounds__(256) void prepare_image_kernel(const unsigned char* __restrict__ bgr, void* __restrict__ out, int out_dtype, int ih,
+                                                            int iw, int oh, int ow, float m0, float m1, float m2, float s0,
+                                                            float s1, float s2) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= oh * ow) return;
+    const int ox = idx % ow, oy = idx / ow;
+    float v0, v1, v2;
+    aa_pixel_rgb<INTERP>(bgr, ih, iw, oh, ow, oy, ox, m0, m1, m2, s0, s1, s2, v0, v1, v2);
     const size_t plane = (size_t)oh * ow;
-    const float v0 = (acc_r / 255.0f - m0) * s0;  // channel 0 = R
-    const float v1 = (acc_g / 255.0f - m1) * s1;  // channel 1 = G
-    const float v2 = (acc_b / 255.0f - m2) * s2;  // channel 2 = B
     if (out_dtype == MDPT_DT_BF16) {
         __bf16* o = (__bf16*)out;
         o[idx] = (__bf16)v0; o[plane + idx] = (__bf16)v1; o[2 * plane + idx] = (__bf16)v2;
@@ -640,6 +648,36 @@ __global__ __launch_bounds__(256) void prepare_image_kernel(const unsigned char*
         float* o = (float*)out;
         o[idx] = v0; o[plane + idx] = v1; o[2 * plane + idx] = v2;
     }
+}
+
+// prepare_image fused with patchify (SURVEY 8(f) row 1 as written; DPTModel.inference = patch_embed.py:103-145 -> :77-99): one thread = one pixel
+// of the model tensor, computed from the uint8 image as above, rounded to the dtype the stand-alone kernel would have written it in (img_dt: the
+// values - and so every bit behind them - equal mdpt_prepare_image + patchify_kernel) and stored straight into its three places of the patch
+// embedding's im2col rows (k = c P^2 + ky P + kx). The normalised image never exists in memory. The first pixel of a patch also zeroes its
+// row's padding columns [3 P^2, Kp).
+template <int INTERP>
+__global__ __launch_bounds__(256) void prepare_patchify_kernel(const unsigned char* __restrict__ bgr, int img_dt, op_t* out_hi, op_t* out_lo, int ih, int iw,
+                                                               int H, int W, int P, int Kp, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int ox = idx % W, oy = idx / W;
+    float v[3];
+    aa_pixel_rgb<INTERP>(bgr, ih, iw, H, W, oy, ox, m0, m1, m2, s0, s1, s2, v[0], v[1], v[2]);
+    const int py = oy / P, ky = oy - py * P, px = ox / P, kx = ox - px * P;
+    const size_t row = ((size_t)py * (W / P) + px) * Kp;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float r = img_dt == MDPT_DT_BF16 ? (float)(__bf16)v[c] : (img_dt == MDPT_DT_F16 ? (float)(_Float16)v[c] : v[c]);
+        const size_t o = row + (size_t)c * P * P + ky * P + kx;
+        const op_t h = to_op(r);
+        out_hi[o] = h;
+        if (out_lo) out_lo[o] = to_op(r - (float)h);
+    }
+    if (ky == 0 && kx == 0)
+        for (int k = 3 * P * P; k < Kp; ++k) {
+            out_hi[row + k] = to_op(0.0f);
+            if (out_lo) out_lo[row + k] = to_op(0.0f);
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -734,11 +772,12 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ i
 // ---------------------------------------------------------------------------------------------------
 // mean[b][k] = operand-format mean over every `step`-th real row t = 0, step, 2 step, ... < nreal of image b of A[(b * rows_per_img + t) * lda + k]
 // (a fixed subsample estimates the shared component as well as all rows do - tests/precision_budget/ - at 1 / step of the traffic).
-// One workgroup = one image x 128 columns: 16 column groups of 8 x 16 row slices (~10 sampled rows per thread at 1297 tokens, loads
-// four deep in flight), slices summed in a fixed order through LDS. The result is the A operand [B, K] of the small GEMM against the
+// One workgroup = one image x 128 columns: 16 column groups of 8 x 64 row slices (<= 3 sampled rows per thread at 1297 tokens, all loaded
+// before the first add: the launch is one round trip to memory long), slices summed in a fixed order through LDS. The result is the A operand [B, K] of the small GEMM against the
 // weight residue plane.
-__global__ __launch_bounds__(256) void colmean_kernel(const op_t* __restrict__ A, int lda, int rows_per_img, int nreal, int step, int K, op_t* __restrict__ mean) {
-    __shared__ float red[16][128];
+__global__ __launch_bounds__(1024) void colmean_kernel(const op_t* __restrict__ A, int lda, int rows_per_img, int nreal, int step, int K, op_t* __restrict__ mean) {
+    constexpr int RS = 64;  // row slices
+    __shared__ float red[RS][128];
     const int b = blockIdx.y, cg = threadIdx.x & 15, rs = threadIdx.x >> 4;
     const int k = blockIdx.x * 128 + cg * 8;
     const int nsamp = (nreal + step - 1) / step;
@@ -747,16 +786,19 @@ __global__ __launch_bounds__(256) void colmean_kernel(const op_t* __restrict__ A
         const op_t* base = A + (size_t)b * rows_per_img * lda + k;
         const size_t rstride = (size_t)step * lda;
         int j = rs;
-        for (; j + 48 < nsamp; j += 64) {  // four independent loads before the first add
-            const opx8 v0 = *(const opx8*)(base + (size_t)j * rstride), v1 = *(const opx8*)(base + (size_t)(j + 16) * rstride);
-            const opx8 v2 = *(const opx8*)(base + (size_t)(j + 32) * rstride), v3 = *(const opx8*)(base + (size_t)(j + 48) * rstride);
+        for (; j + 3 * RS < nsamp; j += 4 * RS) {  // four independent loads before the first add
+            const opx8 v0 = *(const opx8*)(base + (size_t)j * rstride), v1 = *(const opx8*)(base + (size_t)(j + RS) * rstride);
+            const opx8 v2 = *(const opx8*)(base + (size_t)(j + 2 * RS) * rstride), v3 = *(const opx8*)(base + (size_t)(j + 3 * RS) * rstride);
 #pragma unroll
             for (int e = 0; e < 8; ++e) sum[e] = (((sum[e] + (float)v0[e]) + (float)v1[e]) + (float)v2[e]) + (float)v3[e];
         }
-        for (; j < nsamp; j += 16) {
-            const opx8 v = *(const opx8*)(base + (size_t)j * rstride);
+        {   // up to three more rows (the whole job at <= 1536 tokens: 162 samples over 64 slices), loaded together
+            const bool h0 = j < nsamp, h1 = j + RS < nsamp, h2 = j + 2 * RS < nsamp;
+            const opx8 zero = {};
+            const opx8 v0 = h0 ? *(const opx8*)(base + (size_t)j * rstride) : zero, v1 = h1 ? *(const opx8*)(base + (size_t)(j + RS) * rstride) : zero;
+            const opx8 v2 = h2 ? *(const opx8*)(base + (size_t)(j + 2 * RS) * rstride) : zero;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sum[e] += (float)v[e];
+            for (int e = 0; e < 8; ++e) sum[e] = ((sum[e] + (float)v0[e]) + (float)v1[e]) + (float)v2[e];
         }
     }
 #pragma unroll
@@ -766,30 +808,31 @@ __global__ __launch_bounds__(256) void colmean_kernel(const op_t* __restrict__ A
         const int kk = blockIdx.x * 128 + threadIdx.x;
         float tot = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tot += red[r][threadIdx.x];
+        for (int r = 0; r < RS; ++r) tot += red[r][threadIdx.x];
         if (kk < K) mean[(size_t)b * K + kk] = to_op(tot * (1.0f / (float)nsamp));
     }
 }
 
 // out[b][n] = bias[n] + sum_k mean[b][k] * W_lo[n][k]: the [B, K] x [N, K]^T product behind the per-image bias tables. Skinny (B <= 32 rows
 // per pass) and latency-bound, so it gets its own kernel instead of a 64x64 GEMM tile per 64 columns: one workgroup = 16 columns of the
-// table, its four waves take a quarter of K each (v_mfma_f32_16x16x32: both operands are K-contiguous rows, a lane's fragment is one
-// 16-byte global load, no LDS staging), the four partial sums are added in a fixed order. A row of the table depends on its own image only.
+// table, its sixteen waves take a sixteenth of K each (v_mfma_f32_16x16x32: both operands are K-contiguous rows, a lane's fragment is one
+// 16-byte global load, no LDS staging), the partial sums are added in a fixed order. A row of the table depends on its own image only.
 // wscale: the lo plane carries the power-of-two factor of its matrix (weight_scale_kernel): the product is multiplied by 1 / s before the bias is added.
-__global__ __launch_bounds__(256) void wrc_table_kernel(const op_t* __restrict__ mean, const op_t* __restrict__ w_lo, const float* __restrict__ bias,
+__global__ __launch_bounds__(1024) void wrc_table_kernel(const op_t* __restrict__ mean, const op_t* __restrict__ w_lo, const float* __restrict__ bias,
                                                         float* __restrict__ out, int B, int N, int K, const float* __restrict__ wscale) {
-    __shared__ float part[4][2][16][16];  // [wave][image block][image][column]
+    constexpr int NW = 16;  // waves = K ranges (fc2, K = 4096: 8 MFMA steps per wave instead of 32 - the launch is latency, not work)
+    __shared__ float part[NW][2][16][16];  // [wave][image block][image][column]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
     const int n = blockIdx.x * 16 + l15;
     const op_t* wrow = w_lo + (size_t)(n < N ? n : N - 1) * K + kq * 8;
-    const int kw = ((K / 32 + 3) / 4) * 32;  // K range of a wave (multiple of the MFMA's 32)
-    const int k_lo = wave * kw, k_hi = k_lo + kw < K ? k_lo + kw : K;
+    const int kw = ((K / 32 + NW - 1) / NW) * 32;  // K range of a wave (multiple of the MFMA's 32)
+    const int k_lo = wave * kw < K ? wave * kw : K, k_hi = k_lo + kw < K ? k_lo + kw : K;
     for (int b0 = 0; b0 < B; b0 += 32) {
         const int r0 = b0 + l15 < B ? b0 + l15 : B - 1, r1 = b0 + 16 + l15 < B ? b0 + 16 + l15 : B - 1;
         const op_t* a0 = mean + (size_t)r0 * K + kq * 8;
         const op_t* a1 = mean + (size_t)r1 * K + kq * 8;
         f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
+#pragma unroll 8
         for (int k = k_lo; k < k_hi; k += 32) {
             const opx8 w = *(const opx8*)(wrow + k);
             const opx8 x0 = *(const opx8*)(a0 + k), x1 = *(const opx8*)(a1 + k);
@@ -803,12 +846,13 @@ __global__ __launch_bounds__(256) void wrc_table_kernel(const op_t* __restrict__
             part[wave][1][4 * kq + r][l15] = acc1[r];
         }
         __syncthreads();
-        for (int item = threadIdx.x; item < 512; item += 256) {
-            const int blk = item >> 8, img = (item >> 4) & 15, col = item & 15;
+        if (threadIdx.x < 512) {
+            const int item = threadIdx.x, blk = item >> 8, img = (item >> 4) & 15, col = item & 15;
             const int ob = b0 + blk * 16 + img, on = blockIdx.x * 16 + col;
-            if (ob < B && on < N)
-                out[(size_t)ob * N + on] = (((part[0][blk][img][col] + part[1][blk][img][col]) + part[2][blk][img][col]) + part[3][blk][img][col]) * (wscale ? wscale[1] : 1.0f) +
-                                           (bias ? bias[on] : 0.0f);
+            float tot = part[0][blk][img][col];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) tot += part[w][blk][img][col];
+            if (ob < B && on < N) out[(size_t)ob * N + on] = tot * (wscale ? wscale[1] : 1.0f) + (bias ? bias[on] : 0.0f);
         }
     }
 }
@@ -866,14 +910,14 @@ int MDPT_FN(mdpt_launch_ksplit_finish)(const float* part, size_t part_stride, in
 int MDPT_FN(mdpt_launch_colmean)(const op_t* A, int lda, int B, int rows_per_img, int nreal, int step, int K, op_t* mean, hipStream_t stream) {
     if (B <= 0 || nreal <= 0 || nreal > rows_per_img || step <= 0 || (K & 7) || (lda & 7)) return (int)hipErrorInvalidValue;
     MdptProfScope prof("colmean_kernel", 0.0, stream);
-    hipLaunchKernelGGL(colmean_kernel, dim3((K + 127) / 128, B), dim3(256), 0, stream, A, lda, rows_per_img, nreal, step, K, mean);
+    hipLaunchKernelGGL(colmean_kernel, dim3((K + 127) / 128, B), dim3(1024), 0, stream, A, lda, rows_per_img, nreal, step, K, mean);
     LAUNCH_RET();
 }
 
 int MDPT_FN(mdpt_launch_wrc_table)(const op_t* mean, const op_t* w_lo, const float* bias, float* out, int B, int N, int K, hipStream_t stream, const float* wscale) {
     if (B <= 0 || N <= 0 || K <= 0 || (K & 31)) return (int)hipErrorInvalidValue;
     MdptProfScope prof("wrc_table_kernel", 2.0 * B * N * K, stream);
-    hipLaunchKernelGGL(wrc_table_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, mean, w_lo, bias, out, B, N, K, wscale);
+    hipLaunchKernelGGL(wrc_table_kernel, dim3((N + 15) / 16), dim3(1024), 0, stream, mean, w_lo, bias, out, B, N, K, wscale);
     LAUNCH_RET();
 }
 
@@ -1052,6 +1096,20 @@ int MDPT_FN(mdpt_launch_prepare_image)(const unsigned char* bgr, void* out, int 
                            mean[2], inv_std[0], inv_std[1], inv_std[2]);
     else
         hipLaunchKernelGGL(prepare_image_kernel<1>, dim3((oh * ow + 255) / 256), dim3(256), 0, stream, bgr, out, out_dtype, ih, iw, oh, ow, mean[0], mean[1],
+                           mean[2], inv_std[0], inv_std[1], inv_std[2]);
+    LAUNCH_RET();
+}
+
+int MDPT_FN(mdpt_launch_prepare_patchify)(const unsigned char* bgr, int img_dtype, op_t* out_hi, op_t* out_lo, int ih, int iw, int H, int W, int P, int Kp,
+                                         const float mean[3], const float inv_std[3], int interp, hipStream_t stream) {
+    if (ih <= 0 || iw <= 0 || H <= 0 || W <= 0 || P <= 0 || (H % P) || (W % P) || Kp < 3 * P * P || (interp != 0 && interp != 1) || img_dtype < MDPT_DT_F32 || img_dtype > MDPT_DT_F16)
+        return (int)hipErrorInvalidValue;
+    MdptProfScope prof("prepare_patchify_kernel", 0.0, stream);
+    if (interp == 0)
+        hipLaunchKernelGGL(prepare_patchify_kernel<0>, dim3((H * W + 255) / 256), dim3(256), 0, stream, bgr, img_dtype, out_hi, out_lo, ih, iw, H, W, P, Kp, mean[0], mean[1],
+                           mean[2], inv_std[0], inv_std[1], inv_std[2]);
+    else
+        hipLaunchKernelGGL(prepare_patchify_kernel<1>, dim3((H * W + 255) / 256), dim3(256), 0, stream, bgr, img_dtype, out_hi, out_lo, ih, iw, H, W, P, Kp, mean[0], mean[1],
                            mean[2], inv_std[0], inv_std[1], inv_std[2]);
     LAUNCH_RET();
 }

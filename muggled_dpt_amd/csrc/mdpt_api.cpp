@@ -10,6 +10,8 @@ extern "C" {
 int mdpt_abi_version(void) { return MDPT_ABI_VERSION; }
 const char* mdpt_last_error(void) { return g_err.c_str(); }
 
+static constexpr int WRC_ALL = (1 << CLS_QKV) | (1 << CLS_PROJ) | (1 << CLS_FC1) | (1 << CLS_FC2);
+
 int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     if (!cfg || !out) return fail(MDPT_E_INVALID, "null argument");
     *out = nullptr;
@@ -72,6 +74,7 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     // them (MDPT_PREC_FP16) the map does not get better - encoder taps -25 %, map rms +10 ... +37 % on BEiT-L / SwinV2-L, -15 % on ViT-L,
     // profiles/r04_wrc_by_family.txt - for 3.5 % of the step: off there unless asked for
     h->wrc_on = cfg->precision == MDPT_PREC_MIXED;
+    h->wrc_mask = WRC_ALL;
     h->gemm_tile = MDPT_TILE_AUTO;
     h->finalized = false;
     h->has_last = false;
@@ -83,7 +86,7 @@ int mdpt_create(const mdpt_config* cfg, mdpt_handle** out) {
     h->overlap_reasm = 1;
     h->side_prio = 0;
     h->side_probe = 1;
-    h->side_ncand = h->side_rejected = 0;
+    h->side_ncand = h->side_rejected = h->side_unresolved = 0;
     h->side_nfor = 0;
     h->grid_cache = 0;
     h->gen = 0;
@@ -190,8 +193,11 @@ static void rebuild_inventory_keeping_bindings(mdpt_handle* h) {
 int mdpt_set_weight_rounding_compensation(mdpt_handle* h, int32_t on) {
     if (!h) return fail(MDPT_E_INVALID, "null handle");
     if (on && !h->f16) return fail(MDPT_E_UNSUPPORTED, "the token-mean compensation exists for the fp16 operand modes (MDPT_PREC_FP16 / _MIXED / _FP16X3 with single-pass classes)");
-    if (h->wrc_on == (on != 0)) return 0;
+    if (on < 0 || (on > 1 && (on & ~WRC_ALL))) return fail(MDPT_E_INVALID, "0, 1 or a mask of (1 << MDPT_CLASS_QKV | _PROJ | _FC1 | _FC2), got %d", on);
+    const int mask = on > 1 ? on : WRC_ALL;
+    if (h->wrc_on == (on != 0) && (!on || h->wrc_mask == mask)) return 0;
     h->wrc_on = on != 0;
+    if (on) h->wrc_mask = mask;
     rebuild_inventory_keeping_bindings(h);
     return 0;
 }
@@ -357,7 +363,11 @@ static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, int
 // (stream_probe.hip has the why and the measurement): up to four candidates of the default priority class, the first that passes the probe is kept
 // for this caller stream. The probe costs a few launches and ONE host wait, once per (handle, caller stream) - the only host synchronisation of
 // the library, never inside a stream capture (there the current choice, or the first candidate, is used unprobed; the graph keeps no stream).
-// `scratch`: two words of the caller's workspace (free before the forward starts using it).
+// `scratch`: the plan's own 256 probe bytes of the caller's workspace (Plan::probe - no activation ever lives there, so the probe may run after
+// kernels of this forward were queued). A probe in which EVERY candidate was rejected (the waiter spins 150 us at most: a GPU busy with other work
+// can starve the setter) does not pin its fallback: the caller stream is probed again by the next forward, three times at most.
+// Caveats: the host wait invalidates a global-mode stream capture another thread may have open at that moment (probe once before capturing, or
+// switch the probe off, mdpt_debug_set_side_stream_probe); a stream handle the runtime recycles after hipStreamDestroy keeps the earlier pick.
 static int ensure_side_stream(mdpt_handle* h, hipStream_t s0, void* scratch) {
     if (!h->ev_fork) {
         CHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -382,7 +392,7 @@ static int ensure_side_stream(mdpt_handle* h, hipStream_t s0, void* scratch) {
         if (!h->side_stream) { CHK(candidate(0)); h->side_stream = h->side_cand[0]; }
         return 0;
     }
-    int chosen = 0;
+    int chosen = -1;
     for (int i = 0; i < 4; ++i) {
         CHK(candidate(i));
         unsigned* words = (unsigned*)scratch;
@@ -393,6 +403,11 @@ static int ensure_side_stream(mdpt_handle* h, hipStream_t s0, void* scratch) {
         CHK(hipStreamSynchronize(h->side_cand[i]));
         if (seen) { chosen = i; break; }
         ++h->side_rejected;
+    }
+    if (chosen < 0) {  // nobody ran beside the caller's stream this time
+        h->side_stream = h->side_cand[0];
+        if (++h->side_unresolved <= 3) return 0;  // not recorded: probed again next time
+        chosen = 0;
     }
     h->side_stream = h->side_cand[chosen];
     h->side_for[h->side_nfor & 3] = s0;
@@ -418,7 +433,7 @@ int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t image_dtype, in
         const size_t off1 = rup256(p0.total);
         if (workspace_bytes < off1 + p1.total) return fail(MDPT_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", off1 + p1.total, workspace_bytes);
         hipStream_t s0 = (hipStream_t)stream;
-        CHK(ensure_side_stream(h, s0, workspace));
+        CHK(ensure_side_stream(h, s0, (char*)workspace + p0.probe));
         CHK(hipEventRecord(h->ev_fork, s0));
         CHK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
         Ctx c0, c1;
@@ -451,6 +466,26 @@ int mdpt_forward(mdpt_handle* h, const void* image_bchw, int32_t image_dtype, in
     return 0;
 }
 
+// ---- DPTModel.inference's device half (reference dpt_model.py:87-109: prepare_image_bgr -> forward), SURVEY 8(f) row 1 "fused with patchify"
+int mdpt_forward_bgr(mdpt_handle* h, const void* bgr_u8_hwc, int32_t in_h, int32_t in_w, int32_t image_dtype, int32_t H, int32_t W, const float rgb_mean[3],
+                     const float rgb_std[3], int32_t interpolation, void* depth_hw, int32_t depth_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !bgr_u8_hwc || !depth_hw || !rgb_mean || !rgb_std) return fail(MDPT_E_INVALID, "null argument");
+    for (int dt : {image_dtype, depth_dtype})
+        if (dt != MDPT_DTYPE_F32 && dt != MDPT_DTYPE_BF16 && dt != MDPT_DTYPE_F16) return fail(MDPT_E_INVALID, "bad tensor dtype %d", dt);
+    if (interpolation != MDPT_INTERP_BILINEAR && interpolation != MDPT_INTERP_BICUBIC)
+        return fail(MDPT_E_UNSUPPORTED, "interpolation %d: antialiased resize exists for bilinear and bicubic only (as in torch)", interpolation);
+    if (in_h <= 0 || in_w <= 0) return fail(MDPT_E_INVALID, "bad image size %dx%d", in_h, in_w);
+    const bool hit = h->cache_hit(workspace, 1, H, W);
+    Ctx c;
+    CHK(make_ctx(h, 1, H, W, workspace, workspace_bytes, stream, &c));
+    c.consts_cached = hit;
+    c.bgr.ptr = (const unsigned char*)bgr_u8_hwc; c.bgr.ih = in_h; c.bgr.iw = in_w; c.bgr.round_dtype = image_dtype; c.bgr.interp = interpolation;
+    for (int i = 0; i < 3; ++i) { c.bgr.mean[i] = rgb_mean[i]; c.bgr.inv_std[i] = 1.0f / rgb_std[i]; }  // patch_embed.py:38-39,62
+    CHK(forward_one(h, c, nullptr, image_dtype, depth_hw, depth_dtype));
+    if (h->grid_cache && h->dbg_block < 0) h->cache_store(0, workspace, 1, H, W);
+    return 0;
+}
+
 static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, int image_dtype, void* depth_bhw, int depth_dtype) {
     if (h->swin) {
         CHK(run_patch_embed_swin(c, image_bchw, image_dtype, nullptr));
@@ -472,7 +507,7 @@ static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, int
     if (!c.split && overlap && h->dbg_block < 0) {
         // unsplit (small-batch) forward: reassembly branches run on the side stream beside the encoder (run_encoder, Ctx::tap_stream); whatever
         // happens in between, the side stream is joined back into the caller's stream before anything else is queued or returned
-        CHK(ensure_side_stream(h, c.s, c.ws));
+        CHK(ensure_side_stream(h, c.s, c.ws + c.p.probe));
         Ctx ce = c;
         ce.tap_stream = h->side_stream; ce.tap_event = h->ev_fork;
         const int rc = run_encoder(ce, nullptr);

@@ -140,6 +140,7 @@ struct Plan {
     size_t fused[3], h1, h1u[3], scratch;
     size_t scratch_floats;
     size_t tokr[3], cbuf, relpos_lut, relpos_tq, relpos_tk;  // BEiT: readout-projected tokens, per-image cls term, bias LUT
+    size_t probe;                                             // 256 bytes of their own for the side-stream probe
     size_t wrc_mean, wrc_tab;                                 // [B, wrc_maxk] operand-format column means, fp32 [B, wrc_maxn] per-image bias table
     size_t swi;                                               // ViT-G: fp32 [rows, 2*hidden] output of the doubled inner linear
     size_t kspart;                                            // small batches: 3 x fp32 [rows, F] partial sums of the K-split proj / fc2 (latency mode), else absent
@@ -172,7 +173,8 @@ struct mdpt_handle {
     bool alo(int cls) const { return terms(cls) >= 2; }   // the class reads a lo plane of its ACTIVATIONS (its producers write one)
     // token-mean compensation of the weight rounding (fp16 operand modes, single-pass encoder Linears): see wrc_bias() below
     bool wrc_on;
-    bool wrc(int cls) const { return wrc_on && f16 && np[cls] == 1 && (cls == CLS_QKV || cls == CLS_PROJ || cls == CLS_FC1 || cls == CLS_FC2); }
+    int wrc_mask;  // bit (1 << class): which of the four encoder Linear classes are compensated (mdpt_set_weight_rounding_compensation)
+    bool wrc(int cls) const { return wrc_on && f16 && np[cls] == 1 && (cls == CLS_QKV || cls == CLS_PROJ || cls == CLS_FC1 || cls == CLS_FC2) && ((wrc_mask >> cls) & 1); }
     int wrc_maxn, wrc_maxk;  // widest compensated matrix (table / mean buffers of the plan)
     int gemm_tile;
     std::vector<WeightSpec> specs;
@@ -216,6 +218,7 @@ struct mdpt_handle {
     // the side stream: chosen among up to four candidates as one that really runs beside the caller's stream (stream_probe.hip), per caller stream
     hipStream_t side_stream, side_cand[4], side_for[4];  // side_for[k] -> side_cand[side_pick[k]]: the caller streams probed so far (ring of four)
     int side_pick[4], side_nfor;
+    int side_unresolved;  // probes in which every candidate was rejected (a busy GPU can starve the setter): the choice is not pinned, the stream is probed again (three times at most)
     int side_ncand, side_rejected;  // candidates created; candidates found on the caller's hardware queue so far (mdpt_debug_side_stream_info)
     int side_probe;                 // 1 (default): probe; 0: take the first candidate unseen (mdpt_debug_set_side_stream_probe)
     hipEvent_t ev_fork, ev_join;
@@ -293,6 +296,8 @@ struct Ctx {
     bool side = false;  // this context runs on that side stream, beside the encoder
     bool a1_done = false;  // ... where the first conv of every conv_reassembly unit was queued too: run_fusion skips it
     bool consts_cached = false;  // the per-grid constants of this (workspace, shape) are in place (mdpt_set_grid_cache): skip the kernels that write them
+    // mdpt_forward_bgr: the patch embedding's im2col kernel builds its rows from this uint8 BGR image (resize + normalise fused in) instead of an image tensor
+    struct BgrSource { const unsigned char* ptr = nullptr; int ih = 0, iw = 0, round_dtype = 0, interp = 0; float mean[3] = {0, 0, 0}, inv_std[3] = {1, 1, 1}; } bgr;
     void* const* attn_dump = nullptr;  // per block: where to write softmax(q k^T) as fp32 [B,H,N,N] (null entries: skip)
     void* const* block_dump = nullptr; // per block: where to write the block's output tokens as fp32 [B,N,F] (null entries: skip)
     template <class T> T* at(size_t off) const { return off == SIZE_MAX ? nullptr : (T*)(ws + off); }
@@ -329,6 +334,7 @@ std::string swin_blk(int s, int l);
 GemmParams base_params(const Ctx& c, const Mat& w, Planes a, int M, int lda);
 void as_conv(GemmParams& g, int Hi, int Wi, int Cin, int Ho, int Wo, int stride);
 int run_pos(const Ctx& c);
+int run_patchify(const Ctx& c, const void* image, int image_dtype, const Planes& im, int H, int W);
 int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype);
 int wrc_bias(const Ctx& c, GemmParams& g, const Mat& w, const float* bias, int rows_per_img = 0, int nreal = 0);
 bool fc2_ksplit_fits(int rows, int F);  // batch small enough for the K-split form of fc2 (the 64x64 tile's range): the plan then holds kspart

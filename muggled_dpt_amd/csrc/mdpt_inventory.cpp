@@ -274,6 +274,7 @@ void plan_decoder(Bump& bump, const mdpt_handle* h, Plan& p, size_t min_scratch_
     p.scratch_floats = (size_t)B * fpx * h->Cp;
     if (min_scratch_floats > p.scratch_floats) p.scratch_floats = min_scratch_floats;
     p.scratch = bump.take(p.scratch_floats * 4);
+    p.probe = bump.take(256);  // the side-stream probe's two flag words: nothing else ever lives here (mdpt_api.cpp ensure_side_stream)
 }
 
 int make_plan_swin(const mdpt_handle* h, int B, int H, int W, Plan* pl);

@@ -43,11 +43,19 @@ int run_pos(const Ctx& c) {
                                 h->cfg.base_patch_grid_w, c.p.gh, c.p.gw, h->F, c.s);
 }
 
+// im2col rows of the patch embedding: from an image tensor, or (mdpt_forward_bgr) straight from the caller's uint8 BGR image
+int run_patchify(const Ctx& c, const void* image, int image_dtype, const Planes& im, int H, int W) {
+    const mdpt_handle* h = c.h;
+    if (c.bgr.ptr)
+        return OPLC(mdpt_launch_prepare_patchify, c.bgr.ptr, c.bgr.round_dtype, im.hi, im.lo, c.bgr.ih, c.bgr.iw, H, W, h->P, h->Kpatch, c.bgr.mean, c.bgr.inv_std, c.bgr.interp, c.s);
+    return OPLC(mdpt_launch_patchify, image, image_dtype, im.hi, im.lo, c.p.B, H, W, h->P, h->Kpatch, c.s);
+}
+
 int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype) {
     const mdpt_handle* h = c.h;
     const Plan& p = c.p;
     Planes im = c.pl(p.im2col);
-    CHK(OPLC(mdpt_launch_patchify, image, image_dtype, im.hi, im.lo, p.B, p.H, p.W, h->P, h->Kpatch, c.s));
+    CHK(run_patchify(c, image, image_dtype, im, p.H, p.W));
     const bool beit = is_beit(h);
     if (!beit && !c.consts_cached) CHK(run_pos(c));
     CHK(OPLC(mdpt_launch_init_tokens, c.at<float>(p.resid), h->V("imgencoder.cls_token"), beit ? nullptr : h->V("imgencoder.posenc.cls_embedding"),

@@ -174,10 +174,8 @@ class PatchEmbed(_Stage):
         eng.call("mdpt_patch_embed", x, b, h, w, out, size_hw=(-(-h // tile) * tile, -(-w // tile) * tile), batch=b)
         return eng.as_output(out), (gh, gw)
 
-    def prepare_image(self, image_bgr: np.ndarray, max_side_length: int | None = None, use_square_sizing: bool = True,
-                      interpolation_mode: str = "bilinear") -> Tensor:
-        """uint8 HxWx3 BGR -> normalised [1,3,H',W'] on the model device/dtype (patch_embed.py:103-145).
-        Sides snap to multiples of 2*patch (so a 518x518 image is processed at 504x504)."""
+    def _prepare_plan(self, image_bgr: np.ndarray, max_side_length: int | None, use_square_sizing: bool, interpolation_mode: str):
+        """Size rule and argument checks of prepare_image (patch_embed.py:103-130): -> (model tensor (H, W), MDPT_INTERP_*, parameter, image dtype)."""
         if max_side_length is None:
             max_side_length = self._default_size_px
         img_h, img_w = image_bgr.shape[0:2]
@@ -195,17 +193,31 @@ class PatchEmbed(_Stage):
             raise RuntimeError("prepare_image runs on the GPU only (no CPU fallback): move the model to a cuda device first")
         if not (isinstance(image_bgr, np.ndarray) and image_bgr.dtype == np.uint8 and image_bgr.ndim == 3 and image_bgr.shape[2] == 3):
             raise TypeError("prepare_image expects an OpenCV-style uint8 HxWx3 BGR image (cv2.imread output)")
-        lib = native.load()
         out_dtype = p.dtype if p.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32
+        return scaled_hw, interp, p, out_dtype
+
+    def prepare_image(self, image_bgr: np.ndarray, max_side_length: int | None = None, use_square_sizing: bool = True,
+                      interpolation_mode: str = "bilinear") -> Tensor:
+        """uint8 HxWx3 BGR -> normalised [1,3,H',W'] on the model device/dtype (patch_embed.py:103-145).
+        Sides snap to multiples of 2*patch (so a 518x518 image is processed at 504x504)."""
+        scaled_hw, interp, p, out_dtype = self._prepare_plan(image_bgr, max_side_length, use_square_sizing, interpolation_mode)
+        img_h, img_w = image_bgr.shape[0:2]
+        lib = native.load()
         with torch.cuda.device(p.device):
             src = self._stage_host_image(image_bgr, p.device)
             out = torch.empty((1, 3, scaled_hw[0], scaled_hw[1]), device=p.device, dtype=out_dtype)
             stream = torch.cuda.current_stream(p.device).cuda_stream
-            mean3, std3 = (ctypes.c_float * 3)(*self.rgb_offset), (ctypes.c_float * 3)(*self.rgb_stdev)
+            mean3, std3 = self._norm_constants()
             # the kernel writes the model's dtype (dtype-tagged like mdpt_forward's tensors): nothing but this launch between the copy and the forward
             native.check(lib, lib.mdpt_prepare_image(src.data_ptr(), img_h, img_w, out.data_ptr(), native.dtype_code(out_dtype), scaled_hw[0], scaled_hw[1],
                                                      mean3, std3, interp, stream))
         return out if out.dtype == p.dtype else out.to(p.dtype)
+
+    def _norm_constants(self):
+        c = self.__dict__.get("_norm_c")
+        if c is None:
+            c = self.__dict__["_norm_c"] = ((ctypes.c_float * 3)(*self.rgb_offset), (ctypes.c_float * 3)(*self.rgb_stdev))
+        return c
 
     def _stage_host_image(self, image_bgr: np.ndarray, device: torch.device) -> Tensor:
         """uint8 host image -> device through a reusable PINNED staging buffer (an asynchronous copy from pageable memory is a synchronous
@@ -429,7 +441,7 @@ class _Engine:
             native.check(self.lib, self.lib.mdpt_debug_set_wscale_policy(self.handle, 1))
         wrc = model.__dict__.get("_wrc")
         if wrc is not None:
-            native.check(self.lib, self.lib.mdpt_set_weight_rounding_compensation(self.handle, int(bool(wrc))))
+            native.check(self.lib, self.lib.mdpt_set_weight_rounding_compensation(self.handle, int(wrc)))
         self._workspaces: dict[tuple, torch.Tensor] = {}
         tile = model.__dict__.get("_gemm_tile", 0)
         if tile:
@@ -671,8 +683,13 @@ class DPTModel(nn.Module):
     def set_weight_rounding_compensation(self, on: bool | None) -> None:
         """Token-mean compensation of the weight rounding in the fp16 operand modes (mdpt_set_weight_rounding_compensation): None = the
         mode's default (on for "mixed"; off for single-pass "fp16", where the decoder's own rounding dominates and the map does not improve),
-        True / False force it."""
-        self.__dict__["_wrc"] = None if on is None else bool(on)
+        True / False force it; a collection of class names ("qkv", "proj", "fc1", "fc2") compensates those classes only."""
+        if on is not None and not isinstance(on, bool):  # a collection of class names: compensate those only
+            names = tuple(on)
+            if not names or any(n not in ("qkv", "proj", "fc1", "fc2") for n in names):
+                raise ValueError(f"compensated classes are qkv, proj, fc1, fc2: {names!r}")
+            on = sum(1 << native.OP_CLASSES.index(n) for n in set(names))
+        self.__dict__["_wrc"] = on
         self._invalidate()
 
     def set_gemm_tile(self, tile: int) -> None:
@@ -724,8 +741,23 @@ class DPTModel(nn.Module):
     def inference(self, image_bgr: np.ndarray, max_side_length: int | None = None, use_square_sizing: bool = True) -> Tensor:
         """prepare_image + forward under inference_mode -> [1,H,W] (dpt_model.py:87-109)."""
         with torch.inference_mode():
-            x = self.patch_embed.prepare_image(image_bgr, max_side_length, use_square_sizing)
-            return self(x)
+            probes = self.imgencoder.__dict__.get("_softmax_probes") or []
+            blocks = self.imgencoder.__dict__.get("_block_probes") or []
+            pe = self.patch_embed
+            scaled_hw, interp, p, img_dtype = pe._prepare_plan(image_bgr, max_side_length, use_square_sizing, "bilinear")
+            if img_dtype != p.dtype or any(len(pr._forward_hooks) > 0 for pr in probes) or any(len(node._forward_hooks) > 0 for node, _ in blocks):
+                return self(pe.prepare_image(image_bgr, max_side_length, use_square_sizing))  # (hooks listening: the stage-by-stage route of forward())
+            # mdpt_forward_bgr: the im2col kernel of the patch embedding reads the uint8 image itself (prepare_image fused into patchify) - same bits as
+            # prepare_image + forward, one launch and one trip of the image through memory fewer
+            eng = self._get_engine()
+            h, w = scaled_hw
+            with torch.cuda.device(p.device):
+                src = pe._stage_host_image(image_bgr, p.device)
+                out = torch.empty((1, h, w), device=p.device, dtype=eng.dtype)
+                mean3, std3 = pe._norm_constants()
+                eng.call_checked("mdpt_forward_bgr", src, image_bgr.shape[0], image_bgr.shape[1], native.dtype_code(img_dtype), h, w, mean3, std3, interp,
+                                 out, native.dtype_code(out.dtype), size_hw=(h, w), batch=1)
+            return out
 
     def prepare_image_bgr(self, image_bgr: np.ndarray, max_side_length: int | None = None, use_square_sizing: bool = True,
                           interpolation_mode: str = "bilinear") -> Tensor:

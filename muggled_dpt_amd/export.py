@@ -13,7 +13,7 @@ File layout (little endian; every block starts on a 16-byte boundary):
     int32    config_bytes        sizeof(mdpt_config)
     byte     config[...]         the mdpt_config struct (family, precision and the reference's config keys; include/mdpt.h)
     int32    class_passes[16]    per MDPT_CLASS_*: 0 = the precision mode's default, else 1 / 2 / 3 (mdpt_set_class_passes); unused entries 0
-    int32    wrc                 -1 = mode default, 0 / 1 = mdpt_set_weight_rounding_compensation
+    int32    wrc                 -1 = mode default, 0 / 1 / class mask = mdpt_set_weight_rounding_compensation
     int32    latency_mode        mdpt_set_latency_mode
     float    rgb_mean[3], rgb_std[3]     PatchEmbed.prepare_image normalisation (patch_embed.py:38-39)
     int32    tiling_size, default_side   its size rule (patch_embed.py:69,116-130): sides snap to multiples of tiling_size
@@ -61,7 +61,8 @@ def export_model(model, path: str, dtype: torch.dtype | None = None) -> dict:
     from .dpt_model import model_precision_code, native_config
     p0 = next(model.parameters())
     store = dtype or (p0.dtype if p0.dtype in _TORCH_OF.values() else torch.float32)
-    c = native_config(model.config, model.family, model_precision_code(model, p0.dtype))
+    # the arithmetic is that of the STORED dtype (what both readers of the file bind): an fp32 model exported with dtype=bfloat16 is a bfloat16 model
+    c = native_config(model.config, model.family, model_precision_code(model, store))
     passes = [0] * 16
     for name, n in (model.__dict__.get("_class_passes") or {}).items():
         passes[native.OP_CLASSES.index(name)] = int(n)
@@ -77,7 +78,7 @@ def export_model(model, path: str, dtype: torch.dtype | None = None) -> dict:
         f.write(struct.pack("<2i", native.ABI_VERSION, len(bytes(c))))
         f.write(bytes(c))
         f.write(struct.pack("<16i", *passes))
-        f.write(struct.pack("<2i", -1 if wrc is None else int(bool(wrc)), int(bool(model.__dict__.get("_latency_mode", False)))))
+        f.write(struct.pack("<2i", -1 if wrc is None else int(wrc), int(bool(model.__dict__.get("_latency_mode", False)))))
         f.write(struct.pack("<6f", *pe.rgb_offset, *pe.rgb_stdev))
         f.write(struct.pack("<2i", int(pe._tiling_size), int(pe._default_size_px)))
         f.write(struct.pack("<i", len(blob)) + blob)
@@ -130,7 +131,7 @@ def read_model_file(path: str) -> dict:
         off += nb
         off += (-off) % 16
     return {"abi_version": abi, "config": cfg, "class_passes": {native.OP_CLASSES[i]: v for i, v in enumerate(passes[:len(native.OP_CLASSES)]) if v},
-            "wrc": None if wrc < 0 else bool(wrc), "latency_mode": bool(latency), "rgb_mean": norm[:3], "rgb_std": norm[3:], "tiling_size": tiling,
+            "wrc": None if wrc < 0 else (bool(wrc) if wrc <= 1 else tuple(n for i, n in enumerate(native.OP_CLASSES) if (wrc >> i) & 1)), "latency_mode": bool(latency), "rgb_mean": norm[:3], "rgb_std": norm[3:], "tiling_size": tiling,
             "default_side": default_side, "meta": meta, "tensors": tensors}
 
 

@@ -187,6 +187,7 @@ SYMBOLS = {
     "mdpt_fusion_block": (ctypes.c_int, [_VP, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_head": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "mdpt_prepare_image": (ctypes.c_int, [_VP, _I, _I, _VP, _I, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _I, _VP]),
+    "mdpt_forward_bgr": (ctypes.c_int, [_VP, _VP, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _I, _VP, _I, _VP, _SZ, _VP]),
     "mdpt_post_minmax": (ctypes.c_int, [_VP, _SZ, _VP, _VP, _VP]),
     "mdpt_post_scale_prediction": (ctypes.c_int, [_VP, _I, _I, _I, _VP, _I, _I, _VP, _VP, _VP]),
     "mdpt_post_normalize": (ctypes.c_int, [_VP, _SZ, _VP, _VP, _I, _I, _VP]),

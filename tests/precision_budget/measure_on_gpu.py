@@ -46,6 +46,9 @@ def policies():
             ("f8: reasm, fusion_proj, fusion, head 3F8; fusion_in 2F8", "mixed", {"reasm": 5, "fusion_proj": 5, "fusion": 5, "head": 5, "fusion_in": 4}),
             ("f8: reasm, fusion_proj, fusion, head, fusion_in 3F8", "mixed", {"reasm": 5, "fusion_proj": 5, "fusion": 5, "head": 5, "fusion_in": 5}),
             ("f8: reasm, fusion_proj 3F8; fusion 2F8; head 3F8", "mixed", {"reasm": 5, "fusion_proj": 5, "fusion": 4, "head": 5})]
+    # round 6: the compensation on a subset of the encoder's four Linear classes (two small launches per compensated Linear and block)
+    for sub in (("qkv",), ("qkv", "proj"), ("qkv", "fc1"), ("qkv", "fc2"), ("qkv", "fc1", "fc2"), ("qkv", "proj", "fc1"), ("proj", "fc1", "fc2"), ("fc1", "fc2"), ("proj",), ("fc1",), ("fc2",)):
+        out.append(("wrc: " + " + ".join(sub), "mixed", {"wrc": sub}))
     for c in CLASSES:
         out.append((f"fp16c + {c} x3", "fp16", {c: 3, "wrc": True}))
     out += [("fp16c + decoder x3", "fp16", {"reasm": 3, "fusion": 3, "fusion_proj": 3, "fusion_in": 3, "head": 3, "head_tail": 3, "wrc": True}),

@@ -57,6 +57,31 @@ def test_export_read_rebuild_roundtrip(tmp_path, family, dtype):
     assert names <= set(rec["tensors"]), sorted(names - set(rec["tensors"]))[:5]
 
 
+def test_precision_follows_the_stored_dtype_and_a_class_mask_of_the_compensation_travels(tmp_path):
+    """an fp32 model exported with dtype=bfloat16 stores 2-byte tensors - both readers of the file (the C host through mdpt_config.precision,
+    load_exported through the tensor dtype) have to run the SAME arithmetic: plain bf16, not the fp32 class of the exporting model. And the per-class
+    form of mdpt_set_weight_rounding_compensation (round 6) round-trips as names."""
+    model = _model("v2")  # float32, no explicit precision: bf16x3 as it stands
+    path = str(tmp_path / "m.mdpt")
+    model.export(path, dtype=torch.bfloat16)
+    rec = mexport.read_model_file(path)
+    assert rec["config"].precision == native.PREC_BF16
+    _, again = mexport.load_exported(path)
+    from muggled_dpt_amd.dpt_model import model_precision_code
+    assert model_precision_code(again, next(again.parameters()).dtype) == native.PREC_BF16
+    model.export(path)  # stored as held: the fp32 class
+    assert mexport.read_model_file(path)["config"].precision == native.PREC_BF16X3
+    model.set_precision("mixed")
+    model.set_weight_rounding_compensation(("qkv", "fc2"))
+    model.export(path)
+    rec = mexport.read_model_file(path)
+    assert rec["config"].precision == native.PREC_MIXED and set(rec["wrc"]) == {"qkv", "fc2"}
+    _, again = mexport.load_exported(path)
+    assert again.__dict__["_wrc"] == (1 << native.OP_CLASSES.index("qkv")) | (1 << native.OP_CLASSES.index("fc2"))
+    with pytest.raises(ValueError):
+        model.set_weight_rounding_compensation(("attn",))
+
+
 def test_foreign_and_stale_files_are_refused(tmp_path):
     bad = tmp_path / "x.mdpt"
     bad.write_bytes(b"not a model")
