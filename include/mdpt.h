@@ -238,7 +238,8 @@ int mdpt_set_batch_split(mdpt_handle* h, int32_t min_batch);
  * continuous-position-bias tables, the zero pads of operand planes. On: the first mdpt_forward of a (workspace, B, H, W) leaves them in the
  * workspace and the following mdpt_forward calls on the SAME workspace and shape skip the kernels that write them (same bits). The cached state is
  * dropped by a different shape on that workspace, by any stage-level call on the handle, and by mdpt_finalize. With the cache on the caller must
- * not write into the workspace between calls. */
+ * not write into the workspace between calls, and a caller that frees a workspace and allocates a new one (which may land at the same address)
+ * calls mdpt_set_grid_cache(h, 1) again: setting the switch drops every cached slot (the Python engine does so on every workspace allocation). */
 int mdpt_set_grid_cache(mdpt_handle* h, int32_t on);
 
 /* Latency mode (default off). Off: every image's result is bit-identical whatever batch it is part of (the kernels that run do

@@ -67,6 +67,20 @@ template <bool X3, int QB, int MODE, int HD, bool SPLIT = false, bool RUN4 = fal
 __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     static_assert(!RUN4 || MODE == 2, "the 4-key bias runs exist for the window attention");
     constexpr bool BIAS = MODE != 0;
+    // SwinV2 window attention (round 6): the kernel's VALU work per score was bias add + running max + fma + exp + pack against 16 MFMAs per 4096
+    // scores, and the SQ counters read its SIMDs ~85 % busy issuing it (profiles/r06_sq_counters_swinl.md). Three of those go away:
+    //   LOG2 : the scores arrive in log2 units - the packed logit scale carries log2(e) (mdpt_finalize), the LDS image of the bias table is
+    //          multiplied by it - so exp(s - m) is v_exp_f32(s - m) without the multiply;
+    //   CINIT: the bias is the C operand of the first MFMA of every score block (read from LDS straight into the accumulators), not an add behind it;
+    //   FIXREF (bf16 operands): cosine attention bounds every score of head h by M_h = logit_scale_h (1 + 2^-6) + 16 (|cos| <= 1 up to operand
+    //          rounding, bias = 16 sigmoid(.) < 16: relative_positional_encoder.py:60-93, windowed_attention.py:100-119), and a query's own key scores
+    //          at least logit_scale_h (1 - 2^-7). With the constant reference M_h folded into the table, p = exp(s - M_h) lies in [e^-17.6, 1.2] for a
+    //          row's maximum - harmless in fp32 / bf16, whose exponent ranges agree - and the running maximum, its cross-lane swap, the exp of the
+    //          rescale factor and the O^T rescale are gone. O / l is the same number mathematically; bits depend on the query alone.
+    //          The fp16 operand build keeps the running maximum: an fp16 P of 2^-25 would be subnormal.
+    // (CINIT also serves BEiT's table bias, MODE 1: the gather lands in the accumulators, 64 adds per lane and tile fewer.)
+    constexpr bool LOG2 = MODE == 2, CINIT = BIAS, FIXREF = MODE == 2 && !MDPT_OP_IS_F16;
+    constexpr float kExpScale = LOG2 ? 1.0f : kLog2e;  // exp(x) = v_exp_f32(x * kExpScale)
     constexpr int NPL = X3 ? 2 : 1;           // planes per operand
     constexpr int TILE = 64 * HD * 2;         // one [64 keys][HD] (or [HD][64 keys]) bf16 tile
     constexpr int STAGE = 2 * NPL * TILE;     // K planes then Vt planes
@@ -145,23 +159,26 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const bool masked = MODE == 2 && p.region != nullptr;
     if (BIAS) {
         const float* lut = p.bias_lut + (size_t)h * p.bias_elen;
+        const float bmul = LOG2 ? kLog2e : 1.0f;
+        float badd = 0.0f;
+        if constexpr (FIXREF) badd = -(p.swin_ls[h] * 1.015625f + 16.0f * kLog2e);  // -M_h in log2 units (swin_ls already carries log2 e)
         if (brow) {
             for (int i = tid; i < belen; i += 256) {
                 const int r = i / bstride, c = i - r * bstride;
-                lds_lut[i] = c < brow ? lut[p.bias_elen - 1 - (r * brow + c)] : 0.0f;
+                lds_lut[i] = c < brow ? lut[p.bias_elen - 1 - (r * brow + c)] * bmul + badd : 0.0f;
             }
         } else {
-            for (int i = tid; i < p.bias_elen; i += 256) lds_lut[i] = lut[RUN4 ? p.bias_elen - 1 - i : i];
+            for (int i = tid; i < p.bias_elen; i += 256) lds_lut[i] = lut[RUN4 ? p.bias_elen - 1 - i : i] * bmul + badd;
         }
         const int nk = ((p.N + 63) >> 6) << 6;
-        for (int i = tid; i < nk; i += 256) lds_tk[i] = restride(p.tk[i < p.npad ? i : p.npad - 1]);
+        for (int i = tid; i < nk; i += 256) lds_tk[i] = restride(p.tk[i < p.npad ? i : p.npad - 1]) * (RUN4 ? 4 : 1);  // RUN4: byte offsets (one add per table read)
         if (MODE == 2)
             for (int i = tid; i < nk; i += 256) lds_reg[i] = masked ? p.region[(size_t)win * p.region_ld + (i < p.N ? i : p.N - 1)] : 0;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             const int q = q0 + qb * 32 + l31;
             tqv[qb] = p.tq[q < p.npad ? q : p.npad - 1];
-            if (RUN4) tqv[qb] = restride(p.bias_elen - 1 - tqv[qb]);  // index into the reversed table: lut[tq - tk - e] = rev[(elen - 1 - tq) + tk + e]
+            if (RUN4) tqv[qb] = restride(p.bias_elen - 1 - tqv[qb]) * 4;  // byte offset into the reversed table: lut[tq - tk - e] = rev[(elen - 1 - tq) + tk + e]
             rqv[qb] = masked ? p.region[(size_t)win * p.region_ld + (q < p.N ? q : p.N - 1)] : 0;
         }
     }
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     float m_run[QB], l_run[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        m_run[qb] = -1.0e30f;
+        m_run[qb] = FIXREF ? 0.0f : -1.0e30f;
         l_run[qb] = 0.0f;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
@@ -230,6 +247,30 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         // a zeroed register block: the kernel is VALU-bound and clearing 64 registers per tile costs 32 v_mov_b64
         f32x16 s[QB][2];
         const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (CINIT) {  // the bias (log2 units, minus the fixed reference) is where the accumulators start
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if constexpr (RUN4) {
+                        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                        const int tk0 = lds_tk[t * 64 + blk * 32 + 8 * g + 4 * half];
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) {
+                            const f32x4u b4 = *(const f32x4u*)((const char*)lds_lut + tqv[qb] + tk0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s[qb][blk][4 * g + e] = b4[e];
+                        }
+                    } else {
+                        typedef __attribute__((ext_vector_type(4))) int i32x4c;
+                        const i32x4c tk4 = *(const i32x4c*)(lds_tk + t * 64 + blk * 32 + 8 * g + 4 * half);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s[qb][blk][4 * g + e] = lds_lut[tqv[qb] - tk4[e]];
+                    }
+                }
+        }
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -242,11 +283,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
                     if (X3) {
-                        s[qb][blk] = MDPT_MFMA_32x32x16(kl, qh[qb][ks], ks == 0 ? zero16 : s[qb][blk], 0, 0, 0);
+                        s[qb][blk] = MDPT_MFMA_32x32x16(kl, qh[qb][ks], (ks == 0 && !CINIT) ? zero16 : s[qb][blk], 0, 0, 0);
                         s[qb][blk] = MDPT_MFMA_32x32x16(kh, ql[qb][ks], s[qb][blk], 0, 0, 0);
                         s[qb][blk] = MDPT_MFMA_32x32x16(kh, qh[qb][ks], s[qb][blk], 0, 0, 0);
                     } else {
-                        s[qb][blk] = MDPT_MFMA_32x32x16(kh, qh[qb][ks], ks == 0 ? zero16 : s[qb][blk], 0, 0, 0);
+                        s[qb][blk] = MDPT_MFMA_32x32x16(kh, qh[qb][ks], (ks == 0 && !CINIT) ? zero16 : s[qb][blk], 0, 0, 0);
                     }
                 }
             }
@@ -256,12 +297,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    if constexpr (RUN4) {
+                    if constexpr (CINIT) {
+                        // (already in the accumulators)
+                    } else if constexpr (RUN4) {
                         typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
                         const int tk0 = lds_tk[t * 64 + blk * 32 + 8 * g + 4 * half];
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) {
-                            const f32x4u b4 = *(const f32x4u*)(lds_lut + tqv[qb] + tk0);
+                            const f32x4u b4 = *(const f32x4u*)((const char*)lds_lut + tqv[qb] + tk0);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) s[qb][blk][4 * g + e] += b4[e];
                         }
@@ -277,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) s[qb][blk][4 * g + e] += rqv[qb] != rk4[e] ? -100.0f : 0.0f;
+                            for (int e = 0; e < 4; ++e) s[qb][blk][4 * g + e] += rqv[qb] != rk4[e] ? -100.0f * (LOG2 ? kLog2e : 1.0f) : 0.0f;
                     }
                 }
         }
@@ -296,6 +339,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         // ---- online softmax per query block: this lane and lane^32 share the query
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
+            if constexpr (FIXREF) {  // fixed reference point (already subtracted through the bias table): p = 2^s, nothing to track or rescale
+                f32x2 psum2 = {0.0f, 0.0f};
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float e0 = __builtin_amdgcn_exp2f(s[qb][blk][r]);
+                        const float e1 = __builtin_amdgcn_exp2f(s[qb][blk][r + 1]);
+                        s[qb][blk][r] = e0;
+                        s[qb][blk][r + 1] = e1;
+                        psum2 += f32x2{e0, e1};
+                    }
+                l_run[qb] += psum2[0] + psum2[1];
+                continue;
+            }
             float mloc = s[qb][0][0];
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
@@ -307,17 +365,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                 const unsigned s0 = sw[0], s1 = sw[1];
                 mloc = fmaxf(__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1));
             }
-            const float m_new = mloc > m_run[qb] + kDeferMax ? mloc : m_run[qb];
-            const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kLog2e);
-            const float mb = m_new * kLog2e;
+            const float m_new = mloc > m_run[qb] + kDeferMax * (LOG2 ? kLog2e : 1.0f) ? mloc : m_run[qb];
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kExpScale);
+            const float mb = m_new * kExpScale;
             m_run[qb] = m_new;
             f32x2 psum2 = {0.0f, 0.0f};
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float e0 = __builtin_amdgcn_exp2f(s[qb][blk][r] * kLog2e - mb);
-                    const float e1 = __builtin_amdgcn_exp2f(s[qb][blk][r + 1] * kLog2e - mb);
+                    const float e0 = __builtin_amdgcn_exp2f(LOG2 ? s[qb][blk][r] - mb : s[qb][blk][r] * kLog2e - mb);
+                    const float e1 = __builtin_amdgcn_exp2f(LOG2 ? s[qb][blk][r + 1] - mb : s[qb][blk][r + 1] * kLog2e - mb);
                     s[qb][blk][r] = e0;
                     s[qb][blk][r + 1] = e1;
                     psum2 += f32x2{e0, e1};  // one v_pk_add_f32 per pair
@@ -417,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             for (int qb = 0; qb < QB; ++qb) {
                 const float m_w = src[(qb * (2 + DB * 16) + 0) * 64], l_w = src[(qb * (2 + DB * 16) + 1) * 64];
                 const float m_new = fmaxf(m_run[qb], m_w);
-                const float a = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kLog2e), bsc = __builtin_amdgcn_exp2f((m_w - m_new) * kLog2e);
+                const float a = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * kExpScale), bsc = __builtin_amdgcn_exp2f((m_w - m_new) * kExpScale);
                 m_run[qb] = m_new;
                 l_run[qb] = l_run[qb] * a + l_w * bsc;
 #pragma unroll
@@ -518,6 +576,7 @@ __global__ __launch_bounds__(256) void attn_weights_kernel(const op_t* __restric
         float s = 0.0f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) s += q[d] * ((float)kp[d] + (klp ? (float)klp[d] : 0.0f));
+        if (HD == 32) s *= 0.6931471805599453f;  // the window attention's Q carries log2(e) with its logit scale (attn_kernel LOG2): back to natural units
         if (lut) s += lut[tqr - tk[key]];
         if (reg && reg[key] != rq) s += -100.0f;
         sc[key] = s;
@@ -551,7 +610,7 @@ int MDPT_FN(mdpt_launch_attention)(const AttnParams& p, hipStream_t stream) {
     if ((hd != 64 && hd != 32) || p.F != p.heads * hd || (p.npadv & 63) || p.npadv < ((p.N + 63) & ~63) || p.npad < p.N)
         return (int)hipErrorInvalidValue;
     const bool swin = p.rowmap != nullptr;
-    if (swin && (hd != 32 || !p.bias_lut || p.win_nw <= 0 || p.B % p.win_nw)) return (int)hipErrorInvalidValue;
+    if (swin && (hd != 32 || !p.bias_lut || !p.swin_ls || p.win_nw <= 0 || p.B % p.win_nw)) return (int)hipErrorInvalidValue;
     if (!swin && hd != 64) return (int)hipErrorInvalidValue;
     // 64 queries per wave (256 per workgroup: K / V fragments read once per 64 queries) when that still gives >= 2 workgroups per CU and,
     // at head dim 64, when the query count fills its last 256-query workgroup reasonably: N = 1297 pads to 1536 (+18 %) and N = 577 to 768

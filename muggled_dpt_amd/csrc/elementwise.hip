@@ -447,9 +447,13 @@ __global__ __launch_bounds__(256) void pack_weight_f8_kernel(const void* __restr
 #endif
 }
 
-__global__ __launch_bounds__(256) void pad_copy_kernel(const void* __restrict__ src, int sdt, float* dst, int n, int np, const void* __restrict__ scale, int cdt) {
+__global__ __launch_bounds__(256) void pad_copy_kernel(const void* __restrict__ src, int sdt, float* dst, int n, int np, const void* __restrict__ scale, int cdt, float mul) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < np) dst[i] = i < n ? (scale ? ld_typed(src, i, sdt) * ld_typed(scale, i, cdt) : ld_typed(src, i, sdt)) : 0.0f;
+    if (i < np) {
+        float v = i < n ? (scale ? ld_typed(src, i, sdt) * ld_typed(scale, i, cdt) : ld_typed(src, i, sdt)) : 0.0f;
+        if (mul != 1.0f) v *= mul;
+        dst[i] = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void memset_f32_kernel(float* dst, float value, size_t n) {
@@ -1042,8 +1046,8 @@ int MDPT_FN(mdpt_launch_weight_scale)(const void* src, int src_dtype, int N, int
     LAUNCH_RET();
 }
 
-int MDPT_FN(mdpt_launch_pad_copy_f32)(const void* src, int src_dtype, float* dst, int n, int np, hipStream_t stream, const void* scale, int scale_dtype) {
-    hipLaunchKernelGGL(pad_copy_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, src, src_dtype, dst, n, np, scale, scale_dtype);
+int MDPT_FN(mdpt_launch_pad_copy_f32)(const void* src, int src_dtype, float* dst, int n, int np, hipStream_t stream, const void* scale, int scale_dtype, float mul) {
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, src, src_dtype, dst, n, np, scale, scale_dtype, mul);
     LAUNCH_RET();
 }
 

@@ -310,7 +310,9 @@ int mdpt_finalize(mdpt_handle* h, void* packed_dev, size_t bytes, void* stream) 
             continue;
         }
         const WeightSpec& vs = h->specs[h->spec_index.at(v.src)];
-        CHK(OPLH(mdpt_launch_pad_copy_f32, vs.ptr, vs.dtype, v.ptr, v.n, v.np, st));
+        // SwinV2's per-head logit scale is packed times log2(e): the window attention's scores are in log2 units (attention.hip LOG2)
+        const bool ls2 = v.src.size() > 17 && v.src.compare(v.src.size() - 17, 17, ".attn.logit_scale") == 0;
+        CHK(OPLH(mdpt_launch_pad_copy_f32, vs.ptr, vs.dtype, v.ptr, v.n, v.np, st, nullptr, 0, ls2 ? 1.4426950408889634f : 1.0f));
     }
     h->finalized = true;
     h->has_last = false;

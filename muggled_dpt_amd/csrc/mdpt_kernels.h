@@ -136,6 +136,8 @@ struct AttnParams {
     int bias_run4;       // window width and tokens per window are multiples of 4: four consecutive keys have consecutive bias-table indices
     int bias_row;        // (bias_run4) row length 2 ww - 1 of the table and window width ww: the LDS image of the table is re-strided so that 32
     int bias_ww;         // consecutive query tokens read 32 different banks (attention.hip, round 6); 0 = the table's own row length
+    const float* swin_ls; // (window attention) the packed logit scale per head = exp(clamped logit_scale) * log2(e): Q carries it, the kernel's fixed softmax
+                          // reference point is built from it (attention.hip FIXREF)
     int out_ld;          // row stride of out_hi / out_lo in elements (0 = F); pad columns are the caller's
     int allow_split_kv;  // latency mode: small launches may split the key loop over the waves (not batch-invariant in the last bit)
     int tail_last;  // set by the launcher: dispatch nearly empty last q-tiles after all full ones

@@ -448,7 +448,8 @@ class _Engine:
             native.check(self.lib, self.lib.mdpt_set_gemm_tile(self.handle, tile))
         if model.__dict__.get("_latency_mode", False):
             native.check(self.lib, self.lib.mdpt_set_latency_mode(self.handle, 1))
-        if model.config.get("enable_cache", False):  # the reference's make_*_dpt(..., enable_cache=True): per-grid constants computed once per (workspace, shape)
+        self._grid_cache_on = bool(model.config.get("enable_cache", False))
+        if self._grid_cache_on:  # the reference's make_*_dpt(..., enable_cache=True): per-grid constants computed once per (workspace, shape)
             native.check(self.lib, self.lib.mdpt_set_grid_cache(self.handle, 1))
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
@@ -514,6 +515,10 @@ class _Engine:
                 self._workspaces.clear()
             ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
             self._workspaces[key] = ws
+            # the grid cache (mdpt_set_grid_cache) is keyed on the workspace ADDRESS and trusts the bytes behind it: a fresh allocation may land where a
+            # freed workspace was - drop the slots whenever memory is (re)allocated
+            if self._grid_cache_on:
+                native.check(self.lib, self.lib.mdpt_set_grid_cache(self.handle, 1))
         ptr = (ws.data_ptr() + 255) & ~255
         return ptr, ws.numel() - (ptr - ws.data_ptr())
 
