@@ -139,7 +139,7 @@ def hbm_traffic(args, kernel_name: str):
     if args.model != "vitl" or args.batch != 32 or args.size != 504 or args.precision != "bf16":
         return None
     sha = native.source_hash()
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(REPO, "profiles", f"{tag}_hbm_traffic.json")
         if not os.path.exists(path):
             continue

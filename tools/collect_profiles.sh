@@ -7,7 +7,7 @@
 #   3. the driver-runnable secondary configurations (1036x1036, BEiT-L, SwinV2-L) as plain bench lines
 # Output: gpurun_out/profiles_<tag>/ ; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
@@ -70,6 +70,15 @@ python tools/probes/gpu_wscale_check.py 2>&1 | grep -v amdgpu > "$OUT/wscale_che
 if [ -x tools/probes/_bin/mfma_power ] && [ -x tools/probes/_bin/mfma_power_f16 ]; then
   { echo "== bf16"; tools/probes/_bin/mfma_power | head -3; echo "== fp16"; tools/probes/_bin/mfma_power_f16 | head -3; } > "$OUT/mfma_power_f16_vs_bf16.txt" 2>&1
 fi
+# round 6: fp8 cross-term forms (instruction probes, per-class table under both roundings of the fp16 weight scale), what the token-mean compensation
+# costs under the two-stream split, the fused inference path
+python tools/probes/gpu_family_class_budget.py beitl swinl 2>&1 | grep -v amdgpu > "$OUT/family_class_budget_default_rows.txt"
+MDPT_BUDGET_R06=1 python tools/probes/gpu_family_class_budget.py beitl 2>&1 | grep -v amdgpu > "$OUT/beitl_class_budget_both_roundings.txt"
+python tools/probes/gpu_wrc_cost.py 2>&1 | grep -v amdgpu > "$OUT/wrc_cost.txt"
+python tools/probes/gpu_kernel_share_any.py vitl 504 32 fp16 2>&1 | grep -v amdgpu > "$OUT/kernel_share_fp16.txt"
+python tools/probes/gpu_kernel_share_any.py beitl 384 16 2>&1 | grep -v amdgpu > "$OUT/kernel_share_beitl.txt"
+[ -x tools/probes/_bin/f8_cross_probe ] && tools/probes/_bin/f8_cross_probe > "$OUT/f8_cross_probe.txt" 2>&1
+[ -x tools/probes/_bin/f8_shape_equiv_probe ] && tools/probes/_bin/f8_shape_equiv_probe > "$OUT/f8_shape_equiv_probe.txt" 2>&1
 # side stream: hardware-queue collisions (first stream handed out vs probed), reassembly branches beside the encoder at batch 1
 python tools/probes/gpu_side_stream_queue.py 2>&1 | grep -v amdgpu > "$OUT/side_stream_queue.txt"
 python tools/probes/b1_overlap_ab.py 2>&1 | grep -v amdgpu > "$OUT/b1_overlap_ab.txt"
