@@ -146,7 +146,8 @@ def hbm_traffic(args, kernel_name: str):
         rows = json.load(open(path))
         if rows.get("_meta", {}).get("csrc_sha") != sha:
             continue
-        rec = rows.get(kernel_name)
+        # (rocprofv3 prints every template argument - since round 6 the 16-bit forms end in ", false" (no fp8 cross terms) - the library's own profiler the short name)
+        rec = rows.get(kernel_name) or (rows.get(kernel_name[:-1] + ", false>") if kernel_name.endswith(">") else None)
         return None if rec is None else int((rec["fetch_mb_per_launch"] + rec["write_mb_per_launch"]) * 1e6)
     return None
 
@@ -194,7 +195,7 @@ PRECISION_DTYPE = {"bf16": "bf16", "bf16x3": "bf16x3 (hi/lo split bf16 MFMA oper
                    "fp16": "fp16 (fp16 MFMA operands, single pass, fp32 accumulate)",
                    "fp16x3": "fp16x3 (hi/lo split fp16 MFMA operands, 3 passes, fp32 accumulate)",
                    "mixed": "mixed (fp16 MFMA operands; decoder classes as split products A_hi W_hi + A_lo W_hi [+ A_hi W_lo] with the cross terms on fp8 planes "
-                            "through the block-scaled MFMA: reassembly, fusion convs and 1x1 fusion projections 3 terms, head conv 1 2 terms; patch embed 3 fp16 "
+                            "through the block-scaled MFMA: reassembly, fusion convs, 1x1 fusion projections and head conv 1 3 terms; patch embed 3 fp16 "
                             "passes, head tail 2; encoder 1 pass + token-mean compensation; fp32 accumulate)"}
 
 
@@ -331,7 +332,7 @@ def secondary_legs(args, dev, lib, vitl_model):
                 model.set_latency_mode(False)
                 rec["latency_mode"] = {"ms_per_step": round(dt_l * 1e3, 3), "value": round(batch / dt_l, 3)}
                 # what every caller of the reference actually runs (run_image.py:204-207, run_video.py:344): DPTModel.inference on a uint8 HOST
-                # image - pageable numpy -> pinned staging -> H2D -> prepare_image kernel (model dtype) -> forward, depth left on the device
+                # image - pageable numpy -> pinned staging -> H2D -> mdpt_forward_bgr (prepare_image fused into the patch embedding's im2col kernel), depth left on the device
                 rec["inference_b1"] = {"input": f"uint8 host image {size + 14}x{size + 14}x3 (BGR) -> {size}x{size} tensor", **time_inference(model, size + 14, steps),
                                        "latency_mode": inf_l}
             y_m = dt_m = None

@@ -141,8 +141,8 @@ void mdpt_default_mixed_passes(int32_t passes[MDPT_NUM_CLASSES]);               
 void mdpt_default_mixed_passes_for(int32_t family, int32_t passes[MDPT_NUM_CLASSES]);  /* per MDPT_FAMILY_*: the MiDaS v3.1 families keep three
                                                                                           terms on the decoder's whole projection path. Round 6: the
                                                                                           decoder classes name the fp8 forms (MDPT_PASSES_*F8); BEiT adds
-                                                                                          fc1 at 3 and fusion_in at 2F8 (margin under either rounding of
-                                                                                          the fp16 weight scale, profiles/r06_beitl_class_budget.txt) */
+                                                                                          fc1 and fc2 at 3 and fusion_in at 2F8 (margin under either rounding
+                                                                                          of the fp16 weight scale, profiles/r06_beitl_class_budget.txt) */
 void mdpt_default_mixed_passes_r05(int32_t family, int32_t passes[MDPT_NUM_CLASSES]);  /* the 16-bit-plane table of round 5: what MDPT_PREC_MIXED gives a class
                                                                                           of a configuration that cannot run the fp8 forms (mdpt_get_class_f8) */
 /* Token-mean compensation of the weight rounding (fp16 operand modes; on by default in MDPT_PREC_MIXED, available in MDPT_PREC_FP16): a

@@ -114,8 +114,8 @@ void mdpt_destroy(mdpt_handle* h) { delete h; }
 // above paid 2 / 3. Measured on ViT-L 504^2 batch 32, one box, images 0 / 7 / 13 / 31 (tests/precision_budget/measure_on_gpu.py, profiles/r06_precision_budget_f8.md):
 //   round 5's table                                   worst 9.05e-4  rms 9.12e-5  52.40 ms
 //   the same table with fp8 cross terms               worst 9.26e-4  rms 9.15e-5  49.73 ms  (the accuracy of the fp16 cross terms, as the emulation said)
-//   + fusion at THREE terms (its weights split too)   worst 7.97e-4  rms 8.38e-5  50.64 ms  <- shipped: part of the gain is spent on margin
-//   + head at three terms                             worst 7.60e-4  rms 7.96e-5  51.46 ms
+//   + fusion at THREE terms (its weights split too)   worst 7.97e-4  rms 8.38e-5  50.64 ms  (8.61e-4 after an equally valid re-rounding of the compensation's sums)
+//   + head at three terms                             worst 7.60e-4  rms 7.96e-5  51.46 ms  <- shipped: most of the gain is spent on margin
 // A configuration that cannot run the fp8 forms (mdpt_get_class_f8) keeps round 5's table (mdpt_create).
 void mdpt_default_mixed_passes_for(int32_t family, int32_t passes[MDPT_NUM_CLASSES]) {
     const bool midas = family == MDPT_FAMILY_BEIT || family == MDPT_FAMILY_SWINV2;
@@ -124,15 +124,18 @@ void mdpt_default_mixed_passes_for(int32_t family, int32_t passes[MDPT_NUM_CLASS
     passes[CLS_REASM] = MDPT_PASSES_3F8;
     passes[CLS_FUSION] = MDPT_PASSES_3F8;
     passes[CLS_FUSION_PROJ] = MDPT_PASSES_3F8;
-    passes[CLS_HEAD] = midas ? MDPT_PASSES_3F8 : MDPT_PASSES_2F8;
+    passes[CLS_HEAD] = MDPT_PASSES_3F8;  // (Depth-Anything ran it at 2F8 for a while: 7.97e-4 / 8.61e-4 worst image under two equally valid re-roundings; three terms 7.6e-4)
     passes[CLS_HEAD_TAIL] = midas ? 3 : 2;  // (its own kernel, VALU-bound in the halo interpolation: fp16 planes)
     passes[CLS_FUSION_IN] = 1;  // 2 % of the decoder's squared error for a quarter of its FLOPs (profiles/r04_precision_budget.md)
     if (family == MDPT_FAMILY_BEIT) {
         // BEiT-L's reference fixture sits closest to the bound, and which side of it depends on how the fp16 weight scale was rounded
-        // (mdpt_debug_set_wscale_policy: 7.8e-4 under the shipped rule, 1.11e-3 with every folded matrix scaled). What is left is the encoder's
-        // single-pass MLP: fc1 at three passes and the fusion blocks' first conv on fp8 cross terms read 5.95e-4 / 7.51e-4, rms 1.2e-4 (1.58e-4 before),
-        // for 2.5 ms of 16 at batch 16 (profiles/r06_beitl_class_budget.txt). SwinV2-L reads 6.8e-4 under both roundings and keeps its table.
+        // (mdpt_debug_set_wscale_policy: 7.8e-4 under the shipped rule, 1.11e-3 with every folded matrix scaled) - and on any other re-rounding: with
+        // ONE of the two MLP Linears at three passes the same fixture read 5.95e-4 / 7.51e-4 before and 1.016e-3 / 6.18e-4 after a change of the
+        // attention kernel's summation order, the RMS of the error moving between 1.2e-4 and 2.9e-4 (a coherent error component of random
+        // amplitude that the single-pass MLP carries). Both MLP Linears at three passes: 4.6e-4 ... 5.7e-4 in four such samples, rms 0.86e-4 ... 1.4e-4,
+        // for 4 ms of 16.7 at batch 16 (profiles/r06_beitl_class_budget.txt). SwinV2-L reads 6.8e-4 ... 6.9e-4 under every rounding tried and keeps its table.
         passes[CLS_FC1] = 3;
+        passes[CLS_FC2] = 3;
         passes[CLS_FUSION_IN] = MDPT_PASSES_2F8;
     }
 }

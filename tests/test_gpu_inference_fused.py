@@ -37,17 +37,18 @@ def test_inference_equals_prepare_image_then_forward_bit_for_bit(family, dtype, 
 
 def test_inference_with_listening_hooks_takes_the_stage_route():
     """A forward hook on an attention softmax module makes forward() go stage by stage (so the hook sees its tensor); inference() has to do the same."""
-    model, unit = _family_model("v2")
+    from torch import nn
+    from muggled_dpt_amd import make_depthanythingv2_dpt_from_original_state_dict
+    from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict
+    _, model = make_depthanythingv2_dpt_from_original_state_dict(make_synthetic_original_state_dict("tiny", 0), enable_optimizations=False)
     model = model.to("cuda", torch.float32)
     img = np.random.default_rng(4).integers(0, 256, (100, 140, 3), dtype=np.uint8)
-    y = model.inference(img, 4 * unit, True)
+    y = model.inference(img, 112, True)
     seen = []
-    probe = model.imgencoder.__dict__.get("_softmax_probes")[0] if model.imgencoder.__dict__.get("_softmax_probes") else None
-    if probe is None:
-        pytest.skip("this model exposes no softmax probes")
-    hd = probe.register_forward_hook(lambda m, a, out: seen.append(tuple(out.shape)))
+    last = [m for m in model.modules() if isinstance(m, nn.Softmax)][-1]
+    hd = last.register_forward_hook(lambda m, a, out: seen.append(tuple(out.shape)))
     try:
-        y2 = model.inference(img, 4 * unit, True)
+        y2 = model.inference(img, 112, True)
     finally:
         hd.remove()
     assert seen, "the hook did not fire"

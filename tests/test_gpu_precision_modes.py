@@ -24,6 +24,8 @@ pytestmark = pytest.mark.gpu
 REL_TOL_FP16 = 3e-3        # single-pass fp16 operands, full-size models
 REL_TOL_FP16_TOY = 5e-3    # 64-feature toy configurations (bf16: 3e-2; fp16 rounds 8x finer)
 REL_TOL_MIXED = 1e-3       # the north-star bar
+REL_GATE_MIXED = 8.5e-4    # regression gate UNDER the bar for the float32 mixed model at full size: the max-over-pixels metric moves
+                           # by +-10 % under equally valid re-roundings, the shipped table has to leave that much
 
 
 def _oracle():
@@ -116,7 +118,7 @@ def test_vitl_batch32_fp16_and_mixed_every_checked_image_vs_oracle():
     # top of the operand arithmetic. The yardstick is the reference's own float16 path on this configuration (model and input cast to float16
     # against its fp32 run: tests/golden/reference_lowprec_errors.json, 9.9e-3): at most HALF of that.
     tol16_vs_fp32 = ref_lowprec_tol("vitl504", dtype="fp16", factor=0.5)
-    for dtype, precision, tol in ((torch.float16, None, REL_TOL_FP16), (torch.float32, "mixed", REL_TOL_MIXED), (torch.float16, "mixed", REL_TOL_MIXED + 2.0 ** -11)):
+    for dtype, precision, tol in ((torch.float16, None, REL_TOL_FP16), (torch.float32, "mixed", REL_GATE_MIXED), (torch.float16, "mixed", REL_TOL_MIXED + 2.0 ** -11)):
         ref = ref32 if dtype == torch.float32 else ref16
         model, _, _ = _model("vitl", dtype, precision)
         xd = x.to("cuda", dtype)
@@ -320,7 +322,7 @@ def test_raw_c_abi_class_passes_keep_bound_weights_and_reject_bad_arguments():
     lib.mdpt_default_mixed_passes_r05(native.FAMILY_DAV2, want)
     new = (ctypes.c_int32 * len(native.OP_CLASSES))()
     lib.mdpt_default_mixed_passes(new)
-    assert {native.OP_CLASSES[i]: new[i] for i in range(len(native.OP_CLASSES)) if new[i] != want[i]} == {"reasm": 5, "fusion": 5, "fusion_proj": 5, "head": 4}
+    assert {native.OP_CLASSES[i]: new[i] for i in range(len(native.OP_CLASSES)) if new[i] != want[i]} == {"reasm": 5, "fusion": 5, "fusion_proj": 5, "head": 5}
     got = ctypes.c_int32()
     for i in range(len(native.OP_CLASSES)):
         native.check(lib, lib.mdpt_get_class_passes(h, i, ctypes.byref(got)))
@@ -492,8 +494,8 @@ def test_beit_large_and_swin_large_fixtures_in_the_fp16_and_mixed_modes(golden_d
     from muggled_dpt_amd import make_beit_dpt_from_midas_v31_state_dict, make_swinv2_dpt_from_midas_v31_state_dict
     from muggled_dpt_amd.synthetic import make_synthetic_beit_state_dict, make_synthetic_swinv2_state_dict
     from tests.helpers import ref_lowprec_tol
-    for fixture, make, synth, name, mixed_tol in (("beit_large_384", make_beit_dpt_from_midas_v31_state_dict, make_synthetic_beit_state_dict, "beit_large_384", 1e-3),
-                                                  ("swin2_large_384", make_swinv2_dpt_from_midas_v31_state_dict, make_synthetic_swinv2_state_dict, "swin2_large_384", 1e-3)):
+    for fixture, make, synth, name, mixed_tol in (("beit_large_384", make_beit_dpt_from_midas_v31_state_dict, make_synthetic_beit_state_dict, "beit_large_384", 9e-4),
+                                                  ("swin2_large_384", make_swinv2_dpt_from_midas_v31_state_dict, make_synthetic_swinv2_state_dict, "swin2_large_384", 9e-4)):  # (9e-4: 10 % under the bar)
         g = np.load(os.path.join(golden_dir, fixture + ".npz"))
         osd = synth(name, int(g["weight_seed"]))
         x = seeded_input((1, 3, 384, 384), int(g["input_seed"]))

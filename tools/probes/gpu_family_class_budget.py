@@ -26,6 +26,12 @@ if os.environ.get("MDPT_BUDGET_R06"):  # round 6: the fp8 table (shipped) agains
                 ("fc1=3 fusion_in=4", {"fc1": 3, "fusion_in": 4}), ("fc1=3 fc2=3", {"fc1": 3, "fc2": 3}), ("fc1=3 proj=3", {"fc1": 3, "proj": 3}), ("fc1=3 qkv=3", {"fc1": 3, "qkv": 3})]
     if os.environ.get("MDPT_BUDGET_R06") == "2":
         VARIANTS = [VARIANTS[0]] + VARIANTS[-4:]
+    if os.environ.get("MDPT_BUDGET_R06") == "3":  # where BEiT-L's error comes from: classes moved to 3 passes in groups
+        ENC = {"qkv": 3, "attn": 3, "proj": 3, "fc1": 3, "fc2": 3}
+        DEC = {"reasm": 3, "fusion": 3, "fusion_in": 3, "fusion_proj": 3, "head": 3, "head_tail": 3}
+        VARIANTS = [("shipped", {}), ("attn=3", {"attn": 3}), ("qkv=3 attn=3", {"qkv": 3, "attn": 3}), ("encoder 3", ENC), ("decoder 3 (fp16 planes)", DEC),
+                    ("encoder 3, decoder 3", {**ENC, **DEC}), ("fc1=3 fc2=3", {"fc1": 3, "fc2": 3}), ("fc1=3 fc2=3 proj=3", {"fc1": 3, "fc2": 3, "proj": 3}),
+                    ("fc1=3 fc2=3 qkv=3", {"fc1": 3, "fc2": 3, "qkv": 3}), ("qkv=3 proj=3", {"qkv": 3, "proj": 3})]
 BOTH = bool(os.environ.get("MDPT_BUDGET_R06"))
 for name in (sys.argv[1:] or ["beitl", "swinl"]):
     fixture, size, batch = FIX[name]
