@@ -42,8 +42,8 @@ extern "C" {
 #define MDPT_PREC_BF16 0   /* bf16 MFMA operands - the reference's GPU default dtype (demo_helpers/misc.py:73-77) */
 #define MDPT_PREC_BF16X3 1 /* split-bf16 (hi+lo) operands, 3 MFMA passes: fp32-class accuracy (parity mode)        */
 #define MDPT_PREC_FP16 2   /* fp16 MFMA operands (v_mfma_*_f16: the bf16 rate, 11 instead of 8 significand bits; converts saturate at
-                              +-65504 - and turn a NaN into a finite value: a NaN in the input never reaches the depth map as NaN in the
-                              fp16 operand modes; in the bf16 modes the conversions carry it on, the v_max ReLUs may still drop it) - what the reference's device policy hands the model when
+                              +-65504 - and turn a NaN into a finite value; a NaN / inf in the input IMAGE still gives a NaN depth map,
+                              in every mode: mdpt_set_nonfinite_propagation) - what the reference's device policy hands the model when
                               bf16 is not preferred (demo_helpers/misc.py:61-77: float16). The layer-scale-folded matrices are packed
                               times a power of two that the GEMMs undo exactly, so checkpoints with gammas of 1e-2 ... 1e-5 keep their
                               hi / lo planes in fp16's normal range                                                   */
@@ -251,6 +251,15 @@ int mdpt_set_grid_cache(mdpt_handle* h, int32_t on);
  * partial sums are folded in by the LayerNorm that follows (no reduction launch); the long-K 3x3 convs of the coarse decoder levels run as K
  * ranges that store partial planes plus a small finishing kernel. The splits are fixed per shape: results are reproducible run to run. */
 int mdpt_set_latency_mode(mdpt_handle* h, int32_t on);
+
+/* Non-finite propagation (default on; additive to ABI v6). The reference's forward (muggled_dpt/dpt_model.py:61-83) turns an image that holds a
+ * NaN / inf into an all-NaN depth map: the value reaches every token of that image through the first attention, and torch's ReLU keeps it. The
+ * kernels here would hide it (the fp16 operand converts saturate through v_med3, the ReLUs are v_max): so mdpt_forward has its im2col kernel flag
+ * such images (it reads every pixel anyway) and one small launch behind the head writes their depth maps as NaN - in every arithmetic mode, the
+ * other images of the batch untouched. Cost: one B-word memset and one launch per forward, both stream-ordered and graph-capturable. Off = the
+ * earlier behaviour (a finite, meaningless map for such an image). mdpt_forward_bgr's uint8 source cannot hold a non-finite value; the stage-level
+ * entry points (mdpt_patch_embed ...) return what their own arithmetic gives; non-finite WEIGHTS are the caller's to check. */
+int mdpt_set_nonfinite_propagation(mdpt_handle* h, int32_t on);
 
 /* PatchEmbed.prepare_image (v2_depthanything/patch_embed.py:103-145): uint8 [in_h,in_w,3] BGR on the device ->
  * [3,out_h,out_w] RGB in the element type out_dtype (MDPT_DTYPE_*: the model's dtype, what mdpt_forward takes next - no cast kernel in

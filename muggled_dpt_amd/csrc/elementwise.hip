@@ -95,8 +95,11 @@ __device__ __forceinline__ float ld_typed(const void* p, size_t i, int dt) {
     return ((const float*)p)[i];
 }
 
+// `poison` (mdpt_forward, may be null): word b is set when image b holds a NaN / inf - the reference's forward turns such an image's whole depth
+// map into NaN (the value reaches every token through the attention), while here the saturating fp16 converts and the v_max ReLUs would hide it;
+// poison_depth_kernel below writes the NaN map at the end of the forward.
 __global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ img, int img_dt, op_t* out_hi, op_t* out_lo, int B,
-                                                       int H, int W, int P, int Kp) {
+                                                       int H, int W, int P, int Kp, unsigned* __restrict__ poison) {
     const int gw = W / P, gh = H / P;
     const int K = 3 * P * P;
     const int kq = Kp / 4;
@@ -119,7 +122,27 @@ __global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ 
             }
             v[e] = val;
         }
+        if (poison) {
+            bool bad = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bad |= (__float_as_uint(v[e]) & 0x7F800000u) == 0x7F800000u;
+            if (bad) poison[b] = 1u;
+        }
         split_store4(out_hi, out_lo, rowi * Kp + k4, v);
+    }
+}
+
+// The end of mdpt_forward for images patchify_kernel flagged: the whole depth map of such an image is NaN, like the reference's
+// (dpt_model.py:61-83 on an image with a NaN / inf pixel). A workgroup of an unflagged image reads one word and leaves.
+__global__ __launch_bounds__(256) void poison_depth_kernel(void* __restrict__ depth, int dt, const unsigned* __restrict__ poison, size_t hw) {
+    const int b = blockIdx.y;
+    if (!poison[b]) return;
+    const float qnan = __uint_as_float(0x7FC00000u);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = (size_t)b * hw + i;
+        if (dt == MDPT_DT_BF16) ((__bf16*)depth)[o] = (__bf16)qnan;
+        else if (dt == MDPT_DT_F16) ((_Float16*)depth)[o] = (_Float16)qnan;
+        else ((float*)depth)[o] = qnan;
     }
 }
 
@@ -932,10 +955,18 @@ int MDPT_FN(mdpt_launch_swiglu)(const float* in, op_t* out_hi, op_t* out_lo, siz
     LAUNCH_RET();
 }
 
-int MDPT_FN(mdpt_launch_patchify)(const void* img, int img_dtype, op_t* out_hi, op_t* out_lo, int B, int H, int W, int P, int Kp, hipStream_t stream) {
+int MDPT_FN(mdpt_launch_patchify)(const void* img, int img_dtype, op_t* out_hi, op_t* out_lo, int B, int H, int W, int P, int Kp, hipStream_t stream,
+                                  unsigned* poison) {
     const size_t total = (size_t)B * (H / P) * (W / P) * (Kp / 4);
     MdptProfScope prof("patchify_kernel", 0.0, stream);
-    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, stream, img, img_dtype, out_hi, out_lo, B, H, W, P, Kp);
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, stream, img, img_dtype, out_hi, out_lo, B, H, W, P, Kp, poison);
+    LAUNCH_RET();
+}
+
+int MDPT_FN(mdpt_launch_poison_depth)(void* depth, int depth_dtype, const unsigned* poison, int B, size_t hw, hipStream_t stream) {
+    MdptProfScope prof("poison_depth_kernel", 0.0, stream);
+    const unsigned gx = (unsigned)((hw + 256 * 8 - 1) / (256 * 8));
+    hipLaunchKernelGGL(poison_depth_kernel, dim3(gx < 1 ? 1 : gx, B), dim3(256), 0, stream, depth, depth_dtype, poison, hw);
     LAUNCH_RET();
 }
 

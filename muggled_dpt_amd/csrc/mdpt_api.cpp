@@ -356,6 +356,12 @@ int mdpt_set_latency_mode(mdpt_handle* h, int32_t on) {
     return 0;
 }
 
+int mdpt_set_nonfinite_propagation(mdpt_handle* h, int32_t on) {
+    if (!h) return fail(MDPT_E_INVALID, "null handle");
+    h->nonfinite_prop = on ? 1 : 0;
+    return 0;
+}
+
 int mdpt_set_gemm_tile(mdpt_handle* h, int32_t tile) {
     if (!h || tile < 0 || tile > 6 || tile == 3) return fail(MDPT_E_INVALID, "tile must be 0 (auto), 1 (128x128), 2 (256x256 lockstep), 4 (256x128x32), 5 (8-phase 256x256) or 6 (64x64)");
     h->gemm_tile = tile;
@@ -491,7 +497,24 @@ int mdpt_forward_bgr(mdpt_handle* h, const void* bgr_u8_hwc, int32_t in_h, int32
     return 0;
 }
 
-static int forward_one(mdpt_handle* h, const Ctx& c, const void* image_bchw, int image_dtype, void* depth_bhw, int depth_dtype) {
+static int forward_body(mdpt_handle* h, const Ctx& c, const void* image_bchw, int image_dtype, void* depth_bhw, int depth_dtype);
+
+// Non-finite propagation (mdpt_set_nonfinite_propagation, default on): the reference's forward (dpt_model.py:61-83) turns an image with a NaN / inf
+// pixel into an all-NaN depth map - the value reaches every token through the first attention and torch's ReLU keeps it. Here the saturating fp16
+// operand converts (v_med3) and the v_max ReLUs would return a finite, plausible map instead. The im2col kernel, which reads every pixel anyway,
+// flags such images in B words of the plan and one small launch behind the head writes their maps as NaN: two stream-ordered operations per
+// forward (graph-capturable, nothing on the host). uint8 sources (mdpt_forward_bgr) cannot hold a non-finite value and skip both.
+static int forward_one(mdpt_handle* h, const Ctx& c0, const void* image_bchw, int image_dtype, void* depth_bhw, int depth_dtype) {
+    if (!h->nonfinite_prop || !image_bchw || h->dbg_block >= 0) return forward_body(h, c0, image_bchw, image_dtype, depth_bhw, depth_dtype);
+    Ctx c = c0;
+    c.poison = c.at<unsigned>(c.p.poison);
+    CHK(hipMemsetAsync(c.poison, 0, (size_t)c.p.B * 4, c.s));
+    CHK(forward_body(h, c, image_bchw, image_dtype, depth_bhw, depth_dtype));
+    CHK(OPLC(mdpt_launch_poison_depth, depth_bhw, depth_dtype, c.poison, c.p.B, (size_t)c.p.H * c.p.W, c.s));
+    return 0;
+}
+
+static int forward_body(mdpt_handle* h, const Ctx& c, const void* image_bchw, int image_dtype, void* depth_bhw, int depth_dtype) {
     if (h->swin) {
         CHK(run_patch_embed_swin(c, image_bchw, image_dtype, nullptr));
         h->last_plan = c.p;

@@ -141,6 +141,7 @@ struct Plan {
     size_t scratch_floats;
     size_t tokr[3], cbuf, relpos_lut, relpos_tq, relpos_tk;  // BEiT: readout-projected tokens, per-image cls term, bias LUT
     size_t probe;                                             // 256 bytes of their own for the side-stream probe
+    size_t poison;                                            // one word per image: the image holds a NaN / inf (mdpt_forward: its depth map becomes NaN)
     size_t wrc_mean, wrc_tab;                                 // [B, wrc_maxk] operand-format column means, fp32 [B, wrc_maxn] per-image bias table
     size_t swi;                                               // ViT-G: fp32 [rows, 2*hidden] output of the doubled inner linear
     size_t kspart;                                            // small batches: 3 x fp32 [rows, F] partial sums of the K-split proj / fc2 (latency mode), else absent
@@ -196,6 +197,7 @@ struct mdpt_handle {
     // batch split: batches >= split_min run as two halves on the caller's stream and an internal side stream (fork / join with
     // events, no host sync) so that one half's kernels fill the tile-quantisation tails and epilogue phases of the other's
     int split_min;
+    int nonfinite_prop = 1;  // mdpt_set_nonfinite_propagation: an image tensor with a NaN / inf gives a NaN depth map (as the reference does), in every mode
     int wscale_all = 0;  // test policy (mdpt_debug_set_wscale_policy): scale EVERY layer-scale-folded matrix of the fp16 build, not only those below 2^-5
     int latency_mode;  // mdpt_set_latency_mode: small launches may use summation orders that are not batch-invariant
     int side_prio;      // priority class of the side stream: 0 = the default class (default), 1 = lowest, -1 = highest (mdpt_debug_set_side_stream_priority; measured worse)
@@ -295,6 +297,7 @@ struct Ctx {
     hipEvent_t tap_event = nullptr;
     bool side = false;  // this context runs on that side stream, beside the encoder
     bool a1_done = false;  // ... where the first conv of every conv_reassembly unit was queued too: run_fusion skips it
+    unsigned* poison = nullptr;  // mdpt_forward with non-finite propagation on: the plan's per-image words, cleared, for the im2col kernel to set
     bool consts_cached = false;  // the per-grid constants of this (workspace, shape) are in place (mdpt_set_grid_cache): skip the kernels that write them
     // mdpt_forward_bgr: the patch embedding's im2col kernel builds its rows from this uint8 BGR image (resize + normalise fused in) instead of an image tensor
     struct BgrSource { const unsigned char* ptr = nullptr; int ih = 0, iw = 0, round_dtype = 0, interp = 0; float mean[3] = {0, 0, 0}, inv_std[3] = {1, 1, 1}; } bgr;

@@ -275,6 +275,7 @@ void plan_decoder(Bump& bump, const mdpt_handle* h, Plan& p, size_t min_scratch_
     if (min_scratch_floats > p.scratch_floats) p.scratch_floats = min_scratch_floats;
     p.scratch = bump.take(p.scratch_floats * 4);
     p.probe = bump.take(256);  // the side-stream probe's two flag words: nothing else ever lives here (mdpt_api.cpp ensure_side_stream)
+    p.poison = bump.take((size_t)p.B * 4);  // per-image non-finite flags (patchify_kernel sets, poison_depth_kernel reads: mdpt_api.cpp forward_one)
 }
 
 int make_plan_swin(const mdpt_handle* h, int B, int H, int W, Plan* pl);

@@ -48,7 +48,7 @@ int run_patchify(const Ctx& c, const void* image, int image_dtype, const Planes&
     const mdpt_handle* h = c.h;
     if (c.bgr.ptr)
         return OPLC(mdpt_launch_prepare_patchify, c.bgr.ptr, c.bgr.round_dtype, im.hi, im.lo, c.bgr.ih, c.bgr.iw, H, W, h->P, h->Kpatch, c.bgr.mean, c.bgr.inv_std, c.bgr.interp, c.s);
-    return OPLC(mdpt_launch_patchify, image, image_dtype, im.hi, im.lo, c.p.B, H, W, h->P, h->Kpatch, c.s);
+    return OPLC(mdpt_launch_patchify, image, image_dtype, im.hi, im.lo, c.p.B, H, W, h->P, h->Kpatch, c.s, c.poison);
 }
 
 int run_patch_embed_fused(const Ctx& c, const void* image, int image_dtype) {

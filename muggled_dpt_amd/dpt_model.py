@@ -448,6 +448,8 @@ class _Engine:
             native.check(self.lib, self.lib.mdpt_set_gemm_tile(self.handle, tile))
         if model.__dict__.get("_latency_mode", False):
             native.check(self.lib, self.lib.mdpt_set_latency_mode(self.handle, 1))
+        if not model.__dict__.get("_nonfinite_propagation", True):
+            native.check(self.lib, self.lib.mdpt_set_nonfinite_propagation(self.handle, 0))
         self._grid_cache_on = bool(model.config.get("enable_cache", False))
         if self._grid_cache_on:  # the reference's make_*_dpt(..., enable_cache=True): per-grid constants computed once per (workspace, shape)
             native.check(self.lib, self.lib.mdpt_set_grid_cache(self.handle, 1))
@@ -709,6 +711,15 @@ class DPTModel(nn.Module):
         eng = self.__dict__.get("_engine_obj")
         if eng is not None:
             native.check(eng.lib, eng.lib.mdpt_set_latency_mode(eng.handle, int(bool(on))))
+
+    def set_nonfinite_propagation(self, on: bool = True) -> None:
+        """On (default): an image tensor that holds a NaN / inf gives an all-NaN depth map for that image, in every arithmetic mode - what the
+        reference's forward returns (dpt_model.py:61-83). Off: the saturating converts / v_max ReLUs of the kernels decide (a finite, meaningless
+        map); saves one small launch and one memset per forward (mdpt_set_nonfinite_propagation)."""
+        self.__dict__["_nonfinite_propagation"] = bool(on)
+        eng = self.__dict__.get("_engine_obj")
+        if eng is not None:
+            native.check(eng.lib, eng.lib.mdpt_set_nonfinite_propagation(eng.handle, int(bool(on))))
 
     def export(self, path: str, dtype: torch.dtype | None = None) -> dict:
         """Write the deployment artefact of this model: a `.mdpt` file (configuration incl. family, arithmetic mode and per-class passes,

@@ -195,6 +195,7 @@ SYMBOLS = {
     "mdpt_set_gemm_tile": (ctypes.c_int, [_VP, _I]),
     "mdpt_set_batch_split": (ctypes.c_int, [_VP, _I]),
     "mdpt_set_latency_mode": (ctypes.c_int, [_VP, _I]),
+    "mdpt_set_nonfinite_propagation": (ctypes.c_int, [_VP, _I]),
     "mdpt_debug_gemm": (ctypes.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _VP]),
     "mdpt_debug_attention": (ctypes.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     "mdpt_debug_conv3": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),

@@ -288,20 +288,63 @@ def test_small_layer_scales_do_not_push_the_fp16_planes_into_the_subnormal_range
         assert err <= 1e-4, f"{name}: the fp16x3 update differs from the bf16x3 one by {err:.3e} of its size"
 
 
-def test_fp16_operand_converts_swallow_nan_documented():
-    """the saturating fp32 -> fp16 operand conversion (v_med3_f32) returns a finite value for NaN, so a NaN pixel does not reach the
-    depth map as NaN in the fp16 operand modes, while the bf16 modes carry it through like the reference would. Documented behaviour (include/mdpt.h,
-    csrc/op_types.h); this test pins it so that a change of either side is noticed."""
-    x = seeded_input((1, 3, 56, 56), 3)
-    x[0, 1, 20, 20] = float("nan")
+def test_nonfinite_image_gives_a_nan_depth_map_like_the_reference_in_every_mode():
+    """the saturating fp32 -> fp16 operand conversion (v_med3_f32) returns a finite value for NaN and the ReLUs are v_max, so
+    the kernels alone would answer a NaN / inf pixel with a finite, meaningless map. The reference (dpt_model.py:61-83, run here once through the
+    imported package and pinned by the oracle: tests/test_oracle_golden.py::test_oracle_nonfinite_image_gives_nan_map) returns an all-NaN map for
+    that image and leaves the others alone. mdpt_forward does the same in every mode (mdpt_set_nonfinite_propagation, default on): flags from the
+    im2col kernel, one small launch behind the head."""
+    x = seeded_input((3, 3, 56, 56), 3)
+    clean = x.clone()
+    x[1, 1, 20, 20] = float("nan")
+    x[2, 0, 3, 3] = float("inf")
+    for dtype, prec in ((torch.bfloat16, None), (torch.float16, None), (torch.float32, None), (torch.float32, "mixed")):
+        m, _, _ = _model("tiny", dtype)
+        m.set_precision(prec)
+        y = m(x.to("cuda", dtype)).float()
+        yc = m(clean.to("cuda", dtype)).float()
+        assert bool(torch.isnan(y[1]).all()) and bool(torch.isnan(y[2]).all()), f"{dtype} {prec}: a NaN / inf image must give an all-NaN map"
+        assert bool(torch.isfinite(yc).all())
+        assert torch.equal(y[0], yc[0]), f"{dtype} {prec}: the clean image of the batch must keep its bits"
+        # the flags are cleared by every forward: the same workspace, clean input again
+        assert torch.equal(m(clean.to("cuda", dtype)).float(), yc)
+    # switch off: the kernels' own answer (fp16 operands: finite) - the behaviour of rounds 4-5, still reachable and still pinned
     m_h, _, _ = _model("tiny", torch.float16)
+    m_h.set_nonfinite_propagation(False)
     y = m_h(x.to("cuda", torch.float16)).float()
-    assert bool(torch.isfinite(y).all()), "fp16 operand modes: a NaN pixel becomes a saturated operand, never a NaN depth"
-    # stage level, where no ReLU sits behind the conversion: the bf16 build carries the NaN into the patch tokens, the fp16 build does not
+    assert bool(torch.isfinite(y).all()), "fp16 operand modes without the propagation: a NaN pixel becomes a saturated operand, never a NaN depth"
+    m_h.set_nonfinite_propagation(True)
+    assert bool(torch.isnan(m_h(x.to("cuda", torch.float16)).float()[1]).all())
+    # stage level (not covered by the switch): the bf16 build carries the NaN into the patch tokens, the fp16 build does not
     m_bf, _, _ = _model("tiny", torch.bfloat16)
     tok_bf, _ = m_bf.patch_embed(x.to("cuda", torch.bfloat16))
     tok_h, _ = m_h.patch_embed(x.to("cuda", torch.float16))
     assert bool(torch.isnan(tok_bf.float()).any()) and bool(torch.isfinite(tok_h.float()).all())
+
+
+def test_nonfinite_propagation_under_the_batch_split_and_for_the_other_families():
+    """The two-stream batch split (batch >= 8) runs two plans with a flag array each; SwinV2 and BEiT reach the im2col kernel through their own
+    stage functions; the output dtype of the NaN map follows the model dtype."""
+    x = seeded_input((9, 3, 56, 56), 4)
+    clean = x.clone()
+    x[2, 0, 0, 0] = float("nan")    # first half (images 0-3)
+    x[8, 2, 55, 55] = float("-inf")  # second half (images 4-8), last pixel of the last image
+    for dtype in (torch.float16, torch.bfloat16):
+        m, _, _ = _model("tiny", dtype)
+        y, yc = m(x.to("cuda", dtype)), m(clean.to("cuda", dtype))
+        assert y.dtype == dtype
+        bad = torch.isnan(y.float()).flatten(1).all(1).cpu().tolist()
+        assert bad == [i in (2, 8) for i in range(9)], bad
+        keep = [i for i in range(9) if i not in (2, 8)]
+        assert torch.equal(y[keep], yc[keep]) and bool(torch.isfinite(yc.float()).all())
+    from tests import test_gpu_beit, test_gpu_swinv2
+    for build, name, hw in ((test_gpu_beit._build, "beit_tiny", (96, 160)), (test_gpu_swinv2._build, "swin2_tiny", (192, 320))):
+        m, _, _ = build(name, 1, torch.float16)
+        x = seeded_input((2, 3, *hw), 6)
+        clean = x.clone()
+        x[1, 1, 7, 9] = float("nan")
+        y, yc = m(x.to("cuda", torch.float16)).float(), m(clean.to("cuda", torch.float16)).float()
+        assert bool(torch.isnan(y[1]).all()) and torch.equal(y[0], yc[0]) and bool(torch.isfinite(yc).all()), name
 
 
 def test_raw_c_abi_class_passes_keep_bound_weights_and_reject_bad_arguments():

@@ -148,3 +148,22 @@ def test_vit_giant_swiglu_oracle(golden_dir):
     assert float((depth - torch.from_numpy(g["depth"])).abs().max()) <= ATOL
     for i in range(4):
         assert float((st["stages"][i] - torch.from_numpy(g[f"tap{i}"])).abs().max()) <= ATOL
+
+
+def test_oracle_nonfinite_image_gives_nan_map():
+    """What mdpt_forward's non-finite propagation reproduces (include/mdpt.h: mdpt_set_nonfinite_propagation): the reference's forward
+    (muggled_dpt/dpt_model.py:61-83; checked once in the build container through the imported package on these very inputs: image 0 finite,
+    images 1 and 2 all NaN) and the oracle turn an image with a NaN or inf pixel into an all-NaN depth map and leave the other images alone."""
+    from muggled_dpt_amd.state_dict_conversion import convert_state_dict_keys, flatten_components, get_model_config_from_state_dict
+    from muggled_dpt_amd.synthetic import make_synthetic_original_state_dict
+    from oracle import dpt_oracle
+    osd = make_synthetic_original_state_dict("tiny", 0)
+    cfg = get_model_config_from_state_dict(osd)
+    w = flatten_components(convert_state_dict_keys(cfg, osd))
+    x = torch.randn(3, 3, 56, 56, generator=torch.Generator().manual_seed(1))
+    clean0 = dpt_oracle.forward(w, cfg, x[:1].clone())
+    x[1, 1, 20, 20] = float("nan")
+    x[2, 0, 3, 3] = float("inf")
+    y = dpt_oracle.forward(w, cfg, x)
+    assert bool(torch.isnan(y[1]).all()) and bool(torch.isnan(y[2]).all())
+    assert bool(torch.isfinite(y[0]).all()) and torch.allclose(y[:1], clean0, rtol=1e-5, atol=1e-6)  # (CPU kernels differ by batch shape in the last bits)
