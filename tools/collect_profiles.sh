@@ -83,4 +83,6 @@ python tools/probes/gpu_kernel_share_any.py beitl 384 16 2>&1 | grep -v amdgpu >
 python tools/probes/gpu_side_stream_queue.py 2>&1 | grep -v amdgpu > "$OUT/side_stream_queue.txt"
 python tools/probes/b1_overlap_ab.py 2>&1 | grep -v amdgpu > "$OUT/b1_overlap_ab.txt"
 [ -x tools/probes/_bin/exp_throughput ] && tools/probes/_bin/exp_throughput > "$OUT/exp_throughput.txt" 2>&1
+# non-finite propagation (mdpt_set_nonfinite_propagation): cost of its memset + launch
+python tools/probes/gpu_nonfinite_cost.py 2>&1 | grep -v amdgpu > "$OUT/nonfinite_cost.txt"
 ls -la "$OUT"
