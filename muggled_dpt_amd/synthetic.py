@@ -352,3 +352,41 @@ def make_synthetic_original_state_dict(cfg: dict | str, seed: int = 0) -> dict[s
             t = 0.1 * torch.randn(shape, generator=gen)
         sd[key] = t.to(torch.float32).contiguous()
     return sd
+
+
+def realistic_statistics(osd: dict[str, torch.Tensor], seed: int = 0, gamma_lo: float = 1e-4, gamma_hi: float = 1.0) -> dict[str, torch.Tensor]:
+    """A synthetic Depth-Anything checkpoint (upstream key names) perturbed toward the statistics real DINOv2 weights are known for - the stand-in
+    for the real file that cannot be fetched here (tools/probes/gpu_realistic_stats_check.py, tests/test_gpu_precision_modes.py):
+    per-channel log-uniform layer-scale gammas (gamma_lo ... gamma_hi: 1e-4 ... 1 by default, 2 % at 1e-5), log-normal LayerNorm weights with a few x8 / x0.05 channels, encoder
+    Linears with row scales exp(N(0, 0.3)) and one entry in 1000 six times larger, and two "massive activation" channels of the residual stream
+    (fc2 bias of block 4: +150 / -90; position embedding: +40 / -25)."""
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(1000 + int(seed))
+    out = {}
+    for k, v in osd.items():
+        t = v.clone()
+        enc = k.startswith("pretrained.blocks.")
+        if enc and k.endswith("gamma"):
+            import math
+            t = gamma_hi * torch.exp(torch.rand(t.shape, generator=gen) * math.log(gamma_lo / gamma_hi))  # log-uniform gamma_lo ... gamma_hi
+            t[torch.rand(t.shape, generator=gen) < 0.02] = 1e-5
+        elif enc and ".norm" in k and k.endswith("weight"):
+            t = torch.exp(0.5 * torch.randn(t.shape, generator=gen))
+            r = torch.rand(t.shape, generator=gen)
+            t[r < 0.005] *= 8.0
+            t[r > 0.995] *= 0.05
+        elif enc and k.endswith("weight") and t.dim() == 2:
+            t = t * torch.exp(0.3 * torch.randn(t.shape[0], 1, generator=gen))
+            t = t * (1.0 + 5.0 * (torch.rand(t.shape, generator=gen) < 1e-3).float())
+        elif k == "pretrained.blocks.4.mlp.fc2.bias":
+            t[7] += 150.0
+            t[t.numel() // 2 + 9] -= 90.0
+        elif k == "pretrained.pos_embed":
+            t[:, 1:, 7] += 40.0
+            t[:, 1:, t.shape[-1] // 2 + 9] -= 25.0
+        out[k] = t.to(torch.float32).contiguous()
+    g4 = out.get("pretrained.blocks.4.ls2.gamma")
+    if g4 is not None:  # the bias reaches the stream through the layer scale: those two channels pass it on unscaled
+        g4[7] = 1.0
+        g4[g4.numel() // 2 + 9] = 1.0
+    return out
