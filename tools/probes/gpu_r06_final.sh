@@ -18,7 +18,7 @@ python -c "from muggled_dpt_amd import native; print('source hash', native.sourc
 if [ "${1:-}" != "notests" ]; then
   timeout 1500 python -m pytest tests/ -q -m gpu 2>&1 | tail -15 > "$OUT/pytest_gpu.txt"
   cp gpurun_out/parity_report.json "$OUT/parity_report.json" 2>/dev/null
-  python tools/summarize_parity.py "$OUT/parity_report.json" > "$OUT/parity_report.md" 2>/dev/null
+  python tools/summarize_parity.py "$OUT/parity_report.json" "$OUT/parity_report.md" > /dev/null 2>&1
 fi
 python bench.py --steps 20 --warmup 3 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 cd /tmp && export TMPDIR=/tmp
